@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.  RUNS ONLY IN THE BUILD CONTAINER (needs
+/root/reference); the fixtures it writes are data (inputs + expected outputs) and travel to the GPU box, this
+script's inputs do not.
+
+Sources of truth, all independent of the build's own solver code (oracle/bluerov2_oracle.c and the HIP kernels):
+  * model layer  -- the reference's CasADi-generated C (c_generated_code/bluerov2_model/*.c) compiled into
+                    oracle/_ref by oracle/Makefile, called through ctypes (oracle_ffi.CasadiRef);
+  * integrator   -- textbook ERK4 (acados sim_erk, 4 stages / 1 step) written here in numpy, driving expl_vde_forw;
+  * QP           -- full condensing written here in numpy + scipy.optimize.lsq_linear(method='bvls') on the Cholesky
+                    factor of the condensed Hessian (the strictly convex QP has a unique minimiser);
+  * trajectories -- the reference's own data files bluerov2_path/config/traj/{circle,lemniscate}.txt.
+acados itself is not available: these are known answers of the same mathematical problem, not acados
+output -- solver-level parity stays "unpinned".
+
+    python scripts/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+from scipy.linalg import cholesky, solve_triangular
+from scipy.optimize import lsq_linear
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.oracle_ffi import CasadiRef  # noqa: E402  (reference's generated C, not the build's restatement)
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+NX, NU, NP, NY = 12, 4, 16, 16
+# c_generated_code/acados_solver_bluerov2.c:422-481, :559-566
+W = np.array([300, 480, 200, 10, 10, 200, 40, 40, 10, 10, 10, 10, 1, 1, 0.1, 0.05], dtype=float)
+LBU, UBU = -50.0 * np.ones(NU), 50.0 * np.ones(NU)
+# bluerov2_dobmpc/src/bluerov2_dob.cpp:340-353
+P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
+
+
+def model_vectors(ref, n=128, n_rk=64, seed=0):
+    rng = np.random.default_rng(seed)
+    scale = np.array([5, 5, 5, 1.0, 1.0, 3.0, 2, 2, 2, 1, 1, 1.0])
+    X, U, P = np.zeros((n, NX)), np.zeros((n, NU)), np.zeros((n, NP))
+    for t in range(n):
+        x = rng.uniform(-1, 1, NX) * scale
+        x[2] -= 20
+        if t % 5 == 0:  # exercise the |v|v kink: exact zeros and sign changes
+            x[6 + rng.integers(0, 6)] = 0.0
+        if t % 11 == 0:
+            x[6:] = 0.0
+        X[t] = x
+        U[t] = rng.uniform(-50, 50, NU)
+        p = P_NOMINAL.copy()
+        p[:4] = rng.uniform(-300, 300, 4)
+        if t % 3 == 0:  # arbitrary hydrodynamic parameters (AMPC varies them, bluerov2_ampc.cpp:337-380)
+            p = rng.uniform(-5, 5, NP)
+            p[4:8] = np.abs(p[4:8])
+        if t == 1:
+            p[:] = 0.0  # generate_c_code.py:30 / main_bluerov2.c:170-191
+        P[t] = p
+    F = np.stack([ref.f(X[t], U[t], P[t]) for t in range(n)])
+    AB = [ref.jac(X[t], U[t], P[t]) for t in range(n)]
+    A, B = np.stack([a for a, _ in AB]), np.stack([b for _, b in AB])
+    hs = np.array([0.0125, 0.05, 0.1])
+    XN, AD, BD = np.zeros((3, n_rk, NX)), np.zeros((3, n_rk, NX, NX)), np.zeros((3, n_rk, NX, NU))
+    for ih, h in enumerate(hs):
+        for t in range(n_rk):  # RK4 outputs for the leading n_rk points
+            XN[ih, t], AD[ih, t], BD[ih, t] = ref.rk4_sens(X[t], U[t], P[t], h)
+    return dict(x=X, u=U, p=P, f=F, A=A, B=B, h=hs, xn=XN, Ad=AD, Bd=BD)
+
+
+def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU):
+    """one SQP-RTI step: linearise with the reference model, condense, solve the box QP by BVLS, full step."""
+    A, B, b = np.zeros((N, NX, NX)), np.zeros((N, NX, NU)), np.zeros((N, NX))
+    for i in range(N):
+        xn, A[i], B[i] = ref.rk4_sens(x[i], u[i], p[i], Ts)
+        b[i] = xn - x[i + 1]
+    Qd = np.concatenate([np.tile(Ts * Wd[:NX], (N, 1)), Wd[None, :NX]])
+    q = Qd * (x - yref[:, :NX])
+    Rd = np.tile(Ts * Wd[NX:], (N, 1))
+    r = Rd * (u - yref[:N, NX:])
+    d0 = x0 - x[0]
+    # condensing: dx_{i} = G_i dU + c_i
+    G = np.zeros((N + 1, NX, N * NU))
+    c = np.zeros((N + 1, NX))
+    c[0] = d0
+    for i in range(N):
+        G[i + 1] = A[i] @ G[i]
+        G[i + 1][:, i * NU:(i + 1) * NU] += B[i]
+        c[i + 1] = A[i] @ c[i] + b[i]
+    H = np.diag(Rd.ravel()).astype(float)
+    g = r.ravel().copy()
+    for i in range(N + 1):
+        H += G[i].T @ (Qd[i][:, None] * G[i])
+        g += G[i].T @ (Qd[i] * c[i] + q[i])
+    H = 0.5 * (H + H.T)
+    L = cholesky(H, lower=True)
+    rhs = -solve_triangular(L, g, lower=True)
+    lb = (lbu[None, :] - u).ravel()
+    ub = (ubu[None, :] - u).ravel()
+    sol = lsq_linear(L.T, rhs, bounds=(lb, ub), method="bvls", tol=1e-15, max_iter=5000)
+    dU = sol.x
+    grad = H @ dU + g
+    nact = int(np.sum((dU <= lb + 1e-9) | (dU >= ub - 1e-9)))
+    # KKT check of the condensed QP
+    free = (dU > lb + 1e-9) & (dU < ub - 1e-9)
+    kkt = max(np.abs(grad[free]).max(initial=0.0),
+              np.maximum(0, -grad[dU <= lb + 1e-9]).max(initial=0.0),
+              np.maximum(0, grad[dU >= ub - 1e-9]).max(initial=0.0))
+    dX = np.stack([G[i] @ dU + c[i] for i in range(N + 1)])
+    return x + dX, u + dU.reshape(N, NU), dict(nact=nact, qp_kkt=kkt, cond=np.linalg.cond(H))
+
+
+def scenario_list(circ, lem):
+    """(name, N, Ts, nticks, x0(k), yref(k), p, init_x, init_u)"""
+    sc = []
+
+    def circle_ref(N):
+        return lambda k: circ[k:k + N + 1].copy()
+
+    x0c = np.zeros(NX)
+    x0c[:6] = circ[0, :6]
+    x_def = np.zeros(NX)
+    x_def[2] = -20
+    for N in (20, 80):
+        sc.append(dict(name=f"circle_N{N}", N=N, Ts=1.0 / N, ticks=4, x0=x0c, yref=circle_ref(N),
+                       p=np.tile(P_NOMINAL, (N + 1, 1)), xi=x_def, ui=np.zeros(NU)))
+    # c_generated_code/main_bluerov2.c:117-216 -- x0=[0,0,-20,0..], yref=0, p=0, iterate initialised to zero
+    for N in (20, 80):
+        sc.append(dict(name=f"main_harness_N{N}", N=N, Ts=1.0 / N, ticks=2, x0=x_def,
+                       yref=lambda k, N=N: np.zeros((N + 1, NY)), p=np.zeros((N + 1, NP)), xi=np.zeros(NX),
+                       ui=np.zeros(NU)))
+    # saturated: 6 m position error + yaw error => surge/sway/yaw commands hit +-50
+    x0s = np.array([3.0, -4.0, -17.0, 0.05, -0.05, 1.0, 0.2, -0.1, 0.1, 0, 0, 0.1])
+    sc.append(dict(name="saturated_N20", N=20, Ts=0.05, ticks=4, x0=x0s, yref=circle_ref(20),
+                   p=np.tile(P_NOMINAL, (21, 1)), xi=x_def, ui=np.zeros(NU)))
+    sc.append(dict(name="saturated_N80", N=80, Ts=0.0125, ticks=2, x0=x0s, yref=circle_ref(80),
+                   p=np.tile(P_NOMINAL, (81, 1)), xi=x_def, ui=np.zeros(NU)))
+    # DOB-MPC: strong estimated disturbance (10 N / 3 N m through the node's scaling, bluerov2_dob.cpp:334-337)
+    pd = P_NOMINAL.copy()
+    pd[:4] = [10 / 0.032546960744430276, -10 / 0.032546960744430276, 10 / 0.026546960744430276, 3 / 0.026546960744430276]
+    sc.append(dict(name="dob_N20", N=20, Ts=0.05, ticks=4, x0=x0c, yref=circle_ref(20), p=np.tile(pd, (21, 1)),
+                   xi=x_def, ui=np.zeros(NU)))
+    # lemniscate tracking from its first row
+    x0l = np.zeros(NX)
+    x0l[:6] = lem[0, :6]
+    sc.append(dict(name="lemniscate_N20", N=20, Ts=0.05, ticks=4, x0=x0l, yref=lambda k: lem[k:k + 21].copy(),
+                   p=np.tile(P_NOMINAL, (21, 1)), xi=x_def, ui=np.zeros(NU)))
+    # weakly active: moderate error so that only a few stages saturate
+    x0w = np.array([-2.0, 1.2, -19.5, 0, 0, -1.2, 0, 0, 0, 0, 0, 0])
+    sc.append(dict(name="weak_N20", N=20, Ts=0.05, ticks=4, x0=x0w, yref=circle_ref(20),
+                   p=np.tile(P_NOMINAL, (21, 1)), xi=x_def, ui=np.zeros(NU)))
+    return sc
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = CasadiRef()
+    circ_path = f"{REF}/bluerov2_path/config/traj/circle.txt"
+    lem_path = f"{REF}/bluerov2_path/config/traj/lemniscate.txt"
+    circ, lem = np.loadtxt(circ_path), np.loadtxt(lem_path)
+    assert circ.shape == (4801, 16) and lem.shape == (1201, 16)
+
+    mv = model_vectors(ref)
+    np.savez_compressed(os.path.join(OUT, "model_vectors.npz"), **mv)
+    print("model_vectors:", {k: v.shape for k, v in mv.items()})
+
+    # trajectory fixtures: leading rows of the reference's data files + digests of the full files
+    np.savez_compressed(os.path.join(OUT, "traj_head.npz"), circle=circ[:160], lemniscate=lem[:160],
+                        circle_tail=circ[-4:], lemniscate_tail=lem[-4:],
+                        circle_shape=np.array(circ.shape), lemniscate_shape=np.array(lem.shape),
+                        circle_sha256=np.frombuffer(hashlib.sha256(open(circ_path, "rb").read()).digest(), dtype=np.uint8),
+                        lemniscate_sha256=np.frombuffer(hashlib.sha256(open(lem_path, "rb").read()).digest(), dtype=np.uint8))
+
+    out = {}
+    for sc in scenario_list(circ, lem):
+        N, Ts = sc["N"], sc["Ts"]
+        x = np.tile(sc["xi"], (N + 1, 1))
+        u = np.tile(sc["ui"], (N, 1))
+        name = sc["name"]
+        out[f"{name}/N"] = np.array(N)
+        out[f"{name}/Ts"] = np.array(Ts)
+        out[f"{name}/x0_meas"] = sc["x0"]
+        out[f"{name}/p"] = sc["p"]
+        out[f"{name}/x_init"] = x.copy()
+        out[f"{name}/u_init"] = u.copy()
+        for k in range(sc["ticks"]):
+            yref = sc["yref"](k)
+            x, u, info = rti_step_independent(ref, N, Ts, sc["x0"], yref, sc["p"], x, u)
+            out[f"{name}/yref{k}"] = yref
+            out[f"{name}/x{k}"] = x.copy()
+            out[f"{name}/u{k}"] = u.copy()
+            out[f"{name}/info{k}"] = np.array([info["nact"], info["qp_kkt"], info["cond"]])
+            print(f"{name} tick {k}: u0={u[0]}, active={info['nact']}/{N * NU}, qp_kkt={info['qp_kkt']:.2e}, cond={info['cond']:.1e}")
+    np.savez_compressed(os.path.join(OUT, "rti_known_answers.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
