@@ -1,0 +1,128 @@
+// bluerov2_model.hpp -- device-side BlueROV2 model for gfx950 (FP64).
+//
+// Hand-derived f(x,u,p) and the action of its Jacobian on a direction (A_c s), exploiting the 48/144 sparsity of
+// df/dx, the constancy of df/du and the rotation-matrix structure of the kinematic rows.  Follows the OCP definition
+// /root/reference/bluerov2_dobmpc/scripts/bluerov2.py:77-137 (incl. the sin(psi) term of dphi, :133) and the
+// derivative conventions of the generated c_generated_code/bluerov2_model/bluerov2_expl_vde_forw.c
+// (d|v|v/dv = sign(v) v + |v| = 2|v|, zero at v = 0, :65).  Not a translation of the CasADi code: no common file
+// structure, ~130 flops per Jacobian-vector product instead of a 4.5k-statement dense VDE.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace brov {
+
+constexpr int NX = 12, NU = 4, NP = 16, NY = 16;
+
+// bluerov2.py:77-84
+constexpr double kMass = 11.26, kIx = 0.3, kIy = 0.63, kIz = 0.58, kZG = 0.02, kG = 9.81, kBouy = 0.66;
+constexpr double kRotor = 0.026546960744430276;
+constexpr double kMzg = kMass * kZG * kG;
+
+// parameter-derived constants of one stage (p = [dist4 | added mass4 | linear damping4 | quadratic damping4])
+struct ModelPar {
+    double dx, dy, dz, dn;      // disturbances
+    double imx, imy, imz, imn;  // 1/(m+Xa), 1/(m+Ya), 1/(m+Za), 1/(Iz+Na)
+    double lx, ly, lz, ln;      // linear damping
+    double qx, qy, qz, qn;      // quadratic damping
+};
+
+__device__ __forceinline__ ModelPar make_par(const double* __restrict__ p) {
+    ModelPar m;
+    m.dx = p[0]; m.dy = p[1]; m.dz = p[2]; m.dn = p[3];
+    m.imx = 1.0 / (kMass + p[4]); m.imy = 1.0 / (kMass + p[5]); m.imz = 1.0 / (kMass + p[6]);
+    m.imn = 1.0 / (kIz + p[7]);
+    m.lx = p[8]; m.ly = p[9]; m.lz = p[10]; m.ln = p[11];
+    m.qx = p[12]; m.qy = p[13]; m.qz = p[14]; m.qn = p[15];
+    return m;
+}
+
+// generalised forces of the 6 thrusters for the 4 wrench commands (bluerov2.py:95-121), constant over an RK step
+struct Wrench { double k0, k1, k2, k5; };
+
+__device__ __forceinline__ Wrench make_wrench(const double* __restrict__ u) {
+    const double ir = 1.0 / kRotor;
+    const double t0 = (-u[0] + u[1] + u[3]) * ir, t1 = (-u[0] - u[1] - u[3]) * ir;
+    const double t2 = (u[0] + u[1] - u[3]) * ir, t3 = (u[0] - u[1] + u[3]) * ir;
+    const double t4 = -u[2] * ir;
+    Wrench w;
+    w.k0 = 0.707 * t0 + 0.707 * t1 - 0.707 * t2 - 0.707 * t3;
+    w.k1 = 0.707 * t0 - 0.707 * t1 + 0.707 * t2 - 0.707 * t3;
+    w.k2 = t4 + t4;
+    w.k5 = 0.167 * t0 - 0.167 * t1 - 0.175 * t2 + 0.175 * t3;
+    return w;
+}
+
+// what one RK stage point contributes to the Jacobian: 6 trig values, 1/cos(theta), body velocities and rates
+struct StagePoint {
+    double sph, cph, sth, cth, sps, cps, icth;
+    double vu, vv, vw, wp, wq, wr;
+};
+
+// xdot = f(x,u,p); also returns the stage point record
+__device__ __forceinline__ void model_f(const double (&x)[NX], const Wrench& w, const ModelPar& m, double (&f)[NX],
+                                        StagePoint& sp) {
+    sincos(x[3], &sp.sph, &sp.cph);
+    sincos(x[4], &sp.sth, &sp.cth);
+    sincos(x[5], &sp.sps, &sp.cps);
+    sp.icth = 1.0 / sp.cth;
+    sp.vu = x[6]; sp.vv = x[7]; sp.vw = x[8]; sp.wp = x[9]; sp.wq = x[10]; sp.wr = x[11];
+    const double r00 = sp.cps * sp.cth, r01 = sp.cps * sp.sth * sp.sph - sp.sps * sp.cph,
+                 r02 = sp.sps * sp.sph + sp.cps * sp.cph * sp.sth;
+    const double r10 = sp.sps * sp.cth, r11 = sp.cps * sp.cph + sp.sph * sp.sth * sp.sps,
+                 r12 = sp.sth * sp.sps * sp.cph - sp.cps * sp.sph;
+    const double r21 = sp.cth * sp.sph, r22 = sp.cth * sp.cph;
+    f[0] = r00 * sp.vu + r01 * sp.vv + r02 * sp.vw;
+    f[1] = r10 * sp.vu + r11 * sp.vv + r12 * sp.vw;
+    f[2] = -sp.sth * sp.vu + r21 * sp.vv + r22 * sp.vw;
+    const double tth = sp.sth * sp.icth;
+    f[3] = sp.wp + sp.sps * tth * sp.wq + sp.cph * tth * sp.wr;  // sin(psi): reference quirk, bluerov2.py:133
+    f[4] = sp.cph * sp.wq + sp.sph * sp.wr;
+    f[5] = (sp.sph * sp.wq + sp.cph * sp.wr) * sp.icth;
+    f[6] = (w.k0 - kBouy * sp.sth + m.dx + m.lx * sp.vu + m.qx * fabs(sp.vu) * sp.vu) * m.imx;
+    f[7] = (w.k1 + kBouy * r21 + m.dy + m.ly * sp.vv + m.qy * fabs(sp.vv) * sp.vv) * m.imy;
+    f[8] = (w.k2 + kBouy * r22 + m.dz + m.lz * sp.vw + m.qz * fabs(sp.vw) * sp.vw) * m.imz;
+    f[9] = ((kIy - kIz) * sp.wq * sp.wr - kMzg * r21) * (1.0 / kIx);
+    f[10] = ((kIz - kIx) * sp.wp * sp.wr - kMzg * sp.sth) * (1.0 / kIy);
+    f[11] = (w.k5 - (kIy - kIx) * sp.wp * sp.wq + m.dn + m.ln * sp.wr + m.qn * fabs(sp.wr) * sp.wr) * m.imn;
+}
+
+// o = (df/dx)(stage point) * s.  Columns 0..2 of df/dx vanish (no dependence on position).
+__device__ __forceinline__ void model_jvp(const StagePoint& sp, const ModelPar& m, const double (&s)[NX],
+                                          double (&o)[NX]) {
+    const double r00 = sp.cps * sp.cth, r01 = sp.cps * sp.sth * sp.sph - sp.sps * sp.cph,
+                 r02 = sp.sps * sp.sph + sp.cps * sp.cph * sp.sth;
+    const double r10 = sp.sps * sp.cth, r11 = sp.cps * sp.cph + sp.sph * sp.sth * sp.sps,
+                 r12 = sp.sth * sp.sps * sp.cph - sp.cps * sp.sph;
+    const double r21 = sp.cth * sp.sph, r22 = sp.cth * sp.cph;
+    const double f0 = r00 * sp.vu + r01 * sp.vv + r02 * sp.vw;
+    const double f1 = r10 * sp.vu + r11 * sp.vv + r12 * sp.vw;
+    const double f2 = -sp.sth * sp.vu + r21 * sp.vv + r22 * sp.vw;
+    // d(R v)/d(phi,theta,psi): dR/dphi v = [R02 vv - R01 vw, ..], dR/dtheta v = [cps f2, sps f2, ..], dR/dpsi v = [-f1, f0, 0]
+    o[0] = (r02 * sp.vv - r01 * sp.vw) * s[3] + (sp.cps * f2) * s[4] - f1 * s[5] + r00 * s[6] + r01 * s[7] + r02 * s[8];
+    o[1] = (r12 * sp.vv - r11 * sp.vw) * s[3] + (sp.sps * f2) * s[4] + f0 * s[5] + r10 * s[6] + r11 * s[7] + r12 * s[8];
+    o[2] = (r22 * sp.vv - r21 * sp.vw) * s[3] - (sp.cth * sp.vu + sp.sth * (sp.sph * sp.vv + sp.cph * sp.vw)) * s[4] -
+           sp.sth * s[6] + r21 * s[7] + r22 * s[8];
+    const double tth = sp.sth * sp.icth, ic2 = sp.icth * sp.icth;
+    o[3] = (-sp.sph * tth * sp.wr) * s[3] + ((sp.sps * sp.wq + sp.cph * sp.wr) * ic2) * s[4] + (sp.cps * tth * sp.wq) * s[5] +
+           s[9] + (sp.sps * tth) * s[10] + (sp.cph * tth) * s[11];
+    o[4] = (sp.cph * sp.wr - sp.sph * sp.wq) * s[3] + sp.cph * s[10] + sp.sph * s[11];
+    o[5] = ((sp.cph * sp.wq - sp.sph * sp.wr) * s[3] + (sp.sph * sp.wq + sp.cph * sp.wr) * tth * s[4] + sp.sph * s[10] +
+            sp.cph * s[11]) * sp.icth;
+    o[6] = (-kBouy * sp.cth * s[4] + (m.lx + 2.0 * m.qx * fabs(sp.vu)) * s[6]) * m.imx;
+    o[7] = (kBouy * (r22 * s[3] - sp.sth * sp.sph * s[4]) + (m.ly + 2.0 * m.qy * fabs(sp.vv)) * s[7]) * m.imy;
+    o[8] = (-kBouy * (r21 * s[3] + sp.sth * sp.cph * s[4]) + (m.lz + 2.0 * m.qz * fabs(sp.vw)) * s[8]) * m.imz;
+    o[9] = (kMzg * (sp.sth * sp.sph * s[4] - r22 * s[3]) + (kIy - kIz) * (sp.wr * s[10] + sp.wq * s[11])) * (1.0 / kIx);
+    o[10] = (-kMzg * sp.cth * s[4] + (kIz - kIx) * (sp.wr * s[9] + sp.wp * s[11])) * (1.0 / kIy);
+    o[11] = (-(kIy - kIx) * (sp.wq * s[9] + sp.wp * s[10]) + (m.ln + 2.0 * m.qn * fabs(sp.wr)) * s[11]) * m.imn;
+}
+
+// constant, sparse df/du (5 non-zeros): column j added to rows of o
+__device__ __forceinline__ void model_bcol(const ModelPar& m, int j, double (&o)[NX]) {
+    constexpr double ir = 1.0 / kRotor;
+    if (j == 0) o[6] += (-4.0 * 0.707) * ir * m.imx;
+    if (j == 1) { o[7] += (4.0 * 0.707) * ir * m.imy; o[11] += (0.167 + 0.167 - 0.175 - 0.175) * ir * m.imn; }
+    if (j == 2) o[8] += -2.0 * ir * m.imz;
+    if (j == 3) o[11] += (0.167 + 0.167 + 0.175 + 0.175) * ir * m.imn;
+}
+
+}  // namespace brov

@@ -1,0 +1,421 @@
+// nmpc_api.hip -- host side of the batched solver: owns the HBM state of B OCP instances and implements the C ABI of
+// include/bluerov2_nmpc.h (each entry point there cites the reference call it replaces).  No CPU compute path: without a
+// usable HIP device every entry point fails with BROV_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nmpc_device.hpp"
+
+using namespace brov;
+
+static thread_local std::string g_err;
+extern "C" const char* brov_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e_);                                 \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) \
+                       ? BROV_ERR_NO_DEVICE                                                            \
+                       : BROV_ERR_HIP;                                                                 \
+        }                                                                                              \
+    } while (0)
+
+struct brov_solver {
+    int device = 0, B = 0, N = 0;
+    brov_opts opts{};
+    bool yref_shared = false;
+    // device buffers
+    double *x0 = nullptr, *yref = nullptr, *yref_sh = nullptr, *par = nullptr;
+    double *x = nullptr, *u = nullptr, *pi = nullptr, *lam = nullptr;
+    double *BA = nullptr, *BAt = nullptr, *bvec = nullptr, *kktp = nullptr;
+    double *Ks = nullptr, *Kt = nullptr, *Mt = nullptr, *Pb = nullptr, *kff = nullptr, *vhat = nullptr, *ipm = nullptr,
+           *dxb = nullptr, *cst = nullptr;
+    brov_result* res = nullptr;
+    int* best = nullptr;
+    size_t bytes = 0;
+    std::vector<void*> allocs;
+    hipStream_t last_stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
+    // /root/reference/bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.c:422-481 (W), :559-566 (bounds), :668
+    static const double W[16] = {300, 480, 200, 10, 10, 200, 40, 40, 10, 10, 10, 10, 1, 1, 0.1, 0.05};
+    std::memset(o, 0, sizeof(*o));
+    o->N = N;
+    o->Ts = Ts;
+    for (int j = 0; j < 16; j++) o->W[j] = W[j];
+    for (int j = 0; j < 12; j++) o->We[j] = W[j];
+    for (int j = 0; j < 4; j++) { o->lbu[j] = -50.0; o->ubu[j] = 50.0; }
+    o->qp_iter_max = 50;
+    o->qp_tol_mu = 1e-12;
+    o->qp_tol_stat = 1e-9;
+    o->qp_early_exit = 1;
+}
+
+template <typename T>
+static int dalloc(brov_solver* s, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) {
+        g_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return BROV_ERR_ALLOC;
+    }
+    s->allocs.push_back(q);
+    s->bytes += n * sizeof(T);
+    *p = (T*)q;
+    return BROV_OK;
+}
+
+static int upload_cst(brov_solver* s) {
+    double c[40];
+    std::memset(c, 0, sizeof c);
+    for (int j = 0; j < 16; j++) c[j] = s->opts.W[j];
+    for (int j = 0; j < 12; j++) c[16 + j] = s->opts.We[j];
+    for (int j = 0; j < 4; j++) { c[32 + j] = s->opts.lbu[j]; c[36 + j] = s->opts.ubu[j]; }
+    HIPCHK(hipMemcpy(s->cst, c, sizeof c, hipMemcpyHostToDevice));
+    return BROV_OK;
+}
+
+extern "C" int brov_init_iterate_default(brov_solver* s) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const int B = s->B, N = s->N;
+    std::vector<double> hx((size_t)B * (N + 1) * 12, 0.0);
+    for (size_t k = 0; k < (size_t)B * (N + 1); k++) hx[k * 12 + 2] = -20.0;  // acados_solver_bluerov2.c:689-706
+    HIPCHK(hipMemcpy(s->x, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(s->u, 0, (size_t)B * N * 4 * sizeof(double)));
+    HIPCHK(hipMemset(s->pi, 0, (size_t)B * N * 12 * sizeof(double)));
+    HIPCHK(hipMemset(s->lam, 0, (size_t)B * N * 8 * sizeof(double)));
+    return BROV_OK;
+}
+
+extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts* opts) {
+    if (!out || !opts || B < 1 || opts->N < 1 || opts->N > BROV_MAX_N || !(opts->Ts > 0.0)) {
+        g_err = "brov_create: bad argument";
+        return BROV_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+        g_err = "brov_create: no usable HIP device (this library has no CPU fallback)";
+        return BROV_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    brov_solver* s = new brov_solver();
+    s->device = device;
+    s->B = B;
+    s->N = opts->N;
+    s->opts = *opts;
+    const size_t N = opts->N, Bz = B;
+    int rc = BROV_OK;
+#define AL(ptr, n) if (rc == BROV_OK) rc = dalloc(s, &s->ptr, (n))
+    AL(x0, Bz * 12);
+    AL(yref, Bz * (N + 1) * 16);
+    AL(yref_sh, (N + 1) * 16);
+    AL(par, Bz * (N + 1) * 16);
+    AL(x, Bz * (N + 1) * 12);
+    AL(u, Bz * N * 4);
+    AL(pi, Bz * N * 12);
+    AL(lam, Bz * N * 8);
+    AL(BA, Bz * N * 192);
+    AL(BAt, Bz * N * 256);
+    AL(bvec, Bz * N * 12);
+    AL(kktp, Bz * N);
+    AL(Ks, Bz * N * 64);
+    AL(Kt, Bz * N * 192);
+    AL(Mt, Bz * N * 64);
+    AL(Pb, Bz * N * 12);
+    AL(kff, Bz * N * 4);
+    AL(vhat, Bz * N * 4);
+    AL(ipm, Bz * IPM_NARR * N * 4);
+    AL(dxb, Bz * (N + 1) * 12);
+    AL(cst, 40);
+    AL(res, Bz);
+    AL(best, 2);
+#undef AL
+    if (rc != BROV_OK) { brov_destroy(s); return rc; }
+    // create defaults: yref = 0, p = 0, x0 = [0,0,-20,0..] (acados_solver_bluerov2.c:355-364, 405-420, 520-527)
+    hipMemset(s->yref, 0, Bz * (N + 1) * 16 * sizeof(double));
+    hipMemset(s->yref_sh, 0, (N + 1) * 16 * sizeof(double));
+    hipMemset(s->par, 0, Bz * (N + 1) * 16 * sizeof(double));
+    hipMemset(s->res, 0, Bz * sizeof(brov_result));
+    {
+        std::vector<double> h0(Bz * 12, 0.0);
+        for (size_t k = 0; k < Bz; k++) h0[k * 12 + 2] = -20.0;
+        hipMemcpy(s->x0, h0.data(), h0.size() * sizeof(double), hipMemcpyHostToDevice);
+    }
+    rc = upload_cst(s);
+    if (rc == BROV_OK) rc = brov_init_iterate_default(s);
+    if (rc != BROV_OK) { brov_destroy(s); return rc; }
+    for (int k = 0; k < 3; k++) hipEventCreate(&s->ev[k]);
+    *out = s;
+    return BROV_OK;
+}
+
+extern "C" void brov_destroy(brov_solver* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    for (void* p : s->allocs) hipFree(p);
+    for (int k = 0; k < 3; k++)
+        if (s->ev[k]) hipEventDestroy(s->ev[k]);
+    delete s;
+}
+
+extern "C" int brov_batch(const brov_solver* s) { return s ? s->B : 0; }
+extern "C" int brov_horizon(const brov_solver* s) { return s ? s->N : 0; }
+extern "C" size_t brov_device_bytes(const brov_solver* s) { return s ? s->bytes : 0; }
+
+static int copy_in(brov_solver* s, double* dst, const double* src, size_t n, bool host, void* stream) {
+    if (!s || !src) { g_err = "null argument"; return BROV_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    if (host) {
+        HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return BROV_OK;
+}
+
+extern "C" int brov_set_x0_host(brov_solver* s, const double* x0) { return copy_in(s, s ? s->x0 : nullptr, x0, s ? (size_t)s->B * 12 : 0, true, nullptr); }
+extern "C" int brov_set_x0_device(brov_solver* s, const double* x0, void* st) { return copy_in(s, s ? s->x0 : nullptr, x0, s ? (size_t)s->B * 12 : 0, false, st); }
+
+static int set_yref(brov_solver* s, const double* y, int shared, bool host, void* st) {
+    if (!s) return BROV_ERR_ARG;
+    s->yref_shared = shared != 0;
+    const size_t n = (size_t)(s->N + 1) * 16;
+    return shared ? copy_in(s, s->yref_sh, y, n, host, st) : copy_in(s, s->yref, y, n * s->B, host, st);
+}
+extern "C" int brov_set_yref_host(brov_solver* s, const double* y, int shared) { return set_yref(s, y, shared, true, nullptr); }
+extern "C" int brov_set_yref_device(brov_solver* s, const double* y, int shared, void* st) { return set_yref(s, y, shared, false, st); }
+
+__global__ void bcast_par_kernel(const double* __restrict__ p16, double* __restrict__ par, int B, int N1) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tot = (size_t)B * N1 * 16;
+    if (t >= tot) return;
+    const size_t b = t / ((size_t)N1 * 16);
+    par[t] = p16[b * 16 + (t & 15)];
+}
+
+static int set_par(brov_solver* s, const double* p, int per_stage, bool host, void* st) {
+    if (!s || !p) return BROV_ERR_ARG;
+    const size_t N1 = s->N + 1;
+    if (per_stage) return copy_in(s, s->par, p, (size_t)s->B * N1 * 16, host, st);
+    HIPCHK(hipSetDevice(s->device));
+    const double* src = p;
+    double* tmp = nullptr;
+    if (host) {
+        HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 16 * sizeof(double)));
+        hipError_t e = hipMemcpy(tmp, p, (size_t)s->B * 16 * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(tmp); g_err = hipGetErrorString(e); return BROV_ERR_HIP; }
+        src = tmp;
+    }
+    const size_t tot = (size_t)s->B * N1 * 16;
+    hipLaunchKernelGGL(bcast_par_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)st, src, s->par, s->B, (int)N1);
+    if (host) {
+        hipStreamSynchronize((hipStream_t)st);
+        hipFree(tmp);
+    }
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_set_params_host(brov_solver* s, const double* p, int per_stage) { return set_par(s, p, per_stage, true, nullptr); }
+extern "C" int brov_set_params_device(brov_solver* s, const double* p, int per_stage, void* st) { return set_par(s, p, per_stage, false, st); }
+
+extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, const double* p16) {
+    if (!s || !p16 || inst < 0 || inst >= s->B || stage < 0 || stage > s->N) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpy(s->par + ((size_t)inst * (s->N + 1) + stage) * 16, p16, 16 * sizeof(double), hipMemcpyHostToDevice));
+    return BROV_OK;
+}
+extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, const double* y, int ny) {
+    if (!s || !y || inst < 0 || inst >= s->B || stage < 0 || stage > s->N || ny < 1 || ny > 16) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    if (s->yref_shared) {  // materialise the shared window per instance first
+        for (int b = 0; b < s->B; b++)
+            HIPCHK(hipMemcpy(s->yref + (size_t)b * (s->N + 1) * 16, s->yref_sh, (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
+        s->yref_shared = false;
+    }
+    HIPCHK(hipMemcpy(s->yref + ((size_t)inst * (s->N + 1) + stage) * 16, y, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
+    return BROV_OK;
+}
+
+extern "C" int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const size_t B = s->B, N = s->N;
+    if (x) HIPCHK(hipMemcpy(s->x, x, B * (N + 1) * 12 * sizeof(double), hipMemcpyHostToDevice));
+    if (u) HIPCHK(hipMemcpy(s->u, u, B * N * 4 * sizeof(double), hipMemcpyHostToDevice));
+    if (pi) HIPCHK(hipMemcpy(s->pi, pi, B * N * 12 * sizeof(double), hipMemcpyHostToDevice));
+    if (lam) HIPCHK(hipMemcpy(s->lam, lam, B * N * 8 * sizeof(double), hipMemcpyHostToDevice));
+    return BROV_OK;
+}
+extern "C" int brov_get_iterate_host(brov_solver* s, double* x, double* u, double* pi, double* lam) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    const size_t B = s->B, N = s->N;
+    if (x) HIPCHK(hipMemcpy(x, s->x, B * (N + 1) * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    if (u) HIPCHK(hipMemcpy(u, s->u, B * N * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (pi) HIPCHK(hipMemcpy(pi, s->pi, B * N * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    if (lam) HIPCHK(hipMemcpy(lam, s->lam, B * N * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+extern "C" int brov_reset(brov_solver* s) {  // acados_solver_bluerov2.c:797-830: everything to zero
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const size_t B = s->B, N = s->N;
+    HIPCHK(hipMemset(s->x, 0, B * (N + 1) * 12 * sizeof(double)));
+    HIPCHK(hipMemset(s->u, 0, B * N * 4 * sizeof(double)));
+    HIPCHK(hipMemset(s->pi, 0, B * N * 12 * sizeof(double)));
+    HIPCHK(hipMemset(s->lam, 0, B * N * 8 * sizeof(double)));
+    return BROV_OK;
+}
+
+static DevParams make_params(const brov_solver* s) {
+    DevParams P;
+    std::memset(&P, 0, sizeof P);
+    P.B = s->B; P.N = s->N;
+    P.qp_iter_max = s->opts.qp_iter_max; P.early_exit = s->opts.qp_early_exit;
+    P.Ts = s->opts.Ts; P.tol_mu = s->opts.qp_tol_mu; P.tol_stat = s->opts.qp_tol_stat;
+    for (int j = 0; j < 16; j++) P.W[j] = s->opts.W[j];
+    for (int j = 0; j < 12; j++) P.We[j] = s->opts.We[j];
+    for (int j = 0; j < 4; j++) { P.lbu[j] = s->opts.lbu[j]; P.ubu[j] = s->opts.ubu[j]; }
+    P.x0 = s->x0;
+    P.yref = s->yref_shared ? s->yref_sh : s->yref;
+    P.yref_stride = s->yref_shared ? 0 : (int64_t)(s->N + 1) * 16;
+    P.par = s->par;
+    P.x = s->x; P.u = s->u; P.pi = s->pi; P.lam = s->lam;
+    P.BA = s->BA; P.BAt = s->BAt; P.bvec = s->bvec; P.kktp = s->kktp;
+    P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
+    P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
+    return P;
+}
+
+extern "C" int brov_solve(brov_solver* s, void* stream) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const DevParams P = make_params(s);
+    if (s->timing) hipEventRecord(s->ev[0], st);
+    launch_linearise(P, st);
+    if (s->timing) hipEventRecord(s->ev[1], st);
+    launch_qp(P, st);
+    if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
+    s->last_stream = st;
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_synchronize(brov_solver* s, void* stream) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return BROV_OK;
+}
+extern "C" int brov_enable_timing(brov_solver* s, int on) { if (!s) return BROV_ERR_ARG; s->timing = on != 0; s->ev_valid = false; return BROV_OK; }
+extern "C" int brov_last_solve_seconds(brov_solver* s, double* total, double* k2) {
+    if (!s || !s->ev_valid) return BROV_ERR_ARG;
+    HIPCHK(hipEventSynchronize(s->ev[2]));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    if (total) *total = (a + b) * 1e-3;
+    if (k2) { k2[0] = a * 1e-3; k2[1] = b * 1e-3; }
+    return BROV_OK;
+}
+
+extern "C" int brov_get_results_host(brov_solver* s, brov_result* res) {
+    if (!s || !res) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(hipMemcpy(res, s->res, (size_t)s->B * sizeof(brov_result), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+extern "C" int brov_get_u0_host(brov_solver* s, double* u0) {
+    if (!s || !u0) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(hipMemcpy2D(u0, 4 * sizeof(double), s->res, sizeof(brov_result), 4 * sizeof(double), s->B, hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+extern "C" const brov_result* brov_results_device(const brov_solver* s) { return s ? s->res : nullptr; }
+extern "C" double* brov_x0_device(brov_solver* s) { return s ? s->x0 : nullptr; }
+extern "C" double* brov_yref_device(brov_solver* s) { if (!s) return nullptr; s->yref_shared = false; return s->yref; }
+extern "C" double* brov_params_device(brov_solver* s) { return s ? s->par : nullptr; }
+extern "C" double* brov_x_device(brov_solver* s) { return s ? s->x : nullptr; }
+extern "C" double* brov_u_device(brov_solver* s) { return s ? s->u : nullptr; }
+
+extern "C" int brov_get_linearisation_host(brov_solver* s, double* AB, double* b) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (AB) HIPCHK(hipMemcpy(AB, s->BA, (size_t)s->B * s->N * 192 * sizeof(double), hipMemcpyDeviceToHost));
+    if (b) HIPCHK(hipMemcpy(b, s->bvec, (size_t)s->B * s->N * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+
+// arg-min of cost over successful instances: one block, strided scan + LDS tree
+__global__ void select_best_kernel(const brov_result* __restrict__ res, int B, int* __restrict__ out) {
+    __shared__ double sc[256];
+    __shared__ int si[256];
+    double best = 1e300;
+    int bi = -1;
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        const double c = res[k].cost;
+        if (res[k].status == BROV_STATUS_SUCCESS && c == c && (c < best || (c == best && k < bi))) { best = c; bi = k; }
+    }
+    sc[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double c2 = sc[threadIdx.x + o];
+            const int i2 = si[threadIdx.x + o];
+            if (i2 >= 0 && (si[threadIdx.x] < 0 || c2 < sc[threadIdx.x] || (c2 == sc[threadIdx.x] && i2 < si[threadIdx.x]))) {
+                sc[threadIdx.x] = c2; si[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = si[0];
+}
+
+extern "C" int brov_select_best_host(brov_solver* s, int* best_index, brov_result* best) {
+    if (!s || !best_index) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(256), 0, s->last_stream, s->res, s->B, s->best);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    int idx = -1;
+    HIPCHK(hipMemcpy(&idx, s->best, sizeof(int), hipMemcpyDeviceToHost));
+    *best_index = idx;
+    if (best && idx >= 0) HIPCHK(hipMemcpy(best, s->res + idx, sizeof(brov_result), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+
+extern "C" int brov_get_thrusts_host(brov_solver* s, double* t6) {
+    if (!s || !t6) return BROV_ERR_ARG;
+    std::vector<double> u0((size_t)s->B * 4);
+    int rc = brov_get_u0_host(s, u0.data());
+    if (rc != BROV_OK) return rc;
+    const double c = 0.026546960744430276;  // bluerov2_dob.cpp:390-395
+    for (int b = 0; b < s->B; b++) {
+        const double* u = &u0[(size_t)b * 4];
+        double* t = t6 + (size_t)b * 6;
+        t[0] = (-u[0] + u[1] + u[3]) / c;
+        t[1] = (-u[0] - u[1] - u[3]) / c;
+        t[2] = (u[0] + u[1] - u[3]) / c;
+        t[3] = (u[0] - u[1] + u[3]) / c;
+        t[4] = (-u[2]) / c;
+        t[5] = (-u[2]) / c;
+    }
+    return BROV_OK;
+}

@@ -1,0 +1,59 @@
+// nmpc_device.hpp -- device-side parameter block and HBM layout shared by the kernels and the host API.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bluerov2_nmpc.h"
+
+namespace brov {
+
+// HBM layout (all FP64, instance-major; "tile" = 16x16 doubles stored row-major = MFMA C/D register image,
+// see qp_kernel.hip):
+//   x0    [B][12]             yref [B][N+1][16] or shared [N+1][16]        par [B][N+1][16]
+//   x     [B][N+1][12]        u    [B][N][4]      pi [B][N][12]            lam [B][N][8]
+//   BA    [B][N][12][16]      row k, col c:  d x+_k / d (x,u)_c            (3/4 tile: rows 0..11)
+//   BAt   [B][N][16][16]      row c, col k (cols 12..15 zero)              (full tile)
+//   bvec  [B][N][12]          phi(x_i,u_i) - x_{i+1}
+//   kktp  [B][N]              per-interval partial of the NLP KKT inf-norm
+//   Riccati by-products per stage:  Ks [B][N][4][16] (gain, row m, col c), Kt [B][N][12][16] (gain^T, row c, col m),
+//                                   Mt [B][N][4][16] (Huu^-1, cols 0..3), Pb [B][N][12], kff [B][N][4]
+//   IPM state per instance:         ipm [B][IPM_NARR][N*4]
+struct DevParams {
+    int32_t B, N;
+    int32_t qp_iter_max, early_exit;
+    double Ts, tol_mu, tol_stat;
+    double W[16], We[12], lbu[4], ubu[4];
+    // inputs
+    const double* x0;
+    const double* yref;
+    int64_t yref_stride;  // doubles between instances (0 when one window is shared)
+    const double* par;    // always [B][N+1][16]
+    // iterate
+    double* x;
+    double* u;
+    double* pi;
+    double* lam;
+    // linearisation
+    double* BA;
+    double* BAt;
+    double* bvec;
+    double* kktp;
+    // Riccati storage
+    double* Ks;
+    double* Kt;
+    double* Mt;
+    double* Pb;
+    double* kff;
+    double* vhat;   // [B][N][4] candidate inputs of the current Newton solve
+    double* ipm;    // [B][IPM_NARR][N*4]
+    double* dxb;    // [B][N+1][12] QP primal step of the states
+    const double* cst;  // [W16 | We12 pad4 | lbu4 | ubu4]
+    brov_result* res;
+};
+
+enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_NARR };
+
+void launch_linearise(const DevParams& P, hipStream_t st);
+void launch_qp(const DevParams& P, hipStream_t st);
+
+}  // namespace brov

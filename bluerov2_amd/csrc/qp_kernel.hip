@@ -1,0 +1,585 @@
+// qp_kernel.hip -- RTI feedback phase on gfx950: box-constrained OCP-QP by a Riccati-based primal-dual interior point
+// method + full-step SQP update, ONE WAVEFRONT PER OCP INSTANCE.
+//
+// Replaces what the reference hands to HPIPM through acados (FULL_CONDENSING_HPIPM, qp_iter_max 50;
+// /root/reference/bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.c:146,664-669) and the
+// update_variables step of SQP_RTI (:623,653-654).  Same QP, same unique minimiser; solved in its stage-structured
+// form so the cost is O(N) instead of O(N^3).
+//
+// Mapping to CDNA4.  nx + nu = 12 + 4 = 16 is exactly one v_mfma_f64_16x16x4_f64 tile.  A 16x16 FP64 matrix lives
+// in 4 VGPR pairs per lane in the MFMA C/D image  t[r] @ lane l  <->  element (row = (l>>4) + 4r, col = l&15),
+// which is also its row-major image in HBM (offset r*64 + l: every tile load/store is a coalesced 512 B access).
+// The one primitive is  tn<K4>(Xt, Y, C) = C + Xt^T * Y  (k = rows of Xt and Y): operands are fed to the MFMA
+// straight from the C/D image, so chains of products need no cross-lane movement at all:
+//     PA = P^T [A B]            H = [A B]^T PA + diag(Q,R+Gamma)        (12-deep contractions, 3 MFMA each)
+//     T  = M Hu, S = H - Hu^T T  (Schur complement = next P), K^T = -Hu^T M   (4-deep, 1 MFMA each)
+// with [x;u] ordering so that the input block Hu = [Hux Huu] is rows 12..15 = register 3 of the H tile.
+// Vectors are carried "row-replicated" (lane holds v[row] for every column), which makes every matrix-vector
+// product the same tn<> call.  The 4x4 pivot block is inverted redundantly by all lanes from v_readlane values.
+#include "nmpc_device.hpp"
+
+namespace brov {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// C + Xt^T Y over K4*4 rows
+template <int K4>
+__device__ __forceinline__ d4 tn(const d4& xt, const d4& y, d4 c) {
+#pragma unroll
+    for (int kk = 0; kk < K4; kk++) c = mfma(xt[kk], y[kk], c);
+    return c;
+}
+// 4-deep contraction with explicitly chosen registers
+__device__ __forceinline__ d4 tn1(double xt, double y, d4 c) { return mfma(xt, y, c); }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Data written by some lanes of the wave and read by others goes through global memory (L1/L2 of this CU); a
+// workgroup-scope fence (= s_waitcnt, no cache maintenance) orders the two phases.
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+#define IPM_TAU0 0.1   /* interior push of the start point (fraction of the box width) */
+#define IPM_FTB 0.995  /* fraction to the boundary */
+
+// everything one wave needs to know about its instance
+struct Inst {
+    int lane, rg, cl, N, nv;
+    const double* x;     // [N+1][12] entering iterate
+    const double* u;     // [N][4]
+    const double* yref;  // [N+1][16]
+    const double* BA;    // [N][12][16]
+    const double* BAt;   // [N][16][16]
+    const double* bvec;  // [N][12]
+    double *Ks, *Kt, *Mt, *Pb, *kff, *vhat, *ipm, *dxb;
+    double Ts;
+    double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
+    double Wer[3];  // We[row]
+    double lbm, ubm;  // bounds of input m = rg
+};
+
+__device__ __forceinline__ d4 load_tile3(const double* base, int lane) {  // rows 0..11
+    d4 t;
+    t[0] = base[lane]; t[1] = base[64 + lane]; t[2] = base[128 + lane]; t[3] = 0.0;
+    return t;
+}
+__device__ __forceinline__ d4 load_tile4(const double* base, int lane) {
+    d4 t;
+    t[0] = base[lane]; t[1] = base[64 + lane]; t[2] = base[128 + lane]; t[3] = base[192 + lane];
+    return t;
+}
+// row-replicated 12-vector from contiguous memory
+__device__ __forceinline__ d4 load_vec12(const double* v, int rg) {
+    d4 t;
+    t[0] = v[rg]; t[1] = v[rg + 4]; t[2] = v[rg + 8]; t[3] = 0.0;
+    return t;
+}
+__device__ __forceinline__ void store_vec12(double* v, const d4& t, int rg, int cl) {
+    if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
+// FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
+// not positive definite.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool FACTOR>
+__device__ bool riccati_backward(const Inst& I) {
+    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
+    const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
+    const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
+    wave_fence();
+    d4 P = {0, 0, 0, 0}, pv;
+    {
+        const double* xN = I.x + (size_t)N * 12;
+        const double* yN = I.yref + (size_t)N * 16;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int row = rg + 4 * r;
+            if (FACTOR) P[r] = (row == cl) ? I.Wer[r] : 0.0;
+            pv[r] = I.Wer[r] * (xN[row] - yN[row]);
+        }
+        pv[3] = 0.0;
+    }
+    bool ok = true;
+    for (int i = N - 1; i >= 0; i--) {
+        const d4 ba = load_tile3(I.BA + (size_t)i * 192, lane);
+        const double* xi = I.x + (size_t)i * 12;
+        const double* yi = I.yref + (size_t)i * 16;
+        // cost gradient [q_i ; rtilde_i], row-replicated
+        d4 qr;
+#pragma unroll
+        for (int r = 0; r < 3; r++) qr[r] = I.Ts * I.Wr[r] * (xi[rg + 4 * r] - yi[rg + 4 * r]);
+        qr[3] = rt[i * 4 + rg];
+        if (FACTOR) {
+            const d4 bv = load_vec12(I.bvec + (size_t)i * 12, rg);
+            const d4 z4 = {0, 0, 0, 0};
+            d4 PA = tn<3>(P, ba, z4);
+            d4 Pb = tn<3>(P, bv, z4);
+            store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
+            d4 l;
+#pragma unroll
+            for (int r = 0; r < 4; r++) l[r] = Pb[r] + pv[r];
+            d4 H = tn<3>(ba, PA, z4);
+            d4 g = tn<3>(ba, l, qr);
+            // + diag(Ts*Wx, Ts*Wu + Gamma_i)
+            const double gm = gam[i * 4 + rg];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+                if (rg + 4 * r == cl) H[r] += I.Ts * I.Wr[r];
+            if (12 + rg == cl) H[3] += I.Ts * I.Wr[3] + gm;
+            // ---- 4x4 pivot block Huu = H[12..15][12..15]: lane 16m+12+n holds Huu[m][n] in H[3]
+            const double a00 = readlane_f64(H[3], 12), a10 = readlane_f64(H[3], 28), a11 = readlane_f64(H[3], 29);
+            const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
+            const double a30 = readlane_f64(H[3], 60), a31 = readlane_f64(H[3], 61), a32 = readlane_f64(H[3], 62),
+                         a33 = readlane_f64(H[3], 63);
+            // LDL^T, then M = Huu^-1 = L^-T D^-1 L^-1 (all lanes redundantly; values are wave-uniform)
+            const double d0 = a00, i0 = 1.0 / d0;
+            const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+            const double d1 = a11 - l10 * a10, i1 = 1.0 / d1;
+            const double w21 = a21 - l20 * a10, w31 = a31 - l30 * a10;
+            const double l21 = w21 * i1, l31 = w31 * i1;
+            const double d2 = a22 - l20 * a20 - l21 * w21, i2 = 1.0 / d2;
+            const double w32 = a32 - l30 * a20 - l31 * w21;
+            const double l32 = w32 * i2;
+            const double d3 = a33 - l30 * a30 - l31 * w31 - l32 * w32, i3 = 1.0 / d3;
+            if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
+            const double n10 = -l10, n21 = -l21, n32 = -l32;
+            const double n20 = -l20 - l21 * n10, n31 = -l31 - l32 * n21;
+            const double n30 = -l30 - l31 * n10 - l32 * n20;
+            const double m33 = i3, m32 = n32 * i3, m31 = n31 * i3, m30 = n30 * i3;
+            const double m22 = i2 + n32 * m32, m21 = n21 * i2 + n32 * m31, m20 = n20 * i2 + n32 * m30;
+            const double m11 = i1 + n21 * (n21 * i2) + n31 * m31, m10 = n10 * i1 + n21 * (n20 * i2) + n31 * m30;
+            const double m00 = i0 + n10 * (n10 * i1) + n20 * (n20 * i2) + n30 * m30;
+            // Mtile: lane (rg = m, cl = n < 4) = M[m][n]
+            double mt = 0.0;
+            {
+                const int a = rg > cl ? rg : cl, c = rg > cl ? cl : rg;  // (max, min)
+                const double r0 = m00;
+                const double r1 = (c == 0) ? m10 : m11;
+                const double r2 = (c == 0) ? m20 : ((c == 1) ? m21 : m22);
+                const double r3 = (c == 0) ? m30 : ((c == 1) ? m31 : ((c == 2) ? m32 : m33));
+                const double sel = (a == 0) ? r0 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
+                mt = (cl < 4) ? sel : 0.0;
+            }
+            // T = M Hu (rows 0..3 in reg 0), S = H - Hu^T T, Kt = -(Hu^T M), kff = -M gu, p = gx + K^T gu
+            d4 T = tn1(mt, H[3], z4);
+            const double ks = -T[0];
+            d4 S = tn1(H[3], ks, H);
+            d4 KtT = tn1(H[3], -mt, z4);
+            d4 kf = tn1(mt, g[3], z4);
+            d4 pn = tn1(ks, g[3], g);
+            // store factors
+            I.Ks[(size_t)i * 64 + lane] = ks;
+            I.Mt[(size_t)i * 64 + lane] = mt;
+            double* kt = I.Kt + (size_t)i * 192;
+            kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
+            if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
+            P = S;
+            pv = pn;
+            pv[3] = 0.0;
+        } else {
+            const d4 Pb = load_vec12(I.Pb + (size_t)i * 12, rg);
+            const double ks = I.Ks[(size_t)i * 64 + lane];
+            const double mt = I.Mt[(size_t)i * 64 + lane];
+            const d4 z4 = {0, 0, 0, 0};
+            d4 l;
+#pragma unroll
+            for (int r = 0; r < 4; r++) l[r] = Pb[r] + pv[r];
+            d4 g = tn<3>(ba, l, qr);
+            d4 kf = tn1(mt, g[3], z4);
+            d4 pn = tn1(ks, g[3], g);
+            if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
+            pv = pn;
+            pv[3] = 0.0;
+        }
+    }
+    return ok;
+}
+
+// forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i
+__device__ void riccati_forward(const Inst& I, const d4& d0) {
+    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
+    wave_fence();
+    d4 xx = d0;
+    for (int i = 0; i < N; i++) {
+        const d4 kt = load_tile3(I.Kt + (size_t)i * 192, lane);
+        const d4 bat = load_tile4(I.BAt + (size_t)i * 256, lane);
+        d4 c = {I.kff[i * 4 + rg], 0, 0, 0};
+        d4 v = tn<3>(kt, xx, c);
+        if (cl == 0) I.vhat[i * 4 + rg] = v[0];
+        d4 z = {xx[0], xx[1], xx[2], v[0]};
+        d4 bb = load_vec12(I.bvec + (size_t)i * 12, rg);
+        xx = tn<4>(bat, z, bb);
+        xx[3] = 0.0;
+    }
+    wave_fence();
+}
+
+// Roll the linearised dynamics out for the inputs in `varr`, then run the adjoint recursion.
+// Writes g = Rd v + r + B'pi into garr[N*4].  With COMMIT the multipliers pi are written to the iterate.
+// dx trajectory goes to I.dxb[(N+1)*12].
+template <bool COMMIT>
+__device__ void rollout_adjoint(const Inst& I, const d4& d0, const double* varr, double* garr, double* pi_out) {
+    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
+    wave_fence();
+    d4 xx = d0;
+    store_vec12(I.dxb, xx, rg, cl);
+    for (int i = 0; i < N; i++) {
+        const d4 bat = load_tile4(I.BAt + (size_t)i * 256, lane);
+        d4 z = {xx[0], xx[1], xx[2], varr[i * 4 + rg]};
+        d4 bb = load_vec12(I.bvec + (size_t)i * 12, rg);
+        xx = tn<4>(bat, z, bb);
+        xx[3] = 0.0;
+        store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+    }
+    wave_fence();
+    // adjoint: pi_i = Qd_{i+1} dx_{i+1} + q_{i+1} + A_{i+1}' pi_{i+1};  g_i = Rd v_i + r_i + B_i' pi_i
+    d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
+    for (int i = N - 1; i >= 0; i--) {
+        const double* xn = I.x + (size_t)(i + 1) * 12;
+        const double* yn = I.yref + (size_t)(i + 1) * 16;
+        d4 pi;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int row = rg + 4 * r;
+            const double qd = (i + 1 == N) ? I.Wer[r] : I.Ts * I.Wr[r];
+            pi[r] = qd * (xx[r] + xn[row] - yn[row]) + atpi[r];
+        }
+        pi[3] = 0.0;
+        if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
+        const d4 ba = load_tile3(I.BA + (size_t)i * 192, lane);
+        const d4 z4 = {0, 0, 0, 0};
+        d4 G = tn<3>(ba, pi, z4);
+        const double vi = varr[i * 4 + rg];
+        const double ui = I.u[i * 4 + rg];
+        const double ur = I.yref[(size_t)i * 16 + 12 + rg];
+        const double rd = I.Ts * I.Wr[3];
+        if (cl == 0) garr[i * 4 + rg] = rd * vi + rd * (ui - ur) + G[3];
+        atpi = G;
+        xx = load_vec12(I.dxb + (size_t)i * 12, rg);  // dx_i for the next (earlier) stage
+    }
+    wave_fence();
+}
+
+__global__ __launch_bounds__(256) void qp_kernel(DevParams P) {
+    const double* __restrict__ cst = P.cst;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> SGPR addressing
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= P.B) return;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, nv = 4 * N;
+    Inst I;
+    I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
+    I.x = P.x + (size_t)b * (N + 1) * 12;
+    I.u = P.u + (size_t)b * N * 4;
+    I.yref = P.yref + (size_t)b * P.yref_stride;
+    I.BA = P.BA + (size_t)b * N * 192;
+    I.BAt = P.BAt + (size_t)b * N * 256;
+    I.bvec = P.bvec + (size_t)b * N * 12;
+    I.Ks = P.Ks + (size_t)b * N * 64;
+    I.Kt = P.Kt + (size_t)b * N * 192;
+    I.Mt = P.Mt + (size_t)b * N * 64;
+    I.Pb = P.Pb + (size_t)b * N * 12;
+    I.kff = P.kff + (size_t)b * N * 4;
+    I.vhat = P.vhat + (size_t)b * N * 4;
+    I.ipm = P.ipm + (size_t)b * IPM_NARR * nv;
+    I.dxb = P.dxb + (size_t)b * (N + 1) * 12;
+    I.Ts = P.Ts;
+    // cst = [W16 | We12 pad4 | lbu4 | ubu4]
+#pragma unroll
+    for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
+#pragma unroll
+    for (int r = 0; r < 3; r++) I.Wer[r] = cst[16 + I.rg + 4 * r];
+    I.lbm = cst[32 + I.rg];
+    I.ubm = cst[36 + I.rg];
+    const int rg = I.rg;
+
+    double* x_it = P.x + (size_t)b * (N + 1) * 12;
+    double* u_it = P.u + (size_t)b * N * 4;
+    double* pi_it = P.pi + (size_t)b * N * 12;
+    double* lam_it = P.lam + (size_t)b * N * 8;
+    double* V = I.ipm + (size_t)IPM_V * nv;
+    double* TL = I.ipm + (size_t)IPM_TL * nv;
+    double* TU = I.ipm + (size_t)IPM_TU * nv;
+    double* LL = I.ipm + (size_t)IPM_LL * nv;
+    double* LU = I.ipm + (size_t)IPM_LU * nv;
+    double* GAM = I.ipm + (size_t)IPM_GAM * nv;
+    double* RT = I.ipm + (size_t)IPM_RT * nv;
+    double* DVA = I.ipm + (size_t)IPM_DVA * nv;
+
+    // d0 = x0 - x_0, row-replicated; KKT of the entering iterate = max(LIN partials, |d0|)
+    d4 d0;
+    double kkt = 0.0;
+    {
+        const double* x0 = P.x0 + (size_t)b * 12;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            d0[r] = x0[rg + 4 * r] - I.x[rg + 4 * r];
+            const double a = fabs(d0[r]);
+            kkt = (a != a) ? a : fmax(kkt, a);
+        }
+        d0[3] = 0.0;
+        double part = 0.0;
+        bool nanp = false;
+        for (int j = lane; j < N; j += 64) {
+            const double t = P.kktp[(size_t)b * N + j];
+            if (t != t) nanp = true;
+            part = fmax(part, t);
+        }
+        if (kkt != kkt) nanp = true;
+        kkt = wave_max(fmax(part, (kkt != kkt) ? 0.0 : kkt));
+        if (__ballot(nanp) != 0ull) kkt = __builtin_nan("");
+    }
+
+    // ---- step 0: equality-constrained minimiser (Gamma = 0, rhs = r) ---------------------------------------
+    for (int j = lane; j < nv; j += 64) {
+        const int m = j & 3;
+        GAM[j] = 0.0;
+        RT[j] = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+    }
+    int status = 0, iters = 0;
+    double mu = 0.0, rho = 0.0;
+    bool early = false;
+    bool ok = riccati_backward<true>(I);
+    if (__ballot(!ok) != 0ull) {
+        status = BROV_STATUS_QP_FAILURE;
+    } else {
+        riccati_forward(I, d0);
+        bool feas = true;
+        for (int j = lane; j < nv; j += 64) {
+            const int m = j & 3;
+            const double vj = I.vhat[j], lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
+            if (!(vj >= lb && vj <= ub)) feas = false;
+        }
+        const bool allfeas = (__ballot(!feas) == 0ull);
+        if (allfeas && P.early_exit) {
+            early = true;
+            for (int j = lane; j < nv; j += 64) V[j] = I.vhat[j];
+        } else {
+            // interior start: clamp into the box, multipliers from mu0 = stationarity residual of the clamped point
+            for (int j = lane; j < nv; j += 64) {
+                const int m = j & 3;
+                const double lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
+                const double wdt = ub - lb;
+                double vj = I.vhat[j];
+                const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
+                vj = (vj < lo) ? lo : vj;
+                vj = (vj > hi) ? hi : vj;
+                V[j] = vj; TL[j] = vj - lb; TU[j] = ub - vj;
+            }
+            rollout_adjoint<false>(I, d0, V, DVA, nullptr);
+            double g0 = 0.0;
+            for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(DVA[j]));
+            g0 = wave_max(g0);
+            const double mu0 = fmax(g0, 1e-4);
+            double r0 = 0.0;
+            for (int j = lane; j < nv; j += 64) {
+                const double ll = mu0 / TL[j], lu = mu0 / TU[j];
+                LL[j] = ll; LU[j] = lu;
+                r0 = fmax(r0, fabs(DVA[j] - ll + lu));
+            }
+            rho = wave_max(r0);
+            status = BROV_STATUS_MAXITER;
+            const double inv2nv = 1.0 / (2.0 * nv);
+            for (iters = 1; iters <= P.qp_iter_max; iters++) {
+                double s = 0.0;
+                for (int j = lane; j < nv; j += 64) {
+                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j];
+                    s += ll * tl + lu * tu;
+                    const double gm = ll / tl + lu / tu;
+                    GAM[j] = gm;
+                    const int m = j & 3;
+                    const double rr = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+                    RT[j] = rr - gm * V[j];
+                }
+                mu = wave_sum(s) * inv2nv;
+                ok = riccati_backward<true>(I);
+                if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
+                riccati_forward(I, d0);
+                // predictor step length and centering
+                double aaff = 1.0;
+                for (int j = lane; j < nv; j += 64) {
+                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j];
+                    const double dv = I.vhat[j] - V[j];
+                    DVA[j] = dv;
+                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                    if (dv < 0) aaff = fmin(aaff, -tl / dv);
+                    if (dv > 0) aaff = fmin(aaff, tu / dv);
+                    if (dll < 0) aaff = fmin(aaff, -ll / dll);
+                    if (dlu < 0) aaff = fmin(aaff, -lu / dlu);
+                }
+                aaff = wave_min(aaff);
+                double sa = 0.0;
+                for (int j = lane; j < nv; j += 64) {
+                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dv = DVA[j];
+                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                    sa += (ll + aaff * dll) * (tl + aaff * dv) + (lu + aaff * dlu) * (tu - aaff * dv);
+                }
+                const double muaff = wave_sum(sa) * inv2nv;
+                double sigma = muaff / mu;
+                sigma = sigma * sigma * sigma;
+                const double smu = sigma * mu;
+                for (int j = lane; j < nv; j += 64) {
+                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dv = DVA[j];
+                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                    const double cl_ = dll * dv, cu_ = -dlu * dv;
+                    const int m = j & 3;
+                    const double rr = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+                    RT[j] = rr - GAM[j] * V[j] - (smu - cl_) / tl + (smu - cu_) / tu;
+                }
+                (void)riccati_backward<false>(I);
+                riccati_forward(I, d0);
+                double amax = 1e300;
+                for (int j = lane; j < nv; j += 64) {
+                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dva = DVA[j];
+                    const double dlla = -ll - ll / tl * dva, dlua = -lu + lu / tu * dva;
+                    const double cl_ = dlla * dva, cu_ = -dlua * dva;
+                    const double dv = I.vhat[j] - V[j];
+                    const double dll = (smu - cl_) / tl - ll - ll / tl * dv;
+                    const double dlu = (smu - cu_) / tu - lu + lu / tu * dv;
+                    if (dv < 0) amax = fmin(amax, -tl / dv);
+                    if (dv > 0) amax = fmin(amax, tu / dv);
+                    if (dll < 0) amax = fmin(amax, -ll / dll);
+                    if (dlu < 0) amax = fmin(amax, -lu / dlu);
+                    GAM[j] = dll;  // dual steps parked in GAM / RT (both are rebuilt next iteration)
+                    RT[j] = dlu;
+                }
+                amax = wave_min(amax);
+                double alpha = IPM_FTB * amax;
+                alpha = alpha > 1.0 ? 1.0 : alpha;
+                bool bad = false;
+                double s2 = 0.0;
+                for (int j = lane; j < nv; j += 64) {
+                    const double dv = I.vhat[j] - V[j];
+                    const double vj = V[j] + alpha * dv;
+                    const double tl = TL[j] + alpha * dv, tu = TU[j] - alpha * dv;
+                    const double ll = LL[j] + alpha * GAM[j], lu = LU[j] + alpha * RT[j];
+                    V[j] = vj; TL[j] = tl; TU[j] = tu; LL[j] = ll; LU[j] = lu;
+                    if (!(vj == vj)) bad = true;
+                    s2 += ll * tl + lu * tu;
+                }
+                if (__ballot(bad) != 0ull) { status = BROV_STATUS_NAN; break; }
+                rho *= (1.0 - alpha);
+                mu = wave_sum(s2) * inv2nv;
+                if (mu <= P.tol_mu && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
+            }
+            if (iters > P.qp_iter_max) iters = P.qp_iter_max;
+        }
+    }
+
+    // ---- finalise: consistent primal/dual for the final inputs, multiplier recovery, full step ---------------
+    double cost = 0.0;
+    if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
+        rollout_adjoint<true>(I, d0, V, DVA, pi_it);
+        bool nanv = false;
+        for (int j = lane; j < nv; j += 64) {
+            const double vj = V[j];
+            if (!(vj == vj)) nanv = true;
+        }
+        for (int j = lane; j < (N + 1) * 12; j += 64) {
+            const double dj = I.dxb[j];
+            if (!(dj == dj)) nanv = true;
+        }
+        if (__ballot(nanv) != 0ull) {
+            status = BROV_STATUS_NAN;
+        } else {
+            for (int j = lane; j < nv; j += 64) {
+                const int i = j >> 2, m = j & 3;
+                const double g = early ? 0.0 : DVA[j];
+                lam_it[i * 8 + m] = g > 0 ? g : 0.0;
+                lam_it[i * 8 + 4 + m] = g < 0 ? -g : 0.0;
+                const double un = u_it[j] + V[j];
+                u_it[j] = un;
+                const double e = un - I.yref[(size_t)i * 16 + 12 + m];
+                cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+            }
+            for (int j = lane; j < (N + 1) * 12; j += 64) {
+                const int i = j / 12, c = j - i * 12;
+                const double xn = x_it[j] + I.dxb[j];
+                x_it[j] = xn;
+                const double e = xn - I.yref[(size_t)i * 16 + c];
+                cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+            }
+        }
+    }
+    if (status != BROV_STATUS_SUCCESS && status != BROV_STATUS_MAXITER) {
+        // iterate untouched; report the cost of the (unchanged) iterate
+        for (int j = lane; j < nv; j += 64) {
+            const int i = j >> 2, m = j & 3;
+            const double e = u_it[j] - I.yref[(size_t)i * 16 + 12 + m];
+            cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+        }
+        for (int j = lane; j < (N + 1) * 12; j += 64) {
+            const int i = j / 12, c = j - i * 12;
+            const double e = x_it[j] - I.yref[(size_t)i * 16 + c];
+            cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+        }
+    }
+    cost = wave_sum(cost);
+    if (lane == 0) {
+        brov_result* r = P.res + b;
+        r->cost = cost;
+        r->kkt = kkt;
+        r->status = status;
+        r->qp_iter = early ? 0 : iters;
+    }
+    wave_fence();
+    if (lane < 4) P.res[b].u0[lane] = u_it[lane];
+}
+
+void launch_qp(const DevParams& P, hipStream_t st) {
+    const int waves_per_block = 4;
+    const int blocks = (P.B + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL(qp_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, P);
+}
+
+}  // namespace brov
+
+// ---- test hook: the tile primitive alone (tests/test_gpu_tiles.py checks it against numpy with asymmetric data) ----
+namespace brov {
+__global__ void tile_tn_kernel(const double* xt, const double* y, const double* c, double* out, int k4) {
+    const int lane = threadIdx.x;
+    d4 X = load_tile4(xt, lane), Y = load_tile4(y, lane), C = load_tile4(c, lane);
+    d4 D = C;
+    if (k4 == 1) D = tn<1>(X, Y, C);
+    if (k4 == 2) D = tn<2>(X, Y, C);
+    if (k4 == 3) D = tn<3>(X, Y, C);
+    if (k4 == 4) D = tn<4>(X, Y, C);
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[r * 64 + lane] = D[r];
+}
+}  // namespace brov
+
+extern "C" int brov_selftest_tile_tn(const double* xt, const double* y, const double* c, double* out, int k4) {
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, 4 * 256 * sizeof(double)) != hipSuccess) return BROV_ERR_NO_DEVICE;
+    hipMemcpy(d, xt, 256 * sizeof(double), hipMemcpyHostToDevice);
+    hipMemcpy(d + 256, y, 256 * sizeof(double), hipMemcpyHostToDevice);
+    hipMemcpy(d + 512, c, 256 * sizeof(double), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(brov::tile_tn_kernel, dim3(1), dim3(64), 0, 0, d, d + 256, d + 512, d + 768, k4);
+    hipError_t e = hipMemcpy(out, d + 768, 256 * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? BROV_OK : BROV_ERR_HIP;
+}

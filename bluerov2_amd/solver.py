@@ -1,0 +1,289 @@
+"""Host-side mirror of include/bluerov2_nmpc.h (ctypes).  Names and argument meaning follow the reference call sites:
+
+    reference (C++ ROS node, per 50 ms tick)                             here (B instances at once)
+    ocp_nlp_constraints_model_set(..,0,"lbx"/"ubx",x0)                   BatchSolver.set_x0(x0[B,12])
+    bluerov2_acados_update_params(capsule,i,p,16)  for i in 0..N         BatchSolver.set_params(p[B,16] | p[B,N+1,16])
+    ocp_nlp_cost_model_set(..,i,"yref",yref[i])    for i in 0..N         BatchSolver.set_yref(yref[N+1,16] | [B,N+1,16])
+    bluerov2_acados_solve(capsule)                                       BatchSolver.solve()
+    ocp_nlp_out_get(..,0,"u",u0) / status / inf_norm_res                 BatchSolver.results() -> u0, cost, kkt, status
+(/root/reference/bluerov2_dobmpc/src/bluerov2_dob.cpp:306-388, src/ctrller/mpc.cpp:40-197).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(HERE, "lib", "libbluerov2_nmpc.so")
+NX, NU, NP, NY = 12, 4, 16, 16
+MAX_N = 128
+
+# nominal hydrodynamic parameters the nodes pass every tick (bluerov2_dob.cpp:340-353); p[0:4] = disturbance
+P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
+ROTOR_CONSTANT = 0.026546960744430276
+
+RESULT_DTYPE = np.dtype([("u0", "f8", (4,)), ("cost", "f8"), ("kkt", "f8"), ("status", "i4"), ("qp_iter", "i4")])
+assert RESULT_DTYPE.itemsize == 56
+
+
+class NoDeviceError(RuntimeError):
+    pass
+
+
+class _Opts(C.Structure):
+    _fields_ = [("N", C.c_int32), ("qp_iter_max", C.c_int32), ("Ts", C.c_double), ("W", C.c_double * 16),
+                ("We", C.c_double * 12), ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("qp_tol_mu", C.c_double),
+                ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int32), ("reserved", C.c_int32)]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", src, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", src, "all"])
+    return _LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch (device memory, streams, torch.distributed) ships its own HIP runtime; it has to be the first one mapped
+    # into the process or hipGetDeviceCount() of a second runtime copy reports no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(_LIB):
+        raise FileNotFoundError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the HIP extension is the only compute path; there is no fallback)")
+    L = C.CDLL(_LIB)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.brov_last_error.restype = C.c_char_p
+    L.brov_default_opts.argtypes = [C.POINTER(_Opts), C.c_int, C.c_double]
+    L.brov_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(_Opts)]
+    L.brov_destroy.argtypes = [vp]
+    L.brov_device_bytes.argtypes = [vp]
+    L.brov_device_bytes.restype = C.c_size_t
+    for name, args in {
+        "brov_set_x0_host": [vp, dp], "brov_set_x0_device": [vp, vp, vp],
+        "brov_set_yref_host": [vp, dp, C.c_int], "brov_set_yref_device": [vp, vp, C.c_int, vp],
+        "brov_set_params_host": [vp, dp, C.c_int], "brov_set_params_device": [vp, vp, C.c_int, vp],
+        "brov_set_param_stage_host": [vp, C.c_int, C.c_int, dp],
+        "brov_set_yref_stage_host": [vp, C.c_int, C.c_int, dp, C.c_int],
+        "brov_set_iterate_host": [vp, dp, dp, dp, dp], "brov_get_iterate_host": [vp, dp, dp, dp, dp],
+        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
+        "brov_get_results_host": [vp, vp], "brov_get_u0_host": [vp, dp],
+        "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
+        "brov_get_thrusts_host": [vp, dp], "brov_last_solve_seconds": [vp, dp, dp], "brov_enable_timing": [vp, C.c_int],
+        "brov_selftest_tile_tn": [dp, dp, dp, dp, C.c_int],
+    }.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name in ("brov_results_device", "brov_x0_device", "brov_yref_device", "brov_params_device", "brov_x_device",
+                 "brov_u_device"):
+        fn = getattr(L, name)
+        fn.argtypes = [vp]
+        fn.restype = vp
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _arr(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+class SolverOptions:
+    """Defaults = the values baked into the reference's generated solver (acados_solver_bluerov2.c:389-669)."""
+
+    def __init__(self, N=20, Ts=None, **kw):
+        self._o = _Opts()
+        _load().brov_default_opts(C.byref(self._o), int(N), float(1.0 / N if Ts is None else Ts))
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, k, v):
+        if k in ("W", "We", "lbu", "ubu"):
+            arr = getattr(self._o, k)
+            if len(v) != len(arr):
+                raise ValueError(f"{k} needs {len(arr)} values")
+            for i, x in enumerate(v):
+                arr[i] = float(x)
+        elif hasattr(self._o, k):
+            setattr(self._o, k, v)
+        else:
+            raise AttributeError(k)
+
+    def __getattr__(self, k):
+        o = object.__getattribute__(self, "_o")
+        v = getattr(o, k)
+        return np.array(v[:]) if k in ("W", "We", "lbu", "ubu") else v
+
+
+def thrust_allocation(u0):
+    """6 thruster commands from the 4 wrench commands (bluerov2_dob.cpp:390-395)."""
+    u0 = np.asarray(u0, dtype=np.float64)
+    c = ROTOR_CONSTANT
+    return np.stack([(-u0[..., 0] + u0[..., 1] + u0[..., 3]) / c, (-u0[..., 0] - u0[..., 1] - u0[..., 3]) / c,
+                     (u0[..., 0] + u0[..., 1] - u0[..., 3]) / c, (u0[..., 0] - u0[..., 1] + u0[..., 3]) / c,
+                     -u0[..., 2] / c, -u0[..., 2] / c], axis=-1)
+
+
+class BatchSolver:
+    """B independent BlueROV2 OCP instances resident on one GPU; one solve() = one RTI step of each."""
+
+    def __init__(self, batch, opts=None, device=0):
+        L = _load()
+        self.opts = opts if opts is not None else SolverOptions()
+        self.B, self.N = int(batch), int(self.opts.N)
+        h = C.c_void_p()
+        rc = L.brov_create(C.byref(h), int(device), self.B, C.byref(self.opts._o))
+        if rc == -2:
+            raise NoDeviceError(L.brov_last_error().decode() or "no HIP device")
+        if rc != 0:
+            raise RuntimeError(f"brov_create failed ({rc}): {L.brov_last_error().decode()}")
+        self._h, self._L, self.device = h, L, int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.brov_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._L.brov_last_error().decode()}")
+
+    @property
+    def device_bytes(self):
+        return int(self._L.brov_device_bytes(self._h))
+
+    # ---- inputs (host numpy) --------------------------------------------------------------------------------
+    def set_x0(self, x0):
+        self._chk(self._L.brov_set_x0_host(self._h, _dp(_arr(x0, (self.B, NX)))), "set_x0")
+
+    def set_yref(self, yref):
+        yref = np.ascontiguousarray(yref, dtype=np.float64)
+        if yref.shape == (self.N + 1, NY):
+            self._chk(self._L.brov_set_yref_host(self._h, _dp(yref), 1), "set_yref")
+        else:
+            self._chk(self._L.brov_set_yref_host(self._h, _dp(_arr(yref, (self.B, self.N + 1, NY))), 0), "set_yref")
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        if p.shape == (NP,):
+            p = np.ascontiguousarray(np.broadcast_to(p, (self.B, NP)))
+        if p.shape == (self.B, NP):
+            self._chk(self._L.brov_set_params_host(self._h, _dp(p), 0), "set_params")
+        else:
+            self._chk(self._L.brov_set_params_host(self._h, _dp(_arr(p, (self.B, self.N + 1, NP))), 1), "set_params")
+
+    # ---- inputs (device pointers, e.g. torch tensors' data_ptr()) ---------------------------------------------
+    def set_x0_device(self, ptr, stream=0):
+        self._chk(self._L.brov_set_x0_device(self._h, C.c_void_p(ptr), C.c_void_p(stream)), "set_x0_device")
+
+    def set_yref_device(self, ptr, shared, stream=0):
+        self._chk(self._L.brov_set_yref_device(self._h, C.c_void_p(ptr), int(bool(shared)), C.c_void_p(stream)), "set_yref_device")
+
+    def set_params_device(self, ptr, per_stage, stream=0):
+        self._chk(self._L.brov_set_params_device(self._h, C.c_void_p(ptr), int(bool(per_stage)), C.c_void_p(stream)), "set_params_device")
+
+    # ---- iterate ----------------------------------------------------------------------------------------------
+    def set_iterate(self, x=None, u=None, pi=None, lam=None):
+        B, N = self.B, self.N
+        ax = _arr(x, (B, N + 1, NX)) if x is not None else None
+        au = _arr(u, (B, N, NU)) if u is not None else None
+        ap = _arr(pi, (B, N, NX)) if pi is not None else None
+        al = _arr(lam, (B, N, 8)) if lam is not None else None
+        f = lambda a: _dp(a) if a is not None else None  # noqa: E731
+        self._chk(self._L.brov_set_iterate_host(self._h, f(ax), f(au), f(ap), f(al)), "set_iterate")
+
+    def get_iterate(self):
+        B, N = self.B, self.N
+        x, u = np.empty((B, N + 1, NX)), np.empty((B, N, NU))
+        pi, lam = np.empty((B, N, NX)), np.empty((B, N, 8))
+        self._chk(self._L.brov_get_iterate_host(self._h, _dp(x), _dp(u), _dp(pi), _dp(lam)), "get_iterate")
+        return x, u, pi, lam
+
+    def reset(self):
+        self._chk(self._L.brov_reset(self._h), "reset")
+
+    def init_iterate_default(self):
+        self._chk(self._L.brov_init_iterate_default(self._h), "init_iterate_default")
+
+    # ---- solve / outputs --------------------------------------------------------------------------------------
+    def solve(self, stream=0, sync=False):
+        self._chk(self._L.brov_solve(self._h, C.c_void_p(stream)), "solve")
+        if sync:
+            self._chk(self._L.brov_synchronize(self._h, C.c_void_p(stream)), "synchronize")
+
+    def results(self):
+        res = np.zeros(self.B, dtype=RESULT_DTYPE)
+        self._chk(self._L.brov_get_results_host(self._h, C.c_void_p(res.ctypes.data)), "results")
+        return res
+
+    def u0(self):
+        u0 = np.empty((self.B, NU))
+        self._chk(self._L.brov_get_u0_host(self._h, _dp(u0)), "u0")
+        return u0
+
+    def thrusts(self):
+        t = np.empty((self.B, 6))
+        self._chk(self._L.brov_get_thrusts_host(self._h, _dp(t)), "thrusts")
+        return t
+
+    def linearisation(self):
+        AB, b = np.empty((self.B, self.N, NX, 16)), np.empty((self.B, self.N, NX))
+        self._chk(self._L.brov_get_linearisation_host(self._h, _dp(AB), _dp(b)), "linearisation")
+        return AB[..., :NX], AB[..., NX:], b
+
+    def select_best(self):
+        idx = C.c_int(-1)
+        rec = np.zeros(1, dtype=RESULT_DTYPE)
+        self._chk(self._L.brov_select_best_host(self._h, C.byref(idx), C.c_void_p(rec.ctypes.data)), "select_best")
+        return idx.value, rec[0]
+
+    def enable_timing(self, on=True):
+        self._chk(self._L.brov_enable_timing(self._h, int(on)), "enable_timing")
+
+    def last_solve_seconds(self):
+        tot, k2 = C.c_double(0), (C.c_double * 2)()
+        self._chk(self._L.brov_last_solve_seconds(self._h, C.byref(tot), k2), "last_solve_seconds")
+        return tot.value, (k2[0], k2[1])
+
+    # device pointers for zero-copy pipelines
+    def results_device_ptr(self):
+        return int(self._L.brov_results_device(self._h))
+
+    def x0_device_ptr(self):
+        return int(self._L.brov_x0_device(self._h))
+
+
+def selftest_tile_tn(xt, y, c, k4):
+    L = _load()
+    xt, y, c = _arr(xt, (16, 16)), _arr(y, (16, 16)), _arr(c, (16, 16))
+    out = np.empty((16, 16))
+    rc = L.brov_selftest_tile_tn(_dp(xt), _dp(y), _dp(c), _dp(out), int(k4))
+    if rc == -2:
+        raise NoDeviceError("no HIP device")
+    if rc != 0:
+        raise RuntimeError(f"selftest failed {rc}")
+    return out

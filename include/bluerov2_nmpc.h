@@ -1,0 +1,146 @@
+/*
+ * bluerov2_nmpc.h -- C ABI of the MI355X-native batched BlueROV2 NMPC (SQP real-time-iteration) solver.
+ *
+ * One handle owns B independent OCP instances (12 states / 4 inputs / 16 parameters, N shooting intervals) resident
+ * in the HBM of ONE GPU.  brov_solve() performs, for every instance, exactly what ONE call of the reference's
+ *     bluerov2_acados_solve(capsule)      bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.c:945-951
+ * performs for its single instance (ocp_nlp_solve with SQP_RTI: ERK4+sensitivities, Gauss-Newton LS cost, box QP,
+ * full step), and the setters replace the per-tick acados calls of the callers:
+ *     brov_set_x0      <- ocp_nlp_constraints_model_set(..,0,"lbx"/"ubx",x0)   bluerov2_dob.cpp:320-321, ctrller/mpc.cpp:121-137
+ *     brov_set_params  <- bluerov2_acados_update_params(capsule,i,p,16)         bluerov2_dob.cpp:324-355, acados_solver_bluerov2.c:835-883
+ *     brov_set_yref    <- ocp_nlp_cost_model_set(..,i,"yref",yref[i])           bluerov2_dob.cpp:370-372, ctrller/mpc.cpp:46-58
+ *     brov_get_u0      <- ocp_nlp_out_get(..,0,"u",u0)                          bluerov2_dob.cpp:388
+ *     brov_get_results <- status / nlp_out->inf_norm_res / "time_tot"           bluerov2_dob.cpp:377-386
+ *     brov_set/get_iterate <- ocp_nlp_out_set/get(..,"x"/"u")                   main_bluerov2.c:211-247
+ *     brov_reset       <- bluerov2_acados_reset                                 acados_solver_bluerov2.c:797-830
+ * The batch=1 acados-shaped shim (include/acados_shim/, libacados_ocp_solver_bluerov2.so) is a veneer over this API.
+ *
+ * Plain C: pointers + sizes, no C++/torch types.  Every pointer argument is tagged HOST or DEVICE below; DEVICE
+ * pointers must be valid on the handle's GPU.  All calls on one handle must come from one thread at a time
+ * (same contract as an acados capsule).  Layouts are instance-major, row-major, FP64:
+ *     x0   [B][12]            yref [B][N+1][16] (or shared [N+1][16])      p [B][16] or [B][N+1][16]
+ *     x    [B][N+1][12]       u    [B][N][4]      pi [B][N][12]            lam [B][N][8] = [lower4 | upper4]
+ * There is no CPU fallback: every entry point that needs the GPU returns BROV_ERR_NO_DEVICE when none is usable.
+ */
+#ifndef BLUEROV2_NMPC_H_
+#define BLUEROV2_NMPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BROV_NX 12
+#define BROV_NU 4
+#define BROV_NP 16
+#define BROV_NY 16
+
+/* error codes of the API itself (solver status per instance uses the acados codes below) */
+#define BROV_OK 0
+#define BROV_ERR_ARG -1
+#define BROV_ERR_NO_DEVICE -2
+#define BROV_ERR_HIP -3
+#define BROV_ERR_ALLOC -4
+
+/* per-instance solver status == acados return codes (acados/utils/types.h as used by the callers) */
+#define BROV_STATUS_SUCCESS 0
+#define BROV_STATUS_NAN 1
+#define BROV_STATUS_MAXITER 2
+#define BROV_STATUS_MINSTEP 3
+#define BROV_STATUS_QP_FAILURE 4
+
+/* options; brov_default_opts() fills the values baked into the reference's generated solver
+ * (acados_solver_bluerov2.c: W :422-481, bounds :559-566, qp_iter_max :668, Ts :389) */
+typedef struct brov_opts {
+    int32_t N;              /* shooting intervals, 1..BROV_MAX_N */
+    int32_t qp_iter_max;    /* 50 */
+    double  Ts;             /* uniform interval length [s]; cost scaling of stages 0..N-1 */
+    double  W[BROV_NY];     /* diagonal stage weight on y = [x;u] */
+    double  We[BROV_NX];    /* diagonal terminal weight */
+    double  lbu[BROV_NU];
+    double  ubu[BROV_NU];
+    double  qp_tol_mu;      /* IPM complementarity target (1e-12) */
+    double  qp_tol_stat;    /* IPM stationarity target   (1e-9)  */
+    int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
+    int32_t reserved;
+} brov_opts;
+
+#define BROV_MAX_N 128
+
+/* 56-byte per-instance result record; this is also the record all-gathered across GPUs */
+typedef struct brov_result {
+    double  u0[BROV_NU];    /* optimal first input after the step  (ocp_nlp_out_get(..,0,"u")) */
+    double  cost;           /* NLS objective at the updated iterate */
+    double  kkt;            /* NLP KKT inf-norm of the iterate entering the step (-> ocp_nlp_out::inf_norm_res) */
+    int32_t status;         /* BROV_STATUS_* */
+    int32_t qp_iter;        /* interior-point iterations used (0 = early exit) */
+} brov_result;
+
+typedef struct brov_solver brov_solver; /* opaque */
+
+void brov_default_opts(brov_opts* o, int N, double Ts);
+
+/* lifecycle.  device = HIP device ordinal.  Allocates all HBM state for B instances; initial iterate, yref, p and
+ * x0 are the reference's create defaults (x_i=[0,0,-20,0..], u_i=0, yref=0, p=0; acados_solver_bluerov2.c:355-364,
+ * 681-708). */
+int  brov_create(brov_solver** out, int device, int B, const brov_opts* opts);
+void brov_destroy(brov_solver* s);
+int  brov_batch(const brov_solver* s);
+int  brov_horizon(const brov_solver* s);
+size_t brov_device_bytes(const brov_solver* s);
+const char* brov_last_error(void);
+
+/* inputs.  *_host variants copy from HOST memory (blocking on the solver's stream); *_device variants take DEVICE
+ * pointers and enqueue a device-to-device copy on `stream` (NULL = default stream); no host sync. */
+int brov_set_x0_host(brov_solver* s, const double* x0 /*[B][12]*/);
+int brov_set_x0_device(brov_solver* s, const double* x0, void* stream);
+/* shared != 0: one [N+1][16] window used by every instance; else per-instance [B][N+1][16] */
+int brov_set_yref_host(brov_solver* s, const double* yref, int shared);
+int brov_set_yref_device(brov_solver* s, const double* yref, int shared, void* stream);
+/* per_stage == 0: p[B][16] applied to all stages (what every reference caller does); else p[B][N+1][16] */
+int brov_set_params_host(brov_solver* s, const double* p, int per_stage);
+int brov_set_params_device(brov_solver* s, const double* p, int per_stage, void* stream);
+/* single-instance, single-stage setters (the shim's update_params / cost_model_set); stage in [0,N] */
+int brov_set_param_stage_host(brov_solver* s, int instance, int stage, const double* p16);
+int brov_set_yref_stage_host(brov_solver* s, int instance, int stage, const double* y, int ny);
+
+/* iterate (warm start) access; any pointer may be NULL to skip that block */
+int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam);
+int brov_get_iterate_host(brov_solver* s, double* x, double* u, double* pi, double* lam);
+int brov_reset(brov_solver* s); /* zero iterate like bluerov2_acados_reset */
+int brov_init_iterate_default(brov_solver* s); /* create-time default iterate */
+
+/* one RTI step for all B instances, enqueued on `stream` (NULL = default).  Asynchronous: returns after launch. */
+int brov_solve(brov_solver* s, void* stream);
+int brov_synchronize(brov_solver* s, void* stream);
+
+/* outputs */
+int brov_get_results_host(brov_solver* s, brov_result* res /*[B]*/); /* syncs the last solve's stream */
+int brov_get_u0_host(brov_solver* s, double* u0 /*[B][4]*/);
+const brov_result* brov_results_device(const brov_solver* s);          /* DEVICE pointer, [B] records */
+/* DEVICE pointers to the resident state for zero-copy producers/consumers (layouts above) */
+double* brov_x0_device(brov_solver* s);
+double* brov_yref_device(brov_solver* s);   /* [B][N+1][16] (always allocated; used when shared == 0) */
+double* brov_params_device(brov_solver* s); /* [B][N+1][16] */
+double* brov_x_device(brov_solver* s);
+double* brov_u_device(brov_solver* s);
+/* linearisation of the LAST solve (row-major per stage: [A|B] as [12][16], b as [12]) for tests */
+int brov_get_linearisation_host(brov_solver* s, double* AB /*[B][N][12][16]*/, double* b /*[B][N][12]*/);
+
+/* argmin of cost over instances with status SUCCESS (config 4 "best-trajectory select"); writes the winning index
+ * and its record; runs on the GPU, result copied to HOST */
+int brov_select_best_host(brov_solver* s, int* best_index, brov_result* best);
+
+/* thrust allocation epilogue (bluerov2_dob.cpp:390-395): t[B][6] from the u0 of the last solve */
+int brov_get_thrusts_host(brov_solver* s, double* t6 /*[B][6]*/);
+
+/* timing of the last brov_solve (HIP events on its stream), seconds: total and per kernel [linearise, qp] */
+int brov_last_solve_seconds(brov_solver* s, double* total, double* kernels2);
+int brov_enable_timing(brov_solver* s, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
