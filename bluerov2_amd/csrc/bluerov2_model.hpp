@@ -52,6 +52,34 @@ __device__ __forceinline__ Wrench make_wrench(const double* __restrict__ u) {
     return w;
 }
 
+// sin and cos together, branch-free: 3-term Cody-Waite reduction by pi/2 (FMA) + the classic degree-13/14 minimax kernels
+// on [-pi/4, pi/4].  Error < 1 ulp for |a| < ~1e6 rad (yaw_sum of the reference grows by 2 pi per lap, i.e. a few
+// hundred rad at most); NaN/Inf propagate.  ocml's sincos() costs ~3x the registers (Payne-Hanek path) and pushed the
+// linearisation kernel into scratch.
+__device__ __forceinline__ void sincos_pio2(double a, double* sn, double* cs) {
+    const double n = rint(a * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632679489655800e+00, a);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    r = fma(-n, -1.49738490485916983e-33, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)n & 3;
+    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 // what one RK stage point contributes to the Jacobian: 6 trig values, 1/cos(theta), body velocities and rates
 struct StagePoint {
     double sph, cph, sth, cth, sps, cps, icth;
@@ -61,9 +89,9 @@ struct StagePoint {
 // xdot = f(x,u,p); also returns the stage point record
 __device__ __forceinline__ void model_f(const double (&x)[NX], const Wrench& w, const ModelPar& m, double (&f)[NX],
                                         StagePoint& sp) {
-    sincos(x[3], &sp.sph, &sp.cph);
-    sincos(x[4], &sp.sth, &sp.cth);
-    sincos(x[5], &sp.sps, &sp.cps);
+    sincos_pio2(x[3], &sp.sph, &sp.cph);
+    sincos_pio2(x[4], &sp.sth, &sp.cth);
+    sincos_pio2(x[5], &sp.sps, &sp.cps);
     sp.icth = 1.0 / sp.cth;
     sp.vu = x[6]; sp.vv = x[7]; sp.vw = x[8]; sp.wp = x[9]; sp.wq = x[10]; sp.wr = x[11];
     const double r00 = sp.cps * sp.cth, r01 = sp.cps * sp.sth * sp.sph - sp.sps * sp.cph,

@@ -99,17 +99,55 @@ __device__ __forceinline__ void store_vec12(double* v, const d4& t, int rg, int 
     if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
 }
 
+// 1/d for a positive, normal d: v_rcp_f64 seed + 2 Newton steps (~1 ulp).  The pivot recursion below is the serial
+// critical path of every Riccati stage; the IEEE-exact division sequence is 3x longer and buys nothing here.
+__device__ __forceinline__ double fast_rcp(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    return fma(y, e, y);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
+// Sweeps.  Every sweep is software-pipelined by hand: all global operands of stage i+-1 are requested (plain loads into
+// a second register set) before stage i is computed, so that HBM/L2 latency overlaps the MFMA chain of the current
+// stage instead of being exposed once per stage (the in-order wave otherwise stalls ~1-2 us per stage).
+// ---------------------------------------------------------------------------------------------------------------
+struct BwdIn {
+    d4 ba;          // [A B] tile, rows 0..11
+    d4 bv;          // FACTOR: b_i;  else: Pb_i = P_{i+1} b_i   (row-replicated)
+    double xv[3], yv[3];  // x_i[row], yref_i[row]
+    double rtv, gm;       // rtilde_i[rg], Gamma_i[rg]
+    double ks, mt;        // stored factors (only !FACTOR)
+};
+
+template <bool FACTOR>
+__device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* gam, const double* rt) {
+    BwdIn s;
+    s.ba = load_tile3(I.BA + (size_t)i * 192, I.lane);
+    s.bv = load_vec12((FACTOR ? I.bvec : I.Pb) + (size_t)i * 12, I.rg);
+    const double* xi = I.x + (size_t)i * 12;
+    const double* yi = I.yref + (size_t)i * 16;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { s.xv[r] = xi[I.rg + 4 * r]; s.yv[r] = yi[I.rg + 4 * r]; }
+    s.rtv = rt[i * 4 + I.rg];
+    s.gm = FACTOR ? gam[i * 4 + I.rg] : 0.0;
+    s.ks = FACTOR ? 0.0 : I.Ks[(size_t)i * 64 + I.lane];
+    s.mt = FACTOR ? 0.0 : I.Mt[(size_t)i * 64 + I.lane];
+    return s;
+}
+
 // backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
 // not positive definite.
-// ---------------------------------------------------------------------------------------------------------------
 template <bool FACTOR>
 __device__ bool riccati_backward(const Inst& I) {
     const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
     wave_fence();
+    BwdIn nx = load_bwd<FACTOR>(I, N - 1, gam, rt);
     d4 P = {0, 0, 0, 0}, pv;
     {
         const double* xN = I.x + (size_t)N * 12;
@@ -123,47 +161,44 @@ __device__ bool riccati_backward(const Inst& I) {
         pv[3] = 0.0;
     }
     bool ok = true;
+    const d4 z4 = {0, 0, 0, 0};
     for (int i = N - 1; i >= 0; i--) {
-        const d4 ba = load_tile3(I.BA + (size_t)i * 192, lane);
-        const double* xi = I.x + (size_t)i * 12;
-        const double* yi = I.yref + (size_t)i * 16;
+        const BwdIn in = nx;
+        if (i > 0) nx = load_bwd<FACTOR>(I, i - 1, gam, rt);
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
-        for (int r = 0; r < 3; r++) qr[r] = I.Ts * I.Wr[r] * (xi[rg + 4 * r] - yi[rg + 4 * r]);
-        qr[3] = rt[i * 4 + rg];
+        for (int r = 0; r < 3; r++) qr[r] = I.Ts * I.Wr[r] * (in.xv[r] - in.yv[r]);
+        qr[3] = in.rtv;
         if (FACTOR) {
-            const d4 bv = load_vec12(I.bvec + (size_t)i * 12, rg);
-            const d4 z4 = {0, 0, 0, 0};
-            d4 PA = tn<3>(P, ba, z4);
-            d4 Pb = tn<3>(P, bv, z4);
+            d4 PA = tn<3>(P, in.ba, z4);
+            d4 Pb = tn<3>(P, in.bv, z4);
+            d4 H = tn<3>(in.ba, PA, z4);
             store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
             d4 l;
 #pragma unroll
             for (int r = 0; r < 4; r++) l[r] = Pb[r] + pv[r];
-            d4 H = tn<3>(ba, PA, z4);
-            d4 g = tn<3>(ba, l, qr);
+            d4 g = tn<3>(in.ba, l, qr);
             // + diag(Ts*Wx, Ts*Wu + Gamma_i)
-            const double gm = gam[i * 4 + rg];
 #pragma unroll
             for (int r = 0; r < 3; r++)
                 if (rg + 4 * r == cl) H[r] += I.Ts * I.Wr[r];
-            if (12 + rg == cl) H[3] += I.Ts * I.Wr[3] + gm;
+            if (12 + rg == cl) H[3] += I.Ts * I.Wr[3] + in.gm;
             // ---- 4x4 pivot block Huu = H[12..15][12..15]: lane 16m+12+n holds Huu[m][n] in H[3]
             const double a00 = readlane_f64(H[3], 12), a10 = readlane_f64(H[3], 28), a11 = readlane_f64(H[3], 29);
             const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
             const double a30 = readlane_f64(H[3], 60), a31 = readlane_f64(H[3], 61), a32 = readlane_f64(H[3], 62),
                          a33 = readlane_f64(H[3], 63);
             // LDL^T, then M = Huu^-1 = L^-T D^-1 L^-1 (all lanes redundantly; values are wave-uniform)
-            const double d0 = a00, i0 = 1.0 / d0;
+            const double d0 = a00, i0 = fast_rcp(d0);
             const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-            const double d1 = a11 - l10 * a10, i1 = 1.0 / d1;
+            const double d1 = a11 - l10 * a10, i1 = fast_rcp(d1);
             const double w21 = a21 - l20 * a10, w31 = a31 - l30 * a10;
             const double l21 = w21 * i1, l31 = w31 * i1;
-            const double d2 = a22 - l20 * a20 - l21 * w21, i2 = 1.0 / d2;
+            const double d2 = a22 - l20 * a20 - l21 * w21, i2 = fast_rcp(d2);
             const double w32 = a32 - l30 * a20 - l31 * w21;
             const double l32 = w32 * i2;
-            const double d3 = a33 - l30 * a30 - l31 * w31 - l32 * w32, i3 = 1.0 / d3;
+            const double d3 = a33 - l30 * a30 - l31 * w31 - l32 * w32, i3 = fast_rcp(d3);
             if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
             const double n10 = -l10, n21 = -l21, n32 = -l32;
             const double n20 = -l20 - l21 * n10, n31 = -l31 - l32 * n21;
@@ -187,9 +222,9 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 T = tn1(mt, H[3], z4);
             const double ks = -T[0];
             d4 S = tn1(H[3], ks, H);
-            d4 KtT = tn1(H[3], -mt, z4);
             d4 kf = tn1(mt, g[3], z4);
             d4 pn = tn1(ks, g[3], g);
+            d4 KtT = tn1(H[3], -mt, z4);
             // store factors
             I.Ks[(size_t)i * 64 + lane] = ks;
             I.Mt[(size_t)i * 64 + lane] = mt;
@@ -200,16 +235,12 @@ __device__ bool riccati_backward(const Inst& I) {
             pv = pn;
             pv[3] = 0.0;
         } else {
-            const d4 Pb = load_vec12(I.Pb + (size_t)i * 12, rg);
-            const double ks = I.Ks[(size_t)i * 64 + lane];
-            const double mt = I.Mt[(size_t)i * 64 + lane];
-            const d4 z4 = {0, 0, 0, 0};
             d4 l;
 #pragma unroll
-            for (int r = 0; r < 4; r++) l[r] = Pb[r] + pv[r];
-            d4 g = tn<3>(ba, l, qr);
-            d4 kf = tn1(mt, g[3], z4);
-            d4 pn = tn1(ks, g[3], g);
+            for (int r = 0; r < 4; r++) l[r] = in.bv[r] + pv[r];
+            d4 g = tn<3>(in.ba, l, qr);
+            d4 kf = tn1(in.mt, g[3], z4);
+            d4 pn = tn1(in.ks, g[3], g);
             if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
             pv = pn;
             pv[3] = 0.0;
@@ -218,72 +249,111 @@ __device__ bool riccati_backward(const Inst& I) {
     return ok;
 }
 
-// forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i
-__device__ void riccati_forward(const Inst& I, const d4& d0) {
-    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
-    wave_fence();
-    d4 xx = d0;
-    for (int i = 0; i < N; i++) {
-        const d4 kt = load_tile3(I.Kt + (size_t)i * 192, lane);
-        const d4 bat = load_tile4(I.BAt + (size_t)i * 256, lane);
-        d4 c = {I.kff[i * 4 + rg], 0, 0, 0};
-        d4 v = tn<3>(kt, xx, c);
-        if (cl == 0) I.vhat[i * 4 + rg] = v[0];
-        d4 z = {xx[0], xx[1], xx[2], v[0]};
-        d4 bb = load_vec12(I.bvec + (size_t)i * 12, rg);
-        xx = tn<4>(bat, z, bb);
-        xx[3] = 0.0;
-    }
-    wave_fence();
+struct FwdIn { d4 kt, bat, bb; double kf; };
+__device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
+    FwdIn s;
+    s.kt = load_tile3(I.Kt + (size_t)i * 192, I.lane);
+    s.bat = load_tile4(I.BAt + (size_t)i * 256, I.lane);
+    s.bb = load_vec12(I.bvec + (size_t)i * 12, I.rg);
+    s.kf = I.kff[i * 4 + I.rg];
+    return s;
 }
 
-// Roll the linearised dynamics out for the inputs in `varr`, then run the adjoint recursion.
-// Writes g = Rd v + r + B'pi into garr[N*4].  With COMMIT the multipliers pi are written to the iterate.
-// dx trajectory goes to I.dxb[(N+1)*12].
-template <bool COMMIT>
-__device__ void rollout_adjoint(const Inst& I, const d4& d0, const double* varr, double* garr, double* pi_out) {
-    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
+// forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i.
+// Leaves vhat in I.vhat and the state steps in I.dxb.
+__device__ void riccati_forward(const Inst& I, const d4& d0) {
+    const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
+    FwdIn nx = load_fwd(I, 0);
     d4 xx = d0;
     store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
-        const d4 bat = load_tile4(I.BAt + (size_t)i * 256, lane);
-        d4 z = {xx[0], xx[1], xx[2], varr[i * 4 + rg]};
-        d4 bb = load_vec12(I.bvec + (size_t)i * 12, rg);
-        xx = tn<4>(bat, z, bb);
+        const FwdIn in = nx;
+        if (i + 1 < N) nx = load_fwd(I, i + 1);
+        d4 c = {in.kf, 0, 0, 0};
+        d4 v = tn<3>(in.kt, xx, c);
+        if (cl == 0) I.vhat[i * 4 + rg] = v[0];
+        d4 z = {xx[0], xx[1], xx[2], v[0]};
+        xx = tn<4>(in.bat, z, in.bb);
         xx[3] = 0.0;
         store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
     }
     wave_fence();
-    // adjoint: pi_i = Qd_{i+1} dx_{i+1} + q_{i+1} + A_{i+1}' pi_{i+1};  g_i = Rd v_i + r_i + B_i' pi_i
-    d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
-    for (int i = N - 1; i >= 0; i--) {
-        const double* xn = I.x + (size_t)(i + 1) * 12;
-        const double* yn = I.yref + (size_t)(i + 1) * 16;
-        d4 pi;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const int row = rg + 4 * r;
-            const double qd = (i + 1 == N) ? I.Wer[r] : I.Ts * I.Wr[r];
-            pi[r] = qd * (xx[r] + xn[row] - yn[row]) + atpi[r];
-        }
-        pi[3] = 0.0;
-        if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
-        const d4 ba = load_tile3(I.BA + (size_t)i * 192, lane);
-        const d4 z4 = {0, 0, 0, 0};
-        d4 G = tn<3>(ba, pi, z4);
-        const double vi = varr[i * 4 + rg];
-        const double ui = I.u[i * 4 + rg];
-        const double ur = I.yref[(size_t)i * 16 + 12 + rg];
-        const double rd = I.Ts * I.Wr[3];
-        if (cl == 0) garr[i * 4 + rg] = rd * vi + rd * (ui - ur) + G[3];
-        atpi = G;
-        xx = load_vec12(I.dxb + (size_t)i * 12, rg);  // dx_i for the next (earlier) stage
+}
+
+struct RollIn { d4 bat, bb; double v; };
+__device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* varr) {
+    RollIn s;
+    s.bat = load_tile4(I.BAt + (size_t)i * 256, I.lane);
+    s.bb = load_vec12(I.bvec + (size_t)i * 12, I.rg);
+    s.v = varr[i * 4 + I.rg];
+    return s;
+}
+// roll the linearised dynamics out for the inputs in varr -> I.dxb
+__device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
+    const int rg = I.rg, cl = I.cl, N = I.N;
+    wave_fence();
+    RollIn nx = load_roll(I, 0, varr);
+    d4 xx = d0;
+    store_vec12(I.dxb, xx, rg, cl);
+    for (int i = 0; i < N; i++) {
+        const RollIn in = nx;
+        if (i + 1 < N) nx = load_roll(I, i + 1, varr);
+        d4 z = {xx[0], xx[1], xx[2], in.v};
+        xx = tn<4>(in.bat, z, in.bb);
+        xx[3] = 0.0;
+        store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
     }
     wave_fence();
 }
 
-__global__ __launch_bounds__(256) void qp_kernel(DevParams P) {
+struct AdjIn { d4 ba; double dx[3], xn[3], yn[3]; double v, u, ur; };
+__device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* varr) {
+    AdjIn s;
+    s.ba = load_tile3(I.BA + (size_t)i * 192, I.lane);
+    const double* dxn = I.dxb + (size_t)(i + 1) * 12;
+    const double* xn = I.x + (size_t)(i + 1) * 12;
+    const double* yn = I.yref + (size_t)(i + 1) * 16;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { s.dx[r] = dxn[I.rg + 4 * r]; s.xn[r] = xn[I.rg + 4 * r]; s.yn[r] = yn[I.rg + 4 * r]; }
+    s.v = varr[i * 4 + I.rg];
+    s.u = I.u[i * 4 + I.rg];
+    s.ur = I.yref[(size_t)i * 16 + 12 + I.rg];
+    return s;
+}
+// adjoint recursion for the state steps in I.dxb and inputs varr:
+//   pi_i = Qd_{i+1} dx_{i+1} + q_{i+1} + A_{i+1}' pi_{i+1};   g_i = Rd v_i + r_i + B_i' pi_i  -> garr[N*4]
+// With COMMIT the multipliers pi are written to pi_out (the iterate).
+template <bool COMMIT>
+__device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
+    const int rg = I.rg, cl = I.cl, N = I.N;
+    wave_fence();
+    AdjIn nx = load_adj(I, N - 1, varr);
+    d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
+    const d4 z4 = {0, 0, 0, 0};
+    for (int i = N - 1; i >= 0; i--) {
+        const AdjIn in = nx;
+        if (i > 0) nx = load_adj(I, i - 1, varr);
+        d4 pi;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const double qd = (i + 1 == N) ? I.Wer[r] : I.Ts * I.Wr[r];
+            pi[r] = qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
+        }
+        pi[3] = 0.0;
+        if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
+        d4 G = tn<3>(in.ba, pi, z4);
+        const double rd = I.Ts * I.Wr[3];
+        if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
+        atpi = G;
+    }
+    wave_fence();
+}
+
+#ifndef BROV_QP_WAVES
+#define BROV_QP_WAVES 2
+#endif
+__global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     const double* __restrict__ cst = P.cst;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> SGPR addressing
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -389,7 +459,8 @@ __global__ __launch_bounds__(256) void qp_kernel(DevParams P) {
                 vj = (vj > hi) ? hi : vj;
                 V[j] = vj; TL[j] = vj - lb; TU[j] = ub - vj;
             }
-            rollout_adjoint<false>(I, d0, V, DVA, nullptr);
+            rollout(I, d0, V);
+            adjoint<false>(I, V, DVA, nullptr);
             double g0 = 0.0;
             for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(DVA[j]));
             g0 = wave_max(g0);
@@ -492,7 +563,8 @@ __global__ __launch_bounds__(256) void qp_kernel(DevParams P) {
     // ---- finalise: consistent primal/dual for the final inputs, multiplier recovery, full step ---------------
     double cost = 0.0;
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
-        rollout_adjoint<true>(I, d0, V, DVA, pi_it);
+        if (!early) rollout(I, d0, V);  // early exit: dxb already holds the states of the accepted Newton point
+        adjoint<true>(I, V, DVA, pi_it);
         bool nanv = false;
         for (int j = lane; j < nv; j += 64) {
             const double vj = V[j];
