@@ -1,0 +1,389 @@
+// acados_shim.cpp -- libacados_ocp_solver_bluerov2.so: the reference's acados-shaped call surface
+// (/root/reference/bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.{h,c} plus the handful of ocp_nlp_*
+// functions its callers use) implemented as a batch-of-one veneer over the MI355X solver (include/bluerov2_nmpc.h).
+// Semantics follow the generated C, cited per function.  The capsule keeps HOST mirrors of x0 / yref / p / iterate so that
+// the ~3(N+1) tiny setter calls a ROS node makes per tick cost nothing; brov_* uploads them once inside solve().
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "acados_solver_bluerov2.h"
+#include "blasfeo/include/blasfeo_d_aux_ext_dep.h"
+#include "bluerov2_nmpc.h"
+
+struct brov_shim_state {
+    brov_solver* solver = nullptr;
+    brov_opts opts{};
+    int N = 0;
+    std::vector<double> x0, yref, par, x, u, pi, lam;
+    bool dirty_x0 = true, dirty_yref = true, dirty_par = true, dirty_iter = false, dirty_opts = false;
+    bool iter_host_valid = true;  // host mirror of the iterate is current
+    int rti_phase = 0;
+    double time_tot = 0.0, time_lin = 0.0, time_qp = 0.0;
+    brov_result last{};
+    int last_status = 0;
+};
+
+static brov_shim_state* st_of(bluerov2_solver_capsule* c) { return c ? c->shim : nullptr; }
+
+static void pull_iterate(brov_shim_state* s) {
+    if (s->iter_host_valid) return;
+    brov_get_iterate_host(s->solver, s->x.data(), s->u.data(), s->pi.data(), s->lam.data());
+    s->iter_host_valid = true;
+}
+
+extern "C" {
+
+bluerov2_solver_capsule* bluerov2_acados_create_capsule(void) {  // acados_solver_bluerov2.c:87-93
+    bluerov2_solver_capsule* c = (bluerov2_solver_capsule*)std::calloc(1, sizeof(bluerov2_solver_capsule));
+    return c;
+}
+int bluerov2_acados_free_capsule(bluerov2_solver_capsule* c) {  // :96-100
+    std::free(c);
+    return 0;
+}
+
+int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N, double* new_time_steps) {  // :734-783
+    if (!c) return 1;
+    if (N != BLUEROV2_N && !new_time_steps) {  // :737-743
+        std::fprintf(stderr,
+                     "bluerov2_acados_create_with_discretization: new_time_steps is NULL but the number of shooting intervals "
+                     "(= %d) differs from the number of shooting intervals (= %d) during code generation! Please provide a new "
+                     "vector of time_stamps!\n", N, BLUEROV2_N);
+        return 1;
+    }
+    double Ts = 0.0125;  // :389
+    if (new_time_steps) {
+        Ts = new_time_steps[0];
+        for (int i = 1; i < N; i++)
+            if (std::fabs(new_time_steps[i] - Ts) > 1e-12 * std::fabs(Ts)) {
+                std::fprintf(stderr, "bluerov2 (MI355X shim): non-uniform time steps are not supported\n");
+                return 1;
+            }
+    }
+    brov_shim_state* s = new brov_shim_state();
+    s->N = N;
+    brov_default_opts(&s->opts, N, Ts);
+    int rc = brov_create(&s->solver, 0, 1, &s->opts);
+    if (rc != BROV_OK) {
+        std::fprintf(stderr, "bluerov2_acados_create: MI355X solver unavailable (%d): %s\n", rc, brov_last_error());
+        delete s;
+        return rc == BROV_ERR_NO_DEVICE ? ACADOS_QP_FAILURE : 1;  // non-zero: the callers exit(1) (bluerov2_dob.cpp:35-38)
+    }
+    brov_enable_timing(s->solver, 1);
+    const size_t n1 = (size_t)N + 1;
+    s->x0.assign(12, 0.0);
+    s->x0[2] = -20.0;  // :520-527 (lbx0 = ubx0 = [0,0,-20,0..])
+    s->yref.assign(n1 * 16, 0.0);  // :405-420
+    s->par.assign(n1 * 16, 0.0);   // :355-364
+    s->x.assign(n1 * 12, 0.0);
+    for (size_t i = 0; i < n1; i++) s->x[i * 12 + 2] = -20.0;  // :689-706
+    s->u.assign((size_t)N * 4, 0.0);
+    s->pi.assign((size_t)N * 12, 0.0);
+    s->lam.assign((size_t)N * 8, 0.0);
+    c->shim = s;
+    c->nlp_np = BLUEROV2_NP;
+    c->nlp_solver_plan = new ocp_nlp_plan_t{N, s};
+    c->nlp_config = new ocp_nlp_config{N, s};
+    c->nlp_dims = new ocp_nlp_dims{N, 12, 4, 16, 16, 12, s};
+    c->nlp_in = new ocp_nlp_in{s};
+    c->nlp_out = new ocp_nlp_out{0.0, s};
+    c->sens_out = new ocp_nlp_out{0.0, s};
+    c->nlp_solver = new ocp_nlp_solver{s};
+    c->nlp_opts = (void*)s;
+    c->forw_vde_casadi = (external_function_param_casadi*)std::calloc(N, sizeof(external_function_param_casadi));
+    c->expl_ode_fun = (external_function_param_casadi*)std::calloc(N, sizeof(external_function_param_casadi));
+    for (int i = 0; i < N; i++) {
+        c->forw_vde_casadi[i].p = c->expl_ode_fun[i].p = &s->par[(size_t)i * 16];
+        c->forw_vde_casadi[i].np = c->expl_ode_fun[i].np = 16;
+    }
+    return 0;
+}
+
+int bluerov2_acados_create(bluerov2_solver_capsule* c) {  // :103-108
+    return bluerov2_acados_create_with_discretization(c, BLUEROV2_N, nullptr);
+}
+
+int bluerov2_acados_update_time_steps(bluerov2_solver_capsule* c, int N, double* ts) {  // :111-131
+    brov_shim_state* s = st_of(c);
+    if (!s || !ts) return 1;
+    if (N != s->N) {
+        std::fprintf(stderr,
+                     "bluerov2_acados_update_time_steps: given number of time steps (= %d) differs from the currently allocated "
+                     "number of time steps (= %d)!\nPlease recreate with new discretization and provide a new vector of time_stamps!\n",
+                     N, s->N);
+        return 1;
+    }
+    for (int i = 1; i < N; i++)
+        if (std::fabs(ts[i] - ts[0]) > 1e-12 * std::fabs(ts[0])) {
+            std::fprintf(stderr, "bluerov2 (MI355X shim): non-uniform time steps are not supported\n");
+            return 1;
+        }
+    s->opts.Ts = ts[0];
+    s->dirty_opts = true;
+    return 0;
+}
+
+int bluerov2_acados_update_qp_solver_cond_N(bluerov2_solver_capsule*, int) {  // :788-794
+    std::printf("\nacados_update_qp_solver_cond_N() failed, since no partial condensing solver is used!\n\n");
+    std::exit(1);
+    return -1;
+}
+
+int bluerov2_acados_reset(bluerov2_solver_capsule* c, int) {  // :797-830: iterate and multipliers to zero
+    brov_shim_state* s = st_of(c);
+    if (!s) return 1;
+    std::fill(s->x.begin(), s->x.end(), 0.0);
+    std::fill(s->u.begin(), s->u.end(), 0.0);
+    std::fill(s->pi.begin(), s->pi.end(), 0.0);
+    std::fill(s->lam.begin(), s->lam.end(), 0.0);
+    s->iter_host_valid = true;
+    s->dirty_iter = true;
+    return 0;
+}
+
+int bluerov2_acados_update_params(bluerov2_solver_capsule* c, int stage, double* p, int np) {  // :835-883
+    const int casadi_np = 16;
+    if (casadi_np != np) {
+        std::printf("acados_update_params: trying to set %i parameters for external functions. External function has %i parameters. "
+                    "Exiting.\n", np, casadi_np);
+        std::exit(1);
+    }
+    brov_shim_state* s = st_of(c);
+    if (!s || !p) return 1;
+    if (stage < 0 || stage > s->N) stage = s->N;  // the generated code treats everything else as the terminal node
+    std::memcpy(&s->par[(size_t)stage * 16], p, 16 * sizeof(double));
+    s->dirty_par = true;
+    return 0;
+}
+
+int bluerov2_acados_update_params_sparse(bluerov2_solver_capsule* c, int stage, int* idx, double* p, int n_update) {  // :886-942
+    const int casadi_np = 16;
+    if (casadi_np < n_update) {
+        std::printf("bluerov2_acados_update_params_sparse: trying to set %d parameters for external functions. External function has "
+                    "%d parameters. Exiting.\n", n_update, casadi_np);
+        std::exit(1);
+    }
+    brov_shim_state* s = st_of(c);
+    if (!s || !p || !idx) return 1;
+    if (stage < 0 || stage > s->N) stage = s->N;
+    for (int k = 0; k < n_update; k++)
+        if (idx[k] >= 0 && idx[k] < 16) s->par[(size_t)stage * 16 + idx[k]] = p[k];
+    s->dirty_par = true;
+    return 0;
+}
+
+static int push_inputs(brov_shim_state* s) {
+    int rc = BROV_OK;
+    if (s->dirty_opts) { rc = brov_set_opts(s->solver, &s->opts); s->dirty_opts = false; if (rc) return rc; }
+    if (s->dirty_x0) { rc = brov_set_x0_host(s->solver, s->x0.data()); s->dirty_x0 = false; if (rc) return rc; }
+    if (s->dirty_yref) { rc = brov_set_yref_host(s->solver, s->yref.data(), 0); s->dirty_yref = false; if (rc) return rc; }
+    if (s->dirty_par) { rc = brov_set_params_host(s->solver, s->par.data(), 1); s->dirty_par = false; if (rc) return rc; }
+    if (s->dirty_iter) {
+        rc = brov_set_iterate_host(s->solver, s->x.data(), s->u.data(), s->pi.data(), s->lam.data());
+        s->dirty_iter = false;
+        if (rc) return rc;
+    }
+    return rc;
+}
+
+int ocp_nlp_solve(ocp_nlp_solver* solver, ocp_nlp_in*, ocp_nlp_out* out) {  // what :948 calls
+    brov_shim_state* s = solver ? solver->shim : nullptr;
+    if (!s) return ACADOS_QP_FAILURE;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = push_inputs(s);
+    if (rc == BROV_OK) rc = brov_solve_phase(s->solver, nullptr, s->rti_phase);
+    brov_result r{};
+    if (rc == BROV_OK) rc = brov_get_results_host(s->solver, &r);
+    if (rc != BROV_OK) {
+        std::fprintf(stderr, "bluerov2_acados_solve: MI355X solver error %d: %s\n", rc, brov_last_error());
+        return ACADOS_QP_FAILURE;
+    }
+    s->iter_host_valid = false;
+    s->last = r;
+    double k2[2] = {0, 0}, tot = 0;
+    if (brov_last_solve_seconds(s->solver, &tot, k2) == BROV_OK) { s->time_lin = k2[0]; s->time_qp = k2[1]; }
+    s->time_tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (s->rti_phase == 1) return ACADOS_SUCCESS;  // preparation only: nothing to report
+    if (out) out->inf_norm_res = r.kkt;
+    s->last_status = r.status;
+    return r.status;
+}
+
+int ocp_nlp_precompute(ocp_nlp_solver*, ocp_nlp_in*, ocp_nlp_out*) { return ACADOS_SUCCESS; }
+
+int bluerov2_acados_solve(bluerov2_solver_capsule* c) {  // :945-951
+    if (!c || !c->shim) return ACADOS_QP_FAILURE;
+    return ocp_nlp_solve(c->nlp_solver, c->nlp_in, c->nlp_out);
+}
+
+int bluerov2_acados_free(bluerov2_solver_capsule* c) {  // :954-998
+    brov_shim_state* s = st_of(c);
+    if (!s) return 0;
+    brov_destroy(s->solver);
+    delete c->nlp_solver_plan; delete c->nlp_config; delete c->nlp_dims; delete c->nlp_in; delete c->nlp_out;
+    delete c->sens_out; delete c->nlp_solver;
+    std::free(c->forw_vde_casadi); std::free(c->expl_ode_fun);
+    delete s;
+    std::memset(c, 0, sizeof(*c));
+    return 0;
+}
+
+void bluerov2_acados_print_stats(bluerov2_solver_capsule* c) {  // :1001-1028 (RTI: one row)
+    brov_shim_state* s = st_of(c);
+    if (!s) return;
+    std::printf("iter\tqp_stat\tqp_iter\n");
+    std::printf("%d\t%d\t%d\n", 1, s->last.status == 0 ? 0 : s->last.status, s->last.qp_iter);
+}
+
+int bluerov2_acados_custom_update(bluerov2_solver_capsule*, double*, int) {  // :1030-1036
+    std::printf("\ndummy function that can be called in between solver calls to update parameters or numerical data efficiently in C.\n");
+    std::printf("nothing set yet..\n");
+    return 1;
+}
+
+ocp_nlp_in* bluerov2_acados_get_nlp_in(bluerov2_solver_capsule* c) { return c->nlp_in; }
+ocp_nlp_out* bluerov2_acados_get_nlp_out(bluerov2_solver_capsule* c) { return c->nlp_out; }
+ocp_nlp_out* bluerov2_acados_get_sens_out(bluerov2_solver_capsule* c) { return c->sens_out; }
+ocp_nlp_solver* bluerov2_acados_get_nlp_solver(bluerov2_solver_capsule* c) { return c->nlp_solver; }
+ocp_nlp_config* bluerov2_acados_get_nlp_config(bluerov2_solver_capsule* c) { return c->nlp_config; }
+void* bluerov2_acados_get_nlp_opts(bluerov2_solver_capsule* c) { return c->nlp_opts; }
+ocp_nlp_dims* bluerov2_acados_get_nlp_dims(bluerov2_solver_capsule* c) { return c->nlp_dims; }
+ocp_nlp_plan_t* bluerov2_acados_get_nlp_plan(bluerov2_solver_capsule* c) { return c->nlp_solver_plan; }
+
+// ---- the ocp_nlp_* setters/getters the callers use --------------------------------------------------------------
+int ocp_nlp_constraints_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int stage, const char* field, void* value) {
+    brov_shim_state* s = in ? in->shim : nullptr;
+    if (!s || !field || !value) return 1;
+    const double* v = (const double*)value;
+    if (!std::strcmp(field, "lbx") || !std::strcmp(field, "ubx")) {
+        // stage 0 only (nbx = 0 elsewhere); all 12 components are equalities (idxbxe, :528-543): x0 := lbx = ubx
+        if (stage != 0) return 1;
+        std::memcpy(s->x0.data(), v, 12 * sizeof(double));
+        s->dirty_x0 = true;
+        return 0;
+    }
+    if (!std::strcmp(field, "lbu") || !std::strcmp(field, "ubu")) {  // :559-573 sets the same box on every stage
+        double* dst = !std::strcmp(field, "lbu") ? s->opts.lbu : s->opts.ubu;
+        std::memcpy(dst, v, 4 * sizeof(double));
+        s->dirty_opts = true;
+        return 0;
+    }
+    if (!std::strcmp(field, "idxbx") || !std::strcmp(field, "idxbu") || !std::strcmp(field, "idxbxe")) return 0;  // fixed structure
+    std::fprintf(stderr, "ocp_nlp_constraints_model_set (MI355X shim): unsupported field '%s'\n", field);
+    return 1;
+}
+
+int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int stage, const char* field, void* value) {
+    brov_shim_state* s = in ? in->shim : nullptr;
+    if (!s || !field || !value || stage < 0 || stage > s->N) return 1;
+    const double* v = (const double*)value;
+    if (!std::strcmp(field, "yref") || !std::strcmp(field, "y_ref")) {
+        const int ny = stage == s->N ? 12 : 16;  // NYN = 12: only the first 12 of the caller's 16-wide row are read
+        std::memcpy(&s->yref[(size_t)stage * 16], v, ny * sizeof(double));
+        s->dirty_yref = true;
+        return 0;
+    }
+    if (!std::strcmp(field, "W")) {  // column-major ny x ny, diagonal (:422-481)
+        const int ny = stage == s->N ? 12 : 16;
+        double* dst = stage == s->N ? s->opts.We : s->opts.W;
+        for (int j = 0; j < ny; j++) dst[j] = v[j + ny * j];
+        s->dirty_opts = true;
+        return 0;
+    }
+    if (!std::strcmp(field, "scaling")) {  // :393: stage cost scaling = Ts
+        if (stage < s->N) { s->opts.Ts = v[0]; s->dirty_opts = true; }
+        return 0;
+    }
+    std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): unsupported field '%s'\n", field);
+    return 1;
+}
+
+int ocp_nlp_in_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int, const char* field, void* value) {
+    brov_shim_state* s = in ? in->shim : nullptr;
+    if (!s || !field || !value) return 1;
+    if (!std::strcmp(field, "Ts")) { s->opts.Ts = *(const double*)value; s->dirty_opts = true; return 0; }
+    return 1;
+}
+
+void ocp_nlp_out_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_out* out, int stage, const char* field, void* value) {
+    brov_shim_state* s = out ? out->shim : nullptr;
+    if (!s || !field || !value || stage < 0 || stage > s->N) return;
+    pull_iterate(s);
+    const double* v = (const double*)value;
+    if (!std::strcmp(field, "x")) std::memcpy(&s->x[(size_t)stage * 12], v, 12 * sizeof(double));
+    else if (!std::strcmp(field, "u")) { if (stage < s->N) std::memcpy(&s->u[(size_t)stage * 4], v, 4 * sizeof(double)); }
+    else if (!std::strcmp(field, "pi")) { if (stage < s->N) std::memcpy(&s->pi[(size_t)stage * 12], v, 12 * sizeof(double)); }
+    else if (!std::strcmp(field, "lam")) { if (stage < s->N) std::memcpy(&s->lam[(size_t)stage * 8], v, 8 * sizeof(double)); }
+    else return;  // sl, su, t, z: this OCP has no slacks / algebraic variables (acados_solver_bluerov2.c:812-818)
+    s->dirty_iter = true;
+}
+
+void ocp_nlp_out_get(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_out* out, int stage, const char* field, void* value) {
+    brov_shim_state* s = out ? out->shim : nullptr;
+    if (!s || !field || !value) return;
+    double* v = (double*)value;
+    if (!std::strcmp(field, "kkt_norm_inf")) { *v = out->inf_norm_res; return; }
+    if (stage < 0 || stage > s->N) return;
+    pull_iterate(s);
+    if (!std::strcmp(field, "x")) std::memcpy(v, &s->x[(size_t)stage * 12], 12 * sizeof(double));
+    else if (!std::strcmp(field, "u")) { if (stage < s->N) std::memcpy(v, &s->u[(size_t)stage * 4], 4 * sizeof(double)); }
+    else if (!std::strcmp(field, "pi")) { if (stage < s->N) std::memcpy(v, &s->pi[(size_t)stage * 12], 12 * sizeof(double)); }
+    else if (!std::strcmp(field, "lam")) { if (stage < s->N) std::memcpy(v, &s->lam[(size_t)stage * 8], 8 * sizeof(double)); }
+}
+
+void ocp_nlp_get(ocp_nlp_config*, ocp_nlp_solver* solver, const char* field, void* value) {
+    brov_shim_state* s = solver ? solver->shim : nullptr;
+    if (!s || !field || !value) return;
+    if (!std::strcmp(field, "time_tot")) *(double*)value = s->time_tot;          // bluerov2_dob.cpp:386
+    else if (!std::strcmp(field, "time_lin")) *(double*)value = s->time_lin;
+    else if (!std::strcmp(field, "time_qp_sol") || !std::strcmp(field, "time_qp")) *(double*)value = s->time_qp;
+    else if (!std::strcmp(field, "sqp_iter")) *(int*)value = 1;                   // RTI: one iteration per call
+    else if (!std::strcmp(field, "qp_iter")) *(int*)value = s->last.qp_iter;
+    else if (!std::strcmp(field, "status")) *(int*)value = s->last_status;
+    else if (!std::strcmp(field, "stat_n")) *(int*)value = 2;
+    else if (!std::strcmp(field, "stat_m")) *(int*)value = 2;
+    else if (!std::strcmp(field, "statistics")) {  // (stat_n+1) x nrow, column-major: [iter, qp_stat, qp_iter]
+        double* st = (double*)value;
+        st[0] = 0; st[1] = 1; st[2] = 0; st[3] = s->last.status; st[4] = 0; st[5] = s->last.qp_iter;
+    } else if (!std::strcmp(field, "cost_value")) *(double*)value = s->last.cost;
+}
+
+int ocp_nlp_solver_opts_set(ocp_nlp_config*, void* opts, const char* field, void* value) {
+    brov_shim_state* s = (brov_shim_state*)opts;
+    if (!s || !field || !value) return 1;
+    if (!std::strcmp(field, "rti_phase")) {  // main_bluerov2.c:217
+        const int ph = *(const int*)value;
+        if (ph < 0 || ph > 2) return 1;
+        s->rti_phase = ph;
+        return 0;
+    }
+    if (!std::strcmp(field, "qp_iter_max")) { s->opts.qp_iter_max = *(const int*)value; s->dirty_opts = true; return 0; }
+    if (!std::strcmp(field, "print_level") || !std::strcmp(field, "qp_warm_start") || !std::strcmp(field, "step_length") ||
+        !std::strcmp(field, "levenberg_marquardt") || !std::strcmp(field, "globalization") || !std::strcmp(field, "qp_hpipm_mode"))
+        return 0;  // fixed by construction (full step, GN Hessian, cold-started QP)
+    return 1;
+}
+
+// ---- BLASFEO print helpers (main_bluerov2.c:229-231) --------------------------------------------------------------
+void d_print_mat(int m, int n, double* A, int lda) {
+    for (int i = 0; i < m; i++) { for (int j = 0; j < n; j++) std::printf("%9.5f ", A[i + lda * j]); std::printf("\n"); }
+    std::printf("\n");
+}
+void d_print_exp_mat(int m, int n, double* A, int lda) {
+    for (int i = 0; i < m; i++) { for (int j = 0; j < n; j++) std::printf("%e\t", A[i + lda * j]); std::printf("\n"); }
+    std::printf("\n");
+}
+void d_print_tran_mat(int row, int col, double* A, int lda) {
+    for (int j = 0; j < col; j++) { for (int i = 0; i < row; i++) std::printf("%9.5f ", A[i + lda * j]); std::printf("\n"); }
+    std::printf("\n");
+}
+void d_print_exp_tran_mat(int row, int col, double* A, int lda) {
+    for (int j = 0; j < col; j++) { for (int i = 0; i < row; i++) std::printf("%e\t", A[i + lda * j]); std::printf("\n"); }
+    std::printf("\n");
+}
+
+}  // extern "C"

@@ -301,18 +301,31 @@ static DevParams make_params(const brov_solver* s) {
     return P;
 }
 
-extern "C" int brov_solve(brov_solver* s, void* stream) {
-    if (!s) return BROV_ERR_ARG;
+extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
+    if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     const DevParams P = make_params(s);
     if (s->timing) hipEventRecord(s->ev[0], st);
-    launch_linearise(P, st);
+    if (rti_phase != 2) launch_linearise(P, st);
     if (s->timing) hipEventRecord(s->ev[1], st);
-    launch_qp(P, st);
+    if (rti_phase != 1) launch_qp(P, st);
     if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
     s->last_stream = st;
     HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phase(s, stream, 0); }
+extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
+    if (!s || !o || o->N != s->N || !(o->Ts > 0.0)) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    s->opts = *o;
+    return upload_cst(s);
+}
+extern "C" int brov_get_opts(const brov_solver* s, brov_opts* o) {
+    if (!s || !o) return BROV_ERR_ARG;
+    *o = s->opts;
     return BROV_OK;
 }
 extern "C" int brov_synchronize(brov_solver* s, void* stream) {

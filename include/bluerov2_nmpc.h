@@ -114,7 +114,13 @@ int brov_init_iterate_default(brov_solver* s); /* create-time default iterate */
 
 /* one RTI step for all B instances, enqueued on `stream` (NULL = default).  Asynchronous: returns after launch. */
 int brov_solve(brov_solver* s, void* stream);
+/* acados' rti_phase (main_bluerov2.c:217): 0 = preparation + feedback (== brov_solve), 1 = preparation only
+ * (linearise at the current iterate), 2 = feedback only (QP + step with the current x0; needs a prior phase 1) */
+int brov_solve_phase(brov_solver* s, void* stream, int rti_phase);
 int brov_synchronize(brov_solver* s, void* stream);
+/* replace weights / bounds / Ts / QP options of an existing solver (N must not change) */
+int brov_set_opts(brov_solver* s, const brov_opts* opts);
+int brov_get_opts(const brov_solver* s, brov_opts* opts);
 
 /* outputs */
 int brov_get_results_host(brov_solver* s, brov_result* res /*[B]*/); /* syncs the last solve's stream */

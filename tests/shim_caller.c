@@ -1,0 +1,60 @@
+/* tests/shim_caller.c -- a C caller written against the acados-shaped drop-in headers (include/acados_shim) that makes the
+ * same sequence of calls as the reference's control tick (BLUEROV2_DOB::solve, bluerov2_dobmpc/src/bluerov2_dob.cpp:306-388):
+ * lbx/ubx <- x0, update_params for stages 0..N, yref for stages 0..N, solve, status / inf_norm_res / time_tot / u0.
+ * Inputs come from a binary file written by the test (x0[12], p[16], nticks, yref[nticks][N+1][16]); results go to stdout. */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "acados/utils/print.h"
+#include "acados_c/ocp_nlp_interface.h"
+#include "acados_c/external_function_interface.h"
+#include "acados/ocp_nlp/ocp_nlp_constraints_bgh.h"
+#include "acados/ocp_nlp/ocp_nlp_cost_ls.h"
+#include "blasfeo/include/blasfeo_d_aux.h"
+#include "blasfeo/include/blasfeo_d_aux_ext_dep.h"
+#include "bluerov2_model/bluerov2_model.h"
+#include "acados_solver_bluerov2.h"
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: shim_caller inputs.bin\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("open"); return 2; }
+    double x0[BLUEROV2_NX], p[BLUEROV2_NP], nt;
+    if (fread(x0, sizeof(double), BLUEROV2_NX, f) != BLUEROV2_NX || fread(p, sizeof(double), BLUEROV2_NP, f) != BLUEROV2_NP ||
+        fread(&nt, sizeof(double), 1, f) != 1) return 2;
+    const int nticks = (int)nt;
+    static double yref[BLUEROV2_N + 1][BLUEROV2_NY];
+    static double acados_param[BLUEROV2_N + 1][BLUEROV2_NP];
+
+    bluerov2_solver_capsule* mpc_capsule = bluerov2_acados_create_capsule();
+    int create_status = bluerov2_acados_create(mpc_capsule);
+    if (create_status != 0) { printf("acados_create() returned status %d. Exiting.\n", create_status); return 1; }
+
+    for (int tick = 0; tick < nticks; tick++) {
+        if (fread(yref, sizeof(double), (BLUEROV2_N + 1) * BLUEROV2_NY, f) != (size_t)(BLUEROV2_N + 1) * BLUEROV2_NY) return 2;
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", x0);
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", x0);
+        for (int i = 0; i < BLUEROV2_N + 1; i++) {
+            for (int j = 0; j < BLUEROV2_NP; j++) acados_param[i][j] = p[j];
+            bluerov2_acados_update_params(mpc_capsule, i, acados_param[i], BLUEROV2_NP);
+        }
+        for (unsigned int i = 0; i <= BLUEROV2_N; i++)
+            ocp_nlp_cost_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, i, "yref", yref[i]);
+        int acados_status = bluerov2_acados_solve(mpc_capsule);
+        double kkt_res = (double)mpc_capsule->nlp_out->inf_norm_res, cpu_time = 0.0, u0[BLUEROV2_NU], x1[BLUEROV2_NX];
+        ocp_nlp_get(mpc_capsule->nlp_config, mpc_capsule->nlp_solver, "time_tot", &cpu_time);
+        ocp_nlp_out_get(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_out, 0, "u", (void*)u0);
+        ocp_nlp_out_get(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_out, 1, "x", (void*)x1);
+        printf("TICK %d status %d kkt %.17g time %.6g u0 %.17g %.17g %.17g %.17g x1 %.17g %.17g %.17g\n", tick, acados_status, kkt_res,
+               cpu_time, u0[0], u0[1], u0[2], u0[3], x1[0], x1[1], x1[2]);
+    }
+    fclose(f);
+    bluerov2_acados_print_stats(mpc_capsule);
+    /* misuse that must not kill the process */
+    int rc = bluerov2_acados_custom_update(mpc_capsule, NULL, 0);
+    printf("custom_update %d\n", rc);
+    rc = bluerov2_acados_free(mpc_capsule);
+    rc |= bluerov2_acados_free_capsule(mpc_capsule);
+    printf("free %d\n", rc);
+    return 0;
+}

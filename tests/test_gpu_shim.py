@@ -1,0 +1,64 @@
+"""GPU tests of the acados-shaped drop-in: a C caller making the reference's per-tick call sequence (tests/shim_caller.c)
+and, when prebuilt in the build container, the reference's own generated example main_bluerov2.c linked against this
+repository's libacados_ocp_solver_bluerov2.so (oracle/_ref/main_bluerov2_shim)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include", "acados_shim")
+LIBDIR = os.path.join(ROOT, "bluerov2_amd", "lib")
+
+
+def test_control_tick_call_sequence_matches_known_answers(tmp_path, golden_rti, oracle):
+    g, name = golden_rti, "circle_N80"
+    exe = tmp_path / "shim_caller"
+    subprocess.check_call(["gcc", "-O2", f"-I{INC}", "-o", str(exe), os.path.join(ROOT, "tests", "shim_caller.c"),
+                           f"-L{LIBDIR}", "-lacados_ocp_solver_bluerov2", f"-Wl,-rpath,{LIBDIR}"])
+    nt = 4
+    blob = np.concatenate([g[f"{name}/x0_meas"], g[f"{name}/p"][0], [float(nt)]] + [g[f"{name}/yref{k}"].ravel() for k in range(nt)])
+    inp = tmp_path / "in.bin"
+    inp.write_bytes(blob.astype(np.float64).tobytes())
+    r = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ticks = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("TICK")]
+    assert len(ticks) == nt
+    # oracle run for the KKT value the shim must report in nlp_out->inf_norm_res
+    op = oracle.opts(80, 0.0125)
+    x, u = g[f"{name}/x_init"].copy(), g[f"{name}/u_init"].copy()
+    pi, lam = np.zeros((80, 12)), np.zeros((80, 8))
+    for k, t in enumerate(ticks):
+        status, kkt, tm = int(t[3]), float(t[5]), float(t[7])
+        u0 = np.array([float(v) for v in t[9:13]])
+        x1 = np.array([float(v) for v in t[14:17]])
+        ro = oracle.rti_step(op, g[f"{name}/x0_meas"], g[f"{name}/yref{k}"], g[f"{name}/p"], x, u, pi, lam)
+        assert status == 0 and 0.0 < tm < 5.0
+        assert np.abs(u0 - g[f"{name}/u{k}"][0]).max() < 1e-6
+        assert np.abs(x1 - g[f"{name}/x{k}"][1, :3]).max() < 1e-6
+        assert abs(kkt - ro["kkt"]) < 1e-6 * (1 + abs(ro["kkt"]))
+    assert "custom_update 1" in r.stdout and "free 0" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "main_bluerov2_shim")),
+                    reason="reference example not prebuilt (oracle/_ref/main_bluerov2_shim)")
+def test_reference_generated_example_runs_on_the_shim(golden_rti):
+    """c_generated_code/main_bluerov2.c, unmodified: x0=[0,0,-20,0..], yref=0, p=0, iterate initialised to zero (its lines
+    117-216).  Its printed input trajectory must equal the independent known answer for that scenario."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "main_bluerov2_shim")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, LD_LIBRARY_PATH=LIBDIR))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "bluerov2_acados_solve(): SUCCESS!" in r.stdout
+    body = r.stdout.split("--- utraj ---")[1].split("solved ocp")[0]
+    vals = np.array([float(v) for v in re.findall(r"[-+]?\d\.\d+e[-+]\d+", body)]).reshape(-1, 4)
+    ref = golden_rti["main_harness_N80/u0"]
+    assert vals.shape == ref.shape
+    assert np.abs(vals - ref).max() < 1e-5  # printed with 7 significant digits
+    xbody = r.stdout.split("--- xtraj ---")[1].split("--- utraj ---")[0]
+    xv = np.array([float(v) for v in re.findall(r"[-+]?\d\.\d+e[-+]\d+", xbody)]).reshape(-1, 12)
+    assert np.abs(xv - golden_rti["main_harness_N80/x0"]).max() < 1e-4
+    m = re.search(r"KKT ([-+0-9.e]+)", r.stdout)
+    assert m and float(m.group(1)) >= 0.0
