@@ -96,13 +96,6 @@ def cpu_baseline(batch, steps, warmup):
                        "run (not vendored/installed) and no published acados timing exists for this OCP")
 
 
-class _DevBuf:
-    """zero-copy view of a raw device pointer for torch.as_tensor"""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ipm", action="store_true", help="qp_early_exit=0 as the headline variant")
+    ap.add_argument("--force-gather", action="store_true", help="run the result all-gather even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -123,11 +117,13 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import bluerov2_amd as ba
+    from bluerov2_amd import distributed as D
     B, N = args.batch, HORIZON
     K, W = args.steps, args.warmup
 
@@ -140,9 +136,8 @@ def main():
 
     def run(s, traj_dev, steps, warmup, gather, timing):
         stream = torch.cuda.current_stream().cuda_stream
-        rec_bytes = 56 * B
-        res_view = torch.as_tensor(_DevBuf(s.results_device_ptr(), rec_bytes), device="cuda") if gather else None
-        gathered = torch.empty(world * rec_bytes, dtype=torch.uint8, device="cuda") if gather else None
+        res_view = D.records_tensor_from_solver(s) if gather else None
+        gathered = torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=f"cuda:{local_rank}") if gather else None
         s.init_iterate_default()
         s.enable_timing(False)
         base = traj_dev.data_ptr()
@@ -177,7 +172,7 @@ def main():
 
     s, circ = make_solver(0 if args.force_ipm else 1)
     traj_dev = torch.from_numpy(circ).to("cuda")
-    gather = world > 1
+    gather = world > 1 or args.force_gather
     # pass 1: the timed region that defines `value` (no per-kernel events inside)
     dt, _ = run(s, traj_dev, K, W, gather, timing=False)
     res = s.results()
@@ -227,22 +222,18 @@ def main():
                              "unit": "GB/s", "frac": value / world * alg_bytes / 1e9 / PEAK_HBM_GBS,
                              "algorithmic_bytes_per_solve": alg_bytes},
         }
-    # forced-IPM companion number (same workload, every instance runs the interior point method)
-    if not args.force_ipm and world == 1:
-        s2, _ = make_solver(0)
-        dti, kseci = run(s2, traj_dev, K, W, False, timing=False)
-        r_i = s2.results()
+    if gather:
+        allrec = D.gather_records(D.records_tensor_from_solver(s))  # every rank takes part in the collective
         if rank == 0:
-            out["forced_ipm"] = {"value": B * K / dti, "unit": "solves/s", "ms_per_step": dti / K * 1e3,
-                                 "mean_qp_iter": float(r_i["qp_iter"].mean()),
-                                 "status_nonzero": int((r_i["status"] != 0).sum())}
-        s2.close()
+            idx, best = D.select_best(allrec)
+            out["select_best"] = {"index": idx, "cost": None if best is None else float(best["cost"]),
+                                  "records_gathered": int(allrec.numel() // D.RECORD_BYTES)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, K, W)
     if rank == 0:
         print(json.dumps(out))
     s.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1,0 +1,70 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm), OCP instances sharded
+contiguously over ranks, no communication during the solve, ONE all-gather of the 56-byte per-instance result records
+afterwards, then an arg-min for best-candidate selection (BASELINE config 4).
+
+The functions below only move/inspect records, so the same code runs under the gloo backend on CPU tensors
+(tests/test_distributed_cpu.py) and under RCCL on device tensors (bench.py --gpus N)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .solver import RESULT_DTYPE
+
+RECORD_BYTES = 56
+
+
+def shard_bounds(total, rank, world):
+    """contiguous partition of range(total): the first total % world ranks get one extra instance"""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DevicePointerView:
+    """zero-copy torch view of raw device memory (e.g. BatchSolver.results_device_ptr())"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def records_tensor_from_solver(solver):
+    return torch.as_tensor(DevicePointerView(solver.results_device_ptr(), RECORD_BYTES * solver.B), device=f"cuda:{solver.device}")
+
+
+def gather_records(local_bytes, group=None):
+    """all-gather of equally sized uint8 record buffers -> [world * n] uint8 tensor on the same device"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_bytes.clone()
+    out = torch.empty(world * local_bytes.numel(), dtype=torch.uint8, device=local_bytes.device)
+    dist.all_gather_into_tensor(out, local_bytes.contiguous(), group=group)
+    return out
+
+
+def gather_records_uneven(local_bytes, counts, group=None):
+    """all-gather when shards differ in size: pad to the largest shard, gather, strip"""
+    world = dist.get_world_size(group)
+    nmax = max(counts) * RECORD_BYTES
+    pad = torch.zeros(nmax, dtype=torch.uint8, device=local_bytes.device)
+    pad[: local_bytes.numel()] = local_bytes
+    allb = gather_records(pad, group)
+    return torch.cat([allb[r * nmax: r * nmax + counts[r] * RECORD_BYTES] for r in range(world)])
+
+
+def records_to_numpy(rec_bytes):
+    return np.frombuffer(rec_bytes.detach().cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+
+
+def select_best(rec_bytes):
+    """index and record of the successful instance with the smallest cost (ties -> lowest index), computed with torch ops on
+    the device holding the gathered records; returns (index, numpy record) or (-1, None)"""
+    n = rec_bytes.numel() // RECORD_BYTES
+    rows = rec_bytes.view(n, RECORD_BYTES)
+    cost = rows[:, 32:40].contiguous().view(torch.float64).view(n)
+    status = rows[:, 48:52].contiguous().view(torch.int32).view(n)
+    ok = (status == 0) & ~torch.isnan(cost)
+    if not bool(ok.any()):
+        return -1, None
+    masked = torch.where(ok, cost, torch.full_like(cost, float("inf")))
+    idx = int(torch.argmin(masked).item())
+    return idx, records_to_numpy(rows[idx])[0]
