@@ -5,7 +5,7 @@ is the thin host-side mirror of that ABI; there is no CPU or PyTorch fallback --
 solver raises.
 """
 from .solver import (BatchSolver, SolverOptions, RESULT_DTYPE, P_NOMINAL, build_library, library_path,  # noqa: F401
-                     NoDeviceError, thrust_allocation)
+                     NoDeviceError, thrust_allocation, PATH_AUTO, PATH_STREAMING, PATH_FUSED)
 
 __all__ = ["BatchSolver", "SolverOptions", "RESULT_DTYPE", "P_NOMINAL", "build_library", "library_path",
-           "NoDeviceError", "thrust_allocation"]
+           "NoDeviceError", "thrust_allocation", "PATH_AUTO", "PATH_STREAMING", "PATH_FUSED"]

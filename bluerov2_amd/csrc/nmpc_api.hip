@@ -45,6 +45,7 @@ struct brov_solver {
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    bool last_fused = false;
 };
 
 extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
@@ -100,7 +101,8 @@ extern "C" int brov_init_iterate_default(brov_solver* s) {
 }
 
 extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts* opts) {
-    if (!out || !opts || B < 1 || opts->N < 1 || opts->N > BROV_MAX_N || !(opts->Ts > 0.0)) {
+    if (!out || !opts || B < 1 || opts->N < 1 || opts->N > BROV_MAX_N || !(opts->Ts > 0.0) || opts->kernel_path < 0 ||
+        opts->kernel_path > 2) {
         g_err = "brov_create: bad argument";
         return BROV_ERR_ARG;
     }
@@ -306,11 +308,20 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     const DevParams P = make_params(s);
+    const int path = s->opts.kernel_path;
+    if (path == BROV_PATH_FUSED && !fused_supported(s->N)) { g_err = "brov_solve: horizon too long for the fused (LDS-resident) path"; return BROV_ERR_ARG; }
+    const bool fused = rti_phase == 0 && path != BROV_PATH_STREAMING && fused_supported(s->N);
     if (s->timing) hipEventRecord(s->ev[0], st);
-    if (rti_phase != 2) launch_linearise(P, st);
-    if (s->timing) hipEventRecord(s->ev[1], st);
-    if (rti_phase != 1) launch_qp(P, st);
+    if (fused) {
+        if (s->timing) hipEventRecord(s->ev[1], st);
+        launch_fused(P, st);
+    } else {
+        if (rti_phase != 2) launch_linearise(P, st);
+        if (s->timing) hipEventRecord(s->ev[1], st);
+        if (rti_phase != 1) launch_qp(P, st);
+    }
     if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
+    s->last_fused = fused;
     s->last_stream = st;
     HIPCHK(hipGetLastError());
     return BROV_OK;

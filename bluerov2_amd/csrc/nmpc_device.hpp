@@ -55,5 +55,7 @@ enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_
 
 void launch_linearise(const DevParams& P, hipStream_t st);
 void launch_qp(const DevParams& P, hipStream_t st);
+void launch_fused(const DevParams& P, hipStream_t st);  // linearise + QP in one kernel, stage blocks in LDS
+bool fused_supported(int N);
 
 }  // namespace brov

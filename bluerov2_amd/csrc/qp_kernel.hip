@@ -16,9 +16,12 @@
 // with [x;u] ordering so that the input block Hu = [Hux Huu] is rows 12..15 = register 3 of the H tile.
 // Vectors are carried "row-replicated" (lane holds v[row] for every column), which makes every matrix-vector
 // product the same tn<> call.  The 4x4 pivot block is inverted redundantly by all lanes from v_readlane values.
+#include "lin_device.hpp"
 #include "nmpc_device.hpp"
 
 namespace brov {
+
+typedef __attribute__((address_space(3))) double lds_f64;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -73,6 +76,9 @@ struct Inst {
     const double* BAt;   // [N][16][16]
     const double* bvec;  // [N][12]
     double *Ks, *Kt, *Mt, *Pb, *kff, *vhat, *ipm, *dxb;
+    const lds_f64* lds_ba;  // fused path: [N][12][kBaStride] (+ b_i behind it), else unused
+    const lds_f64* lds_bv;  // fused path: [N][12]
+    lds_f64* lds_kt;        // fused path: gain transposed, compact [N][12][4]
     double Ts;
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
     double Wer[3];  // We[row]
@@ -99,6 +105,50 @@ __device__ __forceinline__ void store_vec12(double* v, const d4& t, int rg, int 
     if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
 }
 
+// ---- where the per-stage linearisation lives -------------------------------------------------------------------------
+// LDS = false: streamed from HBM (tiles BA / BAt / bvec written by lin_kernel) -- any horizon.
+// LDS = true : the whole horizon's [A_i B_i] (row stride kBaStride doubles, padded so that both the row image and the
+//              transposed image are read without bank conflicts) and b_i stay in this wave's LDS slice (fused kernel).
+constexpr int kBaStride = 13;              // only the 13 non-trivial columns 3..15 are stored (odd stride: no bank conflicts
+constexpr int kBaStage = NX * kBaStride;  // for either image); columns 0..2 of [A B] are exactly e_c
+constexpr int kKtStage = NX * 4;          // K^T compact [12][4] per stage
+
+template <bool LDS>
+__device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: rows k = rg+4r (0..11), cols c = cl
+    if constexpr (LDS) {
+        const int cc = I.cl >= 3 ? I.cl - 3 : 0;
+        const lds_f64* t = I.lds_ba + i * kBaStage + I.rg * kBaStride + cc;
+        d4 r = {t[0], t[4 * kBaStride], t[8 * kBaStride], 0.0};
+        if (I.cl < 3) r = d4{(I.rg == I.cl) ? 1.0 : 0.0, 0.0, 0.0, 0.0};  // rows rg, rg+4, rg+8 of e_cl (cl < 3)
+        return r;
+    } else {
+        return load_tile3(I.BA + (size_t)i * 192, I.lane);
+    }
+}
+template <bool LDS>
+__device__ __forceinline__ d4 get_bat(const Inst& I, int i) {  // [A B]^T image: rows c = rg+4r (0..15), cols k = cl (< 12)
+    if constexpr (LDS) {
+        const int k = I.cl < NX ? I.cl : 0;
+        const lds_f64* t = I.lds_ba + i * kBaStage + k * kBaStride + I.rg;  // column c = rg + 4r is stored at c - 3
+        d4 r;
+        r[0] = (I.rg == 3) ? t[-3] : ((I.rg == I.cl) ? 1.0 : 0.0);  // c = rg: stored (index 0) only for rg == 3, else e_c
+        r[1] = t[1]; r[2] = t[5]; r[3] = t[9];                      // c = rg+4, rg+8, rg+12 -> offsets c - 3 - rg
+        if (I.cl >= NX) r = d4{0, 0, 0, 0};
+        return r;
+    } else {
+        return load_tile4(I.BAt + (size_t)i * 256, I.lane);
+    }
+}
+template <bool LDS>
+__device__ __forceinline__ d4 get_bv(const Inst& I, int i) {  // b_i, row-replicated
+    if constexpr (LDS) {
+        const lds_f64* t = I.lds_bv + i * NX + I.rg;
+        return d4{t[0], t[4], t[8], 0.0};
+    } else {
+        return load_vec12(I.bvec + (size_t)i * 12, I.rg);
+    }
+}
+
 // 1/d for a positive, normal d: v_rcp_f64 seed + 2 Newton steps (~1 ulp).  The pivot recursion below is the serial
 // critical path of every Riccati stage; the IEEE-exact division sequence is 3x longer and buys nothing here.
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -122,11 +172,11 @@ struct BwdIn {
     double ks, mt;        // stored factors (only !FACTOR)
 };
 
-template <bool FACTOR>
+template <bool FACTOR, bool LDS>
 __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* gam, const double* rt) {
     BwdIn s;
-    s.ba = load_tile3(I.BA + (size_t)i * 192, I.lane);
-    s.bv = load_vec12((FACTOR ? I.bvec : I.Pb) + (size_t)i * 12, I.rg);
+    s.ba = get_ba<LDS>(I, i);
+    s.bv = FACTOR ? get_bv<LDS>(I, i) : load_vec12(I.Pb + (size_t)i * 12, I.rg);
     const double* xi = I.x + (size_t)i * 12;
     const double* yi = I.yref + (size_t)i * 16;
 #pragma unroll
@@ -141,13 +191,13 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
 // backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
 // not positive definite.
-template <bool FACTOR>
+template <bool FACTOR, bool LDS>
 __device__ bool riccati_backward(const Inst& I) {
     const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
     wave_fence();
-    BwdIn nx = load_bwd<FACTOR>(I, N - 1, gam, rt);
+    BwdIn nx = load_bwd<FACTOR, LDS>(I, N - 1, gam, rt);
     d4 P = {0, 0, 0, 0}, pv;
     {
         const double* xN = I.x + (size_t)N * 12;
@@ -164,7 +214,7 @@ __device__ bool riccati_backward(const Inst& I) {
     const d4 z4 = {0, 0, 0, 0};
     for (int i = N - 1; i >= 0; i--) {
         const BwdIn in = nx;
-        if (i > 0) nx = load_bwd<FACTOR>(I, i - 1, gam, rt);
+        if (i > 0) nx = load_bwd<FACTOR, LDS>(I, i - 1, gam, rt);
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
@@ -228,8 +278,15 @@ __device__ bool riccati_backward(const Inst& I) {
             // store factors
             I.Ks[(size_t)i * 64 + lane] = ks;
             I.Mt[(size_t)i * 64 + lane] = mt;
-            double* kt = I.Kt + (size_t)i * 192;
-            kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
+            if constexpr (LDS) {
+                if (cl < 4) {
+                    lds_f64* t = I.lds_kt + i * kKtStage + rg * 4 + cl;
+                    t[0] = KtT[0]; t[16] = KtT[1]; t[32] = KtT[2];
+                }
+            } else {
+                double* kt = I.Kt + (size_t)i * 192;
+                kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
+            }
             if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
             P = S;
             pv = pn;
@@ -250,26 +307,34 @@ __device__ bool riccati_backward(const Inst& I) {
 }
 
 struct FwdIn { d4 kt, bat, bb; double kf; };
+template <bool LDS>
 __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
     FwdIn s;
-    s.kt = load_tile3(I.Kt + (size_t)i * 192, I.lane);
-    s.bat = load_tile4(I.BAt + (size_t)i * 256, I.lane);
-    s.bb = load_vec12(I.bvec + (size_t)i * 12, I.rg);
+    if constexpr (LDS) {
+        const lds_f64* t = I.lds_kt + i * kKtStage + I.rg * 4 + (I.cl & 3);
+        s.kt = d4{t[0], t[16], t[32], 0.0};
+        if (I.cl >= 4) s.kt = d4{0, 0, 0, 0};
+    } else {
+        s.kt = load_tile3(I.Kt + (size_t)i * 192, I.lane);
+    }
+    s.bat = get_bat<LDS>(I, i);
+    s.bb = get_bv<LDS>(I, i);
     s.kf = I.kff[i * 4 + I.rg];
     return s;
 }
 
 // forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i.
 // Leaves vhat in I.vhat and the state steps in I.dxb.
+template <bool LDS>
 __device__ void riccati_forward(const Inst& I, const d4& d0) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    FwdIn nx = load_fwd(I, 0);
+    FwdIn nx = load_fwd<LDS>(I, 0);
     d4 xx = d0;
     store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
         const FwdIn in = nx;
-        if (i + 1 < N) nx = load_fwd(I, i + 1);
+        if (i + 1 < N) nx = load_fwd<LDS>(I, i + 1);
         d4 c = {in.kf, 0, 0, 0};
         d4 v = tn<3>(in.kt, xx, c);
         if (cl == 0) I.vhat[i * 4 + rg] = v[0];
@@ -282,23 +347,25 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
 }
 
 struct RollIn { d4 bat, bb; double v; };
+template <bool LDS>
 __device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* varr) {
     RollIn s;
-    s.bat = load_tile4(I.BAt + (size_t)i * 256, I.lane);
-    s.bb = load_vec12(I.bvec + (size_t)i * 12, I.rg);
+    s.bat = get_bat<LDS>(I, i);
+    s.bb = get_bv<LDS>(I, i);
     s.v = varr[i * 4 + I.rg];
     return s;
 }
 // roll the linearised dynamics out for the inputs in varr -> I.dxb
+template <bool LDS>
 __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    RollIn nx = load_roll(I, 0, varr);
+    RollIn nx = load_roll<LDS>(I, 0, varr);
     d4 xx = d0;
     store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
         const RollIn in = nx;
-        if (i + 1 < N) nx = load_roll(I, i + 1, varr);
+        if (i + 1 < N) nx = load_roll<LDS>(I, i + 1, varr);
         d4 z = {xx[0], xx[1], xx[2], in.v};
         xx = tn<4>(in.bat, z, in.bb);
         xx[3] = 0.0;
@@ -308,9 +375,10 @@ __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
 }
 
 struct AdjIn { d4 ba; double dx[3], xn[3], yn[3]; double v, u, ur; };
+template <bool LDS>
 __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* varr) {
     AdjIn s;
-    s.ba = load_tile3(I.BA + (size_t)i * 192, I.lane);
+    s.ba = get_ba<LDS>(I, i);
     const double* dxn = I.dxb + (size_t)(i + 1) * 12;
     const double* xn = I.x + (size_t)(i + 1) * 12;
     const double* yn = I.yref + (size_t)(i + 1) * 16;
@@ -324,16 +392,16 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
 // adjoint recursion for the state steps in I.dxb and inputs varr:
 //   pi_i = Qd_{i+1} dx_{i+1} + q_{i+1} + A_{i+1}' pi_{i+1};   g_i = Rd v_i + r_i + B_i' pi_i  -> garr[N*4]
 // With COMMIT the multipliers pi are written to pi_out (the iterate).
-template <bool COMMIT>
+template <bool COMMIT, bool LDS>
 __device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    AdjIn nx = load_adj(I, N - 1, varr);
+    AdjIn nx = load_adj<LDS>(I, N - 1, varr);
     d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
     const d4 z4 = {0, 0, 0, 0};
     for (int i = N - 1; i >= 0; i--) {
         const AdjIn in = nx;
-        if (i > 0) nx = load_adj(I, i - 1, varr);
+        if (i > 0) nx = load_adj<LDS>(I, i - 1, varr);
         d4 pi;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -350,40 +418,12 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
     wave_fence();
 }
 
-#ifndef BROV_QP_WAVES
-#define BROV_QP_WAVES 2
-#endif
-__global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
+// everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
+// lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
+template <bool LDS>
+__device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan) {
     const double* __restrict__ cst = P.cst;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> SGPR addressing
-    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (b >= P.B) return;
-    const int lane = threadIdx.x & 63;
-    const int N = P.N, nv = 4 * N;
-    Inst I;
-    I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
-    I.x = P.x + (size_t)b * (N + 1) * 12;
-    I.u = P.u + (size_t)b * N * 4;
-    I.yref = P.yref + (size_t)b * P.yref_stride;
-    I.BA = P.BA + (size_t)b * N * 192;
-    I.BAt = P.BAt + (size_t)b * N * 256;
-    I.bvec = P.bvec + (size_t)b * N * 12;
-    I.Ks = P.Ks + (size_t)b * N * 64;
-    I.Kt = P.Kt + (size_t)b * N * 192;
-    I.Mt = P.Mt + (size_t)b * N * 64;
-    I.Pb = P.Pb + (size_t)b * N * 12;
-    I.kff = P.kff + (size_t)b * N * 4;
-    I.vhat = P.vhat + (size_t)b * N * 4;
-    I.ipm = P.ipm + (size_t)b * IPM_NARR * nv;
-    I.dxb = P.dxb + (size_t)b * (N + 1) * 12;
-    I.Ts = P.Ts;
-    // cst = [W16 | We12 pad4 | lbu4 | ubu4]
-#pragma unroll
-    for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
-#pragma unroll
-    for (int r = 0; r < 3; r++) I.Wer[r] = cst[16 + I.rg + 4 * r];
-    I.lbm = cst[32 + I.rg];
-    I.ubm = cst[36 + I.rg];
+    const int lane = I.lane, N = I.N, nv = I.nv;
     const int rg = I.rg;
 
     double* x_it = P.x + (size_t)b * (N + 1) * 12;
@@ -411,13 +451,8 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
             kkt = (a != a) ? a : fmax(kkt, a);
         }
         d0[3] = 0.0;
-        double part = 0.0;
-        bool nanp = false;
-        for (int j = lane; j < N; j += 64) {
-            const double t = P.kktp[(size_t)b * N + j];
-            if (t != t) nanp = true;
-            part = fmax(part, t);
-        }
+        double part = lin_part;
+        bool nanp = lin_nan;
         if (kkt != kkt) nanp = true;
         kkt = wave_max(fmax(part, (kkt != kkt) ? 0.0 : kkt));
         if (__ballot(nanp) != 0ull) kkt = __builtin_nan("");
@@ -432,11 +467,11 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false;
-    bool ok = riccati_backward<true>(I);
+    bool ok = riccati_backward<true, LDS>(I);
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
-        riccati_forward(I, d0);
+        riccati_forward<LDS>(I, d0);
         bool feas = true;
         for (int j = lane; j < nv; j += 64) {
             const int m = j & 3;
@@ -459,8 +494,8 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
                 vj = (vj > hi) ? hi : vj;
                 V[j] = vj; TL[j] = vj - lb; TU[j] = ub - vj;
             }
-            rollout(I, d0, V);
-            adjoint<false>(I, V, DVA, nullptr);
+            rollout<LDS>(I, d0, V);
+            adjoint<false, LDS>(I, V, DVA, nullptr);
             double g0 = 0.0;
             for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(DVA[j]));
             g0 = wave_max(g0);
@@ -486,9 +521,9 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
                     RT[j] = rr - gm * V[j];
                 }
                 mu = wave_sum(s) * inv2nv;
-                ok = riccati_backward<true>(I);
+                ok = riccati_backward<true, LDS>(I);
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
-                riccati_forward(I, d0);
+                riccati_forward<LDS>(I, d0);
                 // predictor step length and centering
                 double aaff = 1.0;
                 for (int j = lane; j < nv; j += 64) {
@@ -520,8 +555,8 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
                     const double rr = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
                     RT[j] = rr - GAM[j] * V[j] - (smu - cl_) / tl + (smu - cu_) / tu;
                 }
-                (void)riccati_backward<false>(I);
-                riccati_forward(I, d0);
+                (void)riccati_backward<false, LDS>(I);
+                riccati_forward<LDS>(I, d0);
                 double amax = 1e300;
                 for (int j = lane; j < nv; j += 64) {
                     const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dva = DVA[j];
@@ -563,8 +598,8 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     // ---- finalise: consistent primal/dual for the final inputs, multiplier recovery, full step ---------------
     double cost = 0.0;
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
-        if (!early) rollout(I, d0, V);  // early exit: dxb already holds the states of the accepted Newton point
-        adjoint<true>(I, V, DVA, pi_it);
+        if (!early) rollout<LDS>(I, d0, V);  // early exit: dxb already holds the states of the accepted Newton point
+        adjoint<true, LDS>(I, V, DVA, pi_it);
         bool nanv = false;
         for (int j = lane; j < nv; j += 64) {
             const double vj = V[j];
@@ -621,10 +656,159 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     if (lane < 4) P.res[b].u0[lane] = u_it[lane];
 }
 
+__device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane) {
+    const int N = P.N, nv = 4 * N;
+    const double* __restrict__ cst = P.cst;
+    I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
+    I.x = P.x + (size_t)b * (N + 1) * 12;
+    I.u = P.u + (size_t)b * N * 4;
+    I.yref = P.yref + (size_t)b * P.yref_stride;
+    I.BA = P.BA + (size_t)b * N * 192;
+    I.BAt = P.BAt + (size_t)b * N * 256;
+    I.bvec = P.bvec + (size_t)b * N * 12;
+    I.Ks = P.Ks + (size_t)b * N * 64;
+    I.Kt = P.Kt + (size_t)b * N * 192;
+    I.Mt = P.Mt + (size_t)b * N * 64;
+    I.Pb = P.Pb + (size_t)b * N * 12;
+    I.kff = P.kff + (size_t)b * N * 4;
+    I.vhat = P.vhat + (size_t)b * N * 4;
+    I.ipm = P.ipm + (size_t)b * IPM_NARR * nv;
+    I.dxb = P.dxb + (size_t)b * (N + 1) * 12;
+    I.Ts = P.Ts;
+    I.lds_ba = nullptr;
+    I.lds_bv = nullptr;
+    // cst = [W16 | We12 pad4 | lbu4 | ubu4]
+#pragma unroll
+    for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
+#pragma unroll
+    for (int r = 0; r < 3; r++) I.Wer[r] = cst[16 + I.rg + 4 * r];
+    I.lbm = cst[32 + I.rg];
+    I.ubm = cst[36 + I.rg];
+}
+
+#ifndef BROV_QP_WAVES
+#define BROV_QP_WAVES 2
+#endif
+// streaming path: linearisation tiles come from HBM (written by lin_kernel); any horizon
+__global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> SGPR addressing
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= P.B) return;
+    const int lane = threadIdx.x & 63;
+    Inst I;
+    setup_inst(P, I, b, lane);
+    double part = 0.0;
+    bool nanp = false;
+    for (int j = lane; j < P.N; j += 64) {
+        const double t = P.kktp[(size_t)b * P.N + j];
+        if (t != t) nanp = true;
+        part = fmax(part, t);
+    }
+    qp_body<false>(P, I, b, part, nanp);
+}
+
+// fused path: ONE wavefront owns one OCP instance from linearisation to the updated iterate.  The wave first integrates
+// all N intervals at once (64/N lanes per interval, lin_device.hpp) and leaves [A_i B_i] and b_i in its LDS slice
+// (N <= kFusedMaxN: 4 waves x 36 KB per CU at N = 20), then runs the Riccati IPM on the LDS-resident stage blocks: they
+// are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
+// (interior-point) instance does not pin the LDS of three finished ones.
+constexpr int kFusedMaxN = 23;
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int N = P.N;
+    const double* __restrict__ cst = P.cst;
+    // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
+    double* ba_s = smem;                          // [N][12][13]
+    double* bv_s = ba_s + (size_t)N * kBaStage;   // [N][12]
+    double* kt_s = bv_s + (size_t)N * NX;         // [N][12][4]
+    double* kff_s = kt_s + (size_t)N * kKtStage;  // [N][4]
+    double* vh_s = kff_s + (size_t)N * 4;         // [N][4]
+    double* dx_s = vh_s + (size_t)N * 4;          // [N+1][12]
+    // ---- preparation: ERK4 + sensitivities.  L = 64/N lanes per interval (3 at N = 20); each lane integrates the state
+    // once (stage points stay in registers) and then walks its share of the 13 non-trivial sensitivity columns; columns
+    // land in LDS, so the scattered 8-byte writes that ruled this mapping out for the HBM-streaming kernel cost nothing.
+    double part = 0.0;
+    bool nanp = false;
+    {
+        const int L = N <= 4 ? 16 : 64 / N;
+        const int g = lane / L, j0 = lane - g * L;
+        const bool active = g < N;
+        const int i = active ? g : N - 1;
+        const double* __restrict__ xi = P.x + ((size_t)b * (N + 1) + i) * NX;
+        const double* __restrict__ ui = P.u + ((size_t)b * N + i) * NU;
+        const double* __restrict__ pp = P.par + ((size_t)b * (N + 1) + i) * NP;
+        double uu[NU];
+#pragma unroll
+        for (int j = 0; j < NU; j++) uu[j] = ui[j];
+        const ModelPar m = make_par(pp);
+        const Wrench w = make_wrench(uu);
+        StagePoint sp[4];
+        double xn[NX];
+        rk4_state(xi, w, m, P.Ts, sp, xn);
+        double* tb = ba_s + i * kBaStage;
+        if (active && j0 == 0) {
+            // position columns are exactly e_c; lane 0 of the group also owns b_i and their stationarity rows
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double e[NX];
+#pragma unroll
+                for (int k = 0; k < NX; k++) e[k] = (k == c) ? 1.0 : 0.0;
+                double bc;
+                const double kk = lin_kkt_lane(P, cst, b, i, c, xi, ui, xn, e, bc);
+                if (kk != kk) nanp = true;
+                part = fmax(part, kk);
+            }
+        }
+#pragma unroll 1
+        for (int c = 3 + j0; c < 16; c += L) {
+            double acc[NX];
+            sens_column(sp, m, P.Ts, c, acc);
+            double bc;
+            const double kk = lin_kkt_lane(P, cst, b, i, c, xi, ui, xn, acc, bc);
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
+                if (c < NX) bv_s[i * NX + c] = bc;
+                if (kk != kk) nanp = true;
+                part = fmax(part, kk);
+            }
+        }
+        // b_i of the position rows (columns 0..2 are not visited by the loop above)
+        if (active && j0 == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) bv_s[i * NX + c] = xn[c] - xi[NX + c];
+        }
+    }
+    __syncthreads();  // single wave: orders the LDS writes above against the reads below
+    Inst I;
+    setup_inst(P, I, b, lane);
+    I.lds_ba = (const lds_f64*)ba_s;
+    I.lds_bv = (const lds_f64*)bv_s;
+    I.lds_kt = (lds_f64*)kt_s;
+    I.kff = kff_s;   // generic pointers into LDS: feed-forward terms, candidate inputs and state steps never leave the CU
+    I.vhat = vh_s;
+    I.dxb = dx_s;
+    qp_body<true>(P, I, b, part, nanp);
+}
+
 void launch_qp(const DevParams& P, hipStream_t st) {
     const int waves_per_block = 4;
     const int blocks = (P.B + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL(qp_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, st, P);
+}
+
+bool fused_supported(int N) { return N <= kFusedMaxN; }
+
+void launch_fused(const DevParams& P, hipStream_t st) {
+    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4) + (size_t)(P.N + 1) * NX) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds, st, P);
 }
 
 }  // namespace brov

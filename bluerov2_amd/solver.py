@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(HERE, "lib", "libbluerov2_nmpc.so")
 NX, NU, NP, NY = 12, 4, 16, 16
 MAX_N = 128
+PATH_AUTO, PATH_STREAMING, PATH_FUSED = 0, 1, 2
 
 # nominal hydrodynamic parameters the nodes pass every tick (bluerov2_dob.cpp:340-353); p[0:4] = disturbance
 P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
@@ -34,7 +35,7 @@ class NoDeviceError(RuntimeError):
 class _Opts(C.Structure):
     _fields_ = [("N", C.c_int32), ("qp_iter_max", C.c_int32), ("Ts", C.c_double), ("W", C.c_double * 16),
                 ("We", C.c_double * 12), ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("qp_tol_mu", C.c_double),
-                ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int32), ("reserved", C.c_int32)]
+                ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int32), ("kernel_path", C.c_int32)]
 
 
 def library_path():

@@ -64,8 +64,12 @@ typedef struct brov_opts {
     double  qp_tol_mu;      /* IPM complementarity target (1e-12) */
     double  qp_tol_stat;    /* IPM stationarity target   (1e-9)  */
     int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
-    int32_t reserved;
+    int32_t kernel_path;    /* BROV_PATH_AUTO (fused when the horizon fits LDS, N <= 23), _STREAMING, _FUSED */
 } brov_opts;
+
+#define BROV_PATH_AUTO 0
+#define BROV_PATH_STREAMING 1 /* lin_kernel + qp_kernel, stage blocks streamed through HBM; any N <= BROV_MAX_N */
+#define BROV_PATH_FUSED 2     /* one kernel, one wavefront per instance, [A B | b] of the whole horizon resident in LDS */
 
 #define BROV_MAX_N 128
 
@@ -132,7 +136,8 @@ double* brov_yref_device(brov_solver* s);   /* [B][N+1][16] (always allocated; u
 double* brov_params_device(brov_solver* s); /* [B][N+1][16] */
 double* brov_x_device(brov_solver* s);
 double* brov_u_device(brov_solver* s);
-/* linearisation of the LAST solve (row-major per stage: [A|B] as [12][16], b as [12]) for tests */
+/* linearisation of the LAST solve that used the streaming path (row-major per stage: [A|B] as [12][16], b as [12]);
+ * the fused path keeps it in LDS and never writes it out.  For tests. */
 int brov_get_linearisation_host(brov_solver* s, double* AB /*[B][N][12][16]*/, double* b /*[B][N][12]*/);
 
 /* argmin of cost over instances with status SUCCESS (config 4 "best-trajectory select"); writes the winning index

@@ -36,9 +36,16 @@ def test_tile_primitive_against_numpy(ba):
         assert np.abs(out - ref).max() < 1e-13, k4
 
 
-def _gpu_run(ba, g, name, **optkw):
+PATHS = [1, 2]  # BROV_PATH_STREAMING, BROV_PATH_FUSED (falls back to streaming when the horizon does not fit LDS)
+
+
+def _path_for(ba, N, path):
+    return path if (path != ba.PATH_FUSED or N <= 23) else ba.PATH_STREAMING
+
+
+def _gpu_run(ba, g, name, path=0, **optkw):
     N, Ts = int(g[f"{name}/N"]), float(g[f"{name}/Ts"])
-    s = ba.BatchSolver(1, ba.SolverOptions(N, Ts, **optkw))
+    s = ba.BatchSolver(1, ba.SolverOptions(N, Ts, kernel_path=_path_for(ba, N, path), **optkw))
     s.set_iterate(x=g[f"{name}/x_init"][None], u=g[f"{name}/u_init"][None], pi=np.zeros((1, N, 12)), lam=np.zeros((1, N, 8)))
     s.set_x0(g[f"{name}/x0_meas"][None])
     s.set_params(g[f"{name}/p"][None])
@@ -50,27 +57,30 @@ def _gpu_run(ba, g, name, **optkw):
     return out
 
 
-def test_known_answers_every_scenario(ba, golden_rti):
+@pytest.mark.parametrize("path", PATHS)
+def test_known_answers_every_scenario(ba, golden_rti, path):
     g = golden_rti
     for name in scenario_names(g):
-        for k, (r, (x, u, pi, lam), _) in enumerate(_gpu_run(ba, g, name)):
+        for k, (r, (x, u, pi, lam), _) in enumerate(_gpu_run(ba, g, name, path)):
             assert r["status"] == 0, (name, k, r)
             assert np.abs(u[0] - g[f"{name}/u{k}"]).max() < 1e-6, (name, k)
             assert np.abs(x[0] - g[f"{name}/x{k}"]).max() < 1e-6, (name, k)
             assert np.array_equal(r["u0"], u[0, 0])
 
 
-def test_against_oracle_every_scenario(ba, oracle, golden_rti):
+@pytest.mark.parametrize("path", PATHS)
+def test_against_oracle_every_scenario(ba, oracle, golden_rti, path):
     g = golden_rti
     for name in scenario_names(g):
         N, Ts = int(g[f"{name}/N"]), float(g[f"{name}/Ts"])
         op = oracle.opts(N, Ts)
         x, u = g[f"{name}/x_init"].copy(), g[f"{name}/u_init"].copy()
         pi, lam = np.zeros((N, 12)), np.zeros((N, 8))
-        for k, (r, (gx, gu, gpi, glam), (A, B, b)) in enumerate(_gpu_run(ba, g, name)):
+        for k, (r, (gx, gu, gpi, glam), (A, B, b)) in enumerate(_gpu_run(ba, g, name, path)):
             ro = oracle.rti_step(op, g[f"{name}/x0_meas"], g[f"{name}/yref{k}"], g[f"{name}/p"], x, u, pi, lam, want_lin=True)
-            assert _rel(A[0], ro["A"]) < TOL_LIN and _rel(B[0], ro["B"]) < TOL_LIN, (name, k)
-            assert np.abs(b[0] - ro["b"]).max() < 1e-10 * (1 + np.abs(ro["b"]).max()), (name, k)
+            if _path_for(ba, N, path) == ba.PATH_STREAMING:  # the fused path keeps the linearisation in LDS
+                assert _rel(A[0], ro["A"]) < TOL_LIN and _rel(B[0], ro["B"]) < TOL_LIN, (name, k)
+                assert np.abs(b[0] - ro["b"]).max() < 1e-10 * (1 + np.abs(ro["b"]).max()), (name, k)
             assert r["status"] == ro["status"] == 0
             assert np.abs(gu[0] - u).max() < TOL_IT and np.abs(gx[0] - x).max() < TOL_IT, (name, k)
             assert abs(r["cost"] - ro["cost"]) < 1e-7 * (1 + abs(ro["cost"])), (name, k)
@@ -101,12 +111,13 @@ def _well_posed(kkt):
     return kkt < 5e3
 
 
-def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj):
+@pytest.mark.parametrize("path", PATHS)
+def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj, path):
     N, nb = 20, 512
     x0, circ = _batch_inputs(golden_traj, N, nb, seed=1, sat_frac=0.25)
     p = np.tile(ba.P_NOMINAL, (nb, 1))
     p[:, :4] = np.random.default_rng(2).uniform(-300, 300, size=(nb, 4))  # DOB-MPC style disturbance draws
-    s = ba.BatchSolver(nb, ba.SolverOptions(N))
+    s = ba.BatchSolver(nb, ba.SolverOptions(N, kernel_path=path))
     s.set_x0(x0); s.set_params(p)
     op = oracle.opts(N)
     x, u, pi, lam = oracle.init_iterate(op, nb)
@@ -131,15 +142,33 @@ def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj):
         x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
     assert n_ipm > 20  # the interior-point branch was exercised
     # batch invariance: instance 37 alone gives bit-identical output
-    s1 = ba.BatchSolver(1, ba.SolverOptions(N))
+    s1 = ba.BatchSolver(1, ba.SolverOptions(N, kernel_path=path))
     s1.set_x0(x0[37:38]); s1.set_params(p[37:38])
     for k in range(3):
         s1.set_yref(circ[k:k + N + 1]); s1.solve()
     assert np.array_equal(s1.get_iterate()[1][0], gu[37])
 
 
+def test_fused_and_streaming_paths_agree(ba, golden_traj):
+    N, nb = 20, 256
+    x0, circ = _batch_inputs(golden_traj, N, nb, seed=21, sat_frac=0.25)
+    its = []
+    for path in (ba.PATH_STREAMING, ba.PATH_FUSED):
+        s = ba.BatchSolver(nb, ba.SolverOptions(N, kernel_path=path))
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+        for k in range(2):
+            s.set_yref(circ[k:k + N + 1]); s.solve()
+        its.append((s.get_iterate(), s.results()))
+    (xa, ua, pa, la), ra = its[0]
+    (xb, ub, pb, lb), rb = its[1]
+    ok = ra["kkt"] < 5e3
+    assert np.abs(ua[ok] - ub[ok]).max() < 1e-9 and np.abs(xa[ok] - xb[ok]).max() < 1e-9
+    assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["qp_iter"][ok], rb["qp_iter"][ok])
+    assert np.abs(ra["kkt"][ok] - rb["kkt"][ok]).max() < 1e-9 * (1 + ra["kkt"][ok].max())
+
+
 def test_horizon_sweep_matches_oracle(ba, oracle, golden_traj):
-    for N in (10, 40, 80):
+    for N in (10, 23, 40, 80):
         nb = 64
         x0, circ = _batch_inputs(golden_traj, N, nb, seed=4, sat_frac=0.25)
         s = ba.BatchSolver(nb, ba.SolverOptions(N))
@@ -156,12 +185,13 @@ def test_horizon_sweep_matches_oracle(ba, oracle, golden_traj):
             assert (res["qp_iter"] > 0).sum() > 0
 
 
-def test_forced_ipm_equals_early_exit(ba, golden_traj):
+@pytest.mark.parametrize("path", PATHS)
+def test_forced_ipm_equals_early_exit(ba, golden_traj, path):
     N, nb = 20, 128
     x0, circ = _batch_inputs(golden_traj, N, nb, seed=7)
     outs = []
     for ee in (1, 0):
-        s = ba.BatchSolver(nb, ba.SolverOptions(N, qp_early_exit=ee))
+        s = ba.BatchSolver(nb, ba.SolverOptions(N, qp_early_exit=ee, kernel_path=path))
         s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1])
         s.solve()
         r = s.results()
