@@ -79,6 +79,8 @@ struct Inst {
     const lds_f64* lds_ba;  // fused path: [N][12][kBaStride] (+ b_i behind it), else unused
     const lds_f64* lds_bv;  // fused path: [N][12]
     lds_f64* lds_kt;        // fused path: gain transposed, compact [N][12][4]
+    const lds_f64* lds_q;   // fused path: cost gradient q_i = s_i W (x_i - xref_i), [N+1][12] (terminal row N)
+    const lds_f64* lds_r;   // fused path: r_i = Ts Wu (u_i - uref_i), [N][4]
     double Ts;
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
     double Wer[3];  // We[row]
@@ -177,10 +179,15 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
     BwdIn s;
     s.ba = get_ba<LDS>(I, i);
     s.bv = FACTOR ? get_bv<LDS>(I, i) : load_vec12(I.Pb + (size_t)i * 12, I.rg);
-    const double* xi = I.x + (size_t)i * 12;
-    const double* yi = I.yref + (size_t)i * 16;
+    if constexpr (LDS) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) { s.xv[r] = xi[I.rg + 4 * r]; s.yv[r] = yi[I.rg + 4 * r]; }
+        for (int r = 0; r < 3; r++) { s.xv[r] = I.lds_q[i * 12 + I.rg + 4 * r]; s.yv[r] = 0.0; }
+    } else {
+        const double* xi = I.x + (size_t)i * 12;
+        const double* yi = I.yref + (size_t)i * 16;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { s.xv[r] = xi[I.rg + 4 * r]; s.yv[r] = yi[I.rg + 4 * r]; }
+    }
     s.rtv = rt[i * 4 + I.rg];
     s.gm = FACTOR ? gam[i * 4 + I.rg] : 0.0;
     s.ks = FACTOR ? 0.0 : I.Ks[(size_t)i * 64 + I.lane];
@@ -191,7 +198,7 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
 // backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
 // not positive definite.
-template <bool FACTOR, bool LDS>
+template <bool FACTOR, bool LDS, bool STORE_IPM = true>
 __device__ bool riccati_backward(const Inst& I) {
     const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
@@ -206,7 +213,8 @@ __device__ bool riccati_backward(const Inst& I) {
         for (int r = 0; r < 3; r++) {
             const int row = rg + 4 * r;
             if (FACTOR) P[r] = (row == cl) ? I.Wer[r] : 0.0;
-            pv[r] = I.Wer[r] * (xN[row] - yN[row]);
+            if constexpr (LDS) pv[r] = I.lds_q[N * 12 + row];
+            else pv[r] = I.Wer[r] * (xN[row] - yN[row]);
         }
         pv[3] = 0.0;
     }
@@ -218,13 +226,13 @@ __device__ bool riccati_backward(const Inst& I) {
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
-        for (int r = 0; r < 3; r++) qr[r] = I.Ts * I.Wr[r] * (in.xv[r] - in.yv[r]);
+        for (int r = 0; r < 3; r++) qr[r] = LDS ? in.xv[r] : I.Ts * I.Wr[r] * (in.xv[r] - in.yv[r]);
         qr[3] = in.rtv;
         if (FACTOR) {
             d4 PA = tn<3>(P, in.ba, z4);
             d4 Pb = tn<3>(P, in.bv, z4);
             d4 H = tn<3>(in.ba, PA, z4);
-            store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
+            if (STORE_IPM) store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
             d4 l;
 #pragma unroll
             for (int r = 0; r < 4; r++) l[r] = Pb[r] + pv[r];
@@ -276,8 +284,10 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 pn = tn1(ks, g[3], g);
             d4 KtT = tn1(H[3], -mt, z4);
             // store factors
-            I.Ks[(size_t)i * 64 + lane] = ks;
-            I.Mt[(size_t)i * 64 + lane] = mt;
+            if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads these
+                I.Ks[(size_t)i * 64 + lane] = ks;
+                I.Mt[(size_t)i * 64 + lane] = mt;
+            }
             if constexpr (LDS) {
                 if (cl < 4) {
                     lds_f64* t = I.lds_kt + i * kKtStage + rg * 4 + cl;
@@ -380,13 +390,20 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
     AdjIn s;
     s.ba = get_ba<LDS>(I, i);
     const double* dxn = I.dxb + (size_t)(i + 1) * 12;
-    const double* xn = I.x + (size_t)(i + 1) * 12;
-    const double* yn = I.yref + (size_t)(i + 1) * 16;
-#pragma unroll
-    for (int r = 0; r < 3; r++) { s.dx[r] = dxn[I.rg + 4 * r]; s.xn[r] = xn[I.rg + 4 * r]; s.yn[r] = yn[I.rg + 4 * r]; }
     s.v = varr[i * 4 + I.rg];
-    s.u = I.u[i * 4 + I.rg];
-    s.ur = I.yref[(size_t)i * 16 + 12 + I.rg];
+    if constexpr (LDS) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) { s.dx[r] = dxn[I.rg + 4 * r]; s.xn[r] = I.lds_q[(i + 1) * 12 + I.rg + 4 * r]; s.yn[r] = 0.0; }
+        s.u = I.lds_r[i * 4 + I.rg];
+        s.ur = 0.0;
+    } else {
+        const double* xn = I.x + (size_t)(i + 1) * 12;
+        const double* yn = I.yref + (size_t)(i + 1) * 16;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { s.dx[r] = dxn[I.rg + 4 * r]; s.xn[r] = xn[I.rg + 4 * r]; s.yn[r] = yn[I.rg + 4 * r]; }
+        s.u = I.u[i * 4 + I.rg];
+        s.ur = I.yref[(size_t)i * 16 + 12 + I.rg];
+    }
     return s;
 }
 // adjoint recursion for the state steps in I.dxb and inputs varr:
@@ -406,13 +423,13 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const double qd = (i + 1 == N) ? I.Wer[r] : I.Ts * I.Wr[r];
-            pi[r] = qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
+            pi[r] = LDS ? qd * in.dx[r] + in.xn[r] + atpi[r] : qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
         }
         pi[3] = 0.0;
         if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
         d4 G = tn<3>(in.ba, pi, z4);
         const double rd = I.Ts * I.Wr[3];
-        if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
+        if (cl == 0) garr[i * 4 + rg] = LDS ? rd * in.v + in.u + G[3] : rd * in.v + rd * (in.u - in.ur) + G[3];
         atpi = G;
     }
     wave_fence();
@@ -462,12 +479,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     for (int j = lane; j < nv; j += 64) {
         const int m = j & 3;
         GAM[j] = 0.0;
-        RT[j] = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+        RT[j] = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
     }
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false;
-    bool ok = riccati_backward<true, LDS>(I);
+    bool ok = riccati_backward<true, LDS, false>(I);
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
@@ -517,7 +534,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const double gm = ll / tl + lu / tu;
                     GAM[j] = gm;
                     const int m = j & 3;
-                    const double rr = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+                    const double rr = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
                     RT[j] = rr - gm * V[j];
                 }
                 mu = wave_sum(s) * inv2nv;
@@ -552,7 +569,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                     const double cl_ = dll * dv, cu_ = -dlu * dv;
                     const int m = j & 3;
-                    const double rr = P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+                    const double rr = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
                     RT[j] = rr - GAM[j] * V[j] - (smu - cl_) / tl + (smu - cu_) / tu;
                 }
                 (void)riccati_backward<false, LDS>(I);
@@ -677,6 +694,9 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.Ts = P.Ts;
     I.lds_ba = nullptr;
     I.lds_bv = nullptr;
+    I.lds_kt = nullptr;
+    I.lds_q = nullptr;
+    I.lds_r = nullptr;
     // cst = [W16 | We12 pad4 | lbu4 | ubu4]
 #pragma unroll
     for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
@@ -726,6 +746,8 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     double* kff_s = kt_s + (size_t)N * kKtStage;  // [N][4]
     double* vh_s = kff_s + (size_t)N * 4;         // [N][4]
     double* dx_s = vh_s + (size_t)N * 4;          // [N+1][12]
+    double* q_s = dx_s + (size_t)(N + 1) * NX;    // [N+1][12] cost gradient w.r.t. x (row N = terminal)
+    double* r_s = q_s + (size_t)(N + 1) * NX;     // [N][4]    cost gradient w.r.t. u
     // ---- preparation: ERK4 + sensitivities.  L = 64/N lanes per interval (3 at N = 20); each lane integrates the state
     // once (stage points stay in registers) and then walks its share of the 13 non-trivial sensitivity columns; columns
     // land in LDS, so the scattered 8-byte writes that ruled this mapping out for the HBM-streaming kernel cost nothing.
@@ -749,6 +771,16 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
         rk4_state(xi, w, m, P.Ts, sp, xn);
         double* tb = ba_s + i * kBaStage;
         if (active && j0 == 0) {
+            // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps
+            const double* __restrict__ yr = P.yref + (size_t)b * P.yref_stride + (size_t)i * NY;
+#pragma unroll
+            for (int k = 0; k < NX; k++) q_s[i * NX + k] = P.Ts * cst[k] * (xi[k] - yr[k]);
+#pragma unroll
+            for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yr[NX + k]);
+            if (i == N - 1) {
+#pragma unroll
+                for (int k = 0; k < NX; k++) q_s[N * NX + k] = cst[16 + k] * (xi[NX + k] - yr[NY + k]);
+            }
             // position columns are exactly e_c; lane 0 of the group also owns b_i and their stationarity rows
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -787,6 +819,8 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     I.lds_ba = (const lds_f64*)ba_s;
     I.lds_bv = (const lds_f64*)bv_s;
     I.lds_kt = (lds_f64*)kt_s;
+    I.lds_q = (const lds_f64*)q_s;
+    I.lds_r = (const lds_f64*)r_s;
     I.kff = kff_s;   // generic pointers into LDS: feed-forward terms, candidate inputs and state steps never leave the CU
     I.vhat = vh_s;
     I.dxb = dx_s;
@@ -802,7 +836,7 @@ void launch_qp(const DevParams& P, hipStream_t st) {
 bool fused_supported(int N) { return N <= kFusedMaxN; }
 
 void launch_fused(const DevParams& P, hipStream_t st) {
-    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4) + (size_t)(P.N + 1) * NX) * sizeof(double);
+    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
