@@ -174,7 +174,7 @@ struct BwdIn {
     double ks, mt;        // stored factors (only !FACTOR)
 };
 
-template <bool FACTOR, bool LDS>
+template <bool FACTOR, bool LDS, bool STEP0 = false>
 __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* gam, const double* rt) {
     BwdIn s;
     s.ba = get_ba<LDS>(I, i);
@@ -188,8 +188,14 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
 #pragma unroll
         for (int r = 0; r < 3; r++) { s.xv[r] = xi[I.rg + 4 * r]; s.yv[r] = yi[I.rg + 4 * r]; }
     }
-    s.rtv = rt[i * 4 + I.rg];
-    s.gm = FACTOR ? gam[i * 4 + I.rg] : 0.0;
+    if constexpr (STEP0) {  // Gamma = 0, rhs = r_i: no IPM arrays involved
+        if constexpr (LDS) s.rtv = I.lds_r[i * 4 + I.rg];
+        else s.rtv = I.Ts * I.Wr[3] * (I.u[i * 4 + I.rg] - I.yref[(size_t)i * 16 + 12 + I.rg]);
+        s.gm = 0.0;
+    } else {
+        s.rtv = rt[i * 4 + I.rg];
+        s.gm = FACTOR ? gam[i * 4 + I.rg] : 0.0;
+    }
     s.ks = FACTOR ? 0.0 : I.Ks[(size_t)i * 64 + I.lane];
     s.mt = FACTOR ? 0.0 : I.Mt[(size_t)i * 64 + I.lane];
     return s;
@@ -198,13 +204,13 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
 // backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
 // not positive definite.
-template <bool FACTOR, bool LDS, bool STORE_IPM = true>
+template <bool FACTOR, bool LDS, bool STORE_IPM = true, bool STEP0 = false>
 __device__ bool riccati_backward(const Inst& I) {
     const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
     wave_fence();
-    BwdIn nx = load_bwd<FACTOR, LDS>(I, N - 1, gam, rt);
+    BwdIn nx = load_bwd<FACTOR, LDS, STEP0>(I, N - 1, gam, rt);
     d4 P = {0, 0, 0, 0}, pv;
     {
         const double* xN = I.x + (size_t)N * 12;
@@ -222,7 +228,7 @@ __device__ bool riccati_backward(const Inst& I) {
     const d4 z4 = {0, 0, 0, 0};
     for (int i = N - 1; i >= 0; i--) {
         const BwdIn in = nx;
-        if (i > 0) nx = load_bwd<FACTOR, LDS>(I, i - 1, gam, rt);
+        if (i > 0) nx = load_bwd<FACTOR, LDS, STEP0>(I, i - 1, gam, rt);
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
@@ -476,29 +482,42 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     }
 
     // ---- step 0: equality-constrained minimiser (Gamma = 0, rhs = r) ---------------------------------------
-    for (int j = lane; j < nv; j += 64) {
-        const int m = j & 3;
-        GAM[j] = 0.0;
-        RT[j] = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+    // fused path: this lane's share of u (needed for the bound check right after the forward sweep) is requested now
+    double ureg[2] = {0.0, 0.0};
+    if constexpr (LDS) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            if (lane + 64 * t < nv) ureg[t] = I.u[lane + 64 * t];
     }
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false;
-    bool ok = riccati_backward<true, LDS, false>(I);
+    bool ok = riccati_backward<true, LDS, false, true>(I);
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
         riccati_forward<LDS>(I, d0);
         bool feas = true;
-        for (int j = lane; j < nv; j += 64) {
-            const int m = j & 3;
-            const double vj = I.vhat[j], lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
-            if (!(vj >= lb && vj <= ub)) feas = false;
+        if constexpr (LDS) {  // nv <= 92: two elements per lane, u already in registers
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int j = lane + 64 * t;
+                if (j < nv) {
+                    const int m = j & 3;
+                    const double vj = I.vhat[j], lb = cst[32 + m] - ureg[t], ub = cst[36 + m] - ureg[t];
+                    if (!(vj >= lb && vj <= ub)) feas = false;
+                }
+            }
+        } else {
+            for (int j = lane; j < nv; j += 64) {
+                const int m = j & 3;
+                const double vj = I.vhat[j], lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
+                if (!(vj >= lb && vj <= ub)) feas = false;
+            }
         }
         const bool allfeas = (__ballot(!feas) == 0ull);
         if (allfeas && P.early_exit) {
-            early = true;
-            for (int j = lane; j < nv; j += 64) V[j] = I.vhat[j];
+            early = true;  // the accepted inputs stay where the forward sweep left them (I.vhat)
         } else {
             // interior start: clamp into the box, multipliers from mu0 = stationarity residual of the clamped point
             for (int j = lane; j < nv; j += 64) {
@@ -613,38 +632,78 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     }
 
     // ---- finalise: consistent primal/dual for the final inputs, multiplier recovery, full step ---------------
+    // Element loops issue all their loads before the first use (UX/UU elements per lane per chunk): at one wave per SIMD
+    // every dependent global round trip is otherwise fully exposed (~2 us each).
+    constexpr int UX = LDS ? 5 : 4, UU = LDS ? 2 : 4;
+    const double* vfin = early ? I.vhat : V;
+    const int nxe = (N + 1) * 12;
     double cost = 0.0;
+    bool wrote_u0 = false;
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
         if (!early) rollout<LDS>(I, d0, V);  // early exit: dxb already holds the states of the accepted Newton point
-        adjoint<true, LDS>(I, V, DVA, pi_it);
+        adjoint<true, LDS>(I, vfin, DVA, pi_it);
         bool nanv = false;
         for (int j = lane; j < nv; j += 64) {
-            const double vj = V[j];
+            const double vj = vfin[j];
             if (!(vj == vj)) nanv = true;
         }
-        for (int j = lane; j < (N + 1) * 12; j += 64) {
+        for (int j = lane; j < nxe; j += 64) {
             const double dj = I.dxb[j];
             if (!(dj == dj)) nanv = true;
         }
         if (__ballot(nanv) != 0ull) {
             status = BROV_STATUS_NAN;
         } else {
-            for (int j = lane; j < nv; j += 64) {
-                const int i = j >> 2, m = j & 3;
-                const double g = early ? 0.0 : DVA[j];
-                lam_it[i * 8 + m] = g > 0 ? g : 0.0;
-                lam_it[i * 8 + 4 + m] = g < 0 ? -g : 0.0;
-                const double un = u_it[j] + V[j];
-                u_it[j] = un;
-                const double e = un - I.yref[(size_t)i * 16 + 12 + m];
-                cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+            for (int j0 = lane; j0 < nv; j0 += 64 * UU) {
+                double uo[UU], vv[UU], gg[UU], ur[UU];
+#pragma unroll
+                for (int t = 0; t < UU; t++) {
+                    const int j = j0 + 64 * t;
+                    const bool in = j < nv;
+                    const int jj = in ? j : 0;
+                    uo[t] = (LDS && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
+                    vv[t] = vfin[jj];
+                    gg[t] = early ? 0.0 : DVA[jj];
+                    ur[t] = I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
+                }
+#pragma unroll
+                for (int t = 0; t < UU; t++) {
+                    const int j = j0 + 64 * t;
+                    if (j < nv) {
+                        const int i = j >> 2, m = j & 3;
+                        lam_it[i * 8 + m] = gg[t] > 0 ? gg[t] : 0.0;
+                        lam_it[i * 8 + 4 + m] = gg[t] < 0 ? -gg[t] : 0.0;
+                        const double un = uo[t] + vv[t];
+                        u_it[j] = un;
+                        if (j < 4) P.res[b].u0[j] = un;
+                        const double e = un - ur[t];
+                        cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+                    }
+                }
             }
-            for (int j = lane; j < (N + 1) * 12; j += 64) {
-                const int i = j / 12, c = j - i * 12;
-                const double xn = x_it[j] + I.dxb[j];
-                x_it[j] = xn;
-                const double e = xn - I.yref[(size_t)i * 16 + c];
-                cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+            wrote_u0 = true;
+            for (int j0 = lane; j0 < nxe; j0 += 64 * UX) {
+                double xo[UX], dj[UX], yr[UX];
+#pragma unroll
+                for (int t = 0; t < UX; t++) {
+                    const int j = j0 + 64 * t;
+                    const int jj = j < nxe ? j : 0;
+                    const int i = jj / 12, c = jj - i * 12;
+                    xo[t] = x_it[jj];
+                    dj[t] = I.dxb[jj];
+                    yr[t] = I.yref[(size_t)i * 16 + c];
+                }
+#pragma unroll
+                for (int t = 0; t < UX; t++) {
+                    const int j = j0 + 64 * t;
+                    if (j < nxe) {
+                        const int i = j / 12, c = j - i * 12;
+                        const double xn = xo[t] + dj[t];
+                        x_it[j] = xn;
+                        const double e = xn - yr[t];
+                        cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+                    }
+                }
             }
         }
     }
@@ -655,7 +714,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             const double e = u_it[j] - I.yref[(size_t)i * 16 + 12 + m];
             cost += 0.5 * P.Ts * cst[12 + m] * e * e;
         }
-        for (int j = lane; j < (N + 1) * 12; j += 64) {
+        for (int j = lane; j < nxe; j += 64) {
             const int i = j / 12, c = j - i * 12;
             const double e = x_it[j] - I.yref[(size_t)i * 16 + c];
             cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
@@ -669,9 +728,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         r->status = status;
         r->qp_iter = early ? 0 : iters;
     }
-    wave_fence();
-    if (lane < 4) P.res[b].u0[lane] = u_it[lane];
+    if (!wrote_u0 && lane < 4) P.res[b].u0[lane] = u_it[lane];
 }
+
 
 __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane) {
     const int N = P.N, nv = 4 * N;
