@@ -8,8 +8,8 @@ hydrodynamic parameters; the reference window advances one row per step and is s
 rank (one process per GPU, torch.distributed / RCCL) owns its own 4096 instances (weak scaling); the only collective is
 the all-gather of the 56-byte result records, issued every step when G > 1.
 
-Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel = qp_kernel, bound
-= FP64 MFMA) and `cpu_baseline` (the C oracle timed on the host cores; the oracle is never the thing measured as `value`).
+Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel: rti_fused_kernel on
+the default path -- linearisation + QP of one instance per wavefront, stage blocks in LDS; bound = FP64 MFMA) and `cpu_baseline` (the C oracle timed on the host cores; the oracle is never the thing measured as `value`).
 """
 import argparse
 import json
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ipm", action="store_true", help="qp_early_exit=0 as the headline variant")
     ap.add_argument("--force-gather", action="store_true", help="run the result all-gather even with one rank")
+    ap.add_argument("--path", type=int, default=0, help="0 auto (fused when the horizon fits LDS), 1 streaming, 2 fused")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +129,7 @@ def main():
     K, W = args.steps, args.warmup
 
     def make_solver(early_exit):
-        s = ba.BatchSolver(B, ba.SolverOptions(N, TS, qp_early_exit=early_exit), device=local_rank)
+        s = ba.BatchSolver(B, ba.SolverOptions(N, TS, qp_early_exit=early_exit, kernel_path=args.path), device=local_rank)
         x0, circ = synthetic_inputs(B, seed=1 + 1000 * rank)
         s.set_x0(x0)
         s.set_params(ba.P_NOMINAL)
@@ -186,8 +187,14 @@ def main():
     if rank == 0:
         qp_fl = qp_flops(res2["qp_iter"], N)
         lin_fl = B * N * F_LIN
-        dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_kernel"
-        dom_fl, dom_t = (qp_fl, ksec[1]) if dom == "qp_kernel" else (lin_fl, ksec[0])
+        fused = s.last_kernel_path() == ba.PATH_FUSED
+        if fused:  # one kernel does both phases
+            dom, dom_fl, dom_t = "rti_fused_kernel", qp_fl + lin_fl, ksec[1]
+            kernel_ms = {"rti_fused_kernel": ksec[1] * 1e3}
+        else:
+            dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_kernel"
+            dom_fl, dom_t = (qp_fl, ksec[1]) if dom == "qp_kernel" else (lin_fl, ksec[0])
+            kernel_ms = {"lin_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3}
         achieved = dom_fl / dom_t / 1e12
         alg_bytes = 8 * (12 + 16 * (N + 1) + 16 * (N + 1) + 2 * (12 * (N + 1) + 4 * N)) + 56
         traffic = None
@@ -212,7 +219,7 @@ def main():
                        "all-gather of 56 B result records" if world > 1 else "single GPU"},
             "solver_status_nonzero": n_bad,
             "mean_qp_iter": float(res2["qp_iter"].mean()),
-            "kernel_ms": {"lin_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3},
+            "kernel_ms": kernel_ms,
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "algorithmic_flops_per_launch": dom_fl,

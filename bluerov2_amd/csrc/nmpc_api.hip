@@ -39,6 +39,10 @@ struct brov_solver {
            *dxb = nullptr, *cst = nullptr;
     brov_result* res = nullptr;
     int* best = nullptr;
+    double* traj = nullptr;
+    int traj_rows = 0;
+    double* scratch3 = nullptr;  // [3][B] candidate parameters
+    int* lines = nullptr;        // [B]
     size_t bytes = 0;
     std::vector<void*> allocs;
     hipStream_t last_stream = nullptr;
@@ -144,6 +148,8 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(cst, 40);
     AL(res, Bz);
     AL(best, 2);
+    AL(scratch3, 3 * Bz);
+    AL(lines, Bz);
 #undef AL
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
     // create defaults: yref = 0, p = 0, x0 = [0,0,-20,0..] (acados_solver_bluerov2.c:355-364, 405-420, 520-527)
@@ -168,6 +174,7 @@ extern "C" void brov_destroy(brov_solver* s) {
     if (!s) return;
     hipSetDevice(s->device);
     for (void* p : s->allocs) hipFree(p);
+    if (s->traj) hipFree(s->traj);
     for (int k = 0; k < 3; k++)
         if (s->ev[k]) hipEventDestroy(s->ev[k]);
     delete s;
@@ -248,6 +255,60 @@ extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, con
         s->yref_shared = false;
     }
     HIPCHK(hipMemcpy(s->yref + ((size_t)inst * (s->N + 1) + stage) * 16, y, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
+    return BROV_OK;
+}
+
+extern "C" int brov_traj_set_host(brov_solver* s, const double* traj, int rows) {
+    if (!s || !traj || rows < 1) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (s->traj) { hipFree(s->traj); s->traj = nullptr; }
+    HIPCHK(hipMalloc((void**)&s->traj, (size_t)rows * 16 * sizeof(double)));
+    HIPCHK(hipMemcpy(s->traj, traj, (size_t)rows * 16 * sizeof(double), hipMemcpyHostToDevice));
+    s->traj_rows = rows;
+    return BROV_OK;
+}
+extern "C" int brov_traj_rows(const brov_solver* s) { return s ? s->traj_rows : 0; }
+extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void* stream) {
+    if (!s || !s->traj || (ncols != 12 && ncols != 16)) { g_err = "brov_set_yref_from_traj: no trajectory or bad ncols"; return BROV_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    launch_window(s->traj, s->traj_rows, nullptr, line, 1, s->N, ncols, s->yref_sh, (hipStream_t)stream);
+    s->yref_shared = true;
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t* lines, int ncols) {
+    if (!s || !s->traj || !lines || (ncols != 12 && ncols != 16)) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpy(s->lines, lines, (size_t)s->B * sizeof(int), hipMemcpyHostToDevice));
+    launch_window(s->traj, s->traj_rows, s->lines, 0, s->B, s->N, ncols, s->yref, nullptr);
+    s->yref_shared = false;
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase,
+                                             double t0, double dt) {
+    if (!s || !p0 || !p1 || !phase || kind < 0 || kind > 1) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const size_t nb = (size_t)s->B * sizeof(double);
+    HIPCHK(hipMemcpy(s->scratch3, p0, nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->scratch3 + s->B, p1, nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->scratch3 + 2 * (size_t)s->B, phase, nb, hipMemcpyHostToDevice));
+    launch_candidates(kind, s->scratch3, s->scratch3 + s->B, s->scratch3 + 2 * (size_t)s->B, t0, dt, s->B, s->N, s->yref, nullptr);
+    s->yref_shared = false;
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_get_yref_host(brov_solver* s, double* yref) {
+    if (!s || !yref) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t per = (size_t)(s->N + 1) * 16;
+    if (s->yref_shared) {
+        for (int b = 0; b < s->B; b++) HIPCHK(hipMemcpy(yref + (size_t)b * per, s->yref_sh, per * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        HIPCHK(hipMemcpy(yref, s->yref, per * s->B * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return BROV_OK;
 }
 
@@ -345,6 +406,7 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return BROV_OK;
 }
+extern "C" int brov_last_kernel_path(const brov_solver* s) { return s ? (s->last_fused ? BROV_PATH_FUSED : BROV_PATH_STREAMING) : BROV_ERR_ARG; }
 extern "C" int brov_enable_timing(brov_solver* s, int on) { if (!s) return BROV_ERR_ARG; s->timing = on != 0; s->ev_valid = false; return BROV_OK; }
 extern "C" int brov_last_solve_seconds(brov_solver* s, double* total, double* k2) {
     if (!s || !s->ev_valid) return BROV_ERR_ARG;

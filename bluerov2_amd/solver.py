@@ -82,11 +82,14 @@ def _load():
         "brov_set_param_stage_host": [vp, C.c_int, C.c_int, dp],
         "brov_set_yref_stage_host": [vp, C.c_int, C.c_int, dp, C.c_int],
         "brov_set_iterate_host": [vp, dp, dp, dp, dp], "brov_get_iterate_host": [vp, dp, dp, dp, dp],
-        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
+        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_last_kernel_path": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
         "brov_get_results_host": [vp, vp], "brov_get_u0_host": [vp, dp],
         "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
         "brov_get_thrusts_host": [vp, dp], "brov_last_solve_seconds": [vp, dp, dp], "brov_enable_timing": [vp, C.c_int],
         "brov_selftest_tile_tn": [dp, dp, dp, dp, C.c_int],
+        "brov_traj_set_host": [vp, dp, C.c_int], "brov_traj_rows": [vp], "brov_set_yref_from_traj": [vp, C.c_int, C.c_int, vp],
+        "brov_set_yref_from_traj_lines_host": [vp, C.POINTER(C.c_int32), C.c_int],
+        "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double], "brov_get_yref_host": [vp, dp],
     }.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -207,6 +210,34 @@ class BatchSolver:
     def set_params_device(self, ptr, per_stage, stream=0):
         self._chk(self._L.brov_set_params_device(self._h, C.c_void_p(ptr), int(bool(per_stage)), C.c_void_p(stream)), "set_params_device")
 
+    # ---- reference windows built on the device (bluerov2_path.cpp:79-118 semantics) ---------------------------
+    def set_trajectory(self, traj):
+        traj = np.ascontiguousarray(traj, dtype=np.float64)
+        if traj.ndim != 2 or traj.shape[1] != NY:
+            raise ValueError("trajectory must be [rows][16]")
+        self._chk(self._L.brov_traj_set_host(self._h, _dp(traj), traj.shape[0]), "set_trajectory")
+
+    def set_yref_from_trajectory(self, line, ncols=16, stream=0):
+        """line: int -> one shared window; array[B] -> per-instance windows"""
+        if np.ndim(line) == 0:
+            self._chk(self._L.brov_set_yref_from_traj(self._h, int(line), int(ncols), C.c_void_p(stream)), "set_yref_from_traj")
+        else:
+            lines = np.ascontiguousarray(line, dtype=np.int32)
+            if lines.shape != (self.B,):
+                raise ValueError("lines must be [B]")
+            self._chk(self._L.brov_set_yref_from_traj_lines_host(self._h, lines.ctypes.data_as(C.POINTER(C.c_int32)), int(ncols)),
+                      "set_yref_from_traj_lines")
+
+    def set_yref_candidates(self, kind, p0, p1, phase, t0=0.0, dt=0.05):
+        k = {"lemniscate": 0, "circle": 1}[kind]
+        a, b, c = (_arr(v, (self.B,)) for v in (p0, p1, phase))
+        self._chk(self._L.brov_set_yref_candidates_host(self._h, k, _dp(a), _dp(b), _dp(c), float(t0), float(dt)), "set_yref_candidates")
+
+    def get_yref(self):
+        y = np.empty((self.B, self.N + 1, NY))
+        self._chk(self._L.brov_get_yref_host(self._h, _dp(y)), "get_yref")
+        return y
+
     # ---- iterate ----------------------------------------------------------------------------------------------
     def set_iterate(self, x=None, u=None, pi=None, lam=None):
         B, N = self.B, self.N
@@ -264,6 +295,9 @@ class BatchSolver:
 
     def enable_timing(self, on=True):
         self._chk(self._L.brov_enable_timing(self._h, int(on)), "enable_timing")
+
+    def last_kernel_path(self):
+        return int(self._L.brov_last_kernel_path(self._h))
 
     def last_solve_seconds(self):
         tot, k2 = C.c_double(0), (C.c_double * 2)()

@@ -110,6 +110,23 @@ int brov_set_params_device(brov_solver* s, const double* p, int per_stage, void*
 int brov_set_param_stage_host(brov_solver* s, int instance, int stage, const double* p16);
 int brov_set_yref_stage_host(brov_solver* s, int instance, int stage, const double* y, int ny);
 
+/* ---- reference windows built on the device (the step before the path: bluerov2_path/src/bluerov2_path.cpp:79-118,
+ * bluerov2_dobmpc/src/bluerov2_dob.cpp:218-265).  A trajectory table [rows][16] (the reference's txt format: x y z phi theta
+ * psi u v w p q r u1..u4, one row per 0.05 s) is kept in HBM; node i of a window that starts at `line` is row
+ * min(line + i, rows - 1).  ncols = 16 copies whole rows (DOB node), ncols = 12 leaves the input reference at zero (CTRL
+ * node, ctrller/mpc.cpp:242-262). */
+int brov_traj_set_host(brov_solver* s, const double* traj /*[rows][16]*/, int rows);
+int brov_traj_rows(const brov_solver* s);
+int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void* stream);                       /* one shared window */
+int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t* lines /*[B]*/, int ncols);     /* per instance      */
+/* analytic per-instance candidate windows (bluerov2_path/config/traj/lemniscate.py:18-39, circle.py:22-56 evaluated at
+ * t0 + i*dt with per-instance shape parameters and phase): kind 0 lemniscate (p0 = amplitude, p1 = frequency),
+ * kind 1 circle (p0 = radius, p1 = speed) */
+int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase /*[B]*/,
+                                  double t0, double dt);
+/* read back the reference windows currently in force, as [B][N+1][16] (shared windows are replicated) */
+int brov_get_yref_host(brov_solver* s, double* yref);
+
 /* iterate (warm start) access; any pointer may be NULL to skip that block */
 int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam);
 int brov_get_iterate_host(brov_solver* s, double* x, double* u, double* pi, double* lam);
@@ -150,6 +167,8 @@ int brov_get_thrusts_host(brov_solver* s, double* t6 /*[B][6]*/);
 /* timing of the last brov_solve (HIP events on its stream), seconds: total and per kernel [linearise, qp] */
 int brov_last_solve_seconds(brov_solver* s, double* total, double* kernels2);
 int brov_enable_timing(brov_solver* s, int on);
+/* which kernels the last brov_solve launched: BROV_PATH_FUSED or BROV_PATH_STREAMING */
+int brov_last_kernel_path(const brov_solver* s);
 
 #ifdef __cplusplus
 }

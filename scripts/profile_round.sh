@@ -16,4 +16,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o w -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -o s -- python $R/bench.py --no-cpu-baseline --steps 10 > /dev/null 2> $OUT/pmc_sq.err
 python $R/bench.py --force-ipm --no-cpu-baseline > $OUT/bench_forced_ipm.json 2> $OUT/bench_forced_ipm.err
+python $R/bench.py --path 1 --no-cpu-baseline > $OUT/bench_streaming.json 2> $OUT/bench_streaming.err
+python $R/bench.py --batch 16384 --no-cpu-baseline > $OUT/bench_b16384.json 2> $OUT/bench_b16384.err
 ls -R $OUT | head -40
