@@ -42,6 +42,8 @@ struct brov_solver {
     double* traj = nullptr;
     int traj_rows = 0;
     double* scratch3 = nullptr;  // [3][B] candidate parameters
+    double* pplant = nullptr;    // [B][16] true plant parameters
+    bool pplant_set = false;
     int* lines = nullptr;        // [B]
     size_t bytes = 0;
     std::vector<void*> allocs;
@@ -150,6 +152,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(best, 2);
     AL(scratch3, 3 * Bz);
     AL(lines, Bz);
+    AL(pplant, Bz * 16);
 #undef AL
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
     // create defaults: yref = 0, p = 0, x0 = [0,0,-20,0..] (acados_solver_bluerov2.c:355-364, 405-420, 520-527)
@@ -310,6 +313,79 @@ extern "C" int brov_get_yref_host(brov_solver* s, double* yref) {
         HIPCHK(hipMemcpy(yref, s->yref, per * s->B * sizeof(double), hipMemcpyDeviceToHost));
     }
     return BROV_OK;
+}
+
+__global__ void copy_stage0_par_kernel(const double* __restrict__ par, double* __restrict__ pp, int B, int N1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B * 16) pp[t] = par[(size_t)(t >> 4) * N1 * 16 + (t & 15)];
+}
+__global__ void gather_status_kernel(const brov_result* __restrict__ res, int* __restrict__ out, int B) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B) out[t] = res[t].status;
+}
+extern "C" int brov_plant_set_params_host(brov_solver* s, const double* p) {
+    if (!s || !p) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpy(s->pplant, p, (size_t)s->B * 16 * sizeof(double), hipMemcpyHostToDevice));
+    s->pplant_set = true;
+    return BROV_OK;
+}
+static int ensure_plant_params(brov_solver* s, hipStream_t st) {
+    if (!s->pplant_set) {  // default: the plant is the controller's model (stage-0 parameters)
+        hipLaunchKernelGGL(copy_stage0_par_kernel, dim3((s->B * 16 + 255) / 256), dim3(256), 0, st, s->par, s->pplant, s->B, s->N + 1);
+        s->pplant_set = true;
+    }
+    return BROV_OK;
+}
+extern "C" int brov_plant_step(brov_solver* s, double dt, int substeps, void* stream) {
+    if (!s || !(dt > 0.0) || substeps < 1) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    ensure_plant_params(s, (hipStream_t)stream);
+    launch_plant(s->x0, s->res, s->pplant, s->B, dt, substeps, nullptr, nullptr, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_get_x0_host(brov_solver* s, double* x0) {
+    if (!s || !x0) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x0, s->x0, (size_t)s->B * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols, double dt, int substeps, double* u_log, double* x_log,
+                                int32_t* st_log) {
+    if (!s || ticks < 1 || !s->traj || (ncols != 12 && ncols != 16) || !(dt > 0.0) || substeps < 1) {
+        g_err = "brov_closed_loop: bad argument (needs a trajectory table, see brov_traj_set_host)";
+        return BROV_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = s->last_stream;
+    const size_t B = s->B;
+    double *dx = nullptr, *du = nullptr;
+    int* dst = nullptr;
+    if (x_log) HIPCHK(hipMalloc((void**)&dx, (size_t)(ticks + 1) * B * 12 * sizeof(double)));
+    if (u_log) HIPCHK(hipMalloc((void**)&du, (size_t)ticks * B * 4 * sizeof(double)));
+    if (st_log) HIPCHK(hipMalloc((void**)&dst, (size_t)ticks * B * sizeof(int)));
+    ensure_plant_params(s, st);
+    if (dx) HIPCHK(hipMemcpyAsync(dx, s->x0, B * 12 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    int rc = BROV_OK;
+    for (int k = 0; k < ticks && rc == BROV_OK; k++) {
+        launch_window(s->traj, s->traj_rows, nullptr, line0 + k, 1, s->N, ncols, s->yref_sh, st);
+        s->yref_shared = true;
+        rc = brov_solve_phase(s, st, 0);
+        if (dst) hipLaunchKernelGGL(gather_status_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, s->res, dst + (size_t)k * B, (int)B);
+        launch_plant(s->x0, s->res, s->pplant, s->B, dt, substeps, dx ? dx + (size_t)(k + 1) * B * 12 : nullptr,
+                     du ? du + (size_t)k * B * 4 : nullptr, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (rc == BROV_OK && e != hipSuccess) { g_err = hipGetErrorString(e); rc = BROV_ERR_HIP; }
+    if (rc == BROV_OK && dx) hipMemcpy(x_log, dx, (size_t)(ticks + 1) * B * 12 * sizeof(double), hipMemcpyDeviceToHost);
+    if (rc == BROV_OK && du) hipMemcpy(u_log, du, (size_t)ticks * B * 4 * sizeof(double), hipMemcpyDeviceToHost);
+    if (rc == BROV_OK && dst) hipMemcpy(st_log, dst, (size_t)ticks * B * sizeof(int), hipMemcpyDeviceToHost);
+    if (dx) hipFree(dx);
+    if (du) hipFree(du);
+    if (dst) hipFree(dst);
+    return rc;
 }
 
 extern "C" int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam) {

@@ -58,6 +58,8 @@ void launch_qp(const DevParams& P, hipStream_t st);
 void launch_fused(const DevParams& P, hipStream_t st);  // linearise + QP in one kernel, stage blocks in LDS
 bool fused_supported(int N);
 void launch_window(const double* traj, int rows, const int* lines, int line0, int B, int N, int ncols, double* out, hipStream_t st);
+void launch_plant(double* x0, const brov_result* res, const double* pplant, int B, double dt, int substeps, double* xlog, double* ulog,
+                  hipStream_t st);
 void launch_candidates(int kind, const double* p0, const double* p1, const double* phase, double t0, double dt, int B, int N,
                        double* out, hipStream_t st);
 

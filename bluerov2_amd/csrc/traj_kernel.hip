@@ -73,3 +73,56 @@ void launch_candidates(int kind, const double* p0, const double* p1, const doubl
 }
 
 }  // namespace brov
+
+// ---- the step immediately AFTER the hot path: plant update for closed-loop Monte-Carlo roll-outs ------
+// x0 <- ERK4(x0, u0, p_plant, dt): the same 12-state model the OCP uses (bluerov2.py:103-137) integrated over one control
+// period with the first optimal input of the last solve, per-instance TRUE parameters (disturbance draw, model mismatch).
+// One lane per instance; ~600 FP64 ops, 240 B in / 96 B out.
+#include "bluerov2_model.hpp"
+namespace brov {
+
+__global__ void plant_kernel(double* __restrict__ x0, const brov_result* __restrict__ res, const double* __restrict__ pplant, int B,
+                             double dt, int substeps, double* __restrict__ xlog, double* __restrict__ ulog) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[NX], u[NU], k[NX], xs[NX], acc[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) x[j] = x0[(size_t)b * NX + j];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = res[b].u0[j];
+    const ModelPar m = make_par(pplant + (size_t)b * NP);
+    const Wrench w = make_wrench(u);
+    const double h = dt / substeps;
+    StagePoint sp;
+    for (int s = 0; s < substeps; s++) {
+        model_f(x, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) { acc[j] = x[j] + (h / 6.0) * k[j]; xs[j] = x[j] + 0.5 * h * k[j]; }
+        model_f(xs, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * k[j]; xs[j] = x[j] + 0.5 * h * k[j]; }
+        model_f(xs, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * k[j]; xs[j] = x[j] + h * k[j]; }
+        model_f(xs, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) x[j] = acc[j] + (h / 6.0) * k[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) x0[(size_t)b * NX + j] = x[j];
+    if (xlog) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) xlog[(size_t)b * NX + j] = x[j];
+    }
+    if (ulog) {
+#pragma unroll
+        for (int j = 0; j < NU; j++) ulog[(size_t)b * NU + j] = u[j];
+    }
+}
+
+void launch_plant(double* x0, const brov_result* res, const double* pplant, int B, double dt, int substeps, double* xlog, double* ulog,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(plant_kernel, dim3((B + 127) / 128), dim3(128), 0, st, x0, res, pplant, B, dt, substeps, xlog, ulog);
+}
+
+}  // namespace brov

@@ -87,6 +87,8 @@ def _load():
         "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
         "brov_get_thrusts_host": [vp, dp], "brov_last_solve_seconds": [vp, dp, dp], "brov_enable_timing": [vp, C.c_int],
         "brov_selftest_tile_tn": [dp, dp, dp, dp, C.c_int],
+        "brov_plant_set_params_host": [vp, dp], "brov_plant_step": [vp, C.c_double, C.c_int, vp], "brov_get_x0_host": [vp, dp],
+        "brov_closed_loop": [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int32)],
         "brov_traj_set_host": [vp, dp, C.c_int], "brov_traj_rows": [vp], "brov_set_yref_from_traj": [vp, C.c_int, C.c_int, vp],
         "brov_set_yref_from_traj_lines_host": [vp, C.POINTER(C.c_int32), C.c_int],
         "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double], "brov_get_yref_host": [vp, dp],
@@ -237,6 +239,30 @@ class BatchSolver:
         y = np.empty((self.B, self.N + 1, NY))
         self._chk(self._L.brov_get_yref_host(self._h, _dp(y)), "get_yref")
         return y
+
+    # ---- closed loop on the device ---------------------------------------------------------------
+    def set_plant_params(self, p):
+        self._chk(self._L.brov_plant_set_params_host(self._h, _dp(_arr(p, (self.B, NP)))), "set_plant_params")
+
+    def plant_step(self, dt=0.05, substeps=1, stream=0):
+        self._chk(self._L.brov_plant_step(self._h, float(dt), int(substeps), C.c_void_p(stream)), "plant_step")
+
+    def get_x0(self):
+        x0 = np.empty((self.B, NX))
+        self._chk(self._L.brov_get_x0_host(self._h, _dp(x0)), "get_x0")
+        return x0
+
+    def closed_loop(self, ticks, line0=0, ncols=16, dt=0.05, substeps=1, log=True):
+        """ticks x (window -> RTI step -> plant step) on the device; returns (u_log, x_log, status_log) or None"""
+        if not log:
+            self._chk(self._L.brov_closed_loop(self._h, int(ticks), int(line0), int(ncols), float(dt), int(substeps), None, None, None),
+                      "closed_loop")
+            return None
+        ul, xl = np.empty((ticks, self.B, NU)), np.empty((ticks + 1, self.B, NX))
+        sl = np.empty((ticks, self.B), dtype=np.int32)
+        self._chk(self._L.brov_closed_loop(self._h, int(ticks), int(line0), int(ncols), float(dt), int(substeps), _dp(ul), _dp(xl),
+                                           sl.ctypes.data_as(C.POINTER(C.c_int32))), "closed_loop")
+        return ul, xl, sl
 
     # ---- iterate ----------------------------------------------------------------------------------------------
     def set_iterate(self, x=None, u=None, pi=None, lam=None):

@@ -127,6 +127,20 @@ int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, co
 /* read back the reference windows currently in force, as [B][N+1][16] (shared windows are replicated) */
 int brov_get_yref_host(brov_solver* s, double* yref);
 
+/* ---- closed-loop roll-outs on the device (the step after the path): plant update + reference advance ------------------
+ * Plant = the OCP's own 12-state model (bluerov2.py:103-137) integrated with ERK4 over one control period with u0 of the
+ * last solve and per-instance TRUE parameters (Monte-Carlo disturbance draws / model mismatch); the thrusters see
+ * bluerov2_dob.cpp:390-395's allocation of that u0 (brov_get_thrusts_host). */
+int brov_plant_set_params_host(brov_solver* s, const double* p /*[B][16]*/);
+int brov_plant_step(brov_solver* s, double dt, int substeps, void* stream);   /* x0 <- ERK4(x0, u0, p_plant, dt) */
+/* `ticks` control ticks entirely on the device: window(line0 + k) -> RTI step -> plant step; like the nodes, the window
+ * advances one trajectory row per tick (bluerov2_dob.cpp:367-368) and the iterate is not shifted.  Optional HOST logs:
+ * u_log [ticks][B][4] (applied inputs), x_log [ticks+1][B][12] (plant state before the first and after every tick),
+ * st_log [ticks][B] (solver status). */
+int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols, double dt, int substeps, double* u_log, double* x_log,
+                     int32_t* st_log);
+int brov_get_x0_host(brov_solver* s, double* x0 /*[B][12]*/);
+
 /* iterate (warm start) access; any pointer may be NULL to skip that block */
 int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam);
 int brov_get_iterate_host(brov_solver* s, double* x, double* u, double* pi, double* lam);
