@@ -119,6 +119,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_gather:
+        # RCCL writes its debug/warn lines to stdout; keep them away from the one JSON line this script must print
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -237,11 +239,12 @@ def main():
                                   "records_gathered": int(allrec.numel() // D.RECORD_BYTES)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, K, W)
-    if rank == 0:
-        print(json.dumps(out))
     s.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.write("\n" + json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
