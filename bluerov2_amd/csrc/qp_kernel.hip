@@ -470,8 +470,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             d0[r] = x0[rg + 4 * r] - I.x[rg + 4 * r];
-            const double a = fabs(d0[r]);
-            kkt = (a != a) ? a : fmax(kkt, a);
+            kkt_upd(kkt, d0[r]);  // NaN-poisoning max (lin_device.hpp)
         }
         d0[3] = 0.0;
         double part = lin_part;
