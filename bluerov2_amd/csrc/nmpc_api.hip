@@ -52,6 +52,7 @@ struct brov_solver {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool ev_valid = false;
     bool last_fused = false;
+    unsigned long long* dbg = nullptr;
 };
 
 extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
@@ -437,6 +438,7 @@ static DevParams make_params(const brov_solver* s) {
     P.BA = s->BA; P.BAt = s->BAt; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
+    P.dbg = s->dbg;
     return P;
 }
 
@@ -483,6 +485,16 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
     return BROV_OK;
 }
 extern "C" int brov_last_kernel_path(const brov_solver* s) { return s ? (s->last_fused ? BROV_PATH_FUSED : BROV_PATH_STREAMING) : BROV_ERR_ARG; }
+// developer hook (not in the public header): per-instance phase timestamps of the last solve, 8 x uint64 per instance
+extern "C" int brov_debug_phase_stamps(brov_solver* s, int enable, unsigned long long* out_host) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (enable && !s->dbg) { HIPCHK(hipMalloc((void**)&s->dbg, (size_t)s->B * 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(s->dbg, 0, (size_t)s->B * 64)); }
+    if (out_host && s->dbg) HIPCHK(hipMemcpy(out_host, s->dbg, (size_t)s->B * 64, hipMemcpyDeviceToHost));
+    if (!enable && s->dbg) { hipFree(s->dbg); s->dbg = nullptr; }
+    return BROV_OK;
+}
 extern "C" int brov_enable_timing(brov_solver* s, int on) { if (!s) return BROV_ERR_ARG; s->timing = on != 0; s->ev_valid = false; return BROV_OK; }
 extern "C" int brov_last_solve_seconds(brov_solver* s, double* total, double* k2) {
     if (!s || !s->ev_valid) return BROV_ERR_ARG;

@@ -49,6 +49,7 @@ struct DevParams {
     double* dxb;    // [B][N+1][12] QP primal step of the states
     const double* cst;  // [W16 | We12 pad4 | lbu4 | ubu4]
     brov_result* res;
+    unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_NARR };

@@ -81,6 +81,8 @@ struct Inst {
     lds_f64* lds_kt;        // fused path: gain transposed, compact [N][12][4]
     const lds_f64* lds_q;   // fused path: cost gradient q_i = s_i W (x_i - xref_i), [N+1][12] (terminal row N)
     const lds_f64* lds_r;   // fused path: r_i = Ts Wu (u_i - uref_i), [N][4]
+    lds_f64 *lds_kff, *lds_vhat, *lds_dxb;  // fused path: same arrays as kff/vhat/dxb, typed as LDS so that the sweeps
+                                            // issue ds_* instead of flat_*
     double Ts;
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
     double Wer[3];  // We[row]
@@ -104,6 +106,10 @@ __device__ __forceinline__ d4 load_vec12(const double* v, int rg) {
     return t;
 }
 __device__ __forceinline__ void store_vec12(double* v, const d4& t, int rg, int cl) {
+    if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
+}
+
+__device__ __forceinline__ void store_vec12_lds(lds_f64* v, const d4& t, int rg, int cl) {
     if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
 }
 
@@ -303,7 +309,7 @@ __device__ bool riccati_backward(const Inst& I) {
                 double* kt = I.Kt + (size_t)i * 192;
                 kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
             }
-            if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
+            if (cl == 0) { if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else I.kff[i * 4 + rg] = -kf[0]; }
             P = S;
             pv = pn;
             pv[3] = 0.0;
@@ -314,7 +320,7 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 g = tn<3>(in.ba, l, qr);
             d4 kf = tn1(in.mt, g[3], z4);
             d4 pn = tn1(in.ks, g[3], g);
-            if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
+            if (cl == 0) { if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else I.kff[i * 4 + rg] = -kf[0]; }
             pv = pn;
             pv[3] = 0.0;
         }
@@ -335,7 +341,7 @@ __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
     }
     s.bat = get_bat<LDS>(I, i);
     s.bb = get_bv<LDS>(I, i);
-    s.kf = I.kff[i * 4 + I.rg];
+    if constexpr (LDS) s.kf = I.lds_kff[i * 4 + I.rg]; else s.kf = I.kff[i * 4 + I.rg];
     return s;
 }
 
@@ -347,17 +353,17 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
     wave_fence();
     FwdIn nx = load_fwd<LDS>(I, 0);
     d4 xx = d0;
-    store_vec12(I.dxb, xx, rg, cl);
+    if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
         const FwdIn in = nx;
         if (i + 1 < N) nx = load_fwd<LDS>(I, i + 1);
         d4 c = {in.kf, 0, 0, 0};
         d4 v = tn<3>(in.kt, xx, c);
-        if (cl == 0) I.vhat[i * 4 + rg] = v[0];
+        if (cl == 0) { if constexpr (LDS) I.lds_vhat[i * 4 + rg] = v[0]; else I.vhat[i * 4 + rg] = v[0]; }
         d4 z = {xx[0], xx[1], xx[2], v[0]};
         xx = tn<4>(in.bat, z, in.bb);
         xx[3] = 0.0;
-        store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+        if constexpr (LDS) store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl); else store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
     }
     wave_fence();
 }
@@ -368,7 +374,7 @@ __device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* 
     RollIn s;
     s.bat = get_bat<LDS>(I, i);
     s.bb = get_bv<LDS>(I, i);
-    s.v = varr[i * 4 + I.rg];
+    if constexpr (LDS) s.v = I.lds_vhat[i * 4 + I.rg]; else s.v = varr[i * 4 + I.rg];  // LDS path: inputs always staged in vhat
     return s;
 }
 // roll the linearised dynamics out for the inputs in varr -> I.dxb
@@ -378,14 +384,14 @@ __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
     wave_fence();
     RollIn nx = load_roll<LDS>(I, 0, varr);
     d4 xx = d0;
-    store_vec12(I.dxb, xx, rg, cl);
+    if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
         const RollIn in = nx;
         if (i + 1 < N) nx = load_roll<LDS>(I, i + 1, varr);
         d4 z = {xx[0], xx[1], xx[2], in.v};
         xx = tn<4>(in.bat, z, in.bb);
         xx[3] = 0.0;
-        store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+        if constexpr (LDS) store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl); else store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
     }
     wave_fence();
 }
@@ -396,10 +402,11 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
     AdjIn s;
     s.ba = get_ba<LDS>(I, i);
     const double* dxn = I.dxb + (size_t)(i + 1) * 12;
-    s.v = varr[i * 4 + I.rg];
+    if constexpr (LDS) s.v = I.lds_vhat[i * 4 + I.rg]; else s.v = varr[i * 4 + I.rg];
     if constexpr (LDS) {
+        const lds_f64* dxl = I.lds_dxb + (i + 1) * 12;
 #pragma unroll
-        for (int r = 0; r < 3; r++) { s.dx[r] = dxn[I.rg + 4 * r]; s.xn[r] = I.lds_q[(i + 1) * 12 + I.rg + 4 * r]; s.yn[r] = 0.0; }
+        for (int r = 0; r < 3; r++) { s.dx[r] = dxl[I.rg + 4 * r]; s.xn[r] = I.lds_q[(i + 1) * 12 + I.rg + 4 * r]; s.yn[r] = 0.0; }
         s.u = I.lds_r[i * 4 + I.rg];
         s.ur = 0.0;
     } else {
@@ -415,6 +422,8 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
 // adjoint recursion for the state steps in I.dxb and inputs varr:
 //   pi_i = Qd_{i+1} dx_{i+1} + q_{i+1} + A_{i+1}' pi_{i+1};   g_i = Rd v_i + r_i + B_i' pi_i  -> garr[N*4]
 // With COMMIT the multipliers pi are written to pi_out (the iterate).
+// LDS path: both outputs go to LDS regions that are dead at this point (g -> the feed-forward array, pi -> the K^T array,
+// 12 of its 48 doubles per stage); per-stage global stores would sit on vmcnt in front of every prefetch wait.
 template <bool COMMIT, bool LDS>
 __device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
@@ -432,10 +441,17 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
             pi[r] = LDS ? qd * in.dx[r] + in.xn[r] + atpi[r] : qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
         }
         pi[3] = 0.0;
-        if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
+        if constexpr (LDS) {
+            if (COMMIT) store_vec12_lds(I.lds_kt + i * 12, pi, rg, cl);
+        } else {
+            if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
+        }
         d4 G = tn<3>(in.ba, pi, z4);
         const double rd = I.Ts * I.Wr[3];
-        if (cl == 0) garr[i * 4 + rg] = LDS ? rd * in.v + in.u + G[3] : rd * in.v + rd * (in.u - in.ur) + G[3];
+        if (cl == 0) {
+            if constexpr (LDS) I.lds_kff[i * 4 + rg] = rd * in.v + in.u + G[3];
+            else garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
+        }
         atpi = G;
     }
     wave_fence();
@@ -443,10 +459,14 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
 
 // everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
 // lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
+// developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
+#define DBG_STAMP(slot) do { if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+
 template <bool LDS>
 __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan) {
     const double* __restrict__ cst = P.cst;
     const int lane = I.lane, N = I.N, nv = I.nv;
+    DBG_STAMP(1);
     const int rg = I.rg;
 
     double* x_it = P.x + (size_t)b * (N + 1) * 12;
@@ -461,6 +481,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     double* GAM = I.ipm + (size_t)IPM_GAM * nv;
     double* RT = I.ipm + (size_t)IPM_RT * nv;
     double* DVA = I.ipm + (size_t)IPM_DVA * nv;
+    // where adjoint<> leaves the input gradient g: HBM array, or (fused path) the dead feed-forward array in LDS
+    const double* GRAD = LDS ? (const double*)I.kff : (const double*)DVA;
 
     // d0 = x0 - x_0, row-replicated; KKT of the entering iterate = max(LIN partials, |d0|)
     d4 d0;
@@ -492,10 +514,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     double mu = 0.0, rho = 0.0;
     bool early = false;
     bool ok = riccati_backward<true, LDS, false, true>(I);
+    DBG_STAMP(2);
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
         riccati_forward<LDS>(I, d0);
+        DBG_STAMP(3);
         bool feas = true;
         if constexpr (LDS) {  // nv <= 92: two elements per lane, u already in registers
 #pragma unroll
@@ -528,18 +552,19 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 vj = (vj < lo) ? lo : vj;
                 vj = (vj > hi) ? hi : vj;
                 V[j] = vj; TL[j] = vj - lb; TU[j] = ub - vj;
+                if constexpr (LDS) I.vhat[j] = vj;  // roll-out / adjoint read their inputs from the LDS copy
             }
             rollout<LDS>(I, d0, V);
             adjoint<false, LDS>(I, V, DVA, nullptr);
             double g0 = 0.0;
-            for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(DVA[j]));
+            for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(GRAD[j]));
             g0 = wave_max(g0);
             const double mu0 = fmax(g0, 1e-4);
             double r0 = 0.0;
             for (int j = lane; j < nv; j += 64) {
                 const double ll = mu0 / TL[j], lu = mu0 / TU[j];
                 LL[j] = ll; LU[j] = lu;
-                r0 = fmax(r0, fabs(DVA[j] - ll + lu));
+                r0 = fmax(r0, fabs(GRAD[j] - ll + lu));
             }
             rho = wave_max(r0);
             status = BROV_STATUS_MAXITER;
@@ -639,8 +664,13 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     double cost = 0.0;
     bool wrote_u0 = false;
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
-        if (!early) rollout<LDS>(I, d0, V);  // early exit: dxb already holds the states of the accepted Newton point
+        if (!early) {  // early exit: dxb already holds the states of the accepted Newton point
+            if constexpr (LDS) { for (int j = lane; j < nv; j += 64) I.vhat[j] = V[j]; }
+            rollout<LDS>(I, d0, V);
+        }
+        DBG_STAMP(4);
         adjoint<true, LDS>(I, vfin, DVA, pi_it);
+        DBG_STAMP(5);
         bool nanv = false;
         for (int j = lane; j < nv; j += 64) {
             const double vj = vfin[j];
@@ -662,7 +692,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const int jj = in ? j : 0;
                     uo[t] = (LDS && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
                     vv[t] = vfin[jj];
-                    gg[t] = early ? 0.0 : DVA[jj];
+                    gg[t] = early ? 0.0 : GRAD[jj];
                     ur[t] = I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
                 }
 #pragma unroll
@@ -681,6 +711,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
             wrote_u0 = true;
+            if constexpr (LDS) {  // multipliers staged in LDS by adjoint<>: [N][12] at the head of the K^T array
+                for (int j = lane; j < N * 12; j += 64) pi_it[j] = I.lds_kt[j];
+            }
             for (int j0 = lane; j0 < nxe; j0 += 64 * UX) {
                 double xo[UX], dj[UX], yr[UX];
 #pragma unroll
@@ -728,6 +761,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         r->qp_iter = early ? 0 : iters;
     }
     if (!wrote_u0 && lane < 4) P.res[b].u0[lane] = u_it[lane];
+    DBG_STAMP(6);
 }
 
 
@@ -755,6 +789,9 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.lds_kt = nullptr;
     I.lds_q = nullptr;
     I.lds_r = nullptr;
+    I.lds_kff = nullptr;
+    I.lds_vhat = nullptr;
+    I.lds_dxb = nullptr;
     // cst = [W16 | We12 pad4 | lbu4 | ubu4]
 #pragma unroll
     for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
@@ -797,6 +834,7 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     const int lane = threadIdx.x;
     const int N = P.N;
     const double* __restrict__ cst = P.cst;
+    DBG_STAMP(0);
     // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
     double* ba_s = smem;                          // [N][12][13]
     double* bv_s = ba_s + (size_t)N * kBaStage;   // [N][12]
@@ -879,9 +917,12 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     I.lds_kt = (lds_f64*)kt_s;
     I.lds_q = (const lds_f64*)q_s;
     I.lds_r = (const lds_f64*)r_s;
-    I.kff = kff_s;   // generic pointers into LDS: feed-forward terms, candidate inputs and state steps never leave the CU
-    I.vhat = vh_s;
+    I.kff = kff_s;   // generic pointers into LDS (element loops): feed-forward terms, candidate inputs and state steps
+    I.vhat = vh_s;   // never leave the CU; the sweeps use the LDS-typed aliases below
     I.dxb = dx_s;
+    I.lds_kff = (lds_f64*)kff_s;
+    I.lds_vhat = (lds_f64*)vh_s;
+    I.lds_dxb = (lds_f64*)dx_s;
     qp_body<true>(P, I, b, part, nanp);
 }
 
