@@ -81,6 +81,11 @@ struct Inst {
     lds_f64* lds_kt;        // fused path: gain transposed, compact [N][12][4]
     const lds_f64* lds_q;   // fused path: cost gradient q_i = s_i W (x_i - xref_i), [N+1][12] (terminal row N)
     const lds_f64* lds_r;   // fused path: r_i = Ts Wu (u_i - uref_i), [N][4]
+    // per-lane element offsets into lds_ba for the three tile images (stage 0) and their per-stage strides: lanes whose
+    // element is a structural constant (0 or 1) point at two constant slots with stride 0, so that a tile register is
+    // ONE ds_read with an address known before the loop -- no select on the loaded value, which would pull the
+    // s_waitcnt of a prefetch to the load itself
+    int ba_off[3], ba_str, bat_off[4], bat_str, bat_str0, kt_off[3], kt_str;
     lds_f64 *lds_kff, *lds_vhat, *lds_dxb;  // fused path: same arrays as kff/vhat/dxb, typed as LDS so that the sweeps
                                             // issue ds_* instead of flat_*
     double Ts;
@@ -124,11 +129,8 @@ constexpr int kKtStage = NX * 4;          // K^T compact [12][4] per stage
 template <bool LDS>
 __device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: rows k = rg+4r (0..11), cols c = cl
     if constexpr (LDS) {
-        const int cc = I.cl >= 3 ? I.cl - 3 : 0;
-        const lds_f64* t = I.lds_ba + i * kBaStage + I.rg * kBaStride + cc;
-        d4 r = {t[0], t[4 * kBaStride], t[8 * kBaStride], 0.0};
-        if (I.cl < 3) r = d4{(I.rg == I.cl) ? 1.0 : 0.0, 0.0, 0.0, 0.0};  // rows rg, rg+4, rg+8 of e_cl (cl < 3)
-        return r;
+        const lds_f64* t = I.lds_ba + i * I.ba_str;
+        return d4{t[I.ba_off[0]], t[I.ba_off[1]], t[I.ba_off[2]], 0.0};
     } else {
         return load_tile3(I.BA + (size_t)i * 192, I.lane);
     }
@@ -136,13 +138,8 @@ __device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: ro
 template <bool LDS>
 __device__ __forceinline__ d4 get_bat(const Inst& I, int i) {  // [A B]^T image: rows c = rg+4r (0..15), cols k = cl (< 12)
     if constexpr (LDS) {
-        const int k = I.cl < NX ? I.cl : 0;
-        const lds_f64* t = I.lds_ba + i * kBaStage + k * kBaStride + I.rg;  // column c = rg + 4r is stored at c - 3
-        d4 r;
-        r[0] = (I.rg == 3) ? t[-3] : ((I.rg == I.cl) ? 1.0 : 0.0);  // c = rg: stored (index 0) only for rg == 3, else e_c
-        r[1] = t[1]; r[2] = t[5]; r[3] = t[9];                      // c = rg+4, rg+8, rg+12 -> offsets c - 3 - rg
-        if (I.cl >= NX) r = d4{0, 0, 0, 0};
-        return r;
+        const lds_f64* t = I.lds_ba + i * I.bat_str;
+        return d4{I.lds_ba[i * I.bat_str0 + I.bat_off[0]], t[I.bat_off[1]], t[I.bat_off[2]], t[I.bat_off[3]]};
     } else {
         return load_tile4(I.BAt + (size_t)i * 256, I.lane);
     }
@@ -333,9 +330,8 @@ template <bool LDS>
 __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
     FwdIn s;
     if constexpr (LDS) {
-        const lds_f64* t = I.lds_kt + i * kKtStage + I.rg * 4 + (I.cl & 3);
-        s.kt = d4{t[0], t[16], t[32], 0.0};
-        if (I.cl >= 4) s.kt = d4{0, 0, 0, 0};
+        const lds_f64* t = I.lds_ba + i * I.kt_str;  // offsets are relative to the start of the LDS slice
+        s.kt = d4{t[I.kt_off[0]], t[I.kt_off[1]], t[I.kt_off[2]], 0.0};
     } else {
         s.kt = load_tile3(I.Kt + (size_t)i * 192, I.lane);
     }
@@ -844,6 +840,8 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     double* dx_s = vh_s + (size_t)N * 4;          // [N+1][12]
     double* q_s = dx_s + (size_t)(N + 1) * NX;    // [N+1][12] cost gradient w.r.t. x (row N = terminal)
     double* r_s = q_s + (size_t)(N + 1) * NX;     // [N][4]    cost gradient w.r.t. u
+    double* const_s = r_s + (size_t)N * 4;        // {0.0, 1.0}: targets of structurally constant tile elements
+    if (lane == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
     // ---- preparation: ERK4 + sensitivities.  L = 64/N lanes per interval (3 at N = 20); each lane integrates the state
     // once (stage points stay in registers) and then walks its share of the 13 non-trivial sensitivity columns; columns
     // land in LDS, so the scattered 8-byte writes that ruled this mapping out for the HBM-streaming kernel cost nothing.
@@ -923,6 +921,24 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     I.lds_kff = (lds_f64*)kff_s;
     I.lds_vhat = (lds_f64*)vh_s;
     I.lds_dxb = (lds_f64*)dx_s;
+    {
+        const int rg = I.rg, cl = I.cl;
+        const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
+        // [A B] image: element (k = rg+4r, c = cl) lives at k*13 + c-3 for c >= 3; columns 0..2 are e_c
+        for (int r = 0; r < 3; r++) I.ba_off[r] = cl >= 3 ? (rg + 4 * r) * kBaStride + cl - 3 : ((r == 0 && rg == cl) ? one : zero);
+        I.ba_str = cl >= 3 ? kBaStage : 0;
+        // [A B]^T image: element (c = rg+4r, k = cl) = [A B](k, c); k >= 12 is padding, c < 3 is e_c
+        for (int r = 0; r < 4; r++) {
+            const int c = rg + 4 * r;
+            I.bat_off[r] = cl >= NX ? zero : (c >= 3 ? cl * kBaStride + c - 3 : (c == cl ? one : zero));
+        }
+        // lanes cl < 12 read real elements in registers 1..3; register 0 (c = rg) is real only for rg == 3, else e_c
+        I.bat_str = cl >= NX ? 0 : kBaStage;
+        I.bat_str0 = (cl < NX && rg == 3) ? kBaStage : 0;
+        // K^T compact [12][4]: element (c = rg+4r, m = cl < 4)
+        for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
+        I.kt_str = cl < 4 ? kKtStage : 0;
+    }
     qp_body<true>(P, I, b, part, nanp);
 }
 
@@ -935,7 +951,7 @@ void launch_qp(const DevParams& P, hipStream_t st) {
 bool fused_supported(int N) { return N <= kFusedMaxN; }
 
 void launch_fused(const DevParams& P, hipStream_t st) {
-    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX) * sizeof(double);
+    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX + 2) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
