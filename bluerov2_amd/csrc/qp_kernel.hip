@@ -86,7 +86,7 @@ struct Inst {
     // ONE ds_read with an address known before the loop -- no select on the loaded value, which would pull the
     // s_waitcnt of a prefetch to the load itself
     int ba_off[3], ba_str, bat_off[4], bat_str, bat_str0, kt_off[3], kt_str;
-    lds_f64 *lds_kff, *lds_vhat, *lds_dxb;  // fused path: same arrays as kff/vhat/dxb, typed as LDS so that the sweeps
+    lds_f64 *lds_kff, *lds_vhat, *lds_dxb, *lds_zero;  // fused path: same arrays as kff/vhat/dxb, typed as LDS so that the sweeps
                                             // issue ds_* instead of flat_*
     double Ts;
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
@@ -114,8 +114,12 @@ __device__ __forceinline__ void store_vec12(double* v, const d4& t, int rg, int 
     if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
 }
 
+// row-replicated vector -> LDS.  All 16 lanes of a row hold the same value and all of them store it (same address, same
+// data): an exec-masked `if (cl == 0)` store becomes a branch, and the compiler then degrades every later lgkmcnt wait in
+// the loop to lgkmcnt(0), exposing the LDS write latency once per stage.
 __device__ __forceinline__ void store_vec12_lds(lds_f64* v, const d4& t, int rg, int cl) {
-    if (cl == 0) { v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2]; }
+    (void)cl;
+    v[rg] = t[0]; v[rg + 4] = t[1]; v[rg + 8] = t[2];
 }
 
 // ---- where the per-stage linearisation lives -------------------------------------------------------------------------
@@ -298,15 +302,16 @@ __device__ bool riccati_backward(const Inst& I) {
                 I.Mt[(size_t)i * 64 + lane] = mt;
             }
             if constexpr (LDS) {
-                if (cl < 4) {
-                    lds_f64* t = I.lds_kt + i * kKtStage + rg * 4 + cl;
-                    t[0] = KtT[0]; t[16] = KtT[1]; t[32] = KtT[2];
-                }
+                // lanes cl >= 4 hold structural zeros of K^T; they rewrite lane (cl & 3)'s slot ... with different data, so they
+                // are parked on the constant-zero slot instead (writes 0.0 over 0.0)
+                lds_f64* t = (cl < 4) ? I.lds_kt + i * kKtStage + rg * 4 + cl : I.lds_zero;
+                const int st = (cl < 4) ? 16 : 0;
+                t[0] = (cl < 4) ? KtT[0] : 0.0; t[st] = (cl < 4) ? KtT[1] : 0.0; t[2 * st] = (cl < 4) ? KtT[2] : 0.0;
             } else {
                 double* kt = I.Kt + (size_t)i * 192;
                 kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
             }
-            if (cl == 0) { if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else I.kff[i * 4 + rg] = -kf[0]; }
+            if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
             P = S;
             pv = pn;
             pv[3] = 0.0;
@@ -317,7 +322,7 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 g = tn<3>(in.ba, l, qr);
             d4 kf = tn1(in.mt, g[3], z4);
             d4 pn = tn1(in.ks, g[3], g);
-            if (cl == 0) { if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else I.kff[i * 4 + rg] = -kf[0]; }
+            if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
             pv = pn;
             pv[3] = 0.0;
         }
@@ -355,7 +360,7 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
         if (i + 1 < N) nx = load_fwd<LDS>(I, i + 1);
         d4 c = {in.kf, 0, 0, 0};
         d4 v = tn<3>(in.kt, xx, c);
-        if (cl == 0) { if constexpr (LDS) I.lds_vhat[i * 4 + rg] = v[0]; else I.vhat[i * 4 + rg] = v[0]; }
+        if constexpr (LDS) I.lds_vhat[i * 4 + rg] = v[0]; else if (cl == 0) I.vhat[i * 4 + rg] = v[0];
         d4 z = {xx[0], xx[1], xx[2], v[0]};
         xx = tn<4>(in.bat, z, in.bb);
         xx[3] = 0.0;
@@ -444,10 +449,8 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
         }
         d4 G = tn<3>(in.ba, pi, z4);
         const double rd = I.Ts * I.Wr[3];
-        if (cl == 0) {
-            if constexpr (LDS) I.lds_kff[i * 4 + rg] = rd * in.v + in.u + G[3];
-            else garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
-        }
+        if constexpr (LDS) I.lds_kff[i * 4 + rg] = rd * in.v + in.u + G[3];
+        else if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
         atpi = G;
     }
     wave_fence();
@@ -788,6 +791,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.lds_kff = nullptr;
     I.lds_vhat = nullptr;
     I.lds_dxb = nullptr;
+    I.lds_zero = nullptr;
     // cst = [W16 | We12 pad4 | lbu4 | ubu4]
 #pragma unroll
     for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
@@ -921,6 +925,7 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     I.lds_kff = (lds_f64*)kff_s;
     I.lds_vhat = (lds_f64*)vh_s;
     I.lds_dxb = (lds_f64*)dx_s;
+    I.lds_zero = (lds_f64*)const_s;
     {
         const int rg = I.rg, cl = I.cl;
         const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
