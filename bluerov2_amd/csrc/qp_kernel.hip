@@ -357,14 +357,34 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
         const FwdIn in = nx;
-        if (i + 1 < N) nx = load_fwd<LDS>(I, i + 1);
-        d4 c = {in.kf, 0, 0, 0};
-        d4 v = tn<3>(in.kt, xx, c);
-        if constexpr (LDS) I.lds_vhat[i * 4 + rg] = v[0]; else if (cl == 0) I.vhat[i * 4 + rg] = v[0];
-        d4 z = {xx[0], xx[1], xx[2], v[0]};
-        xx = tn<4>(in.bat, z, in.bb);
-        xx[3] = 0.0;
-        if constexpr (LDS) store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl); else store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+        if constexpr (LDS) {
+            // branch-free body (the prefetch index is clamped, the last one is redundant) so that the whole stage is one
+            // scheduling region, then ask for the independent work -- next stage's LDS reads, address arithmetic, the
+            // register hand-over -- to be issued in the shadow of the dependent MFMA chain instead of in front of it
+            nx = load_fwd<LDS>(I, i + 1 < N ? i + 1 : N - 1);
+            d4 c = {in.kf, 0, 0, 0};
+            d4 v = tn<3>(in.kt, xx, c);
+            I.lds_vhat[i * 4 + rg] = v[0];
+            d4 z = {xx[0], xx[1], xx[2], v[0]};
+            xx = tn<4>(in.bat, z, in.bb);
+            xx[3] = 0.0;
+            store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // 5 VALU
+            }
+        } else {
+            if (i + 1 < N) nx = load_fwd<LDS>(I, i + 1);
+            d4 c = {in.kf, 0, 0, 0};
+            d4 v = tn<3>(in.kt, xx, c);
+            if (cl == 0) I.vhat[i * 4 + rg] = v[0];
+            d4 z = {xx[0], xx[1], xx[2], v[0]};
+            xx = tn<4>(in.bat, z, in.bb);
+            xx[3] = 0.0;
+            store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+        }
     }
     wave_fence();
 }

@@ -24,3 +24,6 @@ tot = (st[:, 6] - st[:, 0]).astype(np.int64)
 print("cycles per wave (median over instances): total", int(np.median(tot)))
 for n, col in zip(names, d.T):
     print(f"  {n:14s} {int(np.median(col)):8d}  ({100*np.median(col)/np.median(tot):.1f} %)")
+
+w = st[:, 7]
+print("fwd-detail (stage 5): v-chain", int(np.median(w & 0xFFFFF)), "x-chain", int(np.median((w >> 20) & 0xFFFFF)), "end-of-stage5 -> end-of-stage6", int(np.median((w >> 40) & 0xFFFFF)))
