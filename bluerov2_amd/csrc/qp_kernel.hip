@@ -235,7 +235,8 @@ __device__ bool riccati_backward(const Inst& I) {
     const d4 z4 = {0, 0, 0, 0};
     for (int i = N - 1; i >= 0; i--) {
         const BwdIn in = nx;
-        if (i > 0) nx = load_bwd<FACTOR, LDS, STEP0>(I, i - 1, gam, rt);
+        if constexpr (LDS) nx = load_bwd<FACTOR, LDS, STEP0>(I, i > 0 ? i - 1 : 0, gam, rt);  // clamped: one scheduling region
+        else if (i > 0) nx = load_bwd<FACTOR, LDS, STEP0>(I, i - 1, gam, rt);
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
@@ -408,11 +409,20 @@ __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     for (int i = 0; i < N; i++) {
         const RollIn in = nx;
-        if (i + 1 < N) nx = load_roll<LDS>(I, i + 1, varr);
+        if constexpr (LDS) nx = load_roll<LDS>(I, i + 1 < N ? i + 1 : N - 1, varr);
+        else if (i + 1 < N) nx = load_roll<LDS>(I, i + 1, varr);
         d4 z = {xx[0], xx[1], xx[2], in.v};
         xx = tn<4>(in.bat, z, in.bb);
         xx[3] = 0.0;
         if constexpr (LDS) store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl); else store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+        if constexpr (LDS) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        }
     }
     wave_fence();
 }
@@ -454,7 +464,8 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
     const d4 z4 = {0, 0, 0, 0};
     for (int i = N - 1; i >= 0; i--) {
         const AdjIn in = nx;
-        if (i > 0) nx = load_adj<LDS>(I, i - 1, varr);
+        if constexpr (LDS) nx = load_adj<LDS>(I, i > 0 ? i - 1 : 0, varr);
+        else if (i > 0) nx = load_adj<LDS>(I, i - 1, varr);
         d4 pi;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -472,6 +483,14 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
         if constexpr (LDS) I.lds_kff[i * 4 + rg] = rd * in.v + in.u + G[3];
         else if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
         atpi = G;
+        if constexpr (LDS) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
+            }
+        }
     }
     wave_fence();
 }
