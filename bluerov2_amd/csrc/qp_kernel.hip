@@ -261,24 +261,24 @@ __device__ bool riccati_backward(const Inst& I) {
             const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
             const double a30 = readlane_f64(H[3], 60), a31 = readlane_f64(H[3], 61), a32 = readlane_f64(H[3], 62),
                          a33 = readlane_f64(H[3], 63);
-            // LDL^T, then M = Huu^-1 = L^-T D^-1 L^-1 (all lanes redundantly; values are wave-uniform)
-            const double d0 = a00, i0 = fast_rcp(d0);
-            const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-            const double d1 = a11 - l10 * a10, i1 = fast_rcp(d1);
-            const double w21 = a21 - l20 * a10, w31 = a31 - l30 * a10;
-            const double l21 = w21 * i1, l31 = w31 * i1;
-            const double d2 = a22 - l20 * a20 - l21 * w21, i2 = fast_rcp(d2);
-            const double w32 = a32 - l30 * a20 - l31 * w21;
-            const double l32 = w32 * i2;
-            const double d3 = a33 - l30 * a30 - l31 * w31 - l32 * w32, i3 = fast_rcp(d3);
-            if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
-            const double n10 = -l10, n21 = -l21, n32 = -l32;
-            const double n20 = -l20 - l21 * n10, n31 = -l31 - l32 * n21;
-            const double n30 = -l30 - l31 * n10 - l32 * n20;
-            const double m33 = i3, m32 = n32 * i3, m31 = n31 * i3, m30 = n30 * i3;
-            const double m22 = i2 + n32 * m32, m21 = n21 * i2 + n32 * m31, m20 = n20 * i2 + n32 * m30;
-            const double m11 = i1 + n21 * (n21 * i2) + n31 * m31, m10 = n10 * i1 + n21 * (n20 * i2) + n31 * m30;
-            const double m00 = i0 + n10 * (n10 * i1) + n20 * (n20 * i2) + n30 * m30;
+            // M = Huu^-1 by 2x2 block elimination (all lanes redundantly; the values are wave-uniform):
+            //   Huu = [E F; F' G],  X = E^-1 F,  Sc = G - F'X,  M22 = Sc^-1,  M12 = -X M22,  M11 = E^-1 - M12 X'
+            // Two reciprocals in sequence instead of the four of an LDL^T: this algebra is the serial critical path of
+            // every Riccati stage (~26 dependent FP64 operations instead of ~48).  SPD <=> e00, det E, s00, det Sc > 0.
+            const double detE = a00 * a11 - a10 * a10, iE = fast_rcp(detE);
+            const double e00 = a11 * iE, e01 = -a10 * iE, e11 = a00 * iE;           // E^-1
+            // F = [a20 a30; a21 a31]^T block: rows 0,1 x cols 2,3 -> F = [[a20, a30], [a21, a31]]
+            const double x00 = e00 * a20 + e01 * a21, x01 = e00 * a30 + e01 * a31;   // X = E^-1 F
+            const double x10 = e01 * a20 + e11 * a21, x11 = e01 * a30 + e11 * a31;
+            const double s00 = a22 - (a20 * x00 + a21 * x10), s01 = a32 - (a20 * x01 + a21 * x11);
+            const double s11 = a33 - (a30 * x01 + a31 * x11);                          // Sc = G - F'X
+            const double detS = s00 * s11 - s01 * s01, iS = fast_rcp(detS);
+            const double m22 = s11 * iS, m32 = -s01 * iS, m33 = s00 * iS;            // M22 = Sc^-1
+            const double m20 = -(x00 * m22 + x01 * m32), m30 = -(x00 * m32 + x01 * m33);  // M12' (rows 2,3 x cols 0,1)
+            const double m21 = -(x10 * m22 + x11 * m32), m31 = -(x10 * m32 + x11 * m33);
+            const double m00 = e00 - (m20 * x00 + m30 * x01), m10 = e01 - (m20 * x10 + m30 * x11);
+            const double m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
+            if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
             // Mtile: lane (rg = m, cl = n < 4) = M[m][n]
             double mt = 0.0;
             {
