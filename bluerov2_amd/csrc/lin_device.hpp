@@ -120,6 +120,106 @@ __device__ __forceinline__ void sens_column(StagePoint (&sp)[4], const ModelPar&
     for (int j = 0; j < NX; j++) acc[j] += (h / 6.0) * ks[j];
 }
 
+// ---- fused kernel: stage records in LDS -----------------------------------------------------------------------------------
+// The fused kernel runs one wave per SIMD; its column loop is bound by instruction issue, and with the four stage points
+// in registers the loop body exceeds the 256 architectural VGPRs (every use then pays v_accvgpr moves).  There the stage
+// points live in LDS instead: 17 doubles per RK stage = the 13 StagePoint values + the four velocity-damping diagonal
+// entries of df/dx (which removes the model parameters from the loop).
+typedef __attribute__((address_space(3))) double lds_f64;
+constexpr int kRecStage = 17, kRecInterval = 4 * kRecStage;
+
+__device__ __forceinline__ void store_stage_rec(lds_f64* r, const StagePoint& sp, const ModelPar& m) {
+    r[0] = sp.sph; r[1] = sp.cph; r[2] = sp.sth; r[3] = sp.cth; r[4] = sp.sps; r[5] = sp.cps; r[6] = sp.icth;
+    r[7] = sp.vu; r[8] = sp.vv; r[9] = sp.vw; r[10] = sp.wp; r[11] = sp.wq; r[12] = sp.wr;
+    r[13] = (m.lx + 2.0 * m.qx * fabs(sp.vu)) * m.imx;
+    r[14] = (m.ly + 2.0 * m.qy * fabs(sp.vv)) * m.imy;
+    r[15] = (m.lz + 2.0 * m.qz * fabs(sp.vw)) * m.imz;
+    r[16] = (m.ln + 2.0 * m.qn * fabs(sp.wr)) * m.imn;
+}
+
+// o = (df/dx)(stage record) * s + kb (kb = the column of df/du for an input column, zero otherwise); same entries as
+// model_jvp, bluerov2_model.hpp
+__device__ __forceinline__ void jvp_rec(const lds_f64* r, double imx, double imy, double imz, double imn, const double (&kb)[4],
+                                        const double (&s)[NX], double (&o)[NX]) {
+    const double sph = r[0], cph = r[1], sth = r[2], cth = r[3], sps = r[4], cps = r[5], icth = r[6];
+    const double vu = r[7], vv = r[8], vw = r[9], wp = r[10], wq = r[11], wr = r[12];
+    const double r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = sps * sph + cps * cph * sth;
+    const double r10 = sps * cth, r11 = cps * cph + sph * sth * sps, r12 = sth * sps * cph - cps * sph;
+    const double r21 = cth * sph, r22 = cth * cph;
+    const double f0 = r00 * vu + r01 * vv + r02 * vw;
+    const double f1 = r10 * vu + r11 * vv + r12 * vw;
+    const double f2 = -sth * vu + r21 * vv + r22 * vw;
+    o[0] = (r02 * vv - r01 * vw) * s[3] + (cps * f2) * s[4] - f1 * s[5] + r00 * s[6] + r01 * s[7] + r02 * s[8];
+    o[1] = (r12 * vv - r11 * vw) * s[3] + (sps * f2) * s[4] + f0 * s[5] + r10 * s[6] + r11 * s[7] + r12 * s[8];
+    o[2] = (r22 * vv - r21 * vw) * s[3] - (cth * vu + sth * (sph * vv + cph * vw)) * s[4] - sth * s[6] + r21 * s[7] + r22 * s[8];
+    const double tth = sth * icth, ic2 = icth * icth;
+    o[3] = (-sph * tth * wr) * s[3] + ((sps * wq + cph * wr) * ic2) * s[4] + (cps * tth * wq) * s[5] + s[9] + (sps * tth) * s[10] +
+           (cph * tth) * s[11];
+    o[4] = (cph * wr - sph * wq) * s[3] + cph * s[10] + sph * s[11];
+    o[5] = ((cph * wq - sph * wr) * s[3] + (sph * wq + cph * wr) * tth * s[4] + sph * s[10] + cph * s[11]) * icth;
+    o[6] = (-kBouy * cth * s[4]) * imx + r[13] * s[6] + kb[0];
+    o[7] = (kBouy * (r22 * s[3] - sth * sph * s[4])) * imy + r[14] * s[7] + kb[1];
+    o[8] = (-kBouy * (r21 * s[3] + sth * cph * s[4])) * imz + r[15] * s[8] + kb[2];
+    o[9] = (kMzg * (sth * sph * s[4] - r22 * s[3]) + (kIy - kIz) * (wr * s[10] + wq * s[11])) * (1.0 / kIx);
+    o[10] = (-kMzg * cth * s[4] + (kIz - kIx) * (wr * s[9] + wp * s[11])) * (1.0 / kIy);
+    o[11] = (-(kIy - kIx) * (wq * s[9] + wp * s[10])) * imn + r[16] * s[11] + kb[3];
+}
+
+// sensitivity column c (3..15) of interval record rec through the 4 stage records
+__device__ __forceinline__ void sens_column_rec(const lds_f64* rec, const ModelPar& m, double h, int c, double (&acc)[NX]) {
+    double ks[NX], ss[NX], kb[4];
+    const int jc = c - NX;
+    constexpr double ir = 1.0 / kRotor;
+    // df/du column jc (model_bcol), all zero for a state column
+    kb[0] = jc == 0 ? (-4.0 * 0.707) * ir * m.imx : 0.0;
+    kb[1] = jc == 1 ? (4.0 * 0.707) * ir * m.imy : 0.0;
+    kb[2] = jc == 2 ? -2.0 * ir * m.imz : 0.0;
+    kb[3] = jc == 1 ? (0.167 + 0.167 - 0.175 - 0.175) * ir * m.imn : (jc == 3 ? (0.167 + 0.167 + 0.175 + 0.175) * ir * m.imn : 0.0);
+#pragma unroll
+    for (int j = 0; j < NX; j++) ss[j] = (j == c) ? 1.0 : 0.0;
+    jvp_rec(rec, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+#pragma unroll
+    for (int j = 0; j < NX; j++) { acc[j] = ((j == c) ? 1.0 : 0.0) + (h / 6.0) * ks[j]; ss[j] = ((j == c) ? 1.0 : 0.0) + 0.5 * h * ks[j]; }
+    jvp_rec(rec + kRecStage, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+#pragma unroll
+    for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * ks[j]; ss[j] = ((j == c) ? 1.0 : 0.0) + 0.5 * h * ks[j]; }
+    jvp_rec(rec + 2 * kRecStage, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+#pragma unroll
+    for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * ks[j]; ss[j] = ((j == c) ? 1.0 : 0.0) + h * ks[j]; }
+    jvp_rec(rec + 3 * kRecStage, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+#pragma unroll
+    for (int j = 0; j < NX; j++) acc[j] += (h / 6.0) * ks[j];
+}
+
+// stationarity / input-feasibility part of the NLP KKT residual for column c >= 3 of interval i, with the cost gradients
+// already in LDS (q_i, r_i); the dynamics gap and the position columns are handled once per interval by the caller
+__device__ __forceinline__ double lin_kkt_col(const DevParams& P, const double* __restrict__ cst, int b, int i, int c,
+                                              const double* __restrict__ ui, const lds_f64* q_s, const lds_f64* r_s,
+                                              const double (&acc)[NX]) {
+    const int N = P.N;
+    const int jc = c - NX;
+    const double* __restrict__ pil = P.pi + ((size_t)b * N + i) * NX;
+    const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
+    double kkt = 0.0, dotpi = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; j++) dotpi += acc[j] * pil[j];
+    if (jc < 0) {
+        if (i >= 1) kkt_upd(kkt, q_s[i * NX + c] + dotpi - pim1[c]);
+        if (i == N - 1) kkt_upd(kkt, q_s[N * NX + c] - pil[c]);  // terminal: q_N - pi_{N-1}
+    } else {
+        const double* __restrict__ lam = P.lam + ((size_t)b * N + i) * 8;
+        const double ucur = ui[jc];
+        const double ll = lam[jc], lu = lam[4 + jc];
+        kkt_upd(kkt, r_s[i * NU + jc] + dotpi - ll + lu);
+        const double sl = ucur - cst[32 + jc], su = cst[36 + jc] - ucur;
+        if (sl < 0) kkt_upd(kkt, sl);
+        if (su < 0) kkt_upd(kkt, su);
+        kkt_upd(kkt, ll * sl);
+        kkt_upd(kkt, lu * su);
+    }
+    return kkt;
+}
+
 // NLP KKT residual of the entering iterate attributable to variable c of interval i (oracle/bluerov2_oracle.c
 // orc_rti_step): dynamics gap, stationarity w.r.t. x_i / u_i (needs pi_i' S[:,c]), input feasibility and
 // complementarity, terminal stationarity on the last interval.  Returns b_i[c] (c < 12) through bc.

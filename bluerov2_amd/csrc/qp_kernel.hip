@@ -21,7 +21,6 @@
 
 namespace brov {
 
-typedef __attribute__((address_space(3))) double lds_f64;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -907,25 +906,38 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
         double xn[NX];
         rk4_state(xi, w, m, P.Ts, sp, xn);
         double* tb = ba_s + i * kBaStage;
-        if (active && j0 == 0) {
-            // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps
-            const double* __restrict__ yr = P.yref + (size_t)b * P.yref_stride + (size_t)i * NY;
+        // stage records overlay the gain / step arrays, which are dead until the QP phase (4*17 <= 48+4+4+12 doubles per
+        // interval); the L lanes of a group write identical values
+        lds_f64* rec = (lds_f64*)kt_s + i * kRecInterval;
 #pragma unroll
-            for (int k = 0; k < NX; k++) q_s[i * NX + k] = P.Ts * cst[k] * (xi[k] - yr[k]);
+        for (int st = 0; st < 4; st++) store_stage_rec(rec + st * kRecStage, sp[st], m);
+        if (j0 == 0) {
+            // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps;
+            // this lane also owns b_i, the dynamics gap and the stationarity rows of the position columns (exactly e_c)
+            const double* __restrict__ yr = P.yref + (size_t)b * P.yref_stride + (size_t)i * NY;
+            const double* __restrict__ pil = P.pi + ((size_t)b * N + i) * NX;
+            const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
+            double kk = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; k++) {
+                const double qk = P.Ts * cst[k] * (xi[k] - yr[k]);
+                const double bk = xn[k] - xi[NX + k];
+                q_s[i * NX + k] = qk;
+                bv_s[i * NX + k] = bk;
+                kkt_upd(kk, bk);
+                if (k < 3 && i >= 1) kkt_upd(kk, qk + pil[k] - pim1[k]);
+            }
 #pragma unroll
             for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yr[NX + k]);
             if (i == N - 1) {
 #pragma unroll
-                for (int k = 0; k < NX; k++) q_s[N * NX + k] = cst[16 + k] * (xi[NX + k] - yr[NY + k]);
+                for (int k = 0; k < NX; k++) {
+                    const double qn = cst[16 + k] * (xi[NX + k] - yr[NY + k]);
+                    q_s[N * NX + k] = qn;
+                    if (k < 3) kkt_upd(kk, qn - pil[k]);
+                }
             }
-            // position columns are exactly e_c; lane 0 of the group also owns b_i and their stationarity rows
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                double e[NX];
-#pragma unroll
-                for (int k = 0; k < NX; k++) e[k] = (k == c) ? 1.0 : 0.0;
-                double bc;
-                const double kk = lin_kkt_lane(P, cst, b, i, c, xi, ui, xn, e, bc);
+            if (active) {
                 if (kk != kk) nanp = true;
                 part = fmax(part, kk);
             }
@@ -933,21 +945,14 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
 #pragma unroll 1
         for (int c = 3 + j0; c < 16; c += L) {
             double acc[NX];
-            sens_column(sp, m, P.Ts, c, acc);
-            double bc;
-            const double kk = lin_kkt_lane(P, cst, b, i, c, xi, ui, xn, acc, bc);
-            if (active) {
+            sens_column_rec(rec, m, P.Ts, c, acc);
+            const double kk = lin_kkt_col(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s, acc);
 #pragma unroll
-                for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
-                if (c < NX) bv_s[i * NX + c] = bc;
+            for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
+            if (active) {
                 if (kk != kk) nanp = true;
                 part = fmax(part, kk);
             }
-        }
-        // b_i of the position rows (columns 0..2 are not visited by the loop above)
-        if (active && j0 == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) bv_s[i * NX + c] = xn[c] - xi[NX + c];
         }
     }
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
