@@ -137,10 +137,19 @@ __device__ __forceinline__ void store_stage_rec(lds_f64* r, const StagePoint& sp
     r[16] = (m.ln + 2.0 * m.qn * fabs(sp.wr)) * m.imn;
 }
 
+struct StageRec { double v[kRecStage]; };
+__device__ __forceinline__ StageRec load_stage_rec(const lds_f64* r) {
+    StageRec R;
+#pragma unroll
+    for (int k = 0; k < kRecStage; k++) R.v[k] = r[k];
+    return R;
+}
+
 // o = (df/dx)(stage record) * s + kb (kb = the column of df/du for an input column, zero otherwise); same entries as
 // model_jvp, bluerov2_model.hpp
-__device__ __forceinline__ void jvp_rec(const lds_f64* r, double imx, double imy, double imz, double imn, const double (&kb)[4],
+__device__ __forceinline__ void jvp_rec(const StageRec& R, double imx, double imy, double imz, double imn, const double (&kb)[4],
                                         const double (&s)[NX], double (&o)[NX]) {
+    const double* r = R.v;
     const double sph = r[0], cph = r[1], sth = r[2], cth = r[3], sps = r[4], cps = r[5], icth = r[6];
     const double vu = r[7], vv = r[8], vw = r[9], wp = r[10], wq = r[11], wr = r[12];
     const double r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = sps * sph + cps * cph * sth;
@@ -165,7 +174,31 @@ __device__ __forceinline__ void jvp_rec(const lds_f64* r, double imx, double imy
     o[11] = (-(kIy - kIx) * (wq * s[9] + wp * s[10])) * imn + r[16] * s[11] + kb[3];
 }
 
-// sensitivity column c (3..15) of interval record rec through the 4 stage records
+// what the KKT rows of column c need besides the column itself; requested at the top of a trip so that the loads complete
+// under the sensitivity arithmetic (indices clamped: every lane issues the same loads, the unused half is discarded)
+struct KktOperands { double pm1c, ll, lu, ucur, lbu, ubu, grad, qn; };
+__device__ __forceinline__ KktOperands load_kkt_operands(const DevParams& P, const double* __restrict__ cst, int b, int i, int c,
+                                                         const double* __restrict__ ui, const lds_f64* q_s,
+                                                         const lds_f64* r_s) {
+    const int N = P.N;
+    const int jc = c - NX, ju = jc & 3, cx = c < NX ? c : NX - 1;
+    const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
+    const double* __restrict__ lam = P.lam + ((size_t)b * N + i) * 8;
+    KktOperands K;
+    K.pm1c = pim1[cx];
+    K.ll = lam[ju];
+    K.lu = lam[4 + ju];
+    K.ucur = ui[ju];
+    K.lbu = cst[32 + ju];
+    K.ubu = cst[36 + ju];
+    const lds_f64* gp = jc < 0 ? q_s + i * NX + c : r_s + i * NU + jc;
+    K.grad = *gp;
+    K.qn = q_s[N * NX + cx];
+    return K;
+}
+
+// sensitivity column c (3..15) of interval record rec through the 4 stage records.  The next record is requested before
+// the RK bookkeeping of the current stage, which covers most of the LDS latency.
 __device__ __forceinline__ void sens_column_rec(const lds_f64* rec, const ModelPar& m, double h, int c, double (&acc)[NX]) {
     double ks[NX], ss[NX], kb[4];
     const int jc = c - NX;
@@ -175,48 +208,53 @@ __device__ __forceinline__ void sens_column_rec(const lds_f64* rec, const ModelP
     kb[1] = jc == 1 ? (4.0 * 0.707) * ir * m.imy : 0.0;
     kb[2] = jc == 2 ? -2.0 * ir * m.imz : 0.0;
     kb[3] = jc == 1 ? (0.167 + 0.167 - 0.175 - 0.175) * ir * m.imn : (jc == 3 ? (0.167 + 0.167 + 0.175 + 0.175) * ir * m.imn : 0.0);
+    StageRec R = load_stage_rec(rec);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NX; j++) ss[j] = (j == c) ? 1.0 : 0.0;
-    jvp_rec(rec, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    R = load_stage_rec(rec + kRecStage);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NX; j++) { acc[j] = ((j == c) ? 1.0 : 0.0) + (h / 6.0) * ks[j]; ss[j] = ((j == c) ? 1.0 : 0.0) + 0.5 * h * ks[j]; }
-    jvp_rec(rec + kRecStage, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    __builtin_amdgcn_sched_barrier(0);
+    jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    R = load_stage_rec(rec + 2 * kRecStage);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * ks[j]; ss[j] = ((j == c) ? 1.0 : 0.0) + 0.5 * h * ks[j]; }
-    jvp_rec(rec + 2 * kRecStage, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    __builtin_amdgcn_sched_barrier(0);
+    jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    R = load_stage_rec(rec + 3 * kRecStage);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * ks[j]; ss[j] = ((j == c) ? 1.0 : 0.0) + h * ks[j]; }
-    jvp_rec(rec + 3 * kRecStage, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    __builtin_amdgcn_sched_barrier(0);
+    jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
 #pragma unroll
     for (int j = 0; j < NX; j++) acc[j] += (h / 6.0) * ks[j];
 }
 
 // stationarity / input-feasibility part of the NLP KKT residual for column c >= 3 of interval i, with the cost gradients
-// already in LDS (q_i, r_i); the dynamics gap and the position columns are handled once per interval by the caller
-__device__ __forceinline__ double lin_kkt_col(const DevParams& P, const double* __restrict__ cst, int b, int i, int c,
-                                              const double* __restrict__ ui, const lds_f64* q_s, const lds_f64* r_s,
+// already in LDS (q_i, r_i); the dynamics gap and the position columns are handled once per interval by the caller.
+// Branch-free: rows that do not apply contribute 0 to the max.
+__device__ __forceinline__ double lin_kkt_col(const KktOperands& K, int N, int i, int c, const double (&pil)[NX],
                                               const double (&acc)[NX]) {
-    const int N = P.N;
-    const int jc = c - NX;
-    const double* __restrict__ pil = P.pi + ((size_t)b * N + i) * NX;
-    const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
-    double kkt = 0.0, dotpi = 0.0;
+    const bool xcol = c < NX;
+    double kkt = 0.0, dotpi = 0.0, pc = 0.0;
 #pragma unroll
     for (int j = 0; j < NX; j++) dotpi += acc[j] * pil[j];
-    if (jc < 0) {
-        if (i >= 1) kkt_upd(kkt, q_s[i * NX + c] + dotpi - pim1[c]);
-        if (i == N - 1) kkt_upd(kkt, q_s[N * NX + c] - pil[c]);  // terminal: q_N - pi_{N-1}
-    } else {
-        const double* __restrict__ lam = P.lam + ((size_t)b * N + i) * 8;
-        const double ucur = ui[jc];
-        const double ll = lam[jc], lu = lam[4 + jc];
-        kkt_upd(kkt, r_s[i * NU + jc] + dotpi - ll + lu);
-        const double sl = ucur - cst[32 + jc], su = cst[36 + jc] - ucur;
-        if (sl < 0) kkt_upd(kkt, sl);
-        if (su < 0) kkt_upd(kkt, su);
-        kkt_upd(kkt, ll * sl);
-        kkt_upd(kkt, lu * su);
-    }
+#pragma unroll
+    for (int j = 3; j < NX; j++) pc = (j == c) ? pil[j] : pc;
+    const double sx = K.grad + dotpi - K.pm1c;            // x column, i >= 1
+    const double su_ = K.grad + dotpi - K.ll + K.lu;      // u column
+    kkt_upd(kkt, xcol ? (i >= 1 ? sx : 0.0) : su_);
+    kkt_upd(kkt, (xcol && i == N - 1) ? K.qn - pc : 0.0);  // terminal: q_N - pi_{N-1}
+    const double sl = K.ucur - K.lbu, su = K.ubu - K.ucur;
+    kkt_upd(kkt, (!xcol && sl < 0) ? sl : 0.0);
+    kkt_upd(kkt, (!xcol && su < 0) ? su : 0.0);
+    kkt_upd(kkt, xcol ? 0.0 : K.ll * sl);
+    kkt_upd(kkt, xcol ? 0.0 : K.lu * su);
     return kkt;
 }
 

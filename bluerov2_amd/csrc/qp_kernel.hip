@@ -897,56 +897,77 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
         const double* __restrict__ xi = P.x + ((size_t)b * (N + 1) + i) * NX;
         const double* __restrict__ ui = P.u + ((size_t)b * N + i) * NU;
         const double* __restrict__ pp = P.par + ((size_t)b * (N + 1) + i) * NP;
-        double uu[NU];
+        // every global operand of the phase is requested up front: with one wave per SIMD nothing else hides the HBM
+        // round trip, so the references / multipliers travel while the state is being integrated
+        const double* __restrict__ yr = P.yref + (size_t)b * P.yref_stride + (size_t)i * NY;
+        const double* __restrict__ pil = P.pi + ((size_t)b * N + i) * NX;
+        const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
+        double uu[NU], x0r[NX], x1r[NX], yrr[NY], pir[NX], pm1[3];
 #pragma unroll
         for (int j = 0; j < NU; j++) uu[j] = ui[j];
+#pragma unroll
+        for (int j = 0; j < NX; j++) { x0r[j] = xi[j]; x1r[j] = xi[NX + j]; pir[j] = pil[j]; }
+#pragma unroll
+        for (int j = 0; j < NY; j++) yrr[j] = yr[j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) pm1[j] = pim1[j];
+        const unsigned long long tA = P.dbg ? __builtin_readcyclecounter() : 0;
+        const bool last = i == N - 1;
+        double yrn[NX];
+#pragma unroll
+        for (int j = 0; j < NX; j++) yrn[j] = last ? yr[NY + j] : 0.0;
         const ModelPar m = make_par(pp);
         const Wrench w = make_wrench(uu);
+        // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps, and
+        // the stationarity rows of the position columns (exactly e_c).  The L lanes of a group write identical values.
+        double kk0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const double qk = P.Ts * cst[k] * (x0r[k] - yrr[k]);
+            q_s[i * NX + k] = qk;
+            if (k < 3 && i >= 1) kkt_upd(kk0, qk + pir[k] - pm1[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yrr[NX + k]);
+        if (last) {
+#pragma unroll
+            for (int k = 0; k < NX; k++) {
+                const double qn = cst[16 + k] * (x1r[k] - yrn[k]);
+                q_s[N * NX + k] = qn;
+                if (k < 3) kkt_upd(kk0, qn - pir[k]);
+            }
+        }
+        const unsigned long long tB = P.dbg ? __builtin_readcyclecounter() : 0;
         StagePoint sp[4];
         double xn[NX];
-        rk4_state(xi, w, m, P.Ts, sp, xn);
+        rk4_state(x0r, w, m, P.Ts, sp, xn);
+        const unsigned long long tC = P.dbg ? __builtin_readcyclecounter() : 0;
         double* tb = ba_s + i * kBaStage;
         // stage records overlay the gain / step arrays, which are dead until the QP phase (4*17 <= 48+4+4+12 doubles per
-        // interval); the L lanes of a group write identical values
+        // interval)
         lds_f64* rec = (lds_f64*)kt_s + i * kRecInterval;
 #pragma unroll
         for (int st = 0; st < 4; st++) store_stage_rec(rec + st * kRecStage, sp[st], m);
-        if (j0 == 0) {
-            // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps;
-            // this lane also owns b_i, the dynamics gap and the stationarity rows of the position columns (exactly e_c)
-            const double* __restrict__ yr = P.yref + (size_t)b * P.yref_stride + (size_t)i * NY;
-            const double* __restrict__ pil = P.pi + ((size_t)b * N + i) * NX;
-            const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
-            double kk = 0.0;
+        // b_i and the dynamics gap
 #pragma unroll
-            for (int k = 0; k < NX; k++) {
-                const double qk = P.Ts * cst[k] * (xi[k] - yr[k]);
-                const double bk = xn[k] - xi[NX + k];
-                q_s[i * NX + k] = qk;
-                bv_s[i * NX + k] = bk;
-                kkt_upd(kk, bk);
-                if (k < 3 && i >= 1) kkt_upd(kk, qk + pil[k] - pim1[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yr[NX + k]);
-            if (i == N - 1) {
-#pragma unroll
-                for (int k = 0; k < NX; k++) {
-                    const double qn = cst[16 + k] * (xi[NX + k] - yr[NY + k]);
-                    q_s[N * NX + k] = qn;
-                    if (k < 3) kkt_upd(kk, qn - pil[k]);
-                }
-            }
-            if (active) {
-                if (kk != kk) nanp = true;
-                part = fmax(part, kk);
-            }
+        for (int k = 0; k < NX; k++) {
+            const double bk = xn[k] - x1r[k];
+            bv_s[i * NX + k] = bk;
+            kkt_upd(kk0, bk);
         }
+        if (active) {
+            if (kk0 != kk0) nanp = true;
+            part = fmax(part, kk0);
+        }
+        // developer instrumentation, slot 7: loads issued -> cost gradients -> state integrated -> column loop entered
+        if (P.dbg && lane == 0)
+            P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
 #pragma unroll 1
         for (int c = 3 + j0; c < 16; c += L) {
             double acc[NX];
+            const KktOperands ko = load_kkt_operands(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
             sens_column_rec(rec, m, P.Ts, c, acc);
-            const double kk = lin_kkt_col(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s, acc);
+            const double kk = lin_kkt_col(ko, N, i, c, pir, acc);
 #pragma unroll
             for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
             if (active) {

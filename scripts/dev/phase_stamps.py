@@ -26,4 +26,5 @@ for n, col in zip(names, d.T):
     print(f"  {n:14s} {int(np.median(col)):8d}  ({100*np.median(col)/np.median(tot):.1f} %)")
 
 w = st[:, 7]
-print("fwd-detail (stage 5): v-chain", int(np.median(w & 0xFFFFF)), "x-chain", int(np.median((w >> 20) & 0xFFFFF)), "end-of-stage5 -> end-of-stage6", int(np.median((w >> 40) & 0xFFFFF)))
+print("lin detail: cost gradients (incl. load wait)", int(np.median(w & 0xFFFFF)), " state integration", int(np.median((w >> 20) & 0xFFFFF)),
+      " records + gap", int(np.median((w >> 40) & 0xFFFFF)))
