@@ -706,6 +706,25 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             rollout<LDS>(I, d0, V);
         }
         DBG_STAMP(4);
+        // fused path: the iterate and the reference of the commit loops below are requested before the adjoint sweep, which
+        // hides their round trip (the single resident wave has nothing else to switch to)
+        double xpre[UX], ypre[UX], urpre[UU];
+        if constexpr (LDS) {
+#pragma unroll
+            for (int t = 0; t < UX; t++) {
+                const int j = lane + 64 * t;
+                const int jj = j < nxe ? j : 0;
+                const int i = jj / 12, c = jj - i * 12;
+                xpre[t] = x_it[jj];
+                ypre[t] = I.yref[(size_t)i * 16 + c];
+            }
+#pragma unroll
+            for (int t = 0; t < UU; t++) {
+                const int j = lane + 64 * t;
+                const int jj = j < nv ? j : 0;
+                urpre[t] = I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
+            }
+        }
         adjoint<true, LDS>(I, vfin, DVA, pi_it);
         DBG_STAMP(5);
         bool nanv = false;
@@ -730,7 +749,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     uo[t] = (LDS && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
                     vv[t] = vfin[jj];
                     gg[t] = early ? 0.0 : GRAD[jj];
-                    ur[t] = I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
+                    ur[t] = (LDS && j0 == lane) ? urpre[t] : I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
                 }
 #pragma unroll
                 for (int t = 0; t < UU; t++) {
@@ -758,9 +777,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const int j = j0 + 64 * t;
                     const int jj = j < nxe ? j : 0;
                     const int i = jj / 12, c = jj - i * 12;
-                    xo[t] = x_it[jj];
+                    xo[t] = (LDS && j0 == lane) ? xpre[t] : x_it[jj];
                     dj[t] = I.dxb[jj];
-                    yr[t] = I.yref[(size_t)i * 16 + c];
+                    yr[t] = (LDS && j0 == lane) ? ypre[t] : I.yref[(size_t)i * 16 + c];
                 }
 #pragma unroll
                 for (int t = 0; t < UX; t++) {
