@@ -37,6 +37,12 @@ __device__ __forceinline__ d4 tn(const d4& xt, const d4& y, d4 c) {
 // 4-deep contraction with explicitly chosen registers
 __device__ __forceinline__ d4 tn1(double xt, double y, d4 c) { return mfma(xt, y, c); }
 
+// m ? x : y for an all-ones / all-zeros lane mask, as two v_bfi_b32 (never a branch)
+__device__ __forceinline__ double blend(unsigned m, double x, double y) {
+    const unsigned lo = (__double2loint(x) & m) | (__double2loint(y) & ~m);
+    const unsigned hi = (__double2hiint(x) & m) | (__double2hiint(y) & ~m);
+    return __hiloint2double((int)hi, (int)lo);
+}
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -232,6 +238,7 @@ __device__ bool riccati_backward(const Inst& I) {
     }
     bool ok = true;
     const d4 z4 = {0, 0, 0, 0};
+    const unsigned mk_col0 = cl == 0 ? ~0u : 0u;
     for (int i = N - 1; i >= 0; i--) {
         const BwdIn in = nx;
         if constexpr (LDS) nx = load_bwd<FACTOR, LDS, STEP0>(I, i > 0 ? i - 1 : 0, gam, rt);  // clamped: one scheduling region
@@ -242,13 +249,25 @@ __device__ bool riccati_backward(const Inst& I) {
         for (int r = 0; r < 3; r++) qr[r] = LDS ? in.xv[r] : I.Ts * I.Wr[r] * (in.xv[r] - in.yv[r]);
         qr[3] = in.rtv;
         if (FACTOR) {
-            d4 PA = tn<3>(P, in.ba, z4);
-            d4 Pb = tn<3>(P, in.bv, z4);
+            // One wave's FP64 MFMAs and VALU work do not overlap (scripts/dev/mfma_valu_overlap.hip): a stage costs 64 cycles
+            // per MFMA whatever it computes, so P b is not given MFMAs of its own.  Column 0 of [A B] is e_0 (position x) and
+            // P e_0 is column 0 of P itself -- b_i rides in that column, and column 0 of [P A] is restored from P.  From here
+            // on the gradient recursion (P b, l, g, p) lives in column 0 of its tiles (lanes cl == 0); the other columns of
+            // those tiles carry finite don't-care values.
+            d4 ba1, PA;
+#pragma unroll
+            for (int r = 0; r < 3; r++) ba1[r] = blend(mk_col0, in.bv[r], in.ba[r]);
+            ba1[3] = 0.0;
+            const d4 Pb = tn<3>(P, ba1, z4);
+#pragma unroll
+            for (int r = 0; r < 3; r++) PA[r] = blend(mk_col0, P[r], Pb[r]);
+            PA[3] = 0.0;
             d4 H = tn<3>(in.ba, PA, z4);
             if (STORE_IPM) store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
             d4 l;
 #pragma unroll
-            for (int r = 0; r < 4; r++) l[r] = Pb[r] + pv[r];
+            for (int r = 0; r < 3; r++) l[r] = Pb[r] + pv[r];
+            l[3] = 0.0;
             d4 g = tn<3>(in.ba, l, qr);
             // + diag(Ts*Wx, Ts*Wu + Gamma_i)
 #pragma unroll
@@ -311,7 +330,12 @@ __device__ bool riccati_backward(const Inst& I) {
                 double* kt = I.Kt + (size_t)i * 192;
                 kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
             }
-            if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
+            if constexpr (LDS) {  // only column 0 of kf is M gu: the other lanes are parked on the constant-zero slot
+                lds_f64* kp = (cl == 0) ? I.lds_kff + i * 4 + rg : I.lds_zero;
+                *kp = (cl == 0) ? -kf[0] : 0.0;
+            } else if (cl == 0) {
+                I.kff[i * 4 + rg] = -kf[0];
+            }
             P = S;
             pv = pn;
             pv[3] = 0.0;
