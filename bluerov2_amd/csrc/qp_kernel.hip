@@ -314,19 +314,18 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 S = tn1(H[3], ks, H);
             d4 kf = tn1(mt, g[3], z4);
             d4 pn = tn1(ks, g[3], g);
-            d4 KtT = tn1(H[3], -mt, z4);
             // store factors
             if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads these
                 I.Ks[(size_t)i * 64 + lane] = ks;
                 I.Mt[(size_t)i * 64 + lane] = mt;
             }
             if constexpr (LDS) {
-                // lanes cl >= 4 hold structural zeros of K^T; they rewrite lane (cl & 3)'s slot ... with different data, so they
-                // are parked on the constant-zero slot instead (writes 0.0 over 0.0)
-                lds_f64* t = (cl < 4) ? I.lds_kt + i * kKtStage + rg * 4 + cl : I.lds_zero;
-                const int st = (cl < 4) ? 16 : 0;
-                t[0] = (cl < 4) ? KtT[0] : 0.0; t[st] = (cl < 4) ? KtT[1] : 0.0; t[2 * st] = (cl < 4) ? KtT[2] : 0.0;
+                // K^T[k][m] = -T[m][k] is ks at lane (rg = m, cl = k): the compact LDS image [12][4] is written straight from
+                // that register (no transposing MFMA); lanes cl >= 12 are parked on the constant-zero slot
+                lds_f64* t = (cl < NX) ? I.lds_kt + i * kKtStage + cl * 4 + rg : I.lds_zero;
+                *t = (cl < NX) ? ks : 0.0;
             } else {
+                d4 KtT = tn1(H[3], -mt, z4);
                 double* kt = I.Kt + (size_t)i * 192;
                 kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
             }
