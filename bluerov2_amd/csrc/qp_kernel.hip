@@ -239,6 +239,10 @@ __device__ bool riccati_backward(const Inst& I) {
     bool ok = true;
     const d4 z4 = {0, 0, 0, 0};
     const unsigned mk_col0 = cl == 0 ? ~0u : 0u;
+    d4 diagm;  // stage cost diag(Ts*Wx, Ts*Wu) in tile layout
+#pragma unroll
+    for (int r = 0; r < 3; r++) diagm[r] = (rg + 4 * r == cl) ? I.Ts * I.Wr[r] : 0.0;
+    diagm[3] = (12 + rg == cl) ? I.Ts * I.Wr[3] : 0.0;
     for (int i = N - 1; i >= 0; i--) {
         const BwdIn in = nx;
         if constexpr (LDS) nx = load_bwd<FACTOR, LDS, STEP0>(I, i > 0 ? i - 1 : 0, gam, rt);  // clamped: one scheduling region
@@ -271,9 +275,8 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 g = tn<3>(in.ba, l, qr);
             // + diag(Ts*Wx, Ts*Wu + Gamma_i)
 #pragma unroll
-            for (int r = 0; r < 3; r++)
-                if (rg + 4 * r == cl) H[r] += I.Ts * I.Wr[r];
-            if (12 + rg == cl) H[3] += I.Ts * I.Wr[3] + in.gm;
+            for (int r = 0; r < 3; r++) H[r] += diagm[r];
+            H[3] += STEP0 ? diagm[3] : diagm[3] + (12 + rg == cl ? in.gm : 0.0);
             // ---- 4x4 pivot block Huu = H[12..15][12..15]: lane 16m+12+n holds Huu[m][n] in H[3]
             const double a00 = readlane_f64(H[3], 12), a10 = readlane_f64(H[3], 28), a11 = readlane_f64(H[3], 29);
             const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
