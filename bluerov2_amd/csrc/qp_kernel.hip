@@ -48,21 +48,27 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+// Wave reductions.  __shfl_xor is ds_bpermute (an LDS round trip per step, ~700 cycles for the six steps of a 64-lane
+// butterfly with nothing to overlap); here the 16 lanes of a row are reduced with DPP moves (xor 1, xor 2, half-row mirror,
+// row mirror) and the four row results are combined through v_readlane.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v, Op op) {
+    v = op(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = op(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = op(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = op(v, dpp_f64<0x140>(v));  // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, [](double a, double b) { return a + b; }); }
 
 // Data written by some lanes of the wave and read by others goes through global memory (L1/L2 of this CU); a
 // workgroup-scope fence (= s_waitcnt, no cache maintenance) orders the two phases.
