@@ -934,7 +934,7 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 
 // fused path: ONE wavefront owns one OCP instance from linearisation to the updated iterate.  The wave first integrates
 // all N intervals at once (64/N lanes per interval, lin_device.hpp) and leaves [A_i B_i] and b_i in its LDS slice
-// (N <= kFusedMaxN: 4 waves x 36 KB per CU at N = 20), then runs the Riccati IPM on the LDS-resident stage blocks: they
+// (N <= kFusedMaxN: 4 waves x 40.5 KB per CU at N = 20), then runs the Riccati IPM on the LDS-resident stage blocks: they
 // are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
 // (interior-point) instance does not pin the LDS of three finished ones.
 constexpr int kFusedMaxN = 23;
