@@ -35,8 +35,8 @@ assert RESULT_DTYPE.itemsize == 56 == C.sizeof(OrcResult)
 
 def build(force=False):
     """(re)build the oracle and, if the reference tree is present, oracle/_ref."""
-    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
-            os.path.join(HERE, "bluerov2_oracle.c")):
+    srcs = [os.path.join(HERE, f) for f in ("bluerov2_oracle.c", "bluerov2_ekf_oracle.c", "bluerov2_ekf_oracle.h")]
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     if os.path.isdir("/root/reference/bluerov2_dobmpc") and (force or not os.path.exists(REF_SO)):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
@@ -218,3 +218,64 @@ class CasadiRef:
             k, KSx, KSu = self.vde_forw(x + h * ca[s] * k, Sx0 + h * ca[s] * KSx, Su0 + h * ca[s] * KSu, u, p)
             xa, Sxa, Sua = xa + h * cb[s] * k, Sxa + h * cb[s] * KSx, Sua + h * cb[s] * KSu
         return xa, Sxa, Sua
+
+
+# ---- 18-state EKF disturbance observer (oracle/bluerov2_ekf_oracle.c) ------------------
+class OrcEkfPar(C.Structure):
+    _fields_ = [("dt", C.c_double), ("mass", C.c_double), ("Ix", C.c_double), ("Iy", C.c_double), ("Iz", C.c_double),
+                ("ZG", C.c_double), ("g", C.c_double), ("bouyancy", C.c_double), ("added_mass", C.c_double * 6),
+                ("Dl", C.c_double * 6), ("Dnl", C.c_double * 6), ("K", C.c_double * 36), ("Q", C.c_double * 18),
+                ("R", C.c_double), ("fd_step", C.c_double), ("compensate_coef", C.c_double),
+                ("rotor_constant", C.c_double), ("Mdiag", C.c_double * 6), ("invMdiag", C.c_double * 6)]
+
+
+class EkfOracle:
+    """B independent filters; state arrays live in numpy (x [B,18], P [B,18,18]) and are updated in place."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        self.lib = L = C.CDLL(ORACLE_SO)
+        pp = C.POINTER(OrcEkfPar)
+        L.orc_ekf_default_par.argtypes = [pp]
+        L.orc_ekf_derive.argtypes = [pp]
+        L.orc_ekf_init_state.argtypes = [_dp, _dp]
+        L.orc_ekf_f.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_ekf_rk4.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_ekf_h.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_ekf_jac_F.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_ekf_jac_H.argtypes = [pp, _dp, _dp, _dp]
+        L.orc_ekf_update_batch.argtypes = [pp, C.c_int] + [_dp] * 7
+        L.orc_ekf_update_batch.restype = C.c_int
+        self.par = OrcEkfPar()
+        L.orc_ekf_default_par(C.byref(self.par))
+
+    def init_state(self, B=1):
+        x = np.zeros((B, 18)); P = np.zeros((B, 18, 18))
+        for b in range(B):
+            self.lib.orc_ekf_init_state(_p(x[b]), _p(P[b]))
+        return x, P
+
+    def f(self, x, tau):
+        o = np.zeros(18); self.lib.orc_ekf_f(C.byref(self.par), _p(_c(x, (18,))), _p(_c(tau, (6,))), _p(o)); return o
+
+    def rk4(self, x, tau):
+        o = np.zeros(18); self.lib.orc_ekf_rk4(C.byref(self.par), _p(_c(x, (18,))), _p(_c(tau, (6,))), _p(o)); return o
+
+    def h(self, x, acc):
+        o = np.zeros(18); self.lib.orc_ekf_h(C.byref(self.par), _p(_c(x, (18,))), _p(_c(acc, (6,))), _p(o)); return o
+
+    def jac_F(self, x, tau):
+        o = np.zeros((18, 18)); self.lib.orc_ekf_jac_F(C.byref(self.par), _p(_c(x, (18,))), _p(_c(tau, (6,))), _p(o)); return o
+
+    def jac_H(self, x, acc):
+        o = np.zeros((18, 18)); self.lib.orc_ekf_jac_H(C.byref(self.par), _p(_c(x, (18,))), _p(_c(acc, (6,))), _p(o)); return o
+
+    def update(self, x, P, thrust, y12, acc):
+        """in-place update of x [B,18], P [B,18,18]; returns (wf [B,6], mpc_p [B,4], rc)"""
+        B = x.shape[0]
+        assert x.flags.c_contiguous and P.flags.c_contiguous and x.dtype == np.float64 and P.dtype == np.float64
+        thrust = _c(thrust, (B, 6)); y12 = _c(y12, (B, 12)); acc = _c(acc, (B, 6))
+        wf = np.zeros((B, 6)); mp = np.zeros((B, 4))
+        rc = self.lib.orc_ekf_update_batch(C.byref(self.par), B, _p(x), _p(P), _p(thrust), _p(y12), _p(acc), _p(wf), _p(mp))
+        return wf, mp, rc
