@@ -7,5 +7,7 @@ solver raises.
 from .solver import (BatchSolver, SolverOptions, RESULT_DTYPE, P_NOMINAL, build_library, library_path,  # noqa: F401
                      NoDeviceError, thrust_allocation, PATH_AUTO, PATH_STREAMING, PATH_FUSED)
 
-__all__ = ["BatchSolver", "SolverOptions", "RESULT_DTYPE", "P_NOMINAL", "build_library", "library_path",
+from .ekf import BatchEkf, EkfParams  # noqa: F401,E402
+
+__all__ = ["BatchEkf", "EkfParams", "BatchSolver", "SolverOptions", "RESULT_DTYPE", "P_NOMINAL", "build_library", "library_path",
            "NoDeviceError", "thrust_allocation", "PATH_AUTO", "PATH_STREAMING", "PATH_FUSED"]

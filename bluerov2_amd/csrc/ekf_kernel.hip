@@ -1,0 +1,681 @@
+// ekf_kernel.hip -- batched EKF disturbance observer and its C ABI (include/bluerov2_nmpc.h,
+// brov_ekf_*).  B independent copies of the reference's 18-state filter BLUEROV2_DOB::EKF()
+// (/root/reference/bluerov2_dobmpc/src/bluerov2_dob.cpp:495-545): forward-difference Jacobians of the RK4 map (:730-744, RK4
+// with the k2/3 stage quirk :621-634, process model :637-702) and of the measurement model (:705-727, :747-762), Kalman gain
+// through the explicit inverse of the innovation covariance, Joseph-form covariance update, world-frame disturbance, and the
+// hand-over to the NMPC parameters p[0..3] (:334-337).
+//
+// Mapping (gfx950, wave64).  A tick is 2 x 19 evaluations of small nonlinear maps plus nine 18x18x18 products and one 18x18
+// inverse: 18 does not fit the 16-wide FP64 MFMA tile (a 32x32 padding would waste 3/4 of the issue slots, and FP64 MFMA has
+// the same flop rate as FP64 VALU on this part), so the filter runs on the VALU with **one lane per matrix row**:
+//   * 19 lanes per filter, 3 filters per wavefront (57 of 64 lanes): lane r < 18 evaluates the map perturbed in state r,
+//     lane 18 the unperturbed one -- the two finite-difference Jacobians cost one RK4 / one h() evaluation of wall time each;
+//   * lane i < 18 then owns row i of every matrix; a product C = A B is "row i of C += A[i][k] * (row k of B)" with the
+//     right-hand rows broadcast out of LDS (all 18 lanes read the same 144 bytes) and the accumulator row in registers.
+//     Transposed right-hand sides are free for F and H: a lane holds a *column* of those and chooses how to write it.
+//   * four 18x18 LDS buffers per filter (10.4 KB) + a few vectors: 33 KB per wave, 4 waves per CU.
+// HBM traffic per tick and filter: P in and out (2 x 2592 B), x (2 x 144 B), inputs 192 B, outputs 84 B = 5.7 KB against
+// ~0.13 MFLOP: compute-bound on FP64 VALU issue.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bluerov2_model.hpp"
+#include "bluerov2_nmpc.h"
+
+namespace brov {
+
+constexpr int EN = 18;
+constexpr int kGrp = 19;      // lanes per filter
+constexpr int kPerWave = 3;   // filters per wavefront
+constexpr int kMat = EN * EN;
+constexpr int kVecs = 5 * EN + 2 * 40;               // xp, y, ye, xnew, spare | two pivot-row buffers
+constexpr int kLdsPerFilter = 4 * kMat + kVecs;      // doubles
+typedef __attribute__((address_space(3))) double elds;
+typedef double ed2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) ed2 elds2;
+
+struct EkfConst {
+    double dt, mass, bo, mzg, iy_iz, iz_ix, iy_ix, R, d, inv_cc, inv_rc;
+    double Dl[6], Dnl[6], Md[6], iMd[6], K[36], Q[EN];
+};
+struct EkfArgs {
+    EkfConst c;
+    int B;
+    double* x;            // [B][18]
+    double* P;            // [B][18][18]
+    const double* thrust; // [B][6]
+    const double* y12;    // [B][12]
+    const double* acc;    // [B][6]
+    double* wf;           // [B][6]
+    double* mp;           // [B][4]
+    int* status;          // [B]
+};
+
+// first 12 components of the process model (the disturbance states 12..17 have no dynamics), bluerov2_dob.cpp:637-702
+__device__ __forceinline__ void ekf_f12(const EkfConst& c, const double (&x)[EN], const double (&tau)[6], double (&xd)[12]) {
+    double sph, cph, sth, cth, sps, cps;
+    sincos_pio2(x[3], &sph, &cph);
+    sincos_pio2(x[4], &sth, &cth);
+    sincos_pio2(x[5], &sps, &cps);
+    const double m = c.mass;
+    xd[0] = (cps * cth) * x[6] + (-sps * cph + cps * sth * sph) * x[7] + (sps * sph + cps * cph * sth) * x[8];
+    xd[1] = (sps * cth) * x[6] + (cps * cph + sph * sth * sps) * x[7] + (-cps * sph + sth * sps * cph) * x[8];
+    xd[2] = (-sth) * x[6] + (cth * sph) * x[7] + (cth * cph) * x[8];
+    xd[3] = x[9] + (sps * sth / cth) * x[10] + cph * sth / cth * x[11];
+    xd[4] = cph * x[10] + sph * x[11];
+    xd[5] = (sph / cth) * x[10] + (cph / cth) * x[11];
+    xd[6] = c.iMd[0] * (tau[0] + m * x[11] * x[7] - m * x[10] * x[8] - c.bo * sth + x[12] + c.Dl[0] * x[6] + c.Dnl[0] * fabs(x[6]) * x[6]);
+    xd[7] = c.iMd[1] * (tau[1] - m * x[11] * x[6] + m * x[9] * x[8] + c.bo * cth * sph + x[13] + c.Dl[1] * x[7] + c.Dnl[1] * fabs(x[7]) * x[7]);
+    xd[8] = c.iMd[2] * (tau[2] + m * x[10] * x[6] - m * x[9] * x[7] + c.bo * cth * cph + x[14] + c.Dl[2] * x[8] + c.Dnl[2] * fabs(x[8]) * x[8]);
+    xd[9] = c.iMd[3] * (tau[3] + c.iy_iz * x[10] * x[11] - c.mzg * cth * sph + x[15] + c.Dl[3] * x[9] + c.Dnl[3] * fabs(x[9]) * x[9]);
+    xd[10] = c.iMd[4] * (tau[4] + c.iz_ix * x[9] * x[11] - c.mzg * sth + x[16] + c.Dl[4] * x[10] + c.Dnl[4] * fabs(x[10]) * x[10]);
+    xd[11] = c.iMd[5] * (tau[5] - c.iy_ix * x[9] * x[10] + x[17] + c.Dl[5] * x[11] + c.Dnl[5] * fabs(x[11]) * x[11]);
+}
+
+// RK4 of bluerov2_dob.cpp:621-634: classical weights, third stage at x + k2/3 (sic)
+__device__ __forceinline__ void ekf_rk4(const EkfConst& c, const double (&x)[EN], const double (&tau)[6], double (&xn)[EN]) {
+    double k1[12], k2[12], k3[12], k4[12], xs[EN];
+#pragma unroll
+    for (int i = 12; i < EN; i++) { xs[i] = x[i]; xn[i] = x[i]; }
+    ekf_f12(c, x, tau, k1);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k1[i] *= c.dt; xs[i] = x[i] + k1[i] / 2; }
+    ekf_f12(c, xs, tau, k2);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k2[i] *= c.dt; xs[i] = x[i] + k2[i] / 3; }
+    ekf_f12(c, xs, tau, k3);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k3[i] *= c.dt; xs[i] = x[i] + k3[i]; }
+    ekf_f12(c, xs, tau, k4);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k4[i] *= c.dt; xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6; }
+}
+
+// measurement model, bluerov2_dob.cpp:705-727
+__device__ __forceinline__ void ekf_h(const EkfConst& c, const double (&x)[EN], const double (&a)[6], double (&y)[EN]) {
+    double sph, cph, sth, cth;
+    sincos_pio2(x[3], &sph, &cph);
+    sincos_pio2(x[4], &sth, &cth);
+    const double m = c.mass;
+#pragma unroll
+    for (int i = 0; i < 12; i++) y[i] = x[i];
+    y[12] = c.Md[0] * a[0] - m * x[11] * x[7] + m * x[10] * x[8] + c.bo * sth - x[12] - c.Dl[0] * x[6] - c.Dnl[0] * fabs(x[6]) * x[6];
+    y[13] = c.Md[1] * a[1] + m * x[11] * x[6] - m * x[9] * x[8] - c.bo * cth * sph - x[13] - c.Dl[1] * x[7] - c.Dnl[1] * fabs(x[7]) * x[7];
+    y[14] = c.Md[2] * a[2] - m * x[10] * x[6] + m * x[9] * x[7] - c.bo * cth * cph - x[14] - c.Dl[2] * x[8] - c.Dnl[2] * fabs(x[8]) * x[8];
+    y[15] = c.Md[3] * a[3] - c.iy_iz * x[10] * x[11] + c.mzg * cth * sph - x[15] - c.Dl[3] * x[9] - c.Dnl[3] * fabs(x[9]) * x[9];
+    y[16] = c.Md[4] * a[4] - c.iz_ix * x[9] * x[11] + c.mzg * sth - x[16] - c.Dl[4] * x[10] - c.Dnl[4] * fabs(x[10]) * x[10];
+    y[17] = c.Md[5] * a[5] + c.iy_ix * x[9] * x[10] - x[17] - c.Dl[5] * x[11] - c.Dnl[5] * fabs(x[11]) * x[11];
+}
+
+// row <- LDS (contiguous, 16-byte aligned: the row stride is 144 bytes)
+__device__ __forceinline__ void load_row(const elds* p, double (&v)[EN]) {
+#pragma unroll
+    for (int j = 0; j < EN / 2; j++) { const ed2 t = ((const elds2*)p)[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+}
+__device__ __forceinline__ void store_row(elds* p, const double (&v)[EN]) {
+#pragma unroll
+    for (int j = 0; j < EN / 2; j++) ((elds2*)p)[j] = ed2{v[2 * j], v[2 * j + 1]};
+}
+// acc[:] += sum_k a(k) * B(k,:) with a(k) = a0[k * a_sk] (lane-specific) and row k of B either contiguous at b0 + 18 k
+// (B stored row-major) or strided at b0[j * 18 + k] (B^T stored row-major).  The 18 lanes of a filter read the same B row.
+template <bool BT>
+__device__ __forceinline__ void row_gemm(const elds* a0, int a_sk, const elds* b0, double (&acc)[EN]) {
+#pragma unroll 3
+    for (int k = 0; k < EN; k++) {
+        const double a = a0[k * a_sk];
+        double br[EN];
+        if (BT) {
+#pragma unroll
+            for (int j = 0; j < EN; j++) br[j] = b0[j * EN + k];
+        } else {
+            load_row(b0 + k * EN, br);
+        }
+#pragma unroll
+        for (int j = 0; j < EN; j++) acc[j] = fma(a, br[j], acc[j]);
+    }
+}
+
+__global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double esm[];
+    const EkfConst& c = A.c;
+    const int lane = threadIdx.x;
+    const int g0 = lane / kGrp;
+    const bool spare = g0 >= kPerWave;             // lanes 57..63: shadow the base-evaluation lane of the third filter
+    const int g = spare ? kPerWave - 1 : g0;
+    const int r = spare ? EN : lane - g * kGrp;    // 0..17: row / perturbed state, 18: unperturbed evaluation
+    const int inst0 = blockIdx.x * kPerWave + g;
+    const bool live = inst0 < A.B;                 // the tail block recomputes the last filter and drops the result
+    const int inst = live ? inst0 : A.B - 1;
+    const bool row = r < EN;
+    const bool base = (r == EN) && !spare;
+    const int ri = row ? r : 0;                    // safe row index for the base lanes (their matrix work is discarded)
+
+    elds* sm = (elds*)esm + g * kLdsPerFilter;
+    elds* bufA = sm;              // F^T, later H^T, later V
+    elds* bufB = bufA + kMat;     // G, later U, later Kal
+    elds* bufC = bufB + kMat;     // P, later P_pred
+    elds* bufD = bufC + kMat;     // S^-1, later J
+    elds* v_xp = bufD + kMat;     // predicted state
+    elds* v_y = v_xp + EN;        // measurement
+    elds* v_ye = v_y + EN;        // innovation
+    elds* v_xn = v_ye + EN;       // corrected state
+    elds* piv = v_xn + 2 * EN;    // 2 x 40: normalised pivot rows of the Gauss-Jordan sweep (+ reciprocal pivot)
+
+    // ---- inputs: every lane of the group keeps x, tau, acc (wave-broadcast loads)
+    double x[EN], tau[6], ac[6];
+    {
+        const double* xg = A.x + (size_t)inst * EN;
+        const double* tg = A.thrust + (size_t)inst * 6;
+        const double* ag = A.acc + (size_t)inst * 6;
+#pragma unroll
+        for (int j = 0; j < EN; j++) x[j] = xg[j];
+        double th[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { th[j] = tg[j]; ac[j] = ag[j]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {   // tau = K * meas_u (bluerov2_dob.cpp:499-500)
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s += c.K[i * 6 + j] * th[j];
+            tau[i] = s;
+        }
+        if (base) {
+            const double* yg = A.y12 + (size_t)inst * 12;
+#pragma unroll
+            for (int j = 0; j < 12; j++) v_y[j] = yg[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) v_y[12 + j] = tau[j];
+        }
+        // P row i -> LDS (left operand of the first product)
+        if (row) {
+            const double* pg = A.P + (size_t)inst * kMat + (size_t)r * EN;
+            double pr[EN];
+#pragma unroll
+            for (int j = 0; j < EN; j++) pr[j] = pg[j];
+            store_row(bufC + r * EN, pr);
+        }
+    }
+
+    // ---- F = d RK4 / d x by forward differences (column r in lane r), x_pred
+    double col[EN];
+    {
+        double xl[EN], xn[EN];
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((j == r) ? c.d : 0.0);
+        ekf_rk4(c, xl, tau, xn);
+        if (base) store_row(v_xp, xn);
+        __syncthreads();
+        double f0[EN];
+        load_row(v_xp, f0);
+#pragma unroll
+        for (int j = 0; j < EN; j++) col[j] = (xn[j] - f0[j]) / c.d;
+        if (row) store_row(bufA + r * EN, col);   // row r of F^T
+#pragma unroll
+        for (int j = 0; j < EN; j++) x[j] = f0[j];  // from here on x = x_pred
+    }
+    __syncthreads();
+
+    double acc[EN];
+    // G = P F^T  (left: P row i in bufC, right: F^T row-major in bufA)
+#pragma unroll
+    for (int j = 0; j < EN; j++) acc[j] = 0.0;
+    row_gemm<false>(bufC + ri * EN, 1, bufA, acc);
+    if (row) store_row(bufB + r * EN, acc);
+    __syncthreads();
+    // P_pred = F G + Q  (left: F[i][k] = F^T[k][i])
+#pragma unroll
+    for (int j = 0; j < EN; j++) acc[j] = (j == r) ? c.Q[j] : 0.0;
+    row_gemm<false>(bufA + ri, EN, bufB, acc);
+    if (row) store_row(bufC + r * EN, acc);      // P (staged) is dead: every lane read only its own row
+    // ---- H = d h / d x at x_pred by forward differences, innovation
+    {
+        double xl[EN], yv[EN];
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((j == r) ? c.d : 0.0);
+        ekf_h(c, xl, ac, yv);
+        __syncthreads();                           // all reads of F^T (bufA) are done
+        if (base) {
+            double ym[EN], ye[EN];
+            load_row(v_y, ym);
+#pragma unroll
+            for (int j = 0; j < EN; j++) ye[j] = ym[j] - yv[j];
+            store_row(v_ye, ye);
+            store_row(v_xn, yv);                   // y_pred, parked in the x_new slot until the gain exists
+        }
+        __syncthreads();
+        double y0[EN];
+        load_row(v_xn, y0);
+#pragma unroll
+        for (int j = 0; j < EN; j++) col[j] = (yv[j] - y0[j]) / c.d;
+        if (row) store_row(bufA + r * EN, col);    // row r of H^T
+    }
+    __syncthreads();
+    // U = P_pred H^T  (left: P_pred row i in bufC, right: H^T row-major)
+#pragma unroll
+    for (int j = 0; j < EN; j++) acc[j] = 0.0;
+    row_gemm<false>(bufC + ri * EN, 1, bufA, acc);
+    if (row) store_row(bufB + r * EN, acc);      // G is dead
+    __syncthreads();
+    // S = H U + R  (left: H[i][k] = H^T[k][i])
+    double s[EN], t[EN];
+#pragma unroll
+    for (int j = 0; j < EN; j++) s[j] = (j == r) ? c.R : 0.0;
+    row_gemm<false>(bufA + ri, EN, bufB, s);
+    // ---- S^-1 by Gauss-Jordan without pivoting (S = H P H^T + R I is symmetric positive definite); lane i holds row i of
+    // [S | I].  At step k only columns k+1.. of the left block and 0..k of the right block are non-trivial.
+#pragma unroll
+    for (int j = 0; j < EN; j++) t[j] = (j == r) ? 1.0 : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < EN; k++) {
+        elds* pb = piv + (k & 1) * 40;
+        if (r == k) {
+            const double ip = 1.0 / s[k];
+            pb[36] = ip;
+#pragma unroll
+            for (int j = k + 1; j < EN; j++) pb[j] = s[j] * ip;
+#pragma unroll
+            for (int j = 0; j < k; j++) pb[EN + j] = t[j] * ip;
+            pb[EN + k] = ip;
+        }
+        __syncthreads();
+        const double ip = pb[36];
+        ok = ok && (ip > 0.0) && (ip < 1e300);
+        const bool me = (r == k);
+        const double f = me ? 0.0 : s[k];
+#pragma unroll
+        for (int j = k + 1; j < EN; j++) { const double pj = pb[j]; s[j] = me ? pj : fma(-f, pj, s[j]); }
+#pragma unroll
+        for (int j = 0; j <= k; j++) { const double pj = pb[EN + j]; t[j] = me ? pj : fma(-f, pj, t[j]); }
+    }
+    if (row) store_row(bufD + r * EN, t);
+    __syncthreads();
+    // Kal = U S^-1
+    double kal[EN];
+#pragma unroll
+    for (int j = 0; j < EN; j++) kal[j] = 0.0;
+    row_gemm<false>(bufB + ri * EN, 1, bufD, kal);
+    if (!ok) {   // innovation covariance not positive definite (or NaN): keep the prediction, P := P_pred
+#pragma unroll
+        for (int j = 0; j < EN; j++) kal[j] = 0.0;
+    }
+    // x_new = x_pred + Kal (y - y_pred)
+    {
+        double ye[EN];
+        load_row(v_ye, ye);
+        double dxi = 0.0;
+#pragma unroll
+        for (int j = 0; j < EN; j++) dxi = fma(kal[j], ye[j], dxi);
+        double xi = 0.0;
+#pragma unroll
+        for (int j = 0; j < EN; j++) xi = (j == r) ? x[j] : xi;
+        xi += dxi;
+        __syncthreads();                           // y_pred (parked in v_xn) has been consumed by every lane
+        if (row) {
+            v_xn[r] = xi;
+            if (live) A.x[(size_t)inst * EN + r] = xi;
+            store_row(bufB + r * EN, kal);         // U row i was read by lane i only
+        }
+    }
+    __syncthreads();
+    // J = I - Kal H  (right: H[k][j] = H^T[j][k], strided)
+#pragma unroll
+    for (int j = 0; j < EN; j++) acc[j] = 0.0;
+    row_gemm<true>(bufB + ri * EN, 1, bufA, acc);
+#pragma unroll
+    for (int j = 0; j < EN; j++) acc[j] = ((j == r) ? 1.0 : 0.0) - (ok ? acc[j] : 0.0);   // !ok: J = I exactly (H may hold NaN)
+    if (row) store_row(bufD + r * EN, acc);      // S^-1 is dead (consumed before the barrier above)
+    __syncthreads();
+    // V = J P_pred
+#pragma unroll
+    for (int j = 0; j < EN; j++) acc[j] = 0.0;
+    row_gemm<false>(bufD + ri * EN, 1, bufC, acc);
+    if (row) store_row(bufA + r * EN, acc);      // H^T is dead
+    __syncthreads();
+    // P_new = V J^T + R Kal Kal^T   (Joseph form, bluerov2_dob.cpp:537)
+    double pn[EN], kk[EN];
+#pragma unroll
+    for (int j = 0; j < EN; j++) { pn[j] = 0.0; kk[j] = 0.0; }
+    row_gemm<true>(bufA + ri * EN, 1, bufD, pn);
+    row_gemm<true>(bufB + ri * EN, 1, bufB, kk);
+    if (row && live) {
+        double* pg = A.P + (size_t)inst * kMat + (size_t)r * EN;
+#pragma unroll
+        for (int j = 0; j < EN; j++) pg[j] = fma(c.R, kk[j], pn[j]);
+    }
+    // ---- outputs: world-frame disturbance with the MEASURED attitude (:540-545), NMPC parameters (:334-337)
+    if (base && live) {
+        double xn[EN], ym[EN];
+        load_row(v_xn, xn);
+        load_row(v_y, ym);
+        double sph, cph, sth, cth, sps, cps;
+        sincos_pio2(ym[3], &sph, &cph);
+        sincos_pio2(ym[4], &sth, &cth);
+        sincos_pio2(ym[5], &sps, &cps);
+        double* w = A.wf + (size_t)inst * 6;
+        w[0] = (cps * cth) * xn[12] + (-sps * cph + cps * sth * sph) * xn[13] + (sps * sph + cps * cph * sth) * xn[14];
+        w[1] = (sps * cth) * xn[12] + (cps * cph + sph * sth * sps) * xn[13] + (-cps * sph + sth * sps * cph) * xn[14];
+        w[2] = (-sth) * xn[12] + (cth * sph) * xn[13] + (cth * cph) * xn[14];
+        w[3] = xn[15] + (sps * sth / cth) * xn[16] + cph * sth / cth * xn[17];
+        w[4] = cph * xn[16] + sph * xn[17];
+        w[5] = (sph / cth) * xn[16] + (cph / cth) * xn[17];
+        double* mp = A.mp + (size_t)inst * 4;
+        mp[0] = xn[12] * c.inv_cc;
+        mp[1] = xn[13] * c.inv_cc;
+        mp[2] = xn[14] * c.inv_rc;
+        mp[3] = xn[17] * c.inv_rc;
+        bool fin = true;
+#pragma unroll
+        for (int j = 0; j < EN; j++) fin = fin && (fabs(xn[j]) < 1e300);
+        A.status[inst] = !ok ? 1 : (fin ? 0 : 2);
+    }
+}
+
+// measurement assembly for the on-device DOB-MPC loop: y12 = plant state, thrust = allocation of u0 (bluerov2_dob.cpp:390-395)
+// with the OCP model's rotor constant, i.e. exactly the thruster vector brov_plant_step applies; acc = (v - v_prev) / dt
+// (:148-153); one lane per filter
+__global__ void ekf_inputs_from_solver_kernel(int B, double dt, double inv_rc, const double* __restrict__ x0,
+                                              const brov_result* __restrict__ res, double* __restrict__ vprev,
+                                              double* __restrict__ thrust, double* __restrict__ y12, double* __restrict__ acc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* xs = x0 + (size_t)b * 12;
+#pragma unroll
+    for (int j = 0; j < 12; j++) y12[(size_t)b * 12 + j] = xs[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const double v = xs[6 + j];
+        acc[(size_t)b * 6 + j] = (v - vprev[(size_t)b * 6 + j]) / dt;
+        vprev[(size_t)b * 6 + j] = v;
+    }
+    const double u0 = res[b].u0[0], u1 = res[b].u0[1], u2 = res[b].u0[2], u3 = res[b].u0[3];
+    double* t = thrust + (size_t)b * 6;
+    t[0] = (-u0 + u1 + u3) * inv_rc;
+    t[1] = (-u0 - u1 - u3) * inv_rc;
+    t[2] = (u0 + u1 - u3) * inv_rc;
+    t[3] = (u0 - u1 + u3) * inv_rc;
+    t[4] = (-u2) * inv_rc;
+    t[5] = (-u2) * inv_rc;
+}
+
+// p[0..3] of every stage of instance b := estimate of instance b (bluerov2_dob.cpp:332-337)
+__global__ void ekf_apply_kernel(int B, int stages, const double* __restrict__ mp, double* __restrict__ par) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B * stages) return;
+    const int b = k / stages;
+    double* p = par + (size_t)k * 16;
+#pragma unroll
+    for (int j = 0; j < 4; j++) p[j] = mp[(size_t)b * 4 + j];
+}
+
+}  // namespace brov
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+using namespace brov;
+
+static thread_local std::string g_ekf_err;
+#define EKFCHK(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            g_ekf_err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) \
+                       ? BROV_ERR_NO_DEVICE                                                                   \
+                       : BROV_ERR_HIP;                                                                        \
+        }                                                                                                     \
+    } while (0)
+
+struct brov_ekf {
+    int device = 0, B = 0;
+    brov_ekf_params par{};
+    EkfConst c{};
+    double *x = nullptr, *P = nullptr, *thrust = nullptr, *y12 = nullptr, *acc = nullptr, *wf = nullptr, *mp = nullptr,
+           *vprev = nullptr;
+    int* status = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ev_valid = false;
+    std::vector<void*> allocs;
+};
+
+extern "C" const char* brov_ekf_last_error(void) { return g_ekf_err.c_str(); }
+
+extern "C" void brov_ekf_default_params(brov_ekf_params* p) {
+    // bluerov2_dob.h:171-183,208; bluerov2_dob.cpp:52-62
+    static const double am[6] = {1.7182, 0, 5.468, 0, 1.2481, 0.4006};
+    static const double dl[6] = {-11.7391, -20, -31.8678, -25, -44.9085, -5};
+    static const double dnl[6] = {-18.18, -21.66, -36.99, -1.55, -1.55, -1.55};
+    static const double K[36] = {
+        0.7071067811847433,   0.7071067811847433,    -0.7071067811919605, -0.7071067811919605,  0.0,                   0.0,
+        0.7071067811883519,   -0.7071067811883519,   0.7071067811811348,  -0.7071067811811348,  0.0,                   0.0,
+        0,                    0,                     0,                   0,                    1,                     1,
+        0.051265241636155506, -0.05126524163615552,  0.05126524163563227, -0.05126524163563227, -0.11050000000000001,  0.11050000000000003,
+        -0.05126524163589389, -0.051265241635893896, 0.05126524163641713, 0.05126524163641713,  -0.002499999999974481, -0.002499999999974481,
+        0.16652364696949604,  -0.16652364696949604,  -0.17500892834341342, 0.17500892834341342, 0.0,                   0.0};
+    std::memset(p, 0, sizeof(*p));
+    p->dt = 0.05;
+    p->mass = 11.26; p->Ix = 0.3; p->Iy = 0.63; p->Iz = 0.58; p->ZG = 0.02; p->g = 9.81; p->bouyancy = 0.661618;
+    std::memcpy(p->added_mass, am, sizeof am);
+    std::memcpy(p->Dl, dl, sizeof dl);
+    std::memcpy(p->Dnl, dnl, sizeof dnl);
+    std::memcpy(p->K, K, sizeof K);
+    for (int i = 0; i < 6; i++) p->Q[i] = std::pow(p->dt, 4) / 4;
+    for (int i = 6; i < 18; i++) p->Q[i] = std::pow(p->dt, 2);
+    p->R = std::pow(p->dt, 4) / 4;
+    p->fd_step = 1e-6;
+    p->compensate_coef = 0.032546960744430276;
+    p->rotor_constant = 0.026546960744430276;
+}
+
+// diagonal of M and of M^-1 (bluerov2_dob.cpp:41-47); 6x6 Gauss-Jordan with partial pivoting on the host, once
+static void derive_mass(const brov_ekf_params& p, double* Md, double* iMd) {
+    double a[6][12];
+    std::memset(a, 0, sizeof a);
+    const double mv[6] = {p.mass + p.added_mass[0], p.mass + p.added_mass[1], p.mass + p.added_mass[2],
+                          p.Ix + p.added_mass[3],   p.Iy + p.added_mass[4],   p.Iz + p.added_mass[5]};
+    for (int i = 0; i < 6; i++) { a[i][i] = mv[i]; a[i][6 + i] = 1.0; Md[i] = mv[i]; }
+    a[0][4] = p.mass * p.ZG; a[1][3] = -p.mass * p.ZG; a[3][1] = -p.mass * p.ZG; a[4][0] = p.mass * p.ZG;
+    for (int k = 0; k < 6; k++) {
+        int q = k;
+        for (int i = k + 1; i < 6; i++)
+            if (std::fabs(a[i][k]) > std::fabs(a[q][k])) q = i;
+        if (q != k)
+            for (int j = 0; j < 12; j++) std::swap(a[k][j], a[q][j]);
+        const double ip = 1.0 / a[k][k];
+        for (int j = 0; j < 12; j++) a[k][j] *= ip;
+        for (int i = 0; i < 6; i++) {
+            if (i == k) continue;
+            const double f = a[i][k];
+            for (int j = 0; j < 12; j++) a[i][j] -= f * a[k][j];
+        }
+    }
+    for (int i = 0; i < 6; i++) iMd[i] = a[i][6 + i];
+}
+
+static void make_const(const brov_ekf_params& p, EkfConst& c) {
+    c.dt = p.dt; c.mass = p.mass; c.bo = p.bouyancy; c.mzg = p.mass * p.ZG * p.g;
+    c.iy_iz = p.Iy - p.Iz; c.iz_ix = p.Iz - p.Ix; c.iy_ix = p.Iy - p.Ix;
+    c.R = p.R; c.d = p.fd_step; c.inv_cc = 1.0 / p.compensate_coef; c.inv_rc = 1.0 / p.rotor_constant;
+    for (int i = 0; i < 6; i++) { c.Dl[i] = p.Dl[i]; c.Dnl[i] = p.Dnl[i]; }
+    for (int i = 0; i < 36; i++) c.K[i] = p.K[i];
+    for (int i = 0; i < 18; i++) c.Q[i] = p.Q[i];
+    derive_mass(p, c.Md, c.iMd);
+}
+
+template <typename T>
+static int ekf_alloc(brov_ekf* e, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T)) != hipSuccess) { g_ekf_err = "hipMalloc failed"; return BROV_ERR_ALLOC; }
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return BROV_OK;
+}
+
+extern "C" void brov_ekf_destroy(brov_ekf* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (void* q : e->allocs) (void)hipFree(q);
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int brov_ekf_reset(brov_ekf* e, const double* x0, const double* P0) {
+    if (!e) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    static const double xr[18] = {0, 0, -20, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 6, 6, 0, 0, 0};  // bluerov2_dob.cpp:64
+    std::vector<double> hx((size_t)e->B * 18), hp((size_t)e->B * 324, 0.0);
+    for (int b = 0; b < e->B; b++) {
+        std::memcpy(&hx[(size_t)b * 18], x0 ? x0 : xr, sizeof xr);
+        if (P0) std::memcpy(&hp[(size_t)b * 324], P0, 324 * sizeof(double));
+        else for (int i = 0; i < 18; i++) hp[(size_t)b * 324 + i * 19] = 1.0;
+    }
+    EKFCHK(hipMemcpy(e->x, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice));
+    EKFCHK(hipMemcpy(e->P, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+    EKFCHK(hipMemset(e->vprev, 0, (size_t)e->B * 6 * sizeof(double)));
+    return BROV_OK;
+}
+
+extern "C" int brov_ekf_create(brov_ekf** out, int device, int B, const brov_ekf_params* p) {
+    if (!out || B <= 0) { g_ekf_err = "brov_ekf_create: bad arguments"; return BROV_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_ekf_err = "brov_ekf_create: no usable HIP device (the observer has no CPU path)";
+        return BROV_ERR_NO_DEVICE;
+    }
+    EKFCHK(hipSetDevice(device));
+    brov_ekf* e = new brov_ekf();
+    e->device = device; e->B = B;
+    if (p) e->par = *p; else brov_ekf_default_params(&e->par);
+    make_const(e->par, e->c);
+    int rc = BROV_OK;
+    if ((rc = ekf_alloc(e, &e->x, (size_t)B * 18)) || (rc = ekf_alloc(e, &e->P, (size_t)B * 324)) ||
+        (rc = ekf_alloc(e, &e->thrust, (size_t)B * 6)) || (rc = ekf_alloc(e, &e->y12, (size_t)B * 12)) ||
+        (rc = ekf_alloc(e, &e->acc, (size_t)B * 6)) || (rc = ekf_alloc(e, &e->wf, (size_t)B * 6)) ||
+        (rc = ekf_alloc(e, &e->mp, (size_t)B * 4)) || (rc = ekf_alloc(e, &e->vprev, (size_t)B * 6)) ||
+        (rc = ekf_alloc(e, &e->status, (size_t)B))) {
+        brov_ekf_destroy(e);
+        return rc;
+    }
+    if (hipMemset(e->wf, 0, (size_t)B * 6 * sizeof(double)) != hipSuccess || hipMemset(e->mp, 0, (size_t)B * 4 * sizeof(double)) != hipSuccess ||
+        hipMemset(e->status, 0, (size_t)B * sizeof(int)) != hipSuccess || hipEventCreate(&e->ev[0]) != hipSuccess ||
+        hipEventCreate(&e->ev[1]) != hipSuccess) {
+        g_ekf_err = "brov_ekf_create: device initialisation failed";
+        brov_ekf_destroy(e);
+        return BROV_ERR_HIP;
+    }
+    rc = brov_ekf_reset(e, nullptr, nullptr);
+    if (rc) { brov_ekf_destroy(e); return rc; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ekf_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kPerWave * kLdsPerFilter * (int)sizeof(double));
+        attr_set = true;
+    }
+    *out = e;
+    return BROV_OK;
+}
+
+extern "C" int brov_ekf_batch(const brov_ekf* e) { return e ? e->B : 0; }
+
+extern "C" int brov_ekf_set_state_host(brov_ekf* e, const double* x, const double* P) {
+    if (!e) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    if (x) EKFCHK(hipMemcpy(e->x, x, (size_t)e->B * 18 * sizeof(double), hipMemcpyHostToDevice));
+    if (P) EKFCHK(hipMemcpy(e->P, P, (size_t)e->B * 324 * sizeof(double), hipMemcpyHostToDevice));
+    return BROV_OK;
+}
+
+extern "C" int brov_ekf_get_state_host(brov_ekf* e, double* x, double* P) {
+    if (!e) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    EKFCHK(hipStreamSynchronize(e->last_stream));
+    if (x) EKFCHK(hipMemcpy(x, e->x, (size_t)e->B * 18 * sizeof(double), hipMemcpyDeviceToHost));
+    if (P) EKFCHK(hipMemcpy(P, e->P, (size_t)e->B * 324 * sizeof(double), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+
+static int launch_update(brov_ekf* e, const double* thrust, const double* y12, const double* acc, hipStream_t st) {
+    EkfArgs a;
+    a.c = e->c; a.B = e->B; a.x = e->x; a.P = e->P; a.thrust = thrust; a.y12 = y12; a.acc = acc; a.wf = e->wf; a.mp = e->mp;
+    a.status = e->status;
+    const int blocks = (e->B + kPerWave - 1) / kPerWave;
+    EKFCHK(hipEventRecord(e->ev[0], st));
+    hipLaunchKernelGGL(ekf_update_kernel, dim3(blocks), dim3(64), kPerWave * kLdsPerFilter * sizeof(double), st, a);
+    EKFCHK(hipGetLastError());
+    EKFCHK(hipEventRecord(e->ev[1], st));
+    e->ev_valid = true;
+    e->last_stream = st;
+    return BROV_OK;
+}
+
+extern "C" int brov_ekf_update_device(brov_ekf* e, const double* thrust, const double* y12, const double* acc, void* stream) {
+    if (!e || !thrust || !y12 || !acc) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    return launch_update(e, thrust, y12, acc, (hipStream_t)stream);
+}
+
+extern "C" int brov_ekf_update_host(brov_ekf* e, const double* thrust, const double* y12, const double* acc, void* stream) {
+    if (!e || !thrust || !y12 || !acc) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    EKFCHK(hipMemcpyAsync(e->thrust, thrust, (size_t)e->B * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    EKFCHK(hipMemcpyAsync(e->y12, y12, (size_t)e->B * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+    EKFCHK(hipMemcpyAsync(e->acc, acc, (size_t)e->B * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    return launch_update(e, e->thrust, e->y12, e->acc, st);
+}
+
+extern "C" int brov_ekf_get_outputs_host(brov_ekf* e, double* wf, double* mpc_p, int* status) {
+    if (!e) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    EKFCHK(hipStreamSynchronize(e->last_stream));
+    if (wf) EKFCHK(hipMemcpy(wf, e->wf, (size_t)e->B * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    if (mpc_p) EKFCHK(hipMemcpy(mpc_p, e->mp, (size_t)e->B * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) EKFCHK(hipMemcpy(status, e->status, (size_t)e->B * sizeof(int), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+
+extern "C" const double* brov_ekf_x_device(const brov_ekf* e) { return e ? e->x : nullptr; }
+extern "C" const double* brov_ekf_P_device(const brov_ekf* e) { return e ? e->P : nullptr; }
+extern "C" const double* brov_ekf_mpc_p_device(const brov_ekf* e) { return e ? e->mp : nullptr; }
+
+extern "C" int brov_ekf_update_from_solver(brov_ekf* e, brov_solver* s, void* stream) {
+    if (!e || !s || brov_batch(s) != e->B) { g_ekf_err = "brov_ekf_update_from_solver: batch sizes differ"; return BROV_ERR_ARG; }
+    EKFCHK(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ekf_inputs_from_solver_kernel, dim3((e->B + 255) / 256), dim3(256), 0, st, e->B, e->c.dt, 1.0 / kRotor,
+                       (const double*)brov_x0_device(s), brov_results_device(s), e->vprev, e->thrust, e->y12, e->acc);
+    EKFCHK(hipGetLastError());
+    return launch_update(e, e->thrust, e->y12, e->acc, st);
+}
+
+extern "C" int brov_ekf_apply_to_solver(brov_ekf* e, brov_solver* s, void* stream) {
+    if (!e || !s || brov_batch(s) != e->B) { g_ekf_err = "brov_ekf_apply_to_solver: batch sizes differ"; return BROV_ERR_ARG; }
+    EKFCHK(hipSetDevice(e->device));
+    brov_opts o;
+    if (brov_get_opts(s, &o) != BROV_OK) return BROV_ERR_ARG;
+    const int stages = o.N + 1;
+    const long long n = (long long)e->B * stages;
+    hipLaunchKernelGGL(ekf_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->B, stages,
+                       (const double*)e->mp, brov_params_device(s));
+    EKFCHK(hipGetLastError());
+    e->last_stream = (hipStream_t)stream;
+    return BROV_OK;
+}
+
+extern "C" int brov_ekf_last_update_seconds(brov_ekf* e, double* seconds) {
+    if (!e || !seconds || !e->ev_valid) return BROV_ERR_ARG;
+    EKFCHK(hipSetDevice(e->device));
+    EKFCHK(hipEventSynchronize(e->ev[1]));
+    float ms = 0.f;
+    EKFCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    *seconds = ms * 1e-3;
+    return BROV_OK;
+}

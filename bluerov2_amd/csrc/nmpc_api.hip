@@ -315,6 +315,14 @@ extern "C" int brov_get_yref_host(brov_solver* s, double* yref) {
     }
     return BROV_OK;
 }
+// model parameters currently in force, [B][N+1][16]
+extern "C" int brov_get_params_host(brov_solver* s, double* par) {
+    if (!s || !par) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(par, s->par, (size_t)s->B * (s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
 
 __global__ void copy_stage0_par_kernel(const double* __restrict__ par, double* __restrict__ pp, int B, int N1) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

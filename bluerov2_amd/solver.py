@@ -91,7 +91,7 @@ def _load():
         "brov_closed_loop": [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int32)],
         "brov_traj_set_host": [vp, dp, C.c_int], "brov_traj_rows": [vp], "brov_set_yref_from_traj": [vp, C.c_int, C.c_int, vp],
         "brov_set_yref_from_traj_lines_host": [vp, C.POINTER(C.c_int32), C.c_int],
-        "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double], "brov_get_yref_host": [vp, dp],
+        "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
     }.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -243,6 +243,12 @@ class BatchSolver:
     # ---- closed loop on the device ---------------------------------------------------------------
     def set_plant_params(self, p):
         self._chk(self._L.brov_plant_set_params_host(self._h, _dp(_arr(p, (self.B, NP)))), "set_plant_params")
+
+    def get_params(self):
+        """model parameters currently in force, [B, N+1, 16]"""
+        p = np.empty((self.B, self.N + 1, NP))
+        self._chk(self._L.brov_get_params_host(self._h, _dp(p)), "get_params")
+        return p
 
     def plant_step(self, dt=0.05, substeps=1, stream=0):
         self._chk(self._L.brov_plant_step(self._h, float(dt), int(substeps), C.c_void_p(stream)), "plant_step")

@@ -126,6 +126,8 @@ int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, co
                                   double t0, double dt);
 /* read back the reference windows currently in force, as [B][N+1][16] (shared windows are replicated) */
 int brov_get_yref_host(brov_solver* s, double* yref);
+/* read back the model parameters currently in force, [B][N+1][16] */
+int brov_get_params_host(brov_solver* s, double* par);
 
 /* ---- closed-loop roll-outs on the device (the step after the path): plant update + reference advance ------------------
  * Plant = the OCP's own 12-state model (bluerov2.py:103-137) integrated with ERK4 over one control period with u0 of the
@@ -183,6 +185,60 @@ int brov_last_solve_seconds(brov_solver* s, double* total, double* kernels2);
 int brov_enable_timing(brov_solver* s, int on);
 /* which kernels the last brov_solve launched: BROV_PATH_FUSED or BROV_PATH_STREAMING */
 int brov_last_kernel_path(const brov_solver* s);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Batched EKF disturbance observer: B independent copies of the reference's 18-state filter
+ * BLUEROV2_DOB::EKF() (bluerov2_dobmpc/src/bluerov2_dob.cpp:495-545) -- forward-difference Jacobians of the RK4 map
+ * (:730-744, with the k2/3 stage quirk of :630) and of the measurement model (:747-762), gain through the explicit
+ * inverse of the innovation covariance, Joseph-form covariance update.  One call = one EKF tick of every instance.
+ * State [pose(6) | body velocities(6) | body-frame disturbance wrench(6)], instance-major, FP64.
+ * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct brov_ekf brov_ekf;
+typedef struct brov_ekf_params { /* defaults: bluerov2_dob.h:171-183,208 and bluerov2_dob.cpp:41-62 */
+    double dt;
+    double mass, Ix, Iy, Iz, ZG, g, bouyancy;
+    double added_mass[6], Dl[6], Dnl[6];
+    double K[36];          /* propulsion matrix, row-major: tau = K * thrust */
+    double Q[18];          /* process noise (diagonal) */
+    double R;              /* measurement noise R * I */
+    double fd_step;        /* finite-difference step of both Jacobians (1e-6) */
+    double compensate_coef, rotor_constant; /* scaling of the estimate into the NMPC parameters p[0..3] (:334-337) */
+} brov_ekf_params;
+void brov_ekf_default_params(brov_ekf_params* p);
+const char* brov_ekf_last_error(void); /* message of the last failing brov_ekf_* call on this thread */
+int  brov_ekf_create(brov_ekf** out, int device, int batch, const brov_ekf_params* p /* NULL: defaults */);
+void brov_ekf_destroy(brov_ekf* e);
+int  brov_ekf_batch(const brov_ekf* e);
+/* every instance := (x0, P0); NULL = the reference's start [0,0,-20,0..0,6,6,6,0,0,0], P0 = I (bluerov2_dob.cpp:64-65) */
+int brov_ekf_reset(brov_ekf* e, const double* x0 /*[18]*/, const double* P0 /*[18][18]*/);
+int brov_ekf_set_state_host(brov_ekf* e, const double* x /*[B][18]*/, const double* P /*[B][18][18]*/);
+int brov_ekf_get_state_host(brov_ekf* e, double* x /*[B][18] or NULL*/, double* P /*[B][18][18] or NULL*/);
+/* one EKF tick.  thrust = meas_u (thruster outputs, :498), y12 = measured pose + body velocities (:501-502), acc = body
+ * accelerations (finite differences of the velocities, :148-153).  HOST or DEVICE pointers respectively. */
+int brov_ekf_update_host(brov_ekf* e, const double* thrust /*[B][6]*/, const double* y12 /*[B][12]*/,
+                         const double* acc /*[B][6]*/, void* stream);
+int brov_ekf_update_device(brov_ekf* e, const double* thrust, const double* y12, const double* acc, void* stream);
+/* outputs of the last tick: world-frame disturbance (:540-545), NMPC parameters p[0..3] (:334-337), per-instance status
+ * (0 ok; 1 innovation covariance not positive definite or NaN: estimate and covariance left at the prediction;
+ *  2 non-finite estimate, e.g. a NaN measurement: propagated as the reference would) */
+int brov_ekf_get_outputs_host(brov_ekf* e, double* wf /*[B][6] or NULL*/, double* mpc_p /*[B][4] or NULL*/,
+                              int* status /*[B] or NULL*/);
+const double* brov_ekf_x_device(const brov_ekf* e);      /* [B][18] */
+const double* brov_ekf_P_device(const brov_ekf* e);      /* [B][18][18] */
+const double* brov_ekf_mpc_p_device(const brov_ekf* e);  /* [B][4] */
+/* close the DOB-MPC loop on the device (BASELINE config 3), no host round trip:
+ *   brov_ekf_update_from_solver: measurement = the solver's x0 (the plant state after brov_plant_step), thrusts = thrust
+ *     allocation of the solver's last u0 (:390-395) -- the thruster vector brov_plant_step applies --, accelerations =
+ *     (v - v_prev)/dt with v_prev kept in the observer (zero after brov_ekf_reset, like the reference's pre_body_pos);
+ *   brov_ekf_apply_to_solver: p[0..3] of every stage of instance b := the estimate of instance b (:332-337).
+ * Units: the reference's plant is Gazebo, whose thrusters turn a command w into rotor_constant*w|w| newtons, and :334-337
+ * rescale the estimated wrench by 1/compensate_coef resp. 1/rotor_constant into the OCP model's force units.  The device
+ * plant is the OCP model itself (wrench = K * allocation(u)/rotor_constant), so an observer that is to compensate THAT
+ * plant is created with compensate_coef = rotor_constant = 1 in brov_ekf_params. */
+int brov_ekf_update_from_solver(brov_ekf* e, brov_solver* s, void* stream);
+int brov_ekf_apply_to_solver(brov_ekf* e, brov_solver* s, void* stream);
+/* seconds of the last update kernel (HIP events on its stream) */
+int brov_ekf_last_update_seconds(brov_ekf* e, double* seconds);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,20 @@ def test_no_cpu_fallback():
         bluerov2_amd.BatchSolver(4, bluerov2_amd.SolverOptions(20))
 
 
+def test_ekf_has_no_cpu_fallback_and_reference_defaults():
+    import torch
+    import bluerov2_amd
+    p = bluerov2_amd.EkfParams.default()
+    # bluerov2_dob.h:171-183,208; bluerov2_dob.cpp:59-62
+    assert p.dt == 0.05 and p.mass == 11.26 and p.bouyancy == 0.661618 and p.fd_step == 1e-6
+    assert list(p.Dl) == [-11.7391, -20, -31.8678, -25, -44.9085, -5] and list(p.added_mass) == [1.7182, 0, 5.468, 0, 1.2481, 0.4006]
+    assert p.R == 0.05 ** 4 / 4 and list(p.Q) == [0.05 ** 4 / 4] * 6 + [0.05 ** 2] * 12
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bluerov2_amd.NoDeviceError):
+        bluerov2_amd.BatchEkf(4)
+
+
 def test_thrust_allocation_host_helper():
     import bluerov2_amd
     c = 0.026546960744430276
