@@ -39,7 +39,7 @@ typedef double ed2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) ed2 elds2;
 
 struct EkfConst {
-    double dt, mass, bo, mzg, iy_iz, iz_ix, iy_ix, R, d, inv_cc, inv_rc;
+    double dt, mass, bo, mzg, iy_iz, iz_ix, iy_ix, R, d, inv_d, inv_cc, inv_rc;
     double Dl[6], Dnl[6], Md[6], iMd[6], K[36], Q[EN];
 };
 struct EkfArgs {
@@ -65,9 +65,10 @@ __device__ __forceinline__ void ekf_f12(const EkfConst& c, const double (&x)[EN]
     xd[0] = (cps * cth) * x[6] + (-sps * cph + cps * sth * sph) * x[7] + (sps * sph + cps * cph * sth) * x[8];
     xd[1] = (sps * cth) * x[6] + (cps * cph + sph * sth * sps) * x[7] + (-cps * sph + sth * sps * cph) * x[8];
     xd[2] = (-sth) * x[6] + (cth * sph) * x[7] + (cth * cph) * x[8];
-    xd[3] = x[9] + (sps * sth / cth) * x[10] + cph * sth / cth * x[11];
+    const double icth = 1.0 / cth;   // one division per evaluation; the quotients of the reference differ by <= 1 ulp
+    xd[3] = x[9] + (sps * sth * icth) * x[10] + cph * sth * icth * x[11];
     xd[4] = cph * x[10] + sph * x[11];
-    xd[5] = (sph / cth) * x[10] + (cph / cth) * x[11];
+    xd[5] = (sph * icth) * x[10] + (cph * icth) * x[11];
     xd[6] = c.iMd[0] * (tau[0] + m * x[11] * x[7] - m * x[10] * x[8] - c.bo * sth + x[12] + c.Dl[0] * x[6] + c.Dnl[0] * fabs(x[6]) * x[6]);
     xd[7] = c.iMd[1] * (tau[1] - m * x[11] * x[6] + m * x[9] * x[8] + c.bo * cth * sph + x[13] + c.Dl[1] * x[7] + c.Dnl[1] * fabs(x[7]) * x[7]);
     xd[8] = c.iMd[2] * (tau[2] + m * x[10] * x[6] - m * x[9] * x[7] + c.bo * cth * cph + x[14] + c.Dl[2] * x[8] + c.Dnl[2] * fabs(x[8]) * x[8]);
@@ -83,16 +84,16 @@ __device__ __forceinline__ void ekf_rk4(const EkfConst& c, const double (&x)[EN]
     for (int i = 12; i < EN; i++) { xs[i] = x[i]; xn[i] = x[i]; }
     ekf_f12(c, x, tau, k1);
 #pragma unroll
-    for (int i = 0; i < 12; i++) { k1[i] *= c.dt; xs[i] = x[i] + k1[i] / 2; }
+    for (int i = 0; i < 12; i++) { k1[i] *= c.dt; xs[i] = x[i] + k1[i] * 0.5; }
     ekf_f12(c, xs, tau, k2);
 #pragma unroll
-    for (int i = 0; i < 12; i++) { k2[i] *= c.dt; xs[i] = x[i] + k2[i] / 3; }
+    for (int i = 0; i < 12; i++) { k2[i] *= c.dt; xs[i] = x[i] + k2[i] * (1.0 / 3.0); }
     ekf_f12(c, xs, tau, k3);
 #pragma unroll
     for (int i = 0; i < 12; i++) { k3[i] *= c.dt; xs[i] = x[i] + k3[i]; }
     ekf_f12(c, xs, tau, k4);
 #pragma unroll
-    for (int i = 0; i < 12; i++) { k4[i] *= c.dt; xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6; }
+    for (int i = 0; i < 12; i++) { k4[i] *= c.dt; xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (1.0 / 6.0); }
 }
 
 // measurement model, bluerov2_dob.cpp:705-727
@@ -123,19 +124,33 @@ __device__ __forceinline__ void store_row(elds* p, const double (&v)[EN]) {
 // acc[:] += sum_k a(k) * B(k,:) with a(k) = a0[k * a_sk] (lane-specific) and row k of B either contiguous at b0 + 18 k
 // (B stored row-major) or strided at b0[j * 18 + k] (B^T stored row-major).  The 18 lanes of a filter read the same B row.
 template <bool BT>
-__device__ __forceinline__ void row_gemm(const elds* a0, int a_sk, const elds* b0, double (&acc)[EN]) {
-#pragma unroll 3
-    for (int k = 0; k < EN; k++) {
-        const double a = a0[k * a_sk];
-        double br[EN];
-        if (BT) {
+__device__ __forceinline__ void fetch_brow(const elds* b0, int k, double (&br)[EN]) {
+    if (BT) {
 #pragma unroll
-            for (int j = 0; j < EN; j++) br[j] = b0[j * EN + k];
-        } else {
-            load_row(b0 + k * EN, br);
-        }
+        for (int j = 0; j < EN; j++) br[j] = b0[j * EN + k];
+    } else {
+        load_row(b0 + k * EN, br);
+    }
+}
+// The next right-hand row is requested before the 18 FMAs of the current one, so that the LDS pipe and the VALU overlap
+// (there is one wave per SIMD: nothing else hides the LDS round trip).
+template <bool BT>
+__device__ __forceinline__ void row_gemm(const elds* a0, int a_sk, const elds* b0, double (&acc)[EN]) {
+    double br[EN], bn[EN];
+    double a = a0[0], an;
+    fetch_brow<BT>(b0, 0, br);
+#pragma unroll 2
+    for (int k = 0; k < EN; k++) {
+        const int kn = k + 1 < EN ? k + 1 : EN - 1;
+        an = a0[kn * a_sk];
+        fetch_brow<BT>(b0, kn, bn);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < EN; j++) acc[j] = fma(a, br[j], acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        a = an;
+#pragma unroll
+        for (int j = 0; j < EN; j++) br[j] = bn[j];
     }
 }
 
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
         double f0[EN];
         load_row(v_xp, f0);
 #pragma unroll
-        for (int j = 0; j < EN; j++) col[j] = (xn[j] - f0[j]) / c.d;
+        for (int j = 0; j < EN; j++) col[j] = (xn[j] - f0[j]) * c.inv_d;
         if (row) store_row(bufA + r * EN, col);   // row r of F^T
 #pragma unroll
         for (int j = 0; j < EN; j++) x[j] = f0[j];  // from here on x = x_pred
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
         double y0[EN];
         load_row(v_xn, y0);
 #pragma unroll
-        for (int j = 0; j < EN; j++) col[j] = (yv[j] - y0[j]) / c.d;
+        for (int j = 0; j < EN; j++) col[j] = (yv[j] - y0[j]) * c.inv_d;
         if (row) store_row(bufA + r * EN, col);    // row r of H^T
     }
     __syncthreads();
@@ -501,7 +516,7 @@ static void derive_mass(const brov_ekf_params& p, double* Md, double* iMd) {
 static void make_const(const brov_ekf_params& p, EkfConst& c) {
     c.dt = p.dt; c.mass = p.mass; c.bo = p.bouyancy; c.mzg = p.mass * p.ZG * p.g;
     c.iy_iz = p.Iy - p.Iz; c.iz_ix = p.Iz - p.Ix; c.iy_ix = p.Iy - p.Ix;
-    c.R = p.R; c.d = p.fd_step; c.inv_cc = 1.0 / p.compensate_coef; c.inv_rc = 1.0 / p.rotor_constant;
+    c.R = p.R; c.d = p.fd_step; c.inv_d = 1.0 / p.fd_step; c.inv_cc = 1.0 / p.compensate_coef; c.inv_rc = 1.0 / p.rotor_constant;
     for (int i = 0; i < 6; i++) { c.Dl[i] = p.Dl[i]; c.Dnl[i] = p.Dnl[i]; }
     for (int i = 0; i < 36; i++) c.K[i] = p.K[i];
     for (int i = 0; i < 18; i++) c.Q[i] = p.Q[i];

@@ -52,6 +52,33 @@ def main(tag):
     s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05)); s.set_x0(x0); s.set_params(p); s.set_trajectory(circ)
     out["cfg3_B16384_N20_dob_draws"] = run(s, lambda k: s.set_yref_from_trajectory(k))
     s.close()
+    # config 3 closed on the device: plant with per-instance TRUE disturbance draws, EKF observer (section 8 f-3) estimating
+    # them, estimate fed back into p[0..3] of every stage: tick = window -> RTI step -> plant step -> EKF update -> apply
+    pt = np.tile(ba.P_NOMINAL, (B, 1)); pt[:, 0:3] = d[:, 0:3]; pt[:, 3] = d[:, 3]
+    ep = ba.EkfParams.default(); ep.compensate_coef = 1.0; ep.rotor_constant = 1.0
+    for j in range(12, 24):
+        ep.K[j] = 0.0   # the device plant is the OCP model: no roll / pitch thrust, unit force scaling (include/bluerov2_nmpc.h)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05)); s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_plant_params(pt)
+    s.set_trajectory(circ)
+    e = ba.BatchEkf(B, ep)
+
+    def tick(k):
+        s.set_yref_from_trajectory(k); s.solve(); s.plant_step(0.05, 1); e.update_from_solver(s); e.apply_to_solver(s)
+    for k in range(WARM):
+        tick(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(WARM, WARM + TICKS):
+        tick(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    r = s.results(); xe, _ = e.state(); _, mp, st = e.outputs()
+    out["cfg3_B16384_N20_dob_closed_loop_with_ekf"] = dict(
+        closed_loop_ticks_per_s=B * TICKS / dt, ms_per_tick=dt / TICKS * 1e3, ekf_kernel_ms=e.last_update_seconds() * 1e3,
+        status_nonzero=int((r["status"] != 0).sum()), ekf_status_nonzero=int((st != 0).sum()),
+        median_abs_estimate_minus_true_disturbance_after_25_ticks=[float(v) for v in np.median(np.abs(mp - d), axis=0)],
+        note="x/y/z offsets are the rigid-body Coriolis terms of the EKF model (bluerov2_dob.cpp:651-677) that the OCP-model plant does not have; the yaw channel has none")
+    e.close(); s.close()
     # config 4 (one of 8 shards): 8192 lemniscate candidates with per-instance amp/omega/phase, then best-candidate select
     B = 8192
     rng = np.random.default_rng(3)

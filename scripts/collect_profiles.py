@@ -35,7 +35,9 @@ def main(tag, rnd):
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
     bench = {}
-    for name in ("bench_plain", "bench_stats", "bench_forced_ipm", "bench_streaming", "bench_b16384"):
+    if os.path.exists(os.path.join(src, "stats_ekf", "stats_kernel_stats.csv")):
+        shutil.copy(os.path.join(src, "stats_ekf", "stats_kernel_stats.csv"), os.path.join(dst, f"{rnd}_ekf_kernel_stats.csv"))
+    for name in ("bench_plain", "bench_stats", "bench_forced_ipm", "bench_streaming", "bench_b16384", "bench_ekf"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p):
             lines = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]

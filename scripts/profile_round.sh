@@ -18,4 +18,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MF
 python $R/bench.py --force-ipm --no-cpu-baseline > $OUT/bench_forced_ipm.json 2> $OUT/bench_forced_ipm.err
 python $R/bench.py --path 1 --no-cpu-baseline > $OUT/bench_streaming.json 2> $OUT/bench_streaming.err
 python $R/bench.py --batch 16384 --no-cpu-baseline > $OUT/bench_b16384.json 2> $OUT/bench_b16384.err
+python $R/scripts/bench_ekf.py > $OUT/bench_ekf.json 2> $OUT/bench_ekf.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ekf -o stats -- python $R/scripts/bench_ekf.py --no-cpu-baseline > /dev/null 2> $OUT/stats_ekf.err
 ls -R $OUT | head -40
