@@ -281,7 +281,8 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
     for (int j = 0; j < EN; j++) s[j] = (j == r) ? c.R : 0.0;
     row_gemm<false>(bufA + ri, EN, bufB, s);
     // ---- S^-1 by Gauss-Jordan without pivoting (S = H P H^T + R I is symmetric positive definite); lane i holds row i of
-    // [S | I].  At step k only columns k+1.. of the left block and 0..k of the right block are non-trivial.
+    // [S | I].  At step k only columns k.. of the left block and 0..k of the right block are non-trivial.  The pivot lane
+    // publishes its row as it is (nothing in front of the LDS write); every lane forms the reciprocal pivot itself.
 #pragma unroll
     for (int j = 0; j < EN; j++) t[j] = (j == r) ? 1.0 : 0.0;
     bool ok = true;
@@ -289,23 +290,27 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
     for (int k = 0; k < EN; k++) {
         elds* pb = piv + (k & 1) * 40;
         if (r == k) {
-            const double ip = 1.0 / s[k];
-            pb[36] = ip;
 #pragma unroll
-            for (int j = k + 1; j < EN; j++) pb[j] = s[j] * ip;
+            for (int j = k; j < EN; j++) pb[j] = s[j];
 #pragma unroll
-            for (int j = 0; j < k; j++) pb[EN + j] = t[j] * ip;
-            pb[EN + k] = ip;
+            for (int j = 0; j < k; j++) pb[EN + j] = t[j];
         }
         __syncthreads();
-        const double ip = pb[36];
-        ok = ok && (ip > 0.0) && (ip < 1e300);
+        const double pk = pb[k];
+        ok = ok && (pk > 0.0) && (pk < 1e300);
+        double ip = __builtin_amdgcn_rcp(pk);   // v_rcp_f64 + 2 Newton steps (~1 ulp)
+        double e1 = fma(-pk, ip, 1.0);
+        ip = fma(ip, e1, ip);
+        e1 = fma(-pk, ip, 1.0);
+        ip = fma(ip, e1, ip);
         const bool me = (r == k);
-        const double f = me ? 0.0 : s[k];
+        // row_i -= (s_ik / p) * row_k for i != k;  row_k *= 1/p  (written as row_k -= (1 - 1/p) row_k: one code path)
+        const double f = me ? 1.0 - ip : s[k] * ip;
 #pragma unroll
-        for (int j = k + 1; j < EN; j++) { const double pj = pb[j]; s[j] = me ? pj : fma(-f, pj, s[j]); }
+        for (int j = k + 1; j < EN; j++) s[j] = fma(-f, pb[j], s[j]);
 #pragma unroll
-        for (int j = 0; j <= k; j++) { const double pj = pb[EN + j]; t[j] = me ? pj : fma(-f, pj, t[j]); }
+        for (int j = 0; j < k; j++) t[j] = fma(-f, pb[EN + j], t[j]);
+        t[k] = me ? ip : -f;                      // column k of the right block was e_k
     }
     if (row) store_row(bufD + r * EN, t);
     __syncthreads();
