@@ -235,6 +235,65 @@ __device__ __forceinline__ void sens_column_rec(const lds_f64* rec, const ModelP
     for (int j = 0; j < NX; j++) acc[j] += (h / 6.0) * ks[j];
 }
 
+// (df/dx) * s for a vector with only the velocity entries s[6], s[7], s[8], s[11] non-zero (what the first RK stage of an
+// input column produces: df/du has rows 6, 7, 8, 11 only)
+__device__ __forceinline__ void jvp_rec_vel(const StageRec& R, double imn, const double (&kb)[4], double s6, double s7,
+                                            double s8, double s11, double (&o)[NX]) {
+    const double* r = R.v;
+    const double sph = r[0], cph = r[1], sth = r[2], cth = r[3], sps = r[4], cps = r[5], icth = r[6];
+    const double wp = r[10], wq = r[11];
+    const double r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = sps * sph + cps * cph * sth;
+    const double r10 = sps * cth, r11 = cps * cph + sph * sth * sps, r12 = sth * sps * cph - cps * sph;
+    const double r21 = cth * sph, r22 = cth * cph;
+    const double tth = sth * icth;
+    o[0] = r00 * s6 + r01 * s7 + r02 * s8;
+    o[1] = r10 * s6 + r11 * s7 + r12 * s8;
+    o[2] = -sth * s6 + r21 * s7 + r22 * s8;
+    o[3] = (cph * tth) * s11;
+    o[4] = sph * s11;
+    o[5] = (cph * s11) * icth;
+    o[6] = r[13] * s6 + kb[0];
+    o[7] = r[14] * s7 + kb[1];
+    o[8] = r[15] * s8 + kb[2];
+    o[9] = ((kIy - kIz) * (wq * s11)) * (1.0 / kIx);
+    o[10] = ((kIz - kIx) * (wp * s11)) * (1.0 / kIy);
+    o[11] = r[16] * s11 + kb[3];
+    (void)imn;
+}
+
+// sensitivity column of input jc (0..3).  Su starts at zero, so the first RK stage is df/du itself (no Jacobian-vector
+// product) and the second one sees a vector with four non-zero entries: an input column costs ~2.4 of the 4 products of a
+// state column.
+__device__ __forceinline__ void sens_column_rec_u(const lds_f64* rec, const ModelPar& m, double h, int jc, double (&acc)[NX]) {
+    double ks[NX], ss[NX], kb[4];
+    constexpr double ir = 1.0 / kRotor;
+    kb[0] = jc == 0 ? (-4.0 * 0.707) * ir * m.imx : 0.0;
+    kb[1] = jc == 1 ? (4.0 * 0.707) * ir * m.imy : 0.0;
+    kb[2] = jc == 2 ? -2.0 * ir * m.imz : 0.0;
+    kb[3] = jc == 1 ? (0.167 + 0.167 - 0.175 - 0.175) * ir * m.imn : (jc == 3 ? (0.167 + 0.167 + 0.175 + 0.175) * ir * m.imn : 0.0);
+    StageRec R = load_stage_rec(rec + kRecStage);
+    __builtin_amdgcn_sched_barrier(0);
+    // stage 1: k1 = df/du column (rows 6, 7, 8, 11)
+#pragma unroll
+    for (int j = 0; j < NX; j++) acc[j] = 0.0;
+    acc[6] = (h / 6.0) * kb[0]; acc[7] = (h / 6.0) * kb[1]; acc[8] = (h / 6.0) * kb[2]; acc[11] = (h / 6.0) * kb[3];
+    jvp_rec_vel(R, m.imn, kb, 0.5 * h * kb[0], 0.5 * h * kb[1], 0.5 * h * kb[2], 0.5 * h * kb[3], ks);
+    R = load_stage_rec(rec + 2 * kRecStage);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * ks[j]; ss[j] = 0.5 * h * ks[j]; }
+    __builtin_amdgcn_sched_barrier(0);
+    jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+    R = load_stage_rec(rec + 3 * kRecStage);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * ks[j]; ss[j] = h * ks[j]; }
+    __builtin_amdgcn_sched_barrier(0);
+    jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
+#pragma unroll
+    for (int j = 0; j < NX; j++) acc[j] += (h / 6.0) * ks[j];
+}
+
 // stationarity / input-feasibility part of the NLP KKT residual for column c >= 3 of interval i, with the cost gradients
 // already in LDS (q_i, r_i); the dynamics gap and the position columns are handled once per interval by the caller.
 // Branch-free: rows that do not apply contribute 0 to the max.

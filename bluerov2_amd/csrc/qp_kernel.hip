@@ -1054,10 +1054,24 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
         if (P.dbg && lane == 0)
             P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
 #pragma unroll 1
-        for (int c = 3 + j0; c < 16; c += L) {
+        for (int c = 3 + j0; c < NX; c += L) {   // state columns 3..11
             double acc[NX];
             const KktOperands ko = load_kkt_operands(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
             sens_column_rec(rec, m, P.Ts, c, acc);
+            const double kk = lin_kkt_col(ko, N, i, c, pir, acc);
+#pragma unroll
+            for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
+            if (active) {
+                if (kk != kk) nanp = true;
+                part = fmax(part, kk);
+            }
+        }
+#pragma unroll 1
+        for (int jc = j0; jc < NU; jc += L) {    // input columns: cheaper (lin_device.hpp, sens_column_rec_u)
+            const int c = NX + jc;
+            double acc[NX];
+            const KktOperands ko = load_kkt_operands(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+            sens_column_rec_u(rec, m, P.Ts, jc, acc);
             const double kk = lin_kkt_col(ko, N, i, c, pir, acc);
 #pragma unroll
             for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
