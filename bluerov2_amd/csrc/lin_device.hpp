@@ -177,13 +177,15 @@ __device__ __forceinline__ void jvp_rec(const StageRec& R, double imx, double im
 // what the KKT rows of column c need besides the column itself; requested at the top of a trip so that the loads complete
 // under the sensitivity arithmetic (indices clamped: every lane issues the same loads, the unused half is discarded)
 struct KktOperands { double pm1c, ll, lu, ucur, lbu, ubu, grad, qn; };
-__device__ __forceinline__ KktOperands load_kkt_operands(const DevParams& P, const double* __restrict__ cst, int b, int i, int c,
-                                                         const double* __restrict__ ui, const lds_f64* q_s,
+// ig = global interval index (HBM arrays), il = index inside the LDS-resident chunk of nl intervals (row nl of q_s holds the
+// terminal gradient when the chunk ends the horizon)
+__device__ __forceinline__ KktOperands load_kkt_operands(const DevParams& P, const double* __restrict__ cst, int b, int ig, int il,
+                                                         int nl, int c, const double* __restrict__ ui, const lds_f64* q_s,
                                                          const lds_f64* r_s) {
     const int N = P.N;
     const int jc = c - NX, ju = jc & 3, cx = c < NX ? c : NX - 1;
-    const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (i > 0 ? i - 1 : 0)) * NX;
-    const double* __restrict__ lam = P.lam + ((size_t)b * N + i) * 8;
+    const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (ig > 0 ? ig - 1 : 0)) * NX;
+    const double* __restrict__ lam = P.lam + ((size_t)b * N + ig) * 8;
     KktOperands K;
     K.pm1c = pim1[cx];
     K.ll = lam[ju];
@@ -191,9 +193,9 @@ __device__ __forceinline__ KktOperands load_kkt_operands(const DevParams& P, con
     K.ucur = ui[ju];
     K.lbu = cst[32 + ju];
     K.ubu = cst[36 + ju];
-    const lds_f64* gp = jc < 0 ? q_s + i * NX + c : r_s + i * NU + jc;
+    const lds_f64* gp = jc < 0 ? q_s + il * NX + c : r_s + il * NU + jc;
     K.grad = *gp;
-    K.qn = q_s[N * NX + cx];
+    K.qn = q_s[nl * NX + cx];
     return K;
 }
 

@@ -932,6 +932,196 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
     }
 }
 
+// Linearisation of the intervals [i0, i0 + n) of instance b by ONE wavefront (n <= 23): ERK4 + forward sensitivities, b_i,
+// cost gradients and the NLP KKT partials of the entering iterate.  L = 64/n lanes per interval (3 at n = 20); each lane
+// integrates the state once and then walks its share of the 13 non-trivial sensitivity columns; columns land in LDS
+// ([A B] compact [n][12][13]), so the scattered 8-byte writes that rule this mapping out against HBM cost nothing.
+//   ba_s [n][12][13], bv_s [n][12], q_s [n+1][12] (row n: terminal gradient if the chunk ends the horizon), r_s [n][4];
+//   rec_s: scratch for the stage records, n*68 doubles.  part / nanp: this lane's share of the KKT max / NaN flag.
+__device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
+                                          double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
+    const int N = P.N;
+    const double* __restrict__ cst = P.cst;
+    const int L = n <= 4 ? 16 : 64 / n;
+    const int g = lane / L, j0 = lane - g * L;
+    const bool active = g < n;
+    const int i = active ? g : n - 1;   // index inside the chunk
+    const int ig = i0 + i;              // global interval
+    const double* __restrict__ ui = P.u + ((size_t)b * N + ig) * NU;
+    // the chunk's iterate, parameters, reference and multipliers are contiguous: fetch them with 13 wave-wide 16-byte
+    // requests into the (still unused) [A B] area instead of ~90 requests that each touch 20 cache lines, then let every
+    // lane pick its interval's operands out of LDS
+    const int po = i0 > 0 ? 1 : 0;                // the multipliers of interval i0-1 ride along (pi_{i-1} of the first interval)
+    double* sx = ba_s;                            // [n+1][12]
+    double* spar = sx + (size_t)(n + 1) * NX;     // [n][16]
+    double* syr = spar + (size_t)n * NP;          // [n+1][16]
+    double* spi = syr + (size_t)(n + 1) * NY;     // [n+po][12]
+    double* su = spi + (size_t)(n + 1) * NX;      // [n][4]
+    {
+        dbl2 vx[3], vp[3], vy[3], vpi[3], vu[1];
+        stage_issue(P.x + ((size_t)b * (N + 1) + i0) * NX, (n + 1) * NX, lane, vx);
+        stage_issue(P.par + ((size_t)b * (N + 1) + i0) * NP, n * NP, lane, vp);
+        stage_issue(P.yref + (size_t)b * P.yref_stride + (size_t)i0 * NY, (n + 1) * NY, lane, vy);
+        stage_issue(P.pi + ((size_t)b * N + i0 - po) * NX, (n + po) * NX, lane, vpi);
+        stage_issue(P.u + ((size_t)b * N + i0) * NU, n * NU, lane, vu);
+        stage_store(sx, (n + 1) * NX, lane, vx);
+        stage_store(spar, n * NP, lane, vp);
+        stage_store(syr, (n + 1) * NY, lane, vy);
+        stage_store(spi, (n + po) * NX, lane, vpi);
+        stage_store(su, n * NU, lane, vu);
+    }
+    const double* xi = sx + i * NX;
+    const double* pp = spar + i * NP;
+    const double* yr = syr + i * NY;
+    const double* pil = spi + (i + po) * NX;
+    const double* pim1 = spi + (ig > 0 ? i + po - 1 : 0) * NX;
+    double uu[NU], x0r[NX], x1r[NX], yrr[NY], pir[NX], pm1[3];
+#pragma unroll
+    for (int j = 0; j < NU; j++) uu[j] = su[i * NU + j];
+#pragma unroll
+    for (int j = 0; j < NX; j++) { x0r[j] = xi[j]; x1r[j] = xi[NX + j]; pir[j] = pil[j]; }
+#pragma unroll
+    for (int j = 0; j < NY; j++) yrr[j] = yr[j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) pm1[j] = pim1[j];
+    const unsigned long long tA = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
+    const bool last = ig == N - 1;
+    double yrn[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) yrn[j] = last ? yr[NY + j] : 0.0;
+    const ModelPar m = make_par(pp);
+    const Wrench w = make_wrench(uu);
+    // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps, and the
+    // stationarity rows of the position columns (exactly e_c).  The L lanes of a group write identical values.
+    double kk0 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+        const double qk = P.Ts * cst[k] * (x0r[k] - yrr[k]);
+        q_s[i * NX + k] = qk;
+        if (k < 3 && ig >= 1) kkt_upd(kk0, qk + pir[k] - pm1[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yrr[NX + k]);
+    if (last) {
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const double qn = cst[16 + k] * (x1r[k] - yrn[k]);
+            q_s[n * NX + k] = qn;
+            if (k < 3) kkt_upd(kk0, qn - pir[k]);
+        }
+    }
+    const unsigned long long tB = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
+    StagePoint sp[4];
+    double xn[NX];
+    rk4_state(x0r, w, m, P.Ts, sp, xn);
+    const unsigned long long tC = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
+    double* tb = ba_s + i * kBaStage;
+    // stage records: 4*17 doubles per interval (in the fused kernel they overlay the gain / step arrays, which are dead
+    // until the QP phase: 4*17 <= 48+4+4+12)
+    lds_f64* rec = (lds_f64*)rec_s + i * kRecInterval;
+#pragma unroll
+    for (int st = 0; st < 4; st++) store_stage_rec(rec + st * kRecStage, sp[st], m);
+    // b_i and the dynamics gap
+#pragma unroll
+    for (int k = 0; k < NX; k++) {
+        const double bk = xn[k] - x1r[k];
+        bv_s[i * NX + k] = bk;
+        kkt_upd(kk0, bk);
+    }
+    if (active) {
+        if (kk0 != kk0) nanp = true;
+        part = fmax(part, kk0);
+    }
+    // developer instrumentation, slot 7: loads issued -> cost gradients -> state integrated -> column loop entered
+    if (stamp && P.dbg && lane == 0)
+        P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
+#pragma unroll 1
+    for (int c = 3 + j0; c < NX; c += L) {   // state columns 3..11
+        double acc[NX];
+        const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+        sens_column_rec(rec, m, P.Ts, c, acc);
+        const double kk = lin_kkt_col(ko, N, ig, c, pir, acc);
+#pragma unroll
+        for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
+        if (active) {
+            if (kk != kk) nanp = true;
+            part = fmax(part, kk);
+        }
+    }
+#pragma unroll 1
+    for (int jc = j0; jc < NU; jc += L) {    // input columns: cheaper (lin_device.hpp, sens_column_rec_u)
+        const int c = NX + jc;
+        double acc[NX];
+        const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+        sens_column_rec_u(rec, m, P.Ts, jc, acc);
+        const double kk = lin_kkt_col(ko, N, ig, c, pir, acc);
+#pragma unroll
+        for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
+        if (active) {
+            if (kk != kk) nanp = true;
+            part = fmax(part, kk);
+        }
+    }
+}
+
+// Streaming path (any horizon): the same wave-wide linearisation, one wavefront per chunk of <= 21 intervals, followed by a
+// coalesced copy of the chunk out of LDS into the HBM images qp_kernel reads -- [A B] as [12][16] row-major tiles, its
+// transpose as [16][16] tiles, b_i, and one KKT partial per interval.
+constexpr int kLinChunkMax = 21;
+__host__ __device__ inline int lin_chunks(int N) { return (N + kLinChunkMax - 1) / kLinChunkMax; }
+__host__ __device__ inline int lin_chunk_len(int N) { const int nc = lin_chunks(N); return (N + nc - 1) / nc; }
+__global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lsm[];
+    const int N = P.N, lane = threadIdx.x;
+    const int nc = lin_chunks(N), C = lin_chunk_len(N);
+    const int b = blockIdx.x / nc, ch = blockIdx.x - b * nc;
+    const int i0 = ch * C;
+    const int n = (N - i0 < C) ? N - i0 : C;
+    double* ba_s = lsm;                              // [C][12][13] (also the input staging area: 60 C + 28 doubles)
+    double* bv_s = ba_s + (size_t)C * kBaStage;      // [C][12]
+    double* rec_s = bv_s + (size_t)C * NX;           // [C][68]
+    double* q_s = rec_s + (size_t)C * kRecInterval;  // [C+1][12]
+    double* r_s = q_s + (size_t)(C + 1) * NX;        // [C][4]
+    double* part_s = r_s + (size_t)C * NU;           // [64]
+    double part = 0.0;
+    bool nanp = false;
+    lin_phase(P, b, i0, n, lane, ba_s, bv_s, rec_s, q_s, r_s, part, nanp, false);
+    part_s[lane] = nanp ? __builtin_nan("") : part;
+    __syncthreads();
+    const int rg = lane >> 4, cl = lane & 15;
+    const size_t g0 = (size_t)b * N + i0;
+    // [A B] tiles: register image r of the tile = rows rg + 4r, column cl; columns 0..2 are e_c
+    for (int il = 0; il < n; il++) {
+        const double* t = ba_s + il * kBaStage;
+        double* BA = P.BA + (g0 + il) * 192;
+        double* BAt = P.BAt + (g0 + il) * 256;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int row = rg + 4 * r;
+            BA[r * 64 + lane] = cl >= 3 ? t[row * kBaStride + cl - 3] : (row == cl ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = rg + 4 * r;   // row of the transposed tile = column of [A B]
+            BAt[r * 64 + lane] = cl >= NX ? 0.0 : (c >= 3 ? t[cl * kBaStride + c - 3] : (c == cl ? 1.0 : 0.0));
+        }
+    }
+    for (int j = lane; j < n * NX; j += 64) P.bvec[g0 * NX + j] = bv_s[j];
+    // one KKT partial per interval: max over the L lanes of its group, NaN-poisoning
+    {
+        const int L = n <= 4 ? 16 : 64 / n;
+        if (lane < n) {
+            double m = 0.0;
+            bool bad = false;
+            for (int j = 0; j < L; j++) {
+                const double v = part_s[lane * L + j];
+                if (v != v) bad = true; else m = fmax(m, v);
+            }
+            P.kktp[g0 + lane] = bad ? __builtin_nan("") : m;
+        }
+    }
+}
+
 // fused path: ONE wavefront owns one OCP instance from linearisation to the updated iterate.  The wave first integrates
 // all N intervals at once (64/N lanes per interval, lin_device.hpp) and leaves [A_i B_i] and b_i in its LDS slice
 // (N <= kFusedMaxN: 4 waves x 40.5 KB per CU at N = 20), then runs the Riccati IPM on the LDS-resident stage blocks: they
@@ -956,131 +1146,10 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     double* r_s = q_s + (size_t)(N + 1) * NX;     // [N][4]    cost gradient w.r.t. u
     double* const_s = r_s + (size_t)N * 4;        // {0.0, 1.0}: targets of structurally constant tile elements
     if (lane == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
-    // ---- preparation: ERK4 + sensitivities.  L = 64/N lanes per interval (3 at N = 20); each lane integrates the state
-    // once (stage points stay in registers) and then walks its share of the 13 non-trivial sensitivity columns; columns
-    // land in LDS, so the scattered 8-byte writes that ruled this mapping out for the HBM-streaming kernel cost nothing.
+    // ---- preparation: ERK4 + sensitivities of all N intervals at once (lin_phase below)
     double part = 0.0;
     bool nanp = false;
-    {
-        const int L = N <= 4 ? 16 : 64 / N;
-        const int g = lane / L, j0 = lane - g * L;
-        const bool active = g < N;
-        const int i = active ? g : N - 1;
-        const double* __restrict__ ui = P.u + ((size_t)b * N + i) * NU;
-        // the instance's iterate, parameters, reference and multipliers are contiguous: fetch them with 13 wave-wide
-        // 16-byte requests into the (still unused) [A B] area instead of ~90 requests that each touch 20 cache lines, then
-        // let every lane pick its interval's operands out of LDS
-        double* sx = ba_s;                            // [N+1][12]
-        double* spar = sx + (size_t)(N + 1) * NX;     // [N][16]
-        double* syr = spar + (size_t)N * NP;          // [N+1][16]
-        double* spi = syr + (size_t)(N + 1) * NY;     // [N][12]
-        double* su = spi + (size_t)N * NX;            // [N][4]
-        {
-            dbl2 vx[3], vp[3], vy[3], vpi[3], vu[1];
-            stage_issue(P.x + (size_t)b * (N + 1) * NX, (N + 1) * NX, lane, vx);
-            stage_issue(P.par + (size_t)b * (N + 1) * NP, N * NP, lane, vp);
-            stage_issue(P.yref + (size_t)b * P.yref_stride, (N + 1) * NY, lane, vy);
-            stage_issue(P.pi + (size_t)b * N * NX, N * NX, lane, vpi);
-            stage_issue(P.u + (size_t)b * N * NU, N * NU, lane, vu);
-            stage_store(sx, (N + 1) * NX, lane, vx);
-            stage_store(spar, N * NP, lane, vp);
-            stage_store(syr, (N + 1) * NY, lane, vy);
-            stage_store(spi, N * NX, lane, vpi);
-            stage_store(su, N * NU, lane, vu);
-        }
-        const double* xi = sx + i * NX;
-        const double* pp = spar + i * NP;
-        const double* yr = syr + i * NY;
-        const double* pil = spi + i * NX;
-        const double* pim1 = spi + (i > 0 ? i - 1 : 0) * NX;
-        double uu[NU], x0r[NX], x1r[NX], yrr[NY], pir[NX], pm1[3];
-#pragma unroll
-        for (int j = 0; j < NU; j++) uu[j] = su[i * NU + j];
-#pragma unroll
-        for (int j = 0; j < NX; j++) { x0r[j] = xi[j]; x1r[j] = xi[NX + j]; pir[j] = pil[j]; }
-#pragma unroll
-        for (int j = 0; j < NY; j++) yrr[j] = yr[j];
-#pragma unroll
-        for (int j = 0; j < 3; j++) pm1[j] = pim1[j];
-        const unsigned long long tA = P.dbg ? __builtin_readcyclecounter() : 0;
-        const bool last = i == N - 1;
-        double yrn[NX];
-#pragma unroll
-        for (int j = 0; j < NX; j++) yrn[j] = last ? yr[NY + j] : 0.0;
-        const ModelPar m = make_par(pp);
-        const Wrench w = make_wrench(uu);
-        // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps, and
-        // the stationarity rows of the position columns (exactly e_c).  The L lanes of a group write identical values.
-        double kk0 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; k++) {
-            const double qk = P.Ts * cst[k] * (x0r[k] - yrr[k]);
-            q_s[i * NX + k] = qk;
-            if (k < 3 && i >= 1) kkt_upd(kk0, qk + pir[k] - pm1[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yrr[NX + k]);
-        if (last) {
-#pragma unroll
-            for (int k = 0; k < NX; k++) {
-                const double qn = cst[16 + k] * (x1r[k] - yrn[k]);
-                q_s[N * NX + k] = qn;
-                if (k < 3) kkt_upd(kk0, qn - pir[k]);
-            }
-        }
-        const unsigned long long tB = P.dbg ? __builtin_readcyclecounter() : 0;
-        StagePoint sp[4];
-        double xn[NX];
-        rk4_state(x0r, w, m, P.Ts, sp, xn);
-        const unsigned long long tC = P.dbg ? __builtin_readcyclecounter() : 0;
-        double* tb = ba_s + i * kBaStage;
-        // stage records overlay the gain / step arrays, which are dead until the QP phase (4*17 <= 48+4+4+12 doubles per
-        // interval)
-        lds_f64* rec = (lds_f64*)kt_s + i * kRecInterval;
-#pragma unroll
-        for (int st = 0; st < 4; st++) store_stage_rec(rec + st * kRecStage, sp[st], m);
-        // b_i and the dynamics gap
-#pragma unroll
-        for (int k = 0; k < NX; k++) {
-            const double bk = xn[k] - x1r[k];
-            bv_s[i * NX + k] = bk;
-            kkt_upd(kk0, bk);
-        }
-        if (active) {
-            if (kk0 != kk0) nanp = true;
-            part = fmax(part, kk0);
-        }
-        // developer instrumentation, slot 7: loads issued -> cost gradients -> state integrated -> column loop entered
-        if (P.dbg && lane == 0)
-            P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
-#pragma unroll 1
-        for (int c = 3 + j0; c < NX; c += L) {   // state columns 3..11
-            double acc[NX];
-            const KktOperands ko = load_kkt_operands(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-            sens_column_rec(rec, m, P.Ts, c, acc);
-            const double kk = lin_kkt_col(ko, N, i, c, pir, acc);
-#pragma unroll
-            for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
-            if (active) {
-                if (kk != kk) nanp = true;
-                part = fmax(part, kk);
-            }
-        }
-#pragma unroll 1
-        for (int jc = j0; jc < NU; jc += L) {    // input columns: cheaper (lin_device.hpp, sens_column_rec_u)
-            const int c = NX + jc;
-            double acc[NX];
-            const KktOperands ko = load_kkt_operands(P, cst, b, i, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-            sens_column_rec_u(rec, m, P.Ts, jc, acc);
-            const double kk = lin_kkt_col(ko, N, i, c, pir, acc);
-#pragma unroll
-            for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
-            if (active) {
-                if (kk != kk) nanp = true;
-                part = fmax(part, kk);
-            }
-        }
-    }
+    lin_phase(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     Inst I;
     setup_inst(P, I, b, lane);
@@ -1115,6 +1184,17 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
         I.kt_str = cl < 4 ? kKtStage : 0;
     }
     qp_body<true>(P, I, b, part, nanp);
+}
+
+void launch_linearise(const DevParams& P, hipStream_t st) {
+    const int C = lin_chunk_len(P.N);
+    const size_t lds = ((size_t)C * (kBaStage + NX + kRecInterval + NU) + (size_t)(C + 1) * NX + 64) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)lin_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lin_wave_kernel, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
 }
 
 void launch_qp(const DevParams& P, hipStream_t st) {
