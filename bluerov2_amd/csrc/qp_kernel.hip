@@ -184,6 +184,26 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // a second register set) before stage i is computed, so that HBM/L2 latency overlaps the MFMA chain of the current
 // stage instead of being exposed once per stage (the in-order wave otherwise stalls ~1-2 us per stage).
 // ---------------------------------------------------------------------------------------------------------------
+// Streaming path: software pipeline over `count` steps with the HBM operands of step k + D requested before step k is
+// computed (D + 1 register slots, rotated by unrolling so that no slot is ever copied).  One stage of a sweep is 0.6-2 k
+// cycles of issue and two waves share a SIMD, while an HBM round trip under load is 4-5 k cycles: a prefetch distance of
+// one stage leaves the sweeps waiting on memory half of the time.
+template <int D, class In, class Load, class Body>
+__device__ __forceinline__ void pipelined(int count, Load load, Body body) {
+    constexpr int S = D + 1;
+    In slot[S];
+#pragma unroll
+    for (int d = 0; d < D; d++) slot[d] = load(d < count ? d : count - 1);
+    for (int k = 0; k < count; k += S) {
+#pragma unroll
+        for (int d = 0; d < S; d++) {
+            const int kn = k + d + D;
+            slot[(d + D) % S] = load(kn < count ? kn : count - 1);   // clamped: the tail re-requests the last stage
+            if (k + d < count) body(k + d, slot[d]);
+        }
+    }
+}
+
 struct BwdIn {
     d4 ba;          // [A B] tile, rows 0..11
     d4 bv;          // FACTOR: b_i;  else: Pb_i = P_{i+1} b_i   (row-replicated)
@@ -228,7 +248,8 @@ __device__ bool riccati_backward(const Inst& I) {
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
     wave_fence();
-    BwdIn nx = load_bwd<FACTOR, LDS, STEP0>(I, N - 1, gam, rt);
+    BwdIn nx;
+    if constexpr (LDS) nx = load_bwd<FACTOR, LDS, STEP0>(I, N - 1, gam, rt);
     d4 P = {0, 0, 0, 0}, pv;
     {
         const double* xN = I.x + (size_t)N * 12;
@@ -249,10 +270,7 @@ __device__ bool riccati_backward(const Inst& I) {
 #pragma unroll
     for (int r = 0; r < 3; r++) diagm[r] = (rg + 4 * r == cl) ? I.Ts * I.Wr[r] : 0.0;
     diagm[3] = (12 + rg == cl) ? I.Ts * I.Wr[3] : 0.0;
-    for (int i = N - 1; i >= 0; i--) {
-        const BwdIn in = nx;
-        if constexpr (LDS) nx = load_bwd<FACTOR, LDS, STEP0>(I, i > 0 ? i - 1 : 0, gam, rt);  // clamped: one scheduling region
-        else if (i > 0) nx = load_bwd<FACTOR, LDS, STEP0>(I, i - 1, gam, rt);
+    auto stage = [&](int i, const BwdIn& in) __attribute__((always_inline)) {
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
@@ -358,6 +376,22 @@ __device__ bool riccati_backward(const Inst& I) {
             pv = pn;
             pv[3] = 0.0;
         }
+    };
+    if constexpr (LDS) {
+        for (int i = N - 1; i >= 0; i--) {
+            const BwdIn in = nx;
+            nx = load_bwd<FACTOR, LDS, STEP0>(I, i > 0 ? i - 1 : 0, gam, rt);  // clamped: one scheduling region
+            stage(i, in);
+        }
+    } else {
+        // distance 1 here: a stage is ~2 k cycles of issue per wave (4 k with the SIMD's second wave), enough to cover the
+        // round trip, and a second stage in flight (36 VGPRs) pushes the kernel into scratch
+        nx = load_bwd<FACTOR, LDS, STEP0>(I, N - 1, gam, rt);
+        for (int i = N - 1; i >= 0; i--) {
+            const BwdIn in = nx;
+            if (i > 0) nx = load_bwd<FACTOR, LDS, STEP0>(I, i - 1, gam, rt);
+            stage(i, in);
+        }
     }
     return ok;
 }
@@ -384,10 +418,11 @@ template <bool LDS>
 __device__ void riccati_forward(const Inst& I, const d4& d0) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    FwdIn nx = load_fwd<LDS>(I, 0);
+    FwdIn nx;
+    if constexpr (LDS) nx = load_fwd<LDS>(I, 0);
     d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; LDS && i < N; i++) {
         const FwdIn in = nx;
         if constexpr (LDS) {
             // branch-free body (the prefetch index is clamped, the last one is redundant) so that the whole stage is one
@@ -407,8 +442,10 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
                 __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // 5 VALU
             }
-        } else {
-            if (i + 1 < N) nx = load_fwd<LDS>(I, i + 1);
+        }
+    }
+    if constexpr (!LDS) {
+        pipelined<2, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
             d4 c = {in.kf, 0, 0, 0};
             d4 v = tn<3>(in.kt, xx, c);
             if (cl == 0) I.vhat[i * 4 + rg] = v[0];
@@ -416,7 +453,7 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
             xx = tn<4>(in.bat, z, in.bb);
             xx[3] = 0.0;
             store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
-        }
+        });
     }
     wave_fence();
 }
@@ -435,18 +472,18 @@ template <bool LDS>
 __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    RollIn nx = load_roll<LDS>(I, 0, varr);
+    RollIn nx;
+    if constexpr (LDS) nx = load_roll<LDS>(I, 0, varr);
     d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
-    for (int i = 0; i < N; i++) {
-        const RollIn in = nx;
-        if constexpr (LDS) nx = load_roll<LDS>(I, i + 1 < N ? i + 1 : N - 1, varr);
-        else if (i + 1 < N) nx = load_roll<LDS>(I, i + 1, varr);
-        d4 z = {xx[0], xx[1], xx[2], in.v};
-        xx = tn<4>(in.bat, z, in.bb);
-        xx[3] = 0.0;
-        if constexpr (LDS) store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl); else store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
-        if constexpr (LDS) {
+    if constexpr (LDS) {
+        for (int i = 0; i < N; i++) {
+            const RollIn in = nx;
+            nx = load_roll<LDS>(I, i + 1 < N ? i + 1 : N - 1, varr);
+            d4 z = {xx[0], xx[1], xx[2], in.v};
+            xx = tn<4>(in.bat, z, in.bb);
+            xx[3] = 0.0;
+            store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -454,6 +491,13 @@ __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
         }
+    } else {
+        pipelined<3, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
+            d4 z = {xx[0], xx[1], xx[2], in.v};
+            xx = tn<4>(in.bat, z, in.bb);
+            xx[3] = 0.0;
+            store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
+        });
     }
     wave_fence();
 }
@@ -490,13 +534,11 @@ template <bool COMMIT, bool LDS>
 __device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    AdjIn nx = load_adj<LDS>(I, N - 1, varr);
+    AdjIn nx;
+    if constexpr (LDS) nx = load_adj<LDS>(I, N - 1, varr);
     d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
     const d4 z4 = {0, 0, 0, 0};
-    for (int i = N - 1; i >= 0; i--) {
-        const AdjIn in = nx;
-        if constexpr (LDS) nx = load_adj<LDS>(I, i > 0 ? i - 1 : 0, varr);
-        else if (i > 0) nx = load_adj<LDS>(I, i - 1, varr);
+    auto stage = [&](int i, const AdjIn& in) __attribute__((always_inline)) {
         d4 pi;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -514,7 +556,12 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
         if constexpr (LDS) I.lds_kff[i * 4 + rg] = rd * in.v + in.u + G[3];
         else if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
         atpi = G;
-        if constexpr (LDS) {
+    };
+    if constexpr (LDS) {
+        for (int i = N - 1; i >= 0; i--) {
+            const AdjIn in = nx;
+            nx = load_adj<LDS>(I, i > 0 ? i - 1 : 0, varr);
+            stage(i, in);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -522,6 +569,9 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
             }
         }
+    } else {
+        pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
+                            [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
     }
     wave_fence();
 }

@@ -7,7 +7,7 @@ from bench import synthetic_inputs
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ee = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, qp_early_exit=ee, kernel_path=2))
+s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, qp_early_exit=ee, kernel_path=int(sys.argv[4]) if len(sys.argv) > 4 else 2))
 x0, circ = synthetic_inputs(B, 1)
 s.set_x0(x0); s.set_params(ba.P_NOMINAL)
 L = s._L
