@@ -194,9 +194,9 @@ def main():
             dom, dom_fl, dom_t = "rti_fused_kernel", qp_fl + lin_fl, ksec[1]
             kernel_ms = {"rti_fused_kernel": ksec[1] * 1e3}
         else:
-            dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_kernel"
+            dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_wave_kernel"
             dom_fl, dom_t = (qp_fl, ksec[1]) if dom == "qp_kernel" else (lin_fl, ksec[0])
-            kernel_ms = {"lin_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3}
+            kernel_ms = {"lin_wave_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3}
         achieved = dom_fl / dom_t / 1e12
         alg_bytes = 8 * (12 + 16 * (N + 1) + 16 * (N + 1) + 2 * (12 * (N + 1) + 4 * N)) + 56
         traffic = None

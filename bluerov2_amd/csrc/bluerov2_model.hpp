@@ -114,43 +114,4 @@ __device__ __forceinline__ void model_f(const double (&x)[NX], const Wrench& w, 
     f[11] = (w.k5 - (kIy - kIx) * sp.wp * sp.wq + m.dn + m.ln * sp.wr + m.qn * fabs(sp.wr) * sp.wr) * m.imn;
 }
 
-// o = (df/dx)(stage point) * s.  Columns 0..2 of df/dx vanish (no dependence on position).
-__device__ __forceinline__ void model_jvp(const StagePoint& sp, const ModelPar& m, const double (&s)[NX],
-                                          double (&o)[NX]) {
-    const double r00 = sp.cps * sp.cth, r01 = sp.cps * sp.sth * sp.sph - sp.sps * sp.cph,
-                 r02 = sp.sps * sp.sph + sp.cps * sp.cph * sp.sth;
-    const double r10 = sp.sps * sp.cth, r11 = sp.cps * sp.cph + sp.sph * sp.sth * sp.sps,
-                 r12 = sp.sth * sp.sps * sp.cph - sp.cps * sp.sph;
-    const double r21 = sp.cth * sp.sph, r22 = sp.cth * sp.cph;
-    const double f0 = r00 * sp.vu + r01 * sp.vv + r02 * sp.vw;
-    const double f1 = r10 * sp.vu + r11 * sp.vv + r12 * sp.vw;
-    const double f2 = -sp.sth * sp.vu + r21 * sp.vv + r22 * sp.vw;
-    // d(R v)/d(phi,theta,psi): dR/dphi v = [R02 vv - R01 vw, ..], dR/dtheta v = [cps f2, sps f2, ..], dR/dpsi v = [-f1, f0, 0]
-    o[0] = (r02 * sp.vv - r01 * sp.vw) * s[3] + (sp.cps * f2) * s[4] - f1 * s[5] + r00 * s[6] + r01 * s[7] + r02 * s[8];
-    o[1] = (r12 * sp.vv - r11 * sp.vw) * s[3] + (sp.sps * f2) * s[4] + f0 * s[5] + r10 * s[6] + r11 * s[7] + r12 * s[8];
-    o[2] = (r22 * sp.vv - r21 * sp.vw) * s[3] - (sp.cth * sp.vu + sp.sth * (sp.sph * sp.vv + sp.cph * sp.vw)) * s[4] -
-           sp.sth * s[6] + r21 * s[7] + r22 * s[8];
-    const double tth = sp.sth * sp.icth, ic2 = sp.icth * sp.icth;
-    o[3] = (-sp.sph * tth * sp.wr) * s[3] + ((sp.sps * sp.wq + sp.cph * sp.wr) * ic2) * s[4] + (sp.cps * tth * sp.wq) * s[5] +
-           s[9] + (sp.sps * tth) * s[10] + (sp.cph * tth) * s[11];
-    o[4] = (sp.cph * sp.wr - sp.sph * sp.wq) * s[3] + sp.cph * s[10] + sp.sph * s[11];
-    o[5] = ((sp.cph * sp.wq - sp.sph * sp.wr) * s[3] + (sp.sph * sp.wq + sp.cph * sp.wr) * tth * s[4] + sp.sph * s[10] +
-            sp.cph * s[11]) * sp.icth;
-    o[6] = (-kBouy * sp.cth * s[4] + (m.lx + 2.0 * m.qx * fabs(sp.vu)) * s[6]) * m.imx;
-    o[7] = (kBouy * (r22 * s[3] - sp.sth * sp.sph * s[4]) + (m.ly + 2.0 * m.qy * fabs(sp.vv)) * s[7]) * m.imy;
-    o[8] = (-kBouy * (r21 * s[3] + sp.sth * sp.cph * s[4]) + (m.lz + 2.0 * m.qz * fabs(sp.vw)) * s[8]) * m.imz;
-    o[9] = (kMzg * (sp.sth * sp.sph * s[4] - r22 * s[3]) + (kIy - kIz) * (sp.wr * s[10] + sp.wq * s[11])) * (1.0 / kIx);
-    o[10] = (-kMzg * sp.cth * s[4] + (kIz - kIx) * (sp.wr * s[9] + sp.wp * s[11])) * (1.0 / kIy);
-    o[11] = (-(kIy - kIx) * (sp.wq * s[9] + sp.wp * s[10]) + (m.ln + 2.0 * m.qn * fabs(sp.wr)) * s[11]) * m.imn;
-}
-
-// constant, sparse df/du (5 non-zeros): column j added to rows of o
-__device__ __forceinline__ void model_bcol(const ModelPar& m, int j, double (&o)[NX]) {
-    constexpr double ir = 1.0 / kRotor;
-    if (j == 0) o[6] += (-4.0 * 0.707) * ir * m.imx;
-    if (j == 1) { o[7] += (4.0 * 0.707) * ir * m.imy; o[11] += (0.167 + 0.167 - 0.175 - 0.175) * ir * m.imn; }
-    if (j == 2) o[8] += -2.0 * ir * m.imz;
-    if (j == 3) o[11] += (0.167 + 0.167 + 0.175 + 0.175) * ir * m.imn;
-}
-
 }  // namespace brov

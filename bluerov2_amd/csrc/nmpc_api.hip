@@ -34,7 +34,7 @@ struct brov_solver {
     // device buffers
     double *x0 = nullptr, *yref = nullptr, *yref_sh = nullptr, *par = nullptr;
     double *x = nullptr, *u = nullptr, *pi = nullptr, *lam = nullptr;
-    double *BA = nullptr, *BAt = nullptr, *bvec = nullptr, *kktp = nullptr;
+    double *BA = nullptr, *bvec = nullptr, *kktp = nullptr;
     double *Ks = nullptr, *Kt = nullptr, *Mt = nullptr, *Pb = nullptr, *kff = nullptr, *vhat = nullptr, *ipm = nullptr,
            *dxb = nullptr, *cst = nullptr;
     brov_result* res = nullptr;
@@ -137,7 +137,6 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(pi, Bz * N * 12);
     AL(lam, Bz * N * 8);
     AL(BA, Bz * N * 192);
-    AL(BAt, Bz * N * 256);
     AL(bvec, Bz * N * 12);
     AL(kktp, Bz * N);
     AL(Ks, Bz * N * 64);
@@ -443,7 +442,7 @@ static DevParams make_params(const brov_solver* s) {
     P.yref_stride = s->yref_shared ? 0 : (int64_t)(s->N + 1) * 16;
     P.par = s->par;
     P.x = s->x; P.u = s->u; P.pi = s->pi; P.lam = s->lam;
-    P.BA = s->BA; P.BAt = s->BAt; P.bvec = s->bvec; P.kktp = s->kktp;
+    P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
     P.dbg = s->dbg;

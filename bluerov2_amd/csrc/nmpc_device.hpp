@@ -12,7 +12,6 @@ namespace brov {
 //   x0    [B][12]             yref [B][N+1][16] or shared [N+1][16]        par [B][N+1][16]
 //   x     [B][N+1][12]        u    [B][N][4]      pi [B][N][12]            lam [B][N][8]
 //   BA    [B][N][12][16]      row k, col c:  d x+_k / d (x,u)_c            (3/4 tile: rows 0..11)
-//   BAt   [B][N][16][16]      row c, col k (cols 12..15 zero)              (full tile)
 //   bvec  [B][N][12]          phi(x_i,u_i) - x_{i+1}
 //   kktp  [B][N]              per-interval partial of the NLP KKT inf-norm
 //   Riccati by-products per stage:  Ks [B][N][4][16] (gain, row m, col c), Kt [B][N][12][16] (gain^T, row c, col m),
@@ -35,7 +34,6 @@ struct DevParams {
     double* lam;
     // linearisation
     double* BA;
-    double* BAt;
     double* bvec;
     double* kktp;
     // Riccati storage

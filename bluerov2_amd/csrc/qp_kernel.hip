@@ -84,7 +84,6 @@ struct Inst {
     const double* u;     // [N][4]
     const double* yref;  // [N+1][16]
     const double* BA;    // [N][12][16]
-    const double* BAt;   // [N][16][16]
     const double* bvec;  // [N][12]
     double *Ks, *Kt, *Mt, *Pb, *kff, *vhat, *ipm, *dxb;
     const lds_f64* lds_ba;  // fused path: [N][12][kBaStride] (+ b_i behind it), else unused
@@ -134,7 +133,7 @@ __device__ __forceinline__ void store_vec12_lds(lds_f64* v, const d4& t, int rg,
 }
 
 // ---- where the per-stage linearisation lives -------------------------------------------------------------------------
-// LDS = false: streamed from HBM (tiles BA / BAt / bvec written by lin_kernel) -- any horizon.
+// LDS = false: streamed from HBM (tiles BA / bvec written by lin_wave_kernel) -- any horizon.
 // LDS = true : the whole horizon's [A_i B_i] (row stride kBaStride doubles, padded so that both the row image and the
 //              transposed image are read without bank conflicts) and b_i stay in this wave's LDS slice (fused kernel).
 constexpr int kBaStride = 13;              // only the 13 non-trivial columns 3..15 are stored (odd stride: no bank conflicts
@@ -156,7 +155,12 @@ __device__ __forceinline__ d4 get_bat(const Inst& I, int i) {  // [A B]^T image:
         const lds_f64* t = I.lds_ba + i * I.bat_str;
         return d4{I.lds_ba[i * I.bat_str0 + I.bat_off[0]], t[I.bat_off[1]], t[I.bat_off[2]], t[I.bat_off[3]]};
     } else {
-        return load_tile4(I.BAt + (size_t)i * 256, I.lane);
+        // transposed view of the row-major [A B] tile: element (c = rg + 4r, k = cl) = [A B](k, c); lanes cl >= 12 are padding.
+        // Four 8-byte gathers that touch the tile's 12 cache lines -- cheaper than writing and re-reading a second, transposed
+        // copy of every stage (2 KB per stage in round 1's first streaming version).
+        const double* t = I.BA + (size_t)i * 192 + (I.cl < NX ? I.cl * 16 + I.rg : 0);
+        const bool in = I.cl < NX;
+        return d4{in ? t[0] : 0.0, in ? t[4] : 0.0, in ? t[8] : 0.0, in ? t[12] : 0.0};
     }
 }
 template <bool LDS>
@@ -911,7 +915,6 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.u = P.u + (size_t)b * N * 4;
     I.yref = P.yref + (size_t)b * P.yref_stride;
     I.BA = P.BA + (size_t)b * N * 192;
-    I.BAt = P.BAt + (size_t)b * N * 256;
     I.bvec = P.bvec + (size_t)b * N * 12;
     I.Ks = P.Ks + (size_t)b * N * 64;
     I.Kt = P.Kt + (size_t)b * N * 192;
@@ -943,7 +946,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
 #ifndef BROV_QP_WAVES
 #define BROV_QP_WAVES 2
 #endif
-// streaming path: linearisation tiles come from HBM (written by lin_kernel); any horizon
+// streaming path: linearisation tiles come from HBM (written by lin_wave_kernel); any horizon
 __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> SGPR addressing
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -1115,8 +1118,8 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
 }
 
 // Streaming path (any horizon): the same wave-wide linearisation, one wavefront per chunk of <= 21 intervals, followed by a
-// coalesced copy of the chunk out of LDS into the HBM images qp_kernel reads -- [A B] as [12][16] row-major tiles, its
-// transpose as [16][16] tiles, b_i, and one KKT partial per interval.
+// coalesced copy of the chunk out of LDS into the HBM images qp_kernel reads -- [A B] as [12][16] row-major tiles, b_i, and
+// one KKT partial per interval.
 constexpr int kLinChunkMax = 21;
 __host__ __device__ inline int lin_chunks(int N) { return (N + kLinChunkMax - 1) / kLinChunkMax; }
 __host__ __device__ inline int lin_chunk_len(int N) { const int nc = lin_chunks(N); return (N + nc - 1) / nc; }
@@ -1144,16 +1147,10 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
     for (int il = 0; il < n; il++) {
         const double* t = ba_s + il * kBaStage;
         double* BA = P.BA + (g0 + il) * 192;
-        double* BAt = P.BAt + (g0 + il) * 256;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const int row = rg + 4 * r;
             BA[r * 64 + lane] = cl >= 3 ? t[row * kBaStride + cl - 3] : (row == cl ? 1.0 : 0.0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int c = rg + 4 * r;   // row of the transposed tile = column of [A B]
-            BAt[r * 64 + lane] = cl >= NX ? 0.0 : (c >= 3 ? t[cl * kBaStride + c - 3] : (c == cl ? 1.0 : 0.0));
         }
     }
     for (int j = lane; j < n * NX; j += 64) P.bvec[g0 * NX + j] = bv_s[j];

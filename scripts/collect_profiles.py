@@ -60,7 +60,7 @@ def main(tag, rnd):
            "hbm_bytes_per_launch": {}, "raw": {}}
     pf = per_kernel(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
     pw = per_kernel(os.path.join(src, "pmc_write"), "WRITE_SIZE")
-    for k in ("lin_kernel", "qp_kernel", "rti_fused_kernel"):
+    for k in ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel"):
         fv = pf.get(k, [])
         wv = pw.get(k, [])
         if fv and wv and fetch_unit and write_unit:
@@ -71,7 +71,7 @@ def main(tag, rnd):
     for cname in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES",
                   "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
         for k, v in per_kernel(os.path.join(src, "pmc_sq"), cname).items():
-            if k in ("lin_kernel", "qp_kernel", "rti_fused_kernel"):
+            if k in ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel"):
                 sq.setdefault(k, {})[cname] = sum(v[5:]) / max(1, len(v[5:]))
     out["sq_counters_per_launch"] = sq
     json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
