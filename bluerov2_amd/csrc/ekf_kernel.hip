@@ -19,8 +19,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "bluerov2_model.hpp"
@@ -395,6 +397,333 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DPP variant (default).  The LDS-broadcast kernel above is bound by LDS bandwidth: every lane streams the whole right-hand
+// matrix of every product out of LDS (0.5 MB per update against 128 B/clk per CU).  Here a filter lives in ONE 16-lane DPP
+// row (4 filters per wave) and the right-hand rows are broadcast straight out of the registers of the lane that owns them:
+//     v_fmac_f64_dpp acc, B_row_reg, a   row_newbcast:k      (acc += a * (B_row_reg of lane k of my 16-lane row))
+// -- the only DPP control gfx950 offers for 64-bit operands, and exactly the one a row-times-matrix product needs.
+// 18 = 16 + 2: lane l owns row l ("primary"), lanes 0 and 1 additionally own rows 16 and 17 ("secondary" register set, zero
+// in the other lanes); a product is 18 x 18 fmacs for each set.  The left operand's row elements come out of LDS (or a
+// register with a static index), transposes are strided LDS reads, three 18x18 LDS buffers per filter.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kDppFilters = 4;
+constexpr int kDppLds = 3 * kMat + 2 * EN + 4;   // doubles per filter: buffers A, B, C + x_new + flags
+
+struct Rows { double p[EN], s[EN]; };   // row layout: p = row l of the matrix, s = row 16 + l (lanes 0, 1), else 0
+
+template <int K>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double a) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
+}
+// value of `src` in lane K of this lane's 16-lane row (s_nop: a VALU write must be 2 wait states ahead of a DPP read, and the
+// compiler does not see through inline assembly)
+template <int K>
+__device__ __forceinline__ double bcast(double src) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(K));
+    return r;
+}
+template <int... Ks, class F>
+__device__ __forceinline__ void for_k(std::integer_sequence<int, Ks...>, F f) { (f(std::integral_constant<int, Ks>{}), ...); }
+
+// C += A B.  B in row layout (registers); ap(k) / as(k) deliver A[l][k] and A[16+l][k] of this lane (as(k) = 0 for l >= 2).
+// The A elements of a block of k's are requested (LDS) before the fmacs of the previous block are issued.
+template <int K0, int NK, bool SECB, class AP, class AS>
+__device__ __forceinline__ void gemm_block(Rows& C, const Rows& B, const double (&a0)[NK], const double (&a1)[NK]) {
+    for_k(std::make_integer_sequence<int, NK>{}, [&](auto kc) {
+        constexpr int KK = decltype(kc)::value;
+        constexpr int K = K0 + KK;            // lane that owns the B row
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            fmac_bc<K>(C.p[j], SECB ? B.s[j] : B.p[j], a0[KK]);
+            fmac_bc<K>(C.s[j], SECB ? B.s[j] : B.p[j], a1[KK]);
+        }
+    });
+}
+template <class AP, class AS>
+__device__ __forceinline__ void gemm_dpp(Rows& C, const Rows& B, AP ap, AS as) {
+    double p0[6], s0[6], p1[6], s1[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { p0[k] = ap(k); s0[k] = as(k); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { p1[k] = ap(6 + k); s1[k] = as(6 + k); }
+    asm volatile("s_nop 1");
+    gemm_block<0, 6, false, AP, AS>(C, B, p0, s0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p0[k] = ap(12 + k); s0[k] = as(12 + k); }
+    p0[4] = ap(16); s0[4] = as(16); p0[5] = ap(17); s0[5] = as(17);
+    gemm_block<6, 6, false, AP, AS>(C, B, p1, s1);
+    {
+        const double q0[4] = {p0[0], p0[1], p0[2], p0[3]}, q1[4] = {s0[0], s0[1], s0[2], s0[3]};
+        gemm_block<12, 4, false, AP, AS>(C, B, q0, q1);
+        const double r0[2] = {p0[4], p0[5]}, r1[2] = {s0[4], s0[5]};
+        gemm_block<0, 2, true, AP, AS>(C, B, r0, r1);
+    }
+}
+__device__ __forceinline__ void zero_rows(Rows& R) {
+#pragma unroll
+    for (int j = 0; j < EN; j++) { R.p[j] = 0.0; R.s[j] = 0.0; }
+}
+// row layout <-> LDS (row-major 18 x 18): lane l stores / loads row l, lanes 0, 1 also rows 16, 17
+__device__ __forceinline__ void store_rows(elds* m, const Rows& R, int l) {
+    store_row(m + l * EN, R.p);
+    if (l < 2) store_row(m + (16 + l) * EN, R.s);
+}
+__device__ __forceinline__ void load_rows(const elds* m, Rows& R, int l) {
+    load_row(m + l * EN, R.p);
+    double t[EN];
+    load_row(m + (16 + (l < 2 ? l : 0)) * EN, t);
+#pragma unroll
+    for (int j = 0; j < EN; j++) R.s[j] = (l < 2) ? t[j] : 0.0;
+}
+// rows of the TRANSPOSE of the matrix stored row-major at m (strided reads)
+__device__ __forceinline__ void load_rows_t(const elds* m, Rows& R, int l) {
+#pragma unroll
+    for (int j = 0; j < EN; j++) { R.p[j] = m[j * EN + l]; const double t = m[j * EN + 16 + (l < 2 ? l : 0)]; R.s[j] = (l < 2) ? t : 0.0; }
+}
+
+__global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double esm[];
+    const EkfConst& c = A.c;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const int inst0 = blockIdx.x * kDppFilters + g;
+    const bool live = inst0 < A.B;
+    const int inst = live ? inst0 : A.B - 1;
+    const bool sec = l < 2;              // owns a secondary row
+    const int ls = sec ? l : 0;
+
+    elds* sm = (elds*)esm + g * kDppLds;
+    elds* bufA = sm;
+    elds* bufB = bufA + kMat;
+    elds* bufC = bufB + kMat;
+    elds* v_xn = bufC + kMat;            // [18] corrected state (gathered for the output lane)
+
+    // ---- inputs: every lane keeps x, tau, acc, y of its filter
+    double x[EN], tau[6], ac[6], ym[EN];
+    {
+        const double* xg = A.x + (size_t)inst * EN;
+        const double* tg = A.thrust + (size_t)inst * 6;
+        const double* ag = A.acc + (size_t)inst * 6;
+        const double* yg = A.y12 + (size_t)inst * 12;
+#pragma unroll
+        for (int j = 0; j < EN; j++) x[j] = xg[j];
+        double th[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { th[j] = tg[j]; ac[j] = ag[j]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {   // tau = K * meas_u (bluerov2_dob.cpp:499-500)
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += c.K[i * 6 + j] * th[j];
+            tau[i] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 12; j++) ym[j] = yg[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) ym[12 + j] = tau[j];
+        // P -> bufA (left operand of the first product): the filter's 2592 contiguous bytes in 16-byte pieces, 16 lanes wide
+        const ed2* pg = (const ed2*)(A.P + (size_t)inst * kMat);
+        ed2 pv[11];
+#pragma unroll
+        for (int m = 0; m < 11; m++) { const int q = m * 16 + l; pv[m] = pg[q < kMat / 2 ? q : 0]; }
+#pragma unroll
+        for (int m = 0; m < 11; m++) { const int q = m * 16 + l; if (q < kMat / 2) ((elds2*)bufA)[q] = pv[m]; }
+    }
+
+    // ---- F^T by forward differences of the RK4 map: lane l perturbs state l; lanes 0, 1 also states 16, 17; lane 2's second
+    // evaluation is the unperturbed one and is broadcast
+    Rows Ft;
+    {
+        double xl[EN], xa[EN], xb[EN];
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((sec && j == 16 + l) ? c.d : 0.0);
+        ekf_rk4(c, xl, tau, xa);            // lanes 0, 1: perturbed in 16 / 17; all other lanes: unperturbed
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((j == l) ? c.d : 0.0);
+        ekf_rk4(c, xl, tau, xb);
+        double f0[EN];
+#pragma unroll
+        for (int j = 0; j < EN; j++) f0[j] = bcast<2>(xa[j]);
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            Ft.p[j] = (xb[j] - f0[j]) * c.inv_d;
+            Ft.s[j] = sec ? (xa[j] - f0[j]) * c.inv_d : 0.0;
+            x[j] = f0[j];                   // from here on x = x_pred
+        }
+    }
+    __syncthreads();
+    // G = P F^T
+    Rows G;
+    zero_rows(G);
+    gemm_dpp(G, Ft, [&](int k) { return bufA[l * EN + k]; }, [&](int k) { const double t = bufA[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    store_rows(bufC, Ft, l);                // F^T row-major: F[l][k] = bufC[k][l]
+    __syncthreads();
+    // P_pred = F G + Q
+    Rows Pq;
+#pragma unroll
+    for (int j = 0; j < EN; j++) { Pq.p[j] = (j == l) ? c.Q[j] : 0.0; Pq.s[j] = (sec && j == 16 + l) ? c.Q[j] : 0.0; }
+    gemm_dpp(Pq, G, [&](int k) { return bufC[k * EN + l]; }, [&](int k) { const double t = bufC[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    store_rows(bufB, Pq, l);                // P_pred stays in bufB (right operand of V = J P_pred)
+    // ---- H^T by forward differences of h at x_pred, innovation
+    Rows Ht;
+    double ye[EN];
+    {
+        double xl[EN], y0[EN], ya[EN], yb[EN];
+        ekf_h(c, x, ac, y0);
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((sec && j == 16 + l) ? c.d : 0.0);
+        ekf_h(c, xl, ac, ya);
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((j == l) ? c.d : 0.0);
+        ekf_h(c, xl, ac, yb);
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            Ht.p[j] = (yb[j] - y0[j]) * c.inv_d;
+            Ht.s[j] = sec ? (ya[j] - y0[j]) * c.inv_d : 0.0;
+            ye[j] = ym[j] - y0[j];
+        }
+    }
+    __syncthreads();                        // reads of bufC (F^T) are done
+    store_rows(bufC, Ht, l);                // H^T row-major: H[l][k] = bufC[k][l]
+    __syncthreads();
+    // W = H P_pred  (= (P_pred H^T)^T; right operand: P_pred, still in registers)
+    Rows W;
+    zero_rows(W);
+    gemm_dpp(W, Pq, [&](int k) { return bufC[k * EN + l]; }, [&](int k) { const double t = bufC[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    store_rows(bufA, W, l);                 // P is dead
+    __syncthreads();
+    // S = W H^T + R
+    Rows S;
+#pragma unroll
+    for (int j = 0; j < EN; j++) { S.p[j] = (j == l) ? c.R : 0.0; S.s[j] = (sec && j == 16 + l) ? c.R : 0.0; }
+    gemm_dpp(S, Ht, [&](int k) { return bufA[l * EN + k]; }, [&](int k) { const double t = bufA[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    // ---- K^T = S^-1 W by Gauss-Jordan on [S | W] without pivoting (S is SPD); the pivot row is broadcast with DPP.
+    // Secondary rows of lanes >= 2 are zero and stay zero (their factor is 0).
+    Rows T;
+    load_rows(bufA, T, l);
+    bool ok = true;
+    for_k(std::make_integer_sequence<int, EN>{}, [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        constexpr bool PS = K >= 16;          // pivot row in the secondary set (lanes 0, 1)
+        constexpr int KL = PS ? K - 16 : K;   // lane that owns the pivot row
+        const double pk = PS ? bcast<KL>(S.s[K]) : bcast<KL>(S.p[K]);
+        ok = ok && (pk > 0.0) && (pk < 1e300);
+        double ip = __builtin_amdgcn_rcp(pk);
+        double e1 = fma(-pk, ip, 1.0);
+        ip = fma(ip, e1, ip);
+        e1 = fma(-pk, ip, 1.0);
+        ip = fma(ip, e1, ip);
+        // row_i -= (s_ik / p) row_k for i != k;  row_k *= 1/p, written as row_k -= (1 - 1/p) row_k.  The register set that does
+        // NOT hold the pivot row is updated first: both updates read the pivot row, and the second one overwrites it.
+        const double nfp = (!PS && l == KL) ? ip - 1.0 : -(S.p[K] * ip);
+        const double nfs = (PS && l == KL) ? ip - 1.0 : -(S.s[K] * ip);
+#pragma unroll
+        for (int j = K + 1; j < EN; j++) {
+            if (PS) { fmac_bc<KL>(S.p[j], S.s[j], nfp); fmac_bc<KL>(S.s[j], S.s[j], nfs); }
+            else { fmac_bc<KL>(S.s[j], S.p[j], nfs); fmac_bc<KL>(S.p[j], S.p[j], nfp); }
+        }
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            if (PS) { fmac_bc<KL>(T.p[j], T.s[j], nfp); fmac_bc<KL>(T.s[j], T.s[j], nfs); }
+            else { fmac_bc<KL>(T.s[j], T.p[j], nfs); fmac_bc<KL>(T.p[j], T.p[j], nfp); }
+        }
+    });
+    if (!ok) zero_rows(T);                  // innovation covariance not positive definite / NaN: keep the prediction
+    __syncthreads();                        // reads of bufA (W) are done
+    store_rows(bufA, T, l);                 // K^T row-major: Kal[l][k] = bufA[k][l]
+    __syncthreads();
+    // x_new = x_pred + Kal (y - y_pred)
+    {
+        double dp = 0.0, ds = 0.0;
+#pragma unroll
+        for (int k = 0; k < EN; k++) { dp = fma(bufA[k * EN + l], ye[k], dp); ds = fma(bufA[k * EN + 16 + ls], ye[k], ds); }
+        double xp_ = 0.0, xs_ = 0.0;
+#pragma unroll
+        for (int j = 0; j < EN; j++) { xp_ = (j == l) ? x[j] : xp_; xs_ = (j == 16 + ls) ? x[j] : xs_; }
+        xp_ += dp; xs_ += ds;
+        v_xn[l] = xp_;
+        if (sec) v_xn[16 + l] = xs_;
+        if (live) {
+            A.x[(size_t)inst * EN + l] = xp_;
+            if (sec) A.x[(size_t)inst * EN + 16 + l] = xs_;
+        }
+    }
+    // J = I - Kal H   (right operand: H in row layout = columns of H^T)
+    Rows H;
+    load_rows_t(bufC, H, l);
+    Rows J;
+    zero_rows(J);
+    gemm_dpp(J, H, [&](int k) { return -bufA[k * EN + l]; }, [&](int k) { const double t = -bufA[k * EN + 16 + ls]; return sec ? t : 0.0; });
+#pragma unroll
+    for (int j = 0; j < EN; j++) {
+        if (!ok) { J.p[j] = 0.0; J.s[j] = 0.0; }   // H may hold NaN: J = I exactly
+        J.p[j] += (j == l) ? 1.0 : 0.0;
+        J.s[j] += (sec && j == 16 + l) ? 1.0 : 0.0;
+    }
+    __syncthreads();                        // reads of bufC (H^T) are done
+    store_rows(bufC, J, l);                 // J row-major
+    __syncthreads();
+    // V = J P_pred
+    Rows V;
+    {
+        Rows Pr;
+        load_rows(bufB, Pr, l);
+        zero_rows(V);
+        gemm_dpp(V, Pr, [&](int k) { return bufC[l * EN + k]; }, [&](int k) { const double t = bufC[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    }
+    __syncthreads();                        // reads of bufB (P_pred) are done
+    store_rows(bufB, V, l);
+    __syncthreads();
+    // P_new = V J^T + R Kal Kal^T   (Joseph form, bluerov2_dob.cpp:537)
+    Rows Pn;
+    zero_rows(Pn);
+    {
+        Rows Jt;
+        load_rows_t(bufC, Jt, l);
+        gemm_dpp(Pn, Jt, [&](int k) { return bufB[l * EN + k]; }, [&](int k) { const double t = bufB[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+        Rows Kt;
+        load_rows(bufA, Kt, l);
+        gemm_dpp(Pn, Kt, [&](int k) { return c.R * bufA[k * EN + l]; }, [&](int k) { const double t = c.R * bufA[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    }
+    if (live) {
+        double* pg = A.P + (size_t)inst * kMat;
+#pragma unroll
+        for (int j = 0; j < EN; j++) pg[l * EN + j] = Pn.p[j];
+        if (sec) {
+#pragma unroll
+            for (int j = 0; j < EN; j++) pg[(16 + l) * EN + j] = Pn.s[j];
+        }
+    }
+    // ---- outputs: world-frame disturbance with the MEASURED attitude (:540-545), NMPC parameters (:334-337)
+    __syncthreads();
+    if (l == 0 && live) {
+        double xn[EN];
+        load_row(v_xn, xn);
+        double sph, cph, sth, cth, sps, cps;
+        sincos_pio2(ym[3], &sph, &cph);
+        sincos_pio2(ym[4], &sth, &cth);
+        sincos_pio2(ym[5], &sps, &cps);
+        double* w = A.wf + (size_t)inst * 6;
+        w[0] = (cps * cth) * xn[12] + (-sps * cph + cps * sth * sph) * xn[13] + (sps * sph + cps * cph * sth) * xn[14];
+        w[1] = (sps * cth) * xn[12] + (cps * cph + sph * sth * sps) * xn[13] + (-cps * sph + sth * sps * cph) * xn[14];
+        w[2] = (-sth) * xn[12] + (cth * sph) * xn[13] + (cth * cph) * xn[14];
+        w[3] = xn[15] + (sps * sth / cth) * xn[16] + cph * sth / cth * xn[17];
+        w[4] = cph * xn[16] + sph * xn[17];
+        w[5] = (sph / cth) * xn[16] + (cph / cth) * xn[17];
+        double* mp = A.mp + (size_t)inst * 4;
+        mp[0] = xn[12] * c.inv_cc;
+        mp[1] = xn[13] * c.inv_cc;
+        mp[2] = xn[14] * c.inv_rc;
+        mp[3] = xn[17] * c.inv_rc;
+        bool fin = true;
+#pragma unroll
+        for (int j = 0; j < EN; j++) fin = fin && (fabs(xn[j]) < 1e300);
+        A.status[inst] = !ok ? 1 : (fin ? 0 : 2);
+    }
+}
+
 // measurement assembly for the on-device DOB-MPC loop: y12 = plant state, thrust = allocation of u0 (bluerov2_dob.cpp:390-395)
 // with the OCP model's rotor constant, i.e. exactly the thruster vector brov_plant_step applies; acc = (v - v_prev) / dt
 // (:148-153); one lane per filter
@@ -461,6 +790,7 @@ struct brov_ekf {
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool ev_valid = false;
+    int variant = 1;   // 1: DPP row-broadcast kernel (default), 0: LDS-broadcast kernel (BROV_EKF_VARIANT=0, kept for A/B runs)
     std::vector<void*> allocs;
 };
 
@@ -573,6 +903,7 @@ extern "C" int brov_ekf_create(brov_ekf** out, int device, int B, const brov_ekf
     EKFCHK(hipSetDevice(device));
     brov_ekf* e = new brov_ekf();
     e->device = device; e->B = B;
+    if (const char* v = std::getenv("BROV_EKF_VARIANT")) e->variant = std::atoi(v) ? 1 : 0;
     if (p) e->par = *p; else brov_ekf_default_params(&e->par);
     make_const(e->par, e->c);
     int rc = BROV_OK;
@@ -626,9 +957,14 @@ static int launch_update(brov_ekf* e, const double* thrust, const double* y12, c
     EkfArgs a;
     a.c = e->c; a.B = e->B; a.x = e->x; a.P = e->P; a.thrust = thrust; a.y12 = y12; a.acc = acc; a.wf = e->wf; a.mp = e->mp;
     a.status = e->status;
-    const int blocks = (e->B + kPerWave - 1) / kPerWave;
     EKFCHK(hipEventRecord(e->ev[0], st));
-    hipLaunchKernelGGL(ekf_update_kernel, dim3(blocks), dim3(64), kPerWave * kLdsPerFilter * sizeof(double), st, a);
+    if (e->variant == 0) {
+        const int blocks = (e->B + kPerWave - 1) / kPerWave;
+        hipLaunchKernelGGL(ekf_update_kernel, dim3(blocks), dim3(64), kPerWave * kLdsPerFilter * sizeof(double), st, a);
+    } else {
+        const int blocks = (e->B + kDppFilters - 1) / kDppFilters;
+        hipLaunchKernelGGL(ekf_update_kernel_dpp, dim3(blocks), dim3(64), kDppFilters * kDppLds * sizeof(double), st, a);
+    }
     EKFCHK(hipGetLastError());
     EKFCHK(hipEventRecord(e->ev[1], st));
     e->ev_valid = true;
