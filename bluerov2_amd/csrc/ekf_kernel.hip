@@ -5,17 +5,22 @@
 // through the explicit inverse of the innovation covariance, Joseph-form covariance update, world-frame disturbance, and the
 // hand-over to the NMPC parameters p[0..3] (:334-337).
 //
-// Mapping (gfx950, wave64).  A tick is 2 x 19 evaluations of small nonlinear maps plus nine 18x18x18 products and one 18x18
-// inverse: 18 does not fit the 16-wide FP64 MFMA tile (a 32x32 padding would waste 3/4 of the issue slots, and FP64 MFMA has
-// the same flop rate as FP64 VALU on this part), so the filter runs on the VALU with **one lane per matrix row**:
+// Two kernels.  ekf_update_kernel_dpp (default): one filter per 16-lane DPP row, right-hand rows of the products broadcast
+// out of registers with v_fmac_f64_dpp row_newbcast -- see the comment in front of it.  ekf_update_kernel (first version,
+// BROV_EKF_VARIANT=0): 19 lanes per filter, right-hand rows broadcast through LDS; kept for A/B measurements.
+// Common to both: 18 does not fit the 16-wide FP64 MFMA tile (a 32x32 padding would waste 3/4 of the issue slots, and FP64
+// MFMA has the same flop rate as FP64 VALU on this part), so the filter runs on the VALU with one lane per matrix row; the
+// lane that perturbs state r in the finite differences ends up holding column r of the Jacobian, i.e. row r of its
+// transpose, and the products are arranged so that this is the form they need.
+// HBM traffic per tick and filter: P in and out (2 x 2592 B), x (2 x 144 B), inputs 192 B, outputs 84 B = 5.7 KB against
+// ~0.13 MFLOP: compute-bound on FP64 VALU issue.
+//
+// LDS-broadcast kernel (ekf_update_kernel):
 //   * 19 lanes per filter, 3 filters per wavefront (57 of 64 lanes): lane r < 18 evaluates the map perturbed in state r,
 //     lane 18 the unperturbed one -- the two finite-difference Jacobians cost one RK4 / one h() evaluation of wall time each;
 //   * lane i < 18 then owns row i of every matrix; a product C = A B is "row i of C += A[i][k] * (row k of B)" with the
-//     right-hand rows broadcast out of LDS (all 18 lanes read the same 144 bytes) and the accumulator row in registers.
-//     Transposed right-hand sides are free for F and H: a lane holds a *column* of those and chooses how to write it.
-//   * four 18x18 LDS buffers per filter (10.4 KB) + a few vectors: 33 KB per wave, 4 waves per CU.
-// HBM traffic per tick and filter: P in and out (2 x 2592 B), x (2 x 144 B), inputs 192 B, outputs 84 B = 5.7 KB against
-// ~0.13 MFLOP: compute-bound on FP64 VALU issue.
+//     right-hand rows broadcast out of LDS (all 18 lanes read the same 144 bytes) and the accumulator row in registers;
+//   * four 18x18 LDS buffers per filter (10.4 KB) + a few vectors: 33 KB per wave, 4 waves per CU.  Bound by LDS bandwidth.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
 // register with a static index), transposes are strided LDS reads, three 18x18 LDS buffers per filter.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDppFilters = 4;
-constexpr int kDppLds = 3 * kMat + 2 * EN + 4;   // doubles per filter: buffers A, B, C + x_new + flags
+constexpr int kDppLds = 3 * kMat + 4 * EN;       // doubles per filter: buffers A, B, C + x_new, x_pred, innovation, measurement
 
 struct Rows { double p[EN], s[EN]; };   // row layout: p = row l of the matrix, s = row 16 + l (lanes 0, 1), else 0
 
@@ -429,7 +434,9 @@ __device__ __forceinline__ void for_k(std::integer_sequence<int, Ks...>, F f) { 
 
 // C += A B.  B in row layout (registers); ap(k) / as(k) deliver A[l][k] and A[16+l][k] of this lane (as(k) = 0 for l >= 2).
 // The A elements of a block of k's are requested (LDS) before the fmacs of the previous block are issued.
-template <int K0, int NK, bool SECB, class AP, class AS>
+// CORNER: only columns 16, 17 of the secondary rows are accumulated -- for a symmetric result the rest of rows 16, 17 is
+// columns 16, 17 of the primary rows.
+template <int K0, int NK, bool SECB, bool CORNER>
 __device__ __forceinline__ void gemm_block(Rows& C, const Rows& B, const double (&a0)[NK], const double (&a1)[NK]) {
     for_k(std::make_integer_sequence<int, NK>{}, [&](auto kc) {
         constexpr int KK = decltype(kc)::value;
@@ -437,11 +444,11 @@ __device__ __forceinline__ void gemm_block(Rows& C, const Rows& B, const double 
 #pragma unroll
         for (int j = 0; j < EN; j++) {
             fmac_bc<K>(C.p[j], SECB ? B.s[j] : B.p[j], a0[KK]);
-            fmac_bc<K>(C.s[j], SECB ? B.s[j] : B.p[j], a1[KK]);
+            if (!CORNER || j >= 16) fmac_bc<K>(C.s[j], SECB ? B.s[j] : B.p[j], a1[KK]);
         }
     });
 }
-template <class AP, class AS>
+template <bool CORNER = false, class AP, class AS>
 __device__ __forceinline__ void gemm_dpp(Rows& C, const Rows& B, AP ap, AS as) {
     double p0[6], s0[6], p1[6], s1[6];
 #pragma unroll
@@ -449,16 +456,16 @@ __device__ __forceinline__ void gemm_dpp(Rows& C, const Rows& B, AP ap, AS as) {
 #pragma unroll
     for (int k = 0; k < 6; k++) { p1[k] = ap(6 + k); s1[k] = as(6 + k); }
     asm volatile("s_nop 1");
-    gemm_block<0, 6, false, AP, AS>(C, B, p0, s0);
+    gemm_block<0, 6, false, CORNER>(C, B, p0, s0);
 #pragma unroll
     for (int k = 0; k < 4; k++) { p0[k] = ap(12 + k); s0[k] = as(12 + k); }
     p0[4] = ap(16); s0[4] = as(16); p0[5] = ap(17); s0[5] = as(17);
-    gemm_block<6, 6, false, AP, AS>(C, B, p1, s1);
+    gemm_block<6, 6, false, CORNER>(C, B, p1, s1);
     {
         const double q0[4] = {p0[0], p0[1], p0[2], p0[3]}, q1[4] = {s0[0], s0[1], s0[2], s0[3]};
-        gemm_block<12, 4, false, AP, AS>(C, B, q0, q1);
+        gemm_block<12, 4, false, CORNER>(C, B, q0, q1);
         const double r0[2] = {p0[4], p0[5]}, r1[2] = {s0[4], s0[5]};
-        gemm_block<0, 2, true, AP, AS>(C, B, r0, r1);
+        gemm_block<0, 2, true, CORNER>(C, B, r0, r1);
     }
 }
 __device__ __forceinline__ void zero_rows(Rows& R) {
@@ -499,6 +506,9 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     elds* bufB = bufA + kMat;
     elds* bufC = bufB + kMat;
     elds* v_xn = bufC + kMat;            // [18] corrected state (gathered for the output lane)
+    elds* v_xp = v_xn + EN;              // [18] predicted state
+    elds* v_ye = v_xp + EN;              // [18] innovation
+    elds* v_ym = v_ye + EN;              // [18] measurement
 
     // ---- inputs: every lane keeps x, tau, acc, y of its filter
     double x[EN], tau[6], ac[6], ym[EN];
@@ -523,6 +533,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
         for (int j = 0; j < 12; j++) ym[j] = yg[j];
 #pragma unroll
         for (int j = 0; j < 6; j++) ym[12 + j] = tau[j];
+        store_row(v_ym, ym);   // identical values from the 16 lanes of the filter
         // P -> bufA (left operand of the first product): the filter's 2592 contiguous bytes in 16-byte pieces, 16 lanes wide
         const ed2* pg = (const ed2*)(A.P + (size_t)inst * kMat);
         ed2 pv[11];
@@ -552,6 +563,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
             Ft.s[j] = sec ? (xa[j] - f0[j]) * c.inv_d : 0.0;
             x[j] = f0[j];                   // from here on x = x_pred
         }
+        store_row(v_xp, f0);
     }
     __syncthreads();
     // G = P F^T
@@ -568,9 +580,9 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     store_rows(bufB, Pq, l);                // P_pred stays in bufB (right operand of V = J P_pred)
     // ---- H^T by forward differences of h at x_pred, innovation
     Rows Ht;
-    double ye[EN];
     {
-        double xl[EN], y0[EN], ya[EN], yb[EN];
+        double xl[EN], y0[EN], ya[EN], yb[EN], ye[EN], ym2[EN];
+        load_row(v_ym, ym2);
         ekf_h(c, x, ac, y0);
 #pragma unroll
         for (int j = 0; j < EN; j++) xl[j] = x[j] + ((sec && j == 16 + l) ? c.d : 0.0);
@@ -582,8 +594,9 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
         for (int j = 0; j < EN; j++) {
             Ht.p[j] = (yb[j] - y0[j]) * c.inv_d;
             Ht.s[j] = sec ? (ya[j] - y0[j]) * c.inv_d : 0.0;
-            ye[j] = ym[j] - y0[j];
+            ye[j] = ym2[j] - y0[j];
         }
+        store_row(v_ye, ye);
     }
     __syncthreads();                        // reads of bufC (F^T) are done
     store_rows(bufC, Ht, l);                // H^T row-major: H[l][k] = bufC[k][l]
@@ -636,13 +649,11 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     __syncthreads();
     // x_new = x_pred + Kal (y - y_pred)
     {
-        double dp = 0.0, ds = 0.0;
+        double dp = 0.0, ds = 0.0, ye[EN];
+        load_row(v_ye, ye);
 #pragma unroll
         for (int k = 0; k < EN; k++) { dp = fma(bufA[k * EN + l], ye[k], dp); ds = fma(bufA[k * EN + 16 + ls], ye[k], ds); }
-        double xp_ = 0.0, xs_ = 0.0;
-#pragma unroll
-        for (int j = 0; j < EN; j++) { xp_ = (j == l) ? x[j] : xp_; xs_ = (j == 16 + ls) ? x[j] : xs_; }
-        xp_ += dp; xs_ += ds;
+        const double xp_ = v_xp[l] + dp, xs_ = v_xp[16 + ls] + ds;
         v_xn[l] = xp_;
         if (sec) v_xn[16 + l] = xs_;
         if (live) {
@@ -682,19 +693,18 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     {
         Rows Jt;
         load_rows_t(bufC, Jt, l);
-        gemm_dpp(Pn, Jt, [&](int k) { return bufB[l * EN + k]; }, [&](int k) { const double t = bufB[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+        gemm_dpp<true>(Pn, Jt, [&](int k) { return bufB[l * EN + k]; }, [&](int k) { const double t = bufB[(16 + ls) * EN + k]; return sec ? t : 0.0; });
         Rows Kt;
         load_rows(bufA, Kt, l);
-        gemm_dpp(Pn, Kt, [&](int k) { return c.R * bufA[k * EN + l]; }, [&](int k) { const double t = c.R * bufA[k * EN + 16 + ls]; return sec ? t : 0.0; });
+        gemm_dpp<true>(Pn, Kt, [&](int k) { return c.R * bufA[k * EN + l]; }, [&](int k) { const double t = c.R * bufA[k * EN + 16 + ls]; return sec ? t : 0.0; });
     }
-    if (live) {
+    if (live) {   // P_new is symmetric: rows 16, 17 are columns 16, 17 of the primary rows (+ the 2x2 corner from lanes 0, 1)
         double* pg = A.P + (size_t)inst * kMat;
 #pragma unroll
         for (int j = 0; j < EN; j++) pg[l * EN + j] = Pn.p[j];
-        if (sec) {
-#pragma unroll
-            for (int j = 0; j < EN; j++) pg[(16 + l) * EN + j] = Pn.s[j];
-        }
+        pg[16 * EN + l] = Pn.p[16];
+        pg[17 * EN + l] = Pn.p[17];
+        if (sec) { pg[(16 + l) * EN + 16] = Pn.s[16]; pg[(16 + l) * EN + 17] = Pn.s[17]; }
     }
     // ---- outputs: world-frame disturbance with the MEASURED attitude (:540-545), NMPC parameters (:334-337)
     __syncthreads();
@@ -702,9 +712,9 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
         double xn[EN];
         load_row(v_xn, xn);
         double sph, cph, sth, cth, sps, cps;
-        sincos_pio2(ym[3], &sph, &cph);
-        sincos_pio2(ym[4], &sth, &cth);
-        sincos_pio2(ym[5], &sps, &cps);
+        sincos_pio2(v_ym[3], &sph, &cph);
+        sincos_pio2(v_ym[4], &sth, &cth);
+        sincos_pio2(v_ym[5], &sps, &cps);
         double* w = A.wf + (size_t)inst * 6;
         w[0] = (cps * cth) * xn[12] + (-sps * cph + cps * sth * sph) * xn[13] + (sps * sph + cps * cph * sth) * xn[14];
         w[1] = (sps * cth) * xn[12] + (cps * cph + sph * sth * sps) * xn[13] + (-cps * sph + sth * sps * cph) * xn[14];
