@@ -1180,7 +1180,6 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = P.N;
-    const double* __restrict__ cst = P.cst;
     DBG_STAMP(0);
     // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
     double* ba_s = smem;                          // [N][12][13]
