@@ -74,6 +74,20 @@ def main(tag, rnd):
             if k in ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel"):
                 sq.setdefault(k, {})[cname] = sum(v[5:]) / max(1, len(v[5:]))
     out["sq_counters_per_launch"] = sq
+    lds = {}
+    for cname in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_SALU",
+                  "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+        for k, v in per_kernel(os.path.join(src, "pmc_lds"), cname).items():
+            if k in ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel"):
+                lds.setdefault(k, {})[cname] = sum(v[5:]) / max(1, len(v[5:]))
+    out["lds_counters_per_launch"] = lds
+    ekf = {}
+    for cname in ("SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
+                  "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY"):
+        for k, v in per_kernel(os.path.join(src, "pmc_ekf"), cname).items():
+            if k.startswith("ekf_update"):
+                ekf.setdefault(k, {})[cname] = sum(v[2:]) / max(1, len(v[2:]))
+    out["ekf_counters_per_launch_B16384"] = ekf
     json.dump(out, open(os.path.join(dst, f"{rnd}_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -15,6 +15,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch -o f -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o w -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -o s -- python $R/bench.py --no-cpu-baseline --steps 10 > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_lds -o l -- python $R/bench.py --no-cpu-baseline --steps 10 > /dev/null 2> $OUT/pmc_lds.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_ekf -o e -- python $R/scripts/bench_ekf.py --no-cpu-baseline --steps 5 > /dev/null 2> $OUT/pmc_ekf.err
 python $R/bench.py --force-ipm --no-cpu-baseline > $OUT/bench_forced_ipm.json 2> $OUT/bench_forced_ipm.err
 python $R/bench.py --path 1 --no-cpu-baseline > $OUT/bench_streaming.json 2> $OUT/bench_streaming.err
 python $R/bench.py --batch 16384 --no-cpu-baseline > $OUT/bench_b16384.json 2> $OUT/bench_b16384.err
