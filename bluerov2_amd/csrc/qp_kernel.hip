@@ -580,6 +580,15 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
     wave_fence();
 }
 
+// one interior-point vector: two elements per lane in registers (fused path, nv <= 128) or an HBM array (streaming path)
+template <bool REG>
+struct IpmVec {
+    double r[2];
+    double* g;
+    __device__ __forceinline__ double get(int t, int j) const { return REG ? r[t & 1] : g[j]; }
+    __device__ __forceinline__ void set(int t, int j, double v) { if (REG) r[t & 1] = v; else g[j] = v; }
+};
+
 // everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
 // lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
@@ -665,16 +674,24 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         if (allfeas && P.early_exit) {
             early = true;  // the accepted inputs stay where the forward sweep left them (I.vhat)
         } else {
-            // interior start: clamp into the box, multipliers from mu0 = stationarity residual of the clamped point
-            for (int j = lane; j < nv; j += 64) {
+            // interior start: clamp into the box, multipliers from mu0 = stationarity residual of the clamped point.
+            // Fused path: the interior-point vectors (two elements per lane, nv <= 92) live in registers -- at one wave per
+            // SIMD every element loop over HBM-resident vectors costs an exposed L2 round trip; only Gamma and the right-hand
+            // side, which the backward sweep reads by stage, go through memory.
+            IpmVec<LDS> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
+                vDLL{{0, 0}, GAM}, vDLU{{0, 0}, RT};   // dual steps: registers, or parked in GAM / RT (both rebuilt every iteration)
+#define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const int j = lane + 64 * t; j < nv)
+            constexpr int kIpmT = LDS ? 2 : 8;   // streaming path: nv <= 512
+            IPM_FOR(t, j) {
                 const int m = j & 3;
-                const double lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
+                const double uj = LDS ? ureg[t & 1] : I.u[j];
+                const double lb = cst[32 + m] - uj, ub = cst[36 + m] - uj;
                 const double wdt = ub - lb;
                 double vj = I.vhat[j];
                 const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
                 vj = (vj < lo) ? lo : vj;
                 vj = (vj > hi) ? hi : vj;
-                V[j] = vj; TL[j] = vj - lb; TU[j] = ub - vj;
+                vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
                 if constexpr (LDS) I.vhat[j] = vj;  // roll-out / adjoint read their inputs from the LDS copy
             }
             rollout<LDS>(I, d0, V);
@@ -684,9 +701,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             g0 = wave_max(g0);
             const double mu0 = fmax(g0, 1e-4);
             double r0 = 0.0;
-            for (int j = lane; j < nv; j += 64) {
-                const double ll = mu0 / TL[j], lu = mu0 / TU[j];
-                LL[j] = ll; LU[j] = lu;
+            IPM_FOR(t, j) {
+                const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
+                vLL.set(t, j, ll); vLU.set(t, j, lu);
                 r0 = fmax(r0, fabs(GRAD[j] - ll + lu));
             }
             rho = wave_max(r0);
@@ -694,14 +711,16 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             const double inv2nv = 1.0 / (2.0 * nv);
             for (iters = 1; iters <= P.qp_iter_max; iters++) {
                 double s = 0.0;
-                for (int j = lane; j < nv; j += 64) {
-                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j];
+                double gam_r[2] = {0.0, 0.0};
+                IPM_FOR(t, j) {
+                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
                     s += ll * tl + lu * tu;
                     const double gm = ll / tl + lu / tu;
                     GAM[j] = gm;
+                    if constexpr (LDS) gam_r[t & 1] = gm;
                     const int m = j & 3;
                     const double rr = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
-                    RT[j] = rr - gm * V[j];
+                    RT[j] = rr - gm * vV.get(t, j);
                 }
                 mu = wave_sum(s) * inv2nv;
                 ok = riccati_backward<true, LDS>(I);
@@ -709,10 +728,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 riccati_forward<LDS>(I, d0);
                 // predictor step length and centering
                 double aaff = 1.0;
-                for (int j = lane; j < nv; j += 64) {
-                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j];
-                    const double dv = I.vhat[j] - V[j];
-                    DVA[j] = dv;
+                IPM_FOR(t, j) {
+                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
+                    const double dv = I.vhat[j] - vV.get(t, j);
+                    vDVA.set(t, j, dv);
                     const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                     if (dv < 0) aaff = fmin(aaff, -tl / dv);
                     if (dv > 0) aaff = fmin(aaff, tu / dv);
@@ -721,8 +740,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
                 aaff = wave_min(aaff);
                 double sa = 0.0;
-                for (int j = lane; j < nv; j += 64) {
-                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dv = DVA[j];
+                IPM_FOR(t, j) {
+                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dv = vDVA.get(t, j);
                     const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                     sa += (ll + aaff * dll) * (tl + aaff * dv) + (lu + aaff * dlu) * (tu - aaff * dv);
                 }
@@ -730,42 +749,43 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 double sigma = muaff / mu;
                 sigma = sigma * sigma * sigma;
                 const double smu = sigma * mu;
-                for (int j = lane; j < nv; j += 64) {
-                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dv = DVA[j];
+                IPM_FOR(t, j) {
+                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dv = vDVA.get(t, j);
                     const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                     const double cl_ = dll * dv, cu_ = -dlu * dv;
                     const int m = j & 3;
                     const double rr = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
-                    RT[j] = rr - GAM[j] * V[j] - (smu - cl_) / tl + (smu - cu_) / tu;
+                    const double gm = LDS ? gam_r[t & 1] : GAM[j];
+                    RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
                 }
                 (void)riccati_backward<false, LDS>(I);
                 riccati_forward<LDS>(I, d0);
                 double amax = 1e300;
-                for (int j = lane; j < nv; j += 64) {
-                    const double ll = LL[j], lu = LU[j], tl = TL[j], tu = TU[j], dva = DVA[j];
+                IPM_FOR(t, j) {
+                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dva = vDVA.get(t, j);
                     const double dlla = -ll - ll / tl * dva, dlua = -lu + lu / tu * dva;
                     const double cl_ = dlla * dva, cu_ = -dlua * dva;
-                    const double dv = I.vhat[j] - V[j];
+                    const double dv = I.vhat[j] - vV.get(t, j);
                     const double dll = (smu - cl_) / tl - ll - ll / tl * dv;
                     const double dlu = (smu - cu_) / tu - lu + lu / tu * dv;
                     if (dv < 0) amax = fmin(amax, -tl / dv);
                     if (dv > 0) amax = fmin(amax, tu / dv);
                     if (dll < 0) amax = fmin(amax, -ll / dll);
                     if (dlu < 0) amax = fmin(amax, -lu / dlu);
-                    GAM[j] = dll;  // dual steps parked in GAM / RT (both are rebuilt next iteration)
-                    RT[j] = dlu;
+                    vDLL.set(t, j, dll);
+                    vDLU.set(t, j, dlu);
                 }
                 amax = wave_min(amax);
                 double alpha = IPM_FTB * amax;
                 alpha = alpha > 1.0 ? 1.0 : alpha;
                 bool bad = false;
                 double s2 = 0.0;
-                for (int j = lane; j < nv; j += 64) {
-                    const double dv = I.vhat[j] - V[j];
-                    const double vj = V[j] + alpha * dv;
-                    const double tl = TL[j] + alpha * dv, tu = TU[j] - alpha * dv;
-                    const double ll = LL[j] + alpha * GAM[j], lu = LU[j] + alpha * RT[j];
-                    V[j] = vj; TL[j] = tl; TU[j] = tu; LL[j] = ll; LU[j] = lu;
+                IPM_FOR(t, j) {
+                    const double dv = I.vhat[j] - vV.get(t, j);
+                    const double vj = vV.get(t, j) + alpha * dv;
+                    const double tl = vTL.get(t, j) + alpha * dv, tu = vTU.get(t, j) - alpha * dv;
+                    const double ll = vLL.get(t, j) + alpha * vDLL.get(t, j), lu = vLU.get(t, j) + alpha * vDLU.get(t, j);
+                    vV.set(t, j, vj); vTL.set(t, j, tl); vTU.set(t, j, tu); vLL.set(t, j, ll); vLU.set(t, j, lu);
                     if (!(vj == vj)) bad = true;
                     s2 += ll * tl + lu * tu;
                 }
@@ -774,6 +794,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 mu = wave_sum(s2) * inv2nv;
                 if (mu <= P.tol_mu && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
             }
+            // the final inputs go where the finalisation expects them: V (streaming path, already there) / the LDS copy
+            if constexpr (LDS) { IPM_FOR(t, j) I.vhat[j] = vV.get(t, j); }
+#undef IPM_FOR
             if (iters > P.qp_iter_max) iters = P.qp_iter_max;
         }
     }
@@ -782,13 +805,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     // Element loops issue all their loads before the first use (UX/UU elements per lane per chunk): at one wave per SIMD
     // every dependent global round trip is otherwise fully exposed (~2 us each).
     constexpr int UX = LDS ? 5 : 4, UU = LDS ? 2 : 4;
-    const double* vfin = early ? I.vhat : V;
+    const double* vfin = (early || LDS) ? I.vhat : V;   // fused path: the interior-point loop leaves its inputs in the LDS copy
     const int nxe = (N + 1) * 12;
     double cost = 0.0;
     bool wrote_u0 = false;
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
         if (!early) {  // early exit: dxb already holds the states of the accepted Newton point
-            if constexpr (LDS) { for (int j = lane; j < nv; j += 64) I.vhat[j] = V[j]; }
             rollout<LDS>(I, d0, V);
         }
         DBG_STAMP(4);
