@@ -44,6 +44,30 @@ def test_small_and_ragged_shapes(ba, oracle, golden_traj, N, B, path):
     assert np.abs(r["u0"] - ro["u0"]).max() < 1e-7 and np.abs(s.get_iterate()[0] - it[0]).max() < 1e-7
 
 
+@pytest.mark.parametrize("N,B", [(22, 4), (24, 3), (43, 5), (64, 2), (85, 3), (128, 2)])
+def test_streaming_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B):
+    """horizons that split into 2..7 linearisation chunks of unequal length (lin_wave_kernel: <= 21 intervals per wave), up to
+    the shim's maximum N = 128; two RTI ticks so that the second one linearises at a non-trivial iterate with multipliers"""
+    x0, circ = _inputs(golden_traj, B, seed=N, big=1.0)
+    Ts = 2.0 / N
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    assert s.opts.kernel_path == ba.PATH_AUTO
+    s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+    op = oracle.opts(N, Ts)
+    it = oracle.init_iterate(op, B)
+    win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])[:N + 2]   # the golden head is short: pad like the reference
+    for k in range(2):
+        s.set_yref(win[k:k + N + 1]); s.solve()
+        assert s.last_kernel_path() == (ba.PATH_FUSED if N <= 23 else ba.PATH_STREAMING)
+        worst, ro = _oracle_step(oracle, op, x0, win[k:k + N + 1], ba.P_NOMINAL, it)
+        r = s.results()
+        assert np.array_equal(r["status"], ro["status"])
+        assert np.abs(r["u0"] - ro["u0"]).max() < 1e-7
+        np.testing.assert_allclose(r["kkt"], ro["kkt"], rtol=1e-6, atol=1e-9)
+        gx, gu, gpi, glam = s.get_iterate()
+        assert np.abs(gx - it[0]).max() < 1e-7 and np.abs(gu - it[1]).max() < 1e-7
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_nan_input_is_contained(ba, oracle, golden_traj, path):
     N, B = 20, 8
