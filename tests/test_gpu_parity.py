@@ -224,3 +224,32 @@ def test_per_instance_reference_windows(ba, oracle, golden_traj):
     pfull = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (nb, N + 1, 16)))
     worst, ro = oracle.rti_step_batch(op, x0, yref, pfull, x, u, pi, lam)
     assert np.abs(s.results()["u0"] - ro["u0"]).max() < TOL_IT
+
+
+def test_full_size_batch_properties(ba, golden_traj):
+    """BASELINE config 3 size (16384 instances, N=20), size-independent properties: an instance's result does not depend on
+    its position in the batch or on its neighbours (bitwise), duplicates agree bitwise, no instance fails."""
+    B, N, H = 16384, 20, 8192
+    rng = np.random.default_rng(21)
+    circ = golden_traj["circle"]
+    x0h = np.zeros((H, 12)); x0h[:, :6] = circ[0, :6]
+    x0h += rng.normal(size=(H, 12)) * np.array([0.3] * 3 + [0.05] * 3 + [0.1] * 3 + [0.05] * 3)
+    x0h[:64, :3] += rng.uniform(-4, 4, (64, 3))            # some instances with saturated inputs (interior-point branch)
+    ph = np.tile(ba.P_NOMINAL, (H, 1)); ph[:, :4] = rng.uniform(-100, 100, (H, 4))
+    x0 = np.concatenate([x0h, x0h[::-1]]); p = np.concatenate([ph, ph[::-1]])
+    s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05)); s.set_x0(x0); s.set_params(p)
+    recs = []
+    for k in range(3):
+        s.set_yref(circ[k:k + N + 1]); s.solve(); recs.append(s.results().copy())
+    r = recs[-1]
+    assert not r["status"].any() and (r["qp_iter"][:64] > 0).any()
+    for f in ("u0", "cost", "kkt", "qp_iter"):
+        assert np.array_equal(r[f][:H], r[f][H:][::-1]), f
+    pick = np.concatenate([[0, 1, 63, 64, H - 1], rng.integers(0, H, 11)])
+    s2 = ba.BatchSolver(len(pick), ba.SolverOptions(N, 0.05)); s2.set_x0(x0h[pick]); s2.set_params(ph[pick])
+    for k in range(3):
+        s2.set_yref(circ[k:k + N + 1]); s2.solve()
+    r2 = s2.results()
+    for f in ("u0", "cost", "kkt", "qp_iter"):
+        assert np.array_equal(r2[f], r[f][pick]), f
+    s.close(); s2.close()
