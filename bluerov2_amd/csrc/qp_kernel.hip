@@ -253,7 +253,6 @@ __device__ bool riccati_backward(const Inst& I) {
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
     wave_fence();
     BwdIn nx;
-    if constexpr (LDS) nx = load_bwd<FACTOR, LDS, STEP0>(I, N - 1, gam, rt);
     d4 P = {0, 0, 0, 0}, pv;
     {
         const double* xN = I.x + (size_t)N * 12;
@@ -382,11 +381,8 @@ __device__ bool riccati_backward(const Inst& I) {
         }
     };
     if constexpr (LDS) {
-        for (int i = N - 1; i >= 0; i--) {
-            const BwdIn in = nx;
-            nx = load_bwd<FACTOR, LDS, STEP0>(I, i > 0 ? i - 1 : 0, gam, rt);  // clamped: one scheduling region
-            stage(i, in);
-        }
+        pipelined<2, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+                            [&](int k, const BwdIn& in) { stage(N - 1 - k, in); });
     } else {
         // distance 1 here: a stage is ~2 k cycles of issue per wave (4 k with the SIMD's second wave), enough to cover the
         // round trip, and a second stage in flight (36 VGPRs) pushes the kernel into scratch
@@ -422,17 +418,11 @@ template <bool LDS>
 __device__ void riccati_forward(const Inst& I, const d4& d0) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    FwdIn nx;
-    if constexpr (LDS) nx = load_fwd<LDS>(I, 0);
     d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
-    for (int i = 0; LDS && i < N; i++) {
-        const FwdIn in = nx;
-        if constexpr (LDS) {
-            // branch-free body (the prefetch index is clamped, the last one is redundant) so that the whole stage is one
-            // scheduling region, then ask for the independent work -- next stage's LDS reads, address arithmetic, the
-            // register hand-over -- to be issued in the shadow of the dependent MFMA chain instead of in front of it
-            nx = load_fwd<LDS>(I, i + 1 < N ? i + 1 : N - 1);
+    if constexpr (LDS) {
+        // two stages ahead (see adjoint<>): the LDS reads of a stage are in flight for a whole stage before they are needed
+        pipelined<2, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
             d4 c = {in.kf, 0, 0, 0};
             d4 v = tn<3>(in.kt, xx, c);
             I.lds_vhat[i * 4 + rg] = v[0];
@@ -440,13 +430,7 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
             xx = tn<4>(in.bat, z, in.bb);
             xx[3] = 0.0;
             store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl);
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // 5 VALU
-            }
-        }
+        });
     }
     if constexpr (!LDS) {
         pipelined<2, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
@@ -476,25 +460,15 @@ template <bool LDS>
 __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    RollIn nx;
-    if constexpr (LDS) nx = load_roll<LDS>(I, 0, varr);
     d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
-        for (int i = 0; i < N; i++) {
-            const RollIn in = nx;
-            nx = load_roll<LDS>(I, i + 1 < N ? i + 1 : N - 1, varr);
+        pipelined<2, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
             d4 z = {xx[0], xx[1], xx[2], in.v};
             xx = tn<4>(in.bat, z, in.bb);
             xx[3] = 0.0;
             store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
-        }
+        });
     } else {
         pipelined<3, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
             d4 z = {xx[0], xx[1], xx[2], in.v};
@@ -538,8 +512,6 @@ template <bool COMMIT, bool LDS>
 __device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
-    AdjIn nx;
-    if constexpr (LDS) nx = load_adj<LDS>(I, N - 1, varr);
     d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
     const d4 z4 = {0, 0, 0, 0};
     auto stage = [&](int i, const AdjIn& in) __attribute__((always_inline)) {
@@ -562,17 +534,10 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
         atpi = G;
     };
     if constexpr (LDS) {
-        for (int i = N - 1; i >= 0; i--) {
-            const AdjIn in = nx;
-            nx = load_adj<LDS>(I, i > 0 ? i - 1 : 0, varr);
-            stage(i, in);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 DS reads
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // 6 VALU
-            }
-        }
+        // two stages ahead: the LDS reads of stage i-2 are issued a full stage before they are consumed, so the wait at the
+        // top of a stage never sees the ~200 cycles of LDS queue + latency that a one-stage look-ahead leaves exposed
+        pipelined<2, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
+                            [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
     } else {
         pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
                             [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
