@@ -92,24 +92,36 @@ __device__ __forceinline__ void jvp_rec(const StageRec& R, double imx, double im
 struct KktOperands { double pm1c, ll, lu, ucur, lbu, ubu, grad, qn; };
 // ig = global interval index (HBM arrays), il = index inside the LDS-resident chunk of nl intervals (row nl of q_s holds the
 // terminal gradient when the chunk ends the horizon)
-__device__ __forceinline__ KktOperands load_kkt_operands(const DevParams& P, const double* __restrict__ cst, int b, int ig, int il,
-                                                         int nl, int c, const double* __restrict__ ui, const lds_f64* q_s,
-                                                         const lds_f64* r_s) {
+// the part of the operands that comes out of HBM / L2 (the rest is LDS or constant memory)
+struct KktGlobal { double pm1c, ll, lu, ucur; };
+__device__ __forceinline__ KktGlobal load_kkt_global(const DevParams& P, int b, int ig, int c, const double* __restrict__ ui) {
     const int N = P.N;
     const int jc = c - NX, ju = jc & 3, cx = c < NX ? c : NX - 1;
     const double* __restrict__ pim1 = P.pi + ((size_t)b * N + (ig > 0 ? ig - 1 : 0)) * NX;
     const double* __restrict__ lam = P.lam + ((size_t)b * N + ig) * 8;
+    KktGlobal G;
+    G.pm1c = pim1[cx];
+    G.ll = lam[ju];
+    G.lu = lam[4 + ju];
+    G.ucur = ui[ju];
+    return G;
+}
+__device__ __forceinline__ KktOperands finish_kkt_operands(const KktGlobal& G, const double* __restrict__ cst, int il, int nl, int c,
+                                                           const lds_f64* q_s, const lds_f64* r_s) {
+    const int jc = c - NX, ju = jc & 3, cx = c < NX ? c : NX - 1;
     KktOperands K;
-    K.pm1c = pim1[cx];
-    K.ll = lam[ju];
-    K.lu = lam[4 + ju];
-    K.ucur = ui[ju];
+    K.pm1c = G.pm1c; K.ll = G.ll; K.lu = G.lu; K.ucur = G.ucur;
     K.lbu = cst[32 + ju];
     K.ubu = cst[36 + ju];
     const lds_f64* gp = jc < 0 ? q_s + il * NX + c : r_s + il * NU + jc;
     K.grad = *gp;
     K.qn = q_s[nl * NX + cx];
     return K;
+}
+__device__ __forceinline__ KktOperands load_kkt_operands(const DevParams& P, const double* __restrict__ cst, int b, int ig, int il,
+                                                         int nl, int c, const double* __restrict__ ui, const lds_f64* q_s,
+                                                         const lds_f64* r_s) {
+    return finish_kkt_operands(load_kkt_global(P, b, ig, c, ui), cst, il, nl, c, q_s, r_s);
 }
 
 // sensitivity column c (3..15) of interval record rec through the 4 stage records.  The next record is requested before
@@ -207,6 +219,37 @@ __device__ __forceinline__ void sens_column_rec_u(const lds_f64* rec, const Mode
     jvp_rec(R, m.imx, m.imy, m.imz, m.imn, kb, ss, ks);
 #pragma unroll
     for (int j = 0; j < NX; j++) acc[j] += (h / 6.0) * ks[j];
+}
+
+// Sensitivity columns that never leave span{e_0, e_1, e_2, e_r}, r = 6 + j a linear-velocity row: the state columns of the
+// body velocities (c = 6 + j) and the pure force inputs u0 (row 6) and u2 (row 8).  df/dx has no position columns, column
+// 6 + j of df/dx is [R(:, j); 0; d_j e_j; 0] (rotation column + damping diagonal, no Coriolis terms in this model), so every
+// RK stage maps the scalar sigma = s[r] to k = [R_st(:, j) sigma; d_st sigma + kb]: ~25 operations per stage instead of the
+// ~125 of the general Jacobian-vector product.  acc = the full column (rows other than 0..2 and r are e_c resp. 0).
+__device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, int j, bool input, double kbv, double (&acc)[NX]) {
+    const double s0 = input ? 0.0 : 1.0;   // seed: e_c for a state column, 0 for an input column
+    double sig = s0, ar = s0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const lds_f64* r = rec + st * kRecStage;
+        const double sph = r[0], cph = r[1], sth = r[2], cth = r[3], sps = r[4], cps = r[5];
+        const double d = (j == 0) ? r[13] : ((j == 1) ? r[14] : r[15]);
+        const double r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = sps * sph + cps * cph * sth;
+        const double r10 = sps * cth, r11 = cps * cph + sph * sth * sps, r12 = sth * sps * cph - cps * sph;
+        const double r21 = cth * sph, r22 = cth * cph;
+        const double c0 = (j == 0) ? r00 : ((j == 1) ? r01 : r02);
+        const double c1 = (j == 0) ? r10 : ((j == 1) ? r11 : r12);
+        const double c2 = (j == 0) ? -sth : ((j == 1) ? r21 : r22);
+        const double kr = d * sig + kbv;
+        const double w = (st == 0 || st == 3) ? h / 6.0 : h / 3.0;
+        a0 += w * (c0 * sig); a1 += w * (c1 * sig); a2 += w * (c2 * sig);
+        ar += w * kr;
+        sig = s0 + ((st == 2) ? h : 0.5 * h) * kr;   // input of the next stage
+    }
+#pragma unroll
+    for (int k = 0; k < NX; k++) acc[k] = 0.0;
+    acc[0] = a0; acc[1] = a1; acc[2] = a2;
+    acc[6] = (j == 0) ? ar : 0.0; acc[7] = (j == 1) ? ar : 0.0; acc[8] = (j == 2) ? ar : 0.0;
 }
 
 // stationarity / input-feasibility part of the NLP KKT residual for column c >= 3 of interval i, with the cost gradients

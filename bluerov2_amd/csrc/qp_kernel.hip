@@ -1075,11 +1075,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     // developer instrumentation, slot 7: loads issued -> cost gradients -> state integrated -> column loop entered
     if (stamp && P.dbg && lane == 0)
         P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
-#pragma unroll 1
-    for (int c = 3 + j0; c < NX; c += L) {   // state columns 3..11
-        double acc[NX];
-        const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-        sens_column_rec(rec, m, P.Ts, c, acc);
+    auto finish = [&](int c, const KktOperands& ko, const double (&acc)[NX]) __attribute__((always_inline)) {
         const double kk = lin_kkt_col(ko, N, ig, c, pir, acc);
 #pragma unroll
         for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
@@ -1087,19 +1083,59 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             if (kk != kk) nanp = true;
             part = fmax(part, kk);
         }
+    };
+    // Columns by structure, so that the lanes of a trip run the same code:
+    //   (1) attitude angles 3..5 and body rates 9..11: general Jacobian-vector products, 4 per column;
+    //   (2) inputs with a yaw-moment component, u1 (rows 7, 11) and u3 (row 11): first stage is df/du itself;
+    //   (3) body velocities 6..8 and the pure force inputs u0, u2: closed form (sens_column_cheap).
+    // L = 3 at N = 20: 2 + 1 + 2 trips costing about 1, 0.6 and 0.15 of a general one -- 2.9 trip-equivalents (was 5, then 4.3).
+    // A lane whose class has run out of columns repeats the class's last column (same values stored twice).
+#pragma unroll 1
+    for (int q0 = j0; q0 < 6 + j0; q0 += L) {
+        if (q0 - j0 >= 6) break;
+        const int q = q0 < 6 ? q0 : 5;
+        const int c = q < 3 ? 3 + q : 6 + q;
+        double acc[NX];
+        const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+        sens_column_rec(rec, m, P.Ts, c, acc);
+        finish(c, ko, acc);
+    }
+    // the closed-form trips are far too short to hide the L2 round trips of their own KKT operands: requested here, under
+    // the input-column trip
+    constexpr int kCheapTrips = 3;   // ceil(5 / L) <= 3 for L >= 2
+    const int nC = (5 + L - 1) / L;
+    KktGlobal kg[kCheapTrips];
+    int cq[kCheapTrips];
+#pragma unroll
+    for (int t = 0; t < kCheapTrips; t++) {
+        int q = j0 + t * L;
+        q = q < 5 ? q : 4;
+        cq[t] = q;
+        const bool input = q >= 3;
+        const int j = input ? (q == 3 ? 0 : 2) : q;
+        kg[t] = load_kkt_global(P, b, ig, input ? NX + j : 6 + j, ui);
     }
 #pragma unroll 1
-    for (int jc = j0; jc < NU; jc += L) {    // input columns: cheaper (lin_device.hpp, sens_column_rec_u)
-        const int c = NX + jc;
+    for (int q0 = j0; q0 - j0 < 2; q0 += L) {
+        const int q = q0 < 2 ? q0 : 1;
+        const int jc = 1 + 2 * q, c = NX + jc;
         double acc[NX];
         const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
         sens_column_rec_u(rec, m, P.Ts, jc, acc);
-        const double kk = lin_kkt_col(ko, N, ig, c, pir, acc);
+        finish(c, ko, acc);
+    }
 #pragma unroll
-        for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
-        if (active) {
-            if (kk != kk) nanp = true;
-            part = fmax(part, kk);
+    for (int t = 0; t < kCheapTrips; t++) {
+        if (t < nC) {
+            const int q = cq[t];
+            const bool input = q >= 3;
+            const int j = input ? (q == 3 ? 0 : 2) : q;       // velocity row 6 + j
+            const int c = input ? NX + j : 6 + j;
+            constexpr double ir = 1.0 / kRotor;
+            const double kbv = !input ? 0.0 : (j == 0 ? (-4.0 * 0.707) * ir * m.imx : -2.0 * ir * m.imz);   // model_bcol rows 6 / 8
+            double acc[NX];
+            sens_column_cheap(rec, P.Ts, j, input, kbv, acc);
+            finish(c, finish_kkt_operands(kg[t], cst, i, n, c, (const lds_f64*)q_s, (const lds_f64*)r_s), acc);
         }
     }
 }
