@@ -226,7 +226,8 @@ __device__ __forceinline__ void sens_column_rec_u(const lds_f64* rec, const Mode
 // 6 + j of df/dx is [R(:, j); 0; d_j e_j; 0] (rotation column + damping diagonal, no Coriolis terms in this model), so every
 // RK stage maps the scalar sigma = s[r] to k = [R_st(:, j) sigma; d_st sigma + kb]: ~25 operations per stage instead of the
 // ~125 of the general Jacobian-vector product.  acc = the full column (rows other than 0..2 and r are e_c resp. 0).
-__device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, int j, bool input, double kbv, double (&acc)[NX]) {
+// out = {S[0][c], S[1][c], S[2][c], S[6+j][c]}; expand_cheap() builds the full column
+__device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, int j, bool input, double kbv, double (&out)[4]) {
     const double s0 = input ? 0.0 : 1.0;   // seed: e_c for a state column, 0 for an input column
     double sig = s0, ar = s0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
@@ -246,10 +247,13 @@ __device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, 
         ar += w * kr;
         sig = s0 + ((st == 2) ? h : 0.5 * h) * kr;   // input of the next stage
     }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = ar;
+}
+__device__ __forceinline__ void expand_cheap(const double (&v)[4], int j, double (&acc)[NX]) {
 #pragma unroll
     for (int k = 0; k < NX; k++) acc[k] = 0.0;
-    acc[0] = a0; acc[1] = a1; acc[2] = a2;
-    acc[6] = (j == 0) ? ar : 0.0; acc[7] = (j == 1) ? ar : 0.0; acc[8] = (j == 2) ? ar : 0.0;
+    acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2];
+    acc[6] = (j == 0) ? v[3] : 0.0; acc[7] = (j == 1) ? v[3] : 0.0; acc[8] = (j == 2) ? v[3] : 0.0;
 }
 
 // stationarity / input-feasibility part of the NLP KKT residual for column c >= 3 of interval i, with the cost gradients

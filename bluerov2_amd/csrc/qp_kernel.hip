@@ -1124,17 +1124,28 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
         sens_column_rec_u(rec, m, P.Ts, jc, acc);
         finish(c, ko, acc);
     }
+    // all closed-form columns of the lane first (independent chains, interleaved by the compiler), then their KKT rows / stores
+    double cv[kCheapTrips][4];
 #pragma unroll
     for (int t = 0; t < kCheapTrips; t++) {
         if (t < nC) {
             const int q = cq[t];
             const bool input = q >= 3;
             const int j = input ? (q == 3 ? 0 : 2) : q;       // velocity row 6 + j
-            const int c = input ? NX + j : 6 + j;
             constexpr double ir = 1.0 / kRotor;
             const double kbv = !input ? 0.0 : (j == 0 ? (-4.0 * 0.707) * ir * m.imx : -2.0 * ir * m.imz);   // model_bcol rows 6 / 8
+            sens_column_cheap(rec, P.Ts, j, input, kbv, cv[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kCheapTrips; t++) {
+        if (t < nC) {
+            const int q = cq[t];
+            const bool input = q >= 3;
+            const int j = input ? (q == 3 ? 0 : 2) : q;
+            const int c = input ? NX + j : 6 + j;
             double acc[NX];
-            sens_column_cheap(rec, P.Ts, j, input, kbv, acc);
+            expand_cheap(cv[t], j, acc);
             finish(c, finish_kkt_operands(kg[t], cst, i, n, c, (const lds_f64*)q_s, (const lds_f64*)r_s), acc);
         }
     }
