@@ -13,6 +13,14 @@ __device__ __forceinline__ void kkt_upd(double& kkt, double v) {
     kkt = (a != a) ? a : ((kkt != kkt) ? kkt : fmax(kkt, a));
 }
 
+// inf-norm accumulator of the KKT rows with a separate NaN flag: v_max_f64 drops NaN operands, so the maximum is one
+// independent instruction per row (the NaN-propagating kkt_upd is a chain of ~6 dependent ones)
+struct KktAcc {
+    double mx = 0.0;
+    bool nan = false;
+    __device__ __forceinline__ void upd(double v) { mx = fmax(mx, fabs(v)); nan = nan || (v != v); }
+};
+
 // Stage points of the 4 RK stages + x+
 __device__ __forceinline__ void rk4_state(const double* __restrict__ xi, const Wrench& w, const ModelPar& m, double h,
                                           StagePoint (&sp)[4], double (&xn)[NX]) {
@@ -228,20 +236,28 @@ __device__ __forceinline__ void sens_column_rec_u(const lds_f64* rec, const Mode
 // ~125 of the general Jacobian-vector product.  acc = the full column (rows other than 0..2 and r are e_c resp. 0).
 // out = {S[0][c], S[1][c], S[2][c], S[6+j][c]}; expand_cheap() builds the full column
 __device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, int j, bool input, double kbv, double (&out)[4]) {
+    // all four stage records first (one LDS wait instead of one per stage): the six trig values and this row's damping entry
+    double tr[4][6], dd[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const lds_f64* r = rec + st * kRecStage;
+#pragma unroll
+        for (int k = 0; k < 6; k++) tr[st][k] = r[k];
+        const double d0 = r[13], d1 = r[14], d2 = r[15];
+        dd[st] = (j == 0) ? d0 : ((j == 1) ? d1 : d2);
+    }
     const double s0 = input ? 0.0 : 1.0;   // seed: e_c for a state column, 0 for an input column
     double sig = s0, ar = s0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
     for (int st = 0; st < 4; st++) {
-        const lds_f64* r = rec + st * kRecStage;
-        const double sph = r[0], cph = r[1], sth = r[2], cth = r[3], sps = r[4], cps = r[5];
-        const double d = (j == 0) ? r[13] : ((j == 1) ? r[14] : r[15]);
+        const double sph = tr[st][0], cph = tr[st][1], sth = tr[st][2], cth = tr[st][3], sps = tr[st][4], cps = tr[st][5];
         const double r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = sps * sph + cps * cph * sth;
         const double r10 = sps * cth, r11 = cps * cph + sph * sth * sps, r12 = sth * sps * cph - cps * sph;
         const double r21 = cth * sph, r22 = cth * cph;
         const double c0 = (j == 0) ? r00 : ((j == 1) ? r01 : r02);
         const double c1 = (j == 0) ? r10 : ((j == 1) ? r11 : r12);
         const double c2 = (j == 0) ? -sth : ((j == 1) ? r21 : r22);
-        const double kr = d * sig + kbv;
+        const double kr = dd[st] * sig + kbv;
         const double w = (st == 0 || st == 3) ? h / 6.0 : h / 3.0;
         a0 += w * (c0 * sig); a1 += w * (c1 * sig); a2 += w * (c2 * sig);
         ar += w * kr;
@@ -259,24 +275,26 @@ __device__ __forceinline__ void expand_cheap(const double (&v)[4], int j, double
 // stationarity / input-feasibility part of the NLP KKT residual for column c >= 3 of interval i, with the cost gradients
 // already in LDS (q_i, r_i); the dynamics gap and the position columns are handled once per interval by the caller.
 // Branch-free: rows that do not apply contribute 0 to the max.
-__device__ __forceinline__ double lin_kkt_col(const KktOperands& K, int N, int i, int c, const double (&pil)[NX],
-                                              const double (&acc)[NX]) {
+__device__ __forceinline__ void lin_kkt_rows(KktAcc& A, const KktOperands& K, int N, int i, int c, double dotpi, double pc) {
     const bool xcol = c < NX;
-    double kkt = 0.0, dotpi = 0.0, pc = 0.0;
+    const double sx = K.grad + dotpi - K.pm1c;            // x column, i >= 1
+    const double su_ = K.grad + dotpi - K.ll + K.lu;      // u column
+    A.upd(xcol ? (i >= 1 ? sx : 0.0) : su_);
+    A.upd((xcol && i == N - 1) ? K.qn - pc : 0.0);         // terminal: q_N - pi_{N-1}
+    const double sl = K.ucur - K.lbu, su = K.ubu - K.ucur;
+    A.upd((!xcol && sl < 0) ? sl : 0.0);
+    A.upd((!xcol && su < 0) ? su : 0.0);
+    A.upd(xcol ? 0.0 : K.ll * sl);
+    A.upd(xcol ? 0.0 : K.lu * su);
+}
+__device__ __forceinline__ void lin_kkt_col(KktAcc& A, const KktOperands& K, int N, int i, int c, const double (&pil)[NX],
+                                            const double (&acc)[NX]) {
+    double dotpi = 0.0, pc = 0.0;
 #pragma unroll
     for (int j = 0; j < NX; j++) dotpi += acc[j] * pil[j];
 #pragma unroll
     for (int j = 3; j < NX; j++) pc = (j == c) ? pil[j] : pc;
-    const double sx = K.grad + dotpi - K.pm1c;            // x column, i >= 1
-    const double su_ = K.grad + dotpi - K.ll + K.lu;      // u column
-    kkt_upd(kkt, xcol ? (i >= 1 ? sx : 0.0) : su_);
-    kkt_upd(kkt, (xcol && i == N - 1) ? K.qn - pc : 0.0);  // terminal: q_N - pi_{N-1}
-    const double sl = K.ucur - K.lbu, su = K.ubu - K.ucur;
-    kkt_upd(kkt, (!xcol && sl < 0) ? sl : 0.0);
-    kkt_upd(kkt, (!xcol && su < 0) ? su : 0.0);
-    kkt_upd(kkt, xcol ? 0.0 : K.ll * sl);
-    kkt_upd(kkt, xcol ? 0.0 : K.lu * su);
-    return kkt;
+    lin_kkt_rows(A, K, N, i, c, dotpi, pc);
 }
 
 }  // namespace brov

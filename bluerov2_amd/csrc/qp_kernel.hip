@@ -1033,12 +1033,12 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     const Wrench w = make_wrench(uu);
     // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps, and the
     // stationarity rows of the position columns (exactly e_c).  The L lanes of a group write identical values.
-    double kk0 = 0.0;
+    KktAcc ka;
 #pragma unroll
     for (int k = 0; k < NX; k++) {
         const double qk = P.Ts * cst[k] * (x0r[k] - yrr[k]);
         q_s[i * NX + k] = qk;
-        if (k < 3 && ig >= 1) kkt_upd(kk0, qk + pir[k] - pm1[k]);
+        if (k < 3) ka.upd(ig >= 1 ? qk + pir[k] - pm1[k] : 0.0);
     }
 #pragma unroll
     for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yrr[NX + k]);
@@ -1047,7 +1047,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
         for (int k = 0; k < NX; k++) {
             const double qn = cst[16 + k] * (x1r[k] - yrn[k]);
             q_s[n * NX + k] = qn;
-            if (k < 3) kkt_upd(kk0, qn - pir[k]);
+            if (k < 3) ka.upd(qn - pir[k]);
         }
     }
     const unsigned long long tB = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
@@ -1066,23 +1066,15 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     for (int k = 0; k < NX; k++) {
         const double bk = xn[k] - x1r[k];
         bv_s[i * NX + k] = bk;
-        kkt_upd(kk0, bk);
-    }
-    if (active) {
-        if (kk0 != kk0) nanp = true;
-        part = fmax(part, kk0);
+        ka.upd(bk);
     }
     // developer instrumentation, slot 7: loads issued -> cost gradients -> state integrated -> column loop entered
     if (stamp && P.dbg && lane == 0)
         P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
     auto finish = [&](int c, const KktOperands& ko, const double (&acc)[NX]) __attribute__((always_inline)) {
-        const double kk = lin_kkt_col(ko, N, ig, c, pir, acc);
+        lin_kkt_col(ka, ko, N, ig, c, pir, acc);
 #pragma unroll
         for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
-        if (active) {
-            if (kk != kk) nanp = true;
-            part = fmax(part, kk);
-        }
     };
     // Columns by structure, so that the lanes of a trip run the same code:
     //   (1) attitude angles 3..5 and body rates 9..11: general Jacobian-vector products, 4 per column;
@@ -1146,8 +1138,18 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             const int c = input ? NX + j : 6 + j;
             double acc[NX];
             expand_cheap(cv[t], j, acc);
-            finish(c, finish_kkt_operands(kg[t], cst, i, n, c, (const lds_f64*)q_s, (const lds_f64*)r_s), acc);
+            // pi' S[:,c] has four terms here
+            const double pr = (j == 0) ? pir[6] : ((j == 1) ? pir[7] : pir[8]);
+            const double dotpi = cv[t][0] * pir[0] + cv[t][1] * pir[1] + cv[t][2] * pir[2] + cv[t][3] * pr;
+            lin_kkt_rows(ka, finish_kkt_operands(kg[t], cst, i, n, c, (const lds_f64*)q_s, (const lds_f64*)r_s), N, ig, c, dotpi,
+                         input ? 0.0 : pr);
+#pragma unroll
+            for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
         }
+    }
+    if (active) {
+        if (ka.nan) nanp = true;
+        part = fmax(part, ka.mx);
     }
 }
 
