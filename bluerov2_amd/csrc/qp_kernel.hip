@@ -96,6 +96,7 @@ struct Inst {
     // ONE ds_read with an address known before the loop -- no select on the loaded value, which would pull the
     // s_waitcnt of a prefetch to the load itself
     int ba_off[3], ba_str, bat_off[4], bat_str, bat_str0, kt_off[3], kt_str;
+    lds_f64* lds_tr;   // 17 doubles of LDS per wave: row -> column transposition in the backward sweep (+ 1 parking slot)
     lds_f64 *lds_kff, *lds_vhat, *lds_dxb, *lds_zero;  // fused path: same arrays as kff/vhat/dxb, typed as LDS so that the sweeps
                                             // issue ds_* instead of flat_*
     double Ts;
@@ -265,6 +266,10 @@ __device__ bool riccati_backward(const Inst& I) {
             else pv[r] = I.Wer[r] * (xN[row] - yN[row]);
         }
         pv[3] = 0.0;
+        if (FACTOR) {   // the factor sweep keeps the gradient in column 0 only
+#pragma unroll
+            for (int r = 0; r < 3; r++) pv[r] = (cl == 0) ? pv[r] : 0.0;
+        }
     }
     bool ok = true;
     const d4 z4 = {0, 0, 0, 0};
@@ -281,25 +286,33 @@ __device__ bool riccati_backward(const Inst& I) {
         qr[3] = in.rtv;
         if (FACTOR) {
             // One wave's FP64 MFMAs and VALU work do not overlap (scripts/dev/mfma_valu_overlap.hip): a stage costs 64 cycles
-            // per MFMA whatever it computes, so P b is not given MFMAs of its own.  Column 0 of [A B] is e_0 (position x) and
-            // P e_0 is column 0 of P itself -- b_i rides in that column, and column 0 of [P A] is restored from P.  From here
-            // on the gradient recursion (P b, l, g, p) lives in column 0 of its tiles (lanes cl == 0); the other columns of
-            // those tiles carry finite don't-care values.
-            d4 ba1, PA;
+            // per MFMA whatever it computes, so the gradient recursion gets no MFMAs of its own -- it rides in column 0 of the
+            // two matrix products.  Column 0 of [A B] is e_0 (position x):
+            //   P [b | A(:,1:) B]        -> column 0 = P b              (the true column 0, P e_0, is column 0 of P: not needed)
+            //   [A B]' [P b + p | ...]   -> column 0 = [A B]'(P b + p)  = g - [q; r]; the true column 0 of H is the transpose of
+            //                               its row 0, which this product delivers intact (row 0 of the result = row 0 of the
+            //                               right operand, because column 0 of [A B] is e_0); H[0][0] = P[0][0].
+            // From here on the gradient recursion (P b, g, p) lives in column 0 of its tiles (lanes cl == 0); the other columns
+            // of those tiles carry finite don't-care values.
+            d4 ba1, Y2;
 #pragma unroll
             for (int r = 0; r < 3; r++) ba1[r] = blend(mk_col0, in.bv[r], in.ba[r]);
             ba1[3] = 0.0;
             const d4 Pb = tn<3>(P, ba1, z4);
-#pragma unroll
-            for (int r = 0; r < 3; r++) PA[r] = blend(mk_col0, P[r], Pb[r]);
-            PA[3] = 0.0;
-            d4 H = tn<3>(in.ba, PA, z4);
             if (STORE_IPM) store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
-            d4 l;
 #pragma unroll
-            for (int r = 0; r < 3; r++) l[r] = Pb[r] + pv[r];
-            l[3] = 0.0;
-            d4 g = tn<3>(in.ba, l, qr);
+            for (int r = 0; r < 3; r++) Y2[r] = Pb[r] + pv[r];   // pv is zero outside column 0
+            Y2[3] = 0.0;
+            d4 H = tn<3>(in.ba, Y2, z4);
+            d4 g;
+#pragma unroll
+            for (int r = 0; r < 4; r++) g[r] = H[r] + qr[r];
+            // column 0 of H := (row 0 of H)': lanes (0, c) hold H[0][c] in register 0, lane (rg, 0) needs H[rg + 4q][0].  Through
+            // LDS; the values are consumed only after the pivot algebra (which touches columns 12..15), so the round trip is
+            // off the chain.  No fence: one wave, LDS executes its operations in order.
+            lds_f64* tr = I.lds_tr;
+            tr[rg == 0 ? cl : 16] = H[0];                 // the other row groups are parked on a spare slot
+            const double t0 = tr[rg], t1 = tr[rg + 4], t2 = tr[rg + 8], t3 = tr[rg + 12];
             // + diag(Ts*Wx, Ts*Wu + Gamma_i)
 #pragma unroll
             for (int r = 0; r < 3; r++) H[r] += diagm[r];
@@ -338,6 +351,10 @@ __device__ bool riccati_backward(const Inst& I) {
                 const double sel = (a == 0) ? r0 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
                 mt = (cl < 4) ? sel : 0.0;
             }
+            H[0] = blend(mk_col0, lane == 0 ? P[0] + diagm[0] : t0, H[0]);   // H[0][0] = (P e_0)[0] + Ts W_0
+            H[1] = blend(mk_col0, t1, H[1]);
+            H[2] = blend(mk_col0, t2, H[2]);
+            H[3] = blend(mk_col0, t3, H[3]);
             // T = M Hu (rows 0..3 in reg 0), S = H - Hu^T T, Kt = -(Hu^T M), kff = -M gu, p = gx + K^T gu
             d4 T = tn1(mt, H[3], z4);
             const double ks = -T[0];
@@ -366,7 +383,8 @@ __device__ bool riccati_backward(const Inst& I) {
                 I.kff[i * 4 + rg] = -kf[0];
             }
             P = S;
-            pv = pn;
+#pragma unroll
+            for (int r = 0; r < 3; r++) pv[r] = blend(mk_col0, pn[r], 0.0);
             pv[3] = 0.0;
         } else {
             d4 l;
@@ -921,6 +939,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.lds_vhat = nullptr;
     I.lds_dxb = nullptr;
     I.lds_zero = nullptr;
+    I.lds_tr = nullptr;
     // cst = [W16 | We12 pad4 | lbu4 | ubu4]
 #pragma unroll
     for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
@@ -939,8 +958,10 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;
     if (b >= P.B) return;
     const int lane = threadIdx.x & 63;
+    __shared__ double tr_s[4 * 17];   // per-wave transposition scratch of the backward sweep
     Inst I;
     setup_inst(P, I, b, lane);
+    I.lds_tr = (lds_f64*)tr_s + wave * 17;
     double part = 0.0;
     bool nanp = false;
     for (int j = lane; j < P.N; j += 64) {
@@ -1247,6 +1268,7 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     I.lds_vhat = (lds_f64*)vh_s;
     I.lds_dxb = (lds_f64*)dx_s;
     I.lds_zero = (lds_f64*)const_s;
+    I.lds_tr = (lds_f64*)const_s + 2;
     {
         const int rg = I.rg, cl = I.cl;
         const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
@@ -1288,7 +1310,7 @@ void launch_qp(const DevParams& P, hipStream_t st) {
 bool fused_supported(int N) { return N <= kFusedMaxN; }
 
 void launch_fused(const DevParams& P, hipStream_t st) {
-    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX + 2) * sizeof(double);
+    const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX + 2 + 17) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
