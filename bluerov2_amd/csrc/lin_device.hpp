@@ -95,6 +95,75 @@ __device__ __forceinline__ void jvp_rec(const StageRec& R, double imx, double im
     o[11] = (-(kIy - kIx) * (wq * s[9] + wp * s[10])) * imn + r[16] * s[11] + kb[3];
 }
 
+// two state columns through the same stage record: the ~45 Jacobian entries are derived once and applied twice
+__device__ __forceinline__ void jvp_rec2(const StageRec& R, double imx, double imy, double imz, double imn, const double (&s)[NX],
+                                         const double (&t)[NX], double (&o)[NX], double (&p)[NX]) {
+    const double* r = R.v;
+    const double sph = r[0], cph = r[1], sth = r[2], cth = r[3], sps = r[4], cps = r[5], icth = r[6];
+    const double vu = r[7], vv = r[8], vw = r[9], wp = r[10], wq = r[11], wr = r[12];
+    const double r00 = cps * cth, r01 = cps * sth * sph - sps * cph, r02 = sps * sph + cps * cph * sth;
+    const double r10 = sps * cth, r11 = cps * cph + sph * sth * sps, r12 = sth * sps * cph - cps * sph;
+    const double r21 = cth * sph, r22 = cth * cph;
+    const double f0 = r00 * vu + r01 * vv + r02 * vw;
+    const double f1 = r10 * vu + r11 * vv + r12 * vw;
+    const double f2 = -sth * vu + r21 * vv + r22 * vw;
+    const double tth = sth * icth, ic2 = icth * icth;
+    const double a03 = r02 * vv - r01 * vw, a04 = cps * f2;
+    const double a13 = r12 * vv - r11 * vw, a14 = sps * f2;
+    const double a23 = r22 * vv - r21 * vw, a24 = cth * vu + sth * (sph * vv + cph * vw);
+    const double a33 = -sph * tth * wr, a34 = (sps * wq + cph * wr) * ic2, a35 = cps * tth * wq, a3a = sps * tth, a3b = cph * tth;
+    const double a43 = cph * wr - sph * wq;
+    const double a53 = cph * wq - sph * wr, a54 = (sph * wq + cph * wr) * tth;
+    const double a64 = -kBouy * cth * imx;
+    const double a73 = kBouy * r22 * imy, a74 = -kBouy * sth * sph * imy;
+    const double a83 = -kBouy * r21 * imz, a84 = -kBouy * sth * cph * imz;
+    const double a93 = -kMzg * r22 * (1.0 / kIx), a94 = kMzg * sth * sph * (1.0 / kIx);
+    const double a9a = (kIy - kIz) * (1.0 / kIx) * wr, a9b = (kIy - kIz) * (1.0 / kIx) * wq;
+    const double aa4 = -kMzg * (1.0 / kIy) * cth, aa9 = (kIz - kIx) * (1.0 / kIy) * wr, aab = (kIz - kIx) * (1.0 / kIy) * wp;
+    const double ab9 = -(kIy - kIx) * imn * wq, aba = -(kIy - kIx) * imn * wp;
+#define BROV_JVP_ROWS(s, o)                                                                                 \
+    o[0] = a03 * s[3] + a04 * s[4] - f1 * s[5] + r00 * s[6] + r01 * s[7] + r02 * s[8];                    \
+    o[1] = a13 * s[3] + a14 * s[4] + f0 * s[5] + r10 * s[6] + r11 * s[7] + r12 * s[8];                    \
+    o[2] = a23 * s[3] - a24 * s[4] - sth * s[6] + r21 * s[7] + r22 * s[8];                                \
+    o[3] = a33 * s[3] + a34 * s[4] + a35 * s[5] + s[9] + a3a * s[10] + a3b * s[11];                       \
+    o[4] = a43 * s[3] + cph * s[10] + sph * s[11];                                                        \
+    o[5] = (a53 * s[3] + a54 * s[4] + sph * s[10] + cph * s[11]) * icth;                                  \
+    o[6] = a64 * s[4] + r[13] * s[6];                                                                     \
+    o[7] = a73 * s[3] + a74 * s[4] + r[14] * s[7];                                                        \
+    o[8] = a83 * s[3] + a84 * s[4] + r[15] * s[8];                                                        \
+    o[9] = a93 * s[3] + a94 * s[4] + a9a * s[10] + a9b * s[11];                                           \
+    o[10] = aa4 * s[4] + aa9 * s[9] + aab * s[11];                                                        \
+    o[11] = ab9 * s[9] + aba * s[10] + r[16] * s[11];
+    BROV_JVP_ROWS(s, o)
+    BROV_JVP_ROWS(t, p)
+#undef BROV_JVP_ROWS
+}
+__device__ __forceinline__ void sens_column_rec2(const lds_f64* rec, const ModelPar& m, double h, int c0, int c1,
+                                                 double (&acc0)[NX], double (&acc1)[NX]) {
+    double k0[NX], s0[NX], k1[NX], s1[NX];
+    StageRec R = load_stage_rec(rec);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NX; j++) { s0[j] = (j == c0) ? 1.0 : 0.0; s1[j] = (j == c1) ? 1.0 : 0.0; }
+    jvp_rec2(R, m.imx, m.imy, m.imz, m.imn, s0, s1, k0, k1);
+#pragma unroll
+    for (int st = 1; st < 4; st++) {
+        R = load_stage_rec(rec + st * kRecStage);
+        __builtin_amdgcn_sched_barrier(0);
+        const double wprev = (st == 1) ? h / 6.0 : h / 3.0, cs = (st == 3) ? h : 0.5 * h;
+#pragma unroll
+        for (int j = 0; j < NX; j++) {
+            const double e0 = (j == c0) ? 1.0 : 0.0, e1 = (j == c1) ? 1.0 : 0.0;
+            acc0[j] = (st == 1 ? e0 : acc0[j]) + wprev * k0[j]; s0[j] = e0 + cs * k0[j];
+            acc1[j] = (st == 1 ? e1 : acc1[j]) + wprev * k1[j]; s1[j] = e1 + cs * k1[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        jvp_rec2(R, m.imx, m.imy, m.imz, m.imn, s0, s1, k0, k1);
+    }
+#pragma unroll
+    for (int j = 0; j < NX; j++) { acc0[j] += (h / 6.0) * k0[j]; acc1[j] += (h / 6.0) * k1[j]; }
+}
+
 // what the KKT rows of column c need besides the column itself; requested at the top of a trip so that the loads complete
 // under the sensitivity arithmetic (indices clamped: every lane issues the same loads, the unused half is discarded)
 struct KktOperands { double pm1c, ll, lu, ucur, lbu, ubu, grad, qn; };

@@ -1104,14 +1104,15 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     // L = 3 at N = 20: 2 + 1 + 2 trips costing about 1, 0.6 and 0.15 of a general one -- 2.9 trip-equivalents (was 5, then 4.3).
     // A lane whose class has run out of columns repeats the class's last column (same values stored twice).
 #pragma unroll 1
-    for (int q0 = j0; q0 < 6 + j0; q0 += L) {
-        if (q0 - j0 >= 6) break;
-        const int q = q0 < 6 ? q0 : 5;
-        const int c = q < 3 ? 3 + q : 6 + q;
-        double acc[NX];
-        const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-        sens_column_rec(rec, m, P.Ts, c, acc);
-        finish(c, ko, acc);
+    for (int q0 = j0; q0 - j0 < 6; q0 += 2 * L) {   // two general columns per trip: the Jacobian entries of a stage are shared
+        const int qa = q0 < 6 ? q0 : 5, qb = q0 + L < 6 ? q0 + L : 5;
+        const int ca = qa < 3 ? 3 + qa : 6 + qa, cb = qb < 3 ? 3 + qb : 6 + qb;
+        double acc0[NX], acc1[NX];
+        const KktOperands koa = load_kkt_operands(P, cst, b, ig, i, n, ca, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+        const KktOperands kob = load_kkt_operands(P, cst, b, ig, i, n, cb, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+        sens_column_rec2(rec, m, P.Ts, ca, cb, acc0, acc1);
+        finish(ca, koa, acc0);
+        finish(cb, kob, acc1);
     }
     // the closed-form trips are far too short to hide the L2 round trips of their own KKT operands: requested here, under
     // the input-column trip
