@@ -598,6 +598,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     double* DVA = I.ipm + (size_t)IPM_DVA * nv;
     // where adjoint<> leaves the input gradient g: HBM array, or (fused path) the dead feed-forward array in LDS
     const double* GRAD = LDS ? (const double*)I.kff : (const double*)DVA;
+    // element accessors: LDS-typed on the fused path (a generic pointer into LDS compiles to flat loads / stores)
+    auto rd_vhat = [&](int j) -> double { if constexpr (LDS) return I.lds_vhat[j]; else return I.vhat[j]; };
+    auto wr_vhat = [&](int j, double v) { if constexpr (LDS) I.lds_vhat[j] = v; else I.vhat[j] = v; };
+    auto rd_dxb = [&](int j) -> double { if constexpr (LDS) return I.lds_dxb[j]; else return I.dxb[j]; };
+    auto rd_grad = [&](int j) -> double { if constexpr (LDS) return I.lds_kff[j]; else return GRAD[j]; };
 
     // d0 = x0 - x_0, row-replicated; KKT of the entering iterate = max(LIN partials, |d0|)
     d4 d0;
@@ -642,14 +647,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 const int j = lane + 64 * t;
                 if (j < nv) {
                     const int m = j & 3;
-                    const double vj = I.vhat[j], lb = cst[32 + m] - ureg[t], ub = cst[36 + m] - ureg[t];
+                    const double vj = rd_vhat(j), lb = cst[32 + m] - ureg[t], ub = cst[36 + m] - ureg[t];
                     if (!(vj >= lb && vj <= ub)) feas = false;
                 }
             }
         } else {
             for (int j = lane; j < nv; j += 64) {
                 const int m = j & 3;
-                const double vj = I.vhat[j], lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
+                const double vj = rd_vhat(j), lb = cst[32 + m] - I.u[j], ub = cst[36 + m] - I.u[j];
                 if (!(vj >= lb && vj <= ub)) feas = false;
             }
         }
@@ -670,24 +675,24 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 const double uj = LDS ? ureg[t & 1] : I.u[j];
                 const double lb = cst[32 + m] - uj, ub = cst[36 + m] - uj;
                 const double wdt = ub - lb;
-                double vj = I.vhat[j];
+                double vj = rd_vhat(j);
                 const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
                 vj = (vj < lo) ? lo : vj;
                 vj = (vj > hi) ? hi : vj;
                 vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
-                if constexpr (LDS) I.vhat[j] = vj;  // roll-out / adjoint read their inputs from the LDS copy
+                if constexpr (LDS) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
             }
             rollout<LDS>(I, d0, V);
             adjoint<false, LDS>(I, V, DVA, nullptr);
             double g0 = 0.0;
-            for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(GRAD[j]));
+            for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(rd_grad(j)));
             g0 = wave_max(g0);
             const double mu0 = fmax(g0, 1e-4);
             double r0 = 0.0;
             IPM_FOR(t, j) {
                 const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
                 vLL.set(t, j, ll); vLU.set(t, j, lu);
-                r0 = fmax(r0, fabs(GRAD[j] - ll + lu));
+                r0 = fmax(r0, fabs(rd_grad(j) - ll + lu));
             }
             rho = wave_max(r0);
             status = BROV_STATUS_MAXITER;
@@ -713,7 +718,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 double aaff = 1.0;
                 IPM_FOR(t, j) {
                     const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
-                    const double dv = I.vhat[j] - vV.get(t, j);
+                    const double dv = rd_vhat(j) - vV.get(t, j);
                     vDVA.set(t, j, dv);
                     const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                     if (dv < 0) aaff = fmin(aaff, -tl / dv);
@@ -748,7 +753,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dva = vDVA.get(t, j);
                     const double dlla = -ll - ll / tl * dva, dlua = -lu + lu / tu * dva;
                     const double cl_ = dlla * dva, cu_ = -dlua * dva;
-                    const double dv = I.vhat[j] - vV.get(t, j);
+                    const double dv = rd_vhat(j) - vV.get(t, j);
                     const double dll = (smu - cl_) / tl - ll - ll / tl * dv;
                     const double dlu = (smu - cu_) / tu - lu + lu / tu * dv;
                     if (dv < 0) amax = fmin(amax, -tl / dv);
@@ -764,7 +769,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 bool bad = false;
                 double s2 = 0.0;
                 IPM_FOR(t, j) {
-                    const double dv = I.vhat[j] - vV.get(t, j);
+                    const double dv = rd_vhat(j) - vV.get(t, j);
                     const double vj = vV.get(t, j) + alpha * dv;
                     const double tl = vTL.get(t, j) + alpha * dv, tu = vTU.get(t, j) - alpha * dv;
                     const double ll = vLL.get(t, j) + alpha * vDLL.get(t, j), lu = vLU.get(t, j) + alpha * vDLU.get(t, j);
@@ -778,7 +783,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if (mu <= P.tol_mu && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
             }
             // the final inputs go where the finalisation expects them: V (streaming path, already there) / the LDS copy
-            if constexpr (LDS) { IPM_FOR(t, j) I.vhat[j] = vV.get(t, j); }
+            if constexpr (LDS) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
 #undef IPM_FOR
             if (iters > P.qp_iter_max) iters = P.qp_iter_max;
         }
@@ -820,11 +825,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         DBG_STAMP(5);
         bool nanv = false;
         for (int j = lane; j < nv; j += 64) {
-            const double vj = vfin[j];
+            const double vj = LDS ? rd_vhat(j) : vfin[j];
             if (!(vj == vj)) nanv = true;
         }
         for (int j = lane; j < nxe; j += 64) {
-            const double dj = I.dxb[j];
+            const double dj = rd_dxb(j);
             if (!(dj == dj)) nanv = true;
         }
         if (__ballot(nanv) != 0ull) {
@@ -838,8 +843,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const bool in = j < nv;
                     const int jj = in ? j : 0;
                     uo[t] = (LDS && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
-                    vv[t] = vfin[jj];
-                    gg[t] = early ? 0.0 : GRAD[jj];
+                    vv[t] = LDS ? rd_vhat(jj) : vfin[jj];
+                    gg[t] = early ? 0.0 : rd_grad(jj);
                     ur[t] = (LDS && j0 == lane) ? urpre[t] : I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
                 }
 #pragma unroll
@@ -869,7 +874,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const int jj = j < nxe ? j : 0;
                     const int i = jj / 12, c = jj - i * 12;
                     xo[t] = (LDS && j0 == lane) ? xpre[t] : x_it[jj];
-                    dj[t] = I.dxb[jj];
+                    dj[t] = rd_dxb(jj);
                     yr[t] = (LDS && j0 == lane) ? ypre[t] : I.yref[(size_t)i * 16 + c];
                 }
 #pragma unroll

@@ -184,3 +184,23 @@ def test_batch_mismatch_is_rejected(ba):
     with pytest.raises(RuntimeError):
         e.apply_to_solver(s)
     e.close(); s.close()
+
+
+def test_dpp_and_lds_broadcast_kernels_agree(ba, orc, monkeypatch):
+    """the default DPP row-broadcast kernel against the first (LDS-broadcast) kernel, kept behind BROV_EKF_VARIANT=0"""
+    c = T.np_consts(orc.par)
+    rng = np.random.default_rng(31)
+    B = 37
+    x = np.stack([T.rand_state(rng) for _ in range(B)]); x[:, 15:17] *= 0.05
+    A = rng.normal(size=(B, 18, 18)) * 0.2
+    P = np.einsum("bij,bkj->bik", A, A) + np.eye(18) * 0.3
+    thrust, y12, acc = consistent_inputs(c, rng, x)
+    out = []
+    for variant in ("1", "0"):
+        monkeypatch.setenv("BROV_EKF_VARIANT", variant)
+        e = ba.BatchEkf(B)
+        e.set_state(x, P); e.update(thrust, y12, acc)
+        out.append(e.state() + e.outputs())
+        e.close()
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
