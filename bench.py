@@ -243,7 +243,7 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.write("\n" + json.dumps(out) + "\n")
+        sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
 
 
