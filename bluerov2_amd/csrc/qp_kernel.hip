@@ -1322,7 +1322,8 @@ void launch_fused(const DevParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds, st, P);
+    static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;  // occupancy probe
+    hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds + pad, st, P);
 }
 
 }  // namespace brov
