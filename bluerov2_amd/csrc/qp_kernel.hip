@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
 // are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
 // (interior-point) instance does not pin the LDS of three finished ones.
 constexpr int kFusedMaxN = 23;
-__global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
+__device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -1295,6 +1295,11 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) {
     }
     qp_body<true>(P, I, b, part, nanp);
 }
+// One wave per SIMD (up to 512 VGPRs): the variant for horizons whose LDS slice admits only four blocks per CU anyway.
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fused_body(P); }
+// Two waves per SIMD (256 VGPRs, some spilled): short horizons (N <= 13, at least six blocks per CU by LDS), where the
+// second wave fills the first one's MFMA / LDS / dependent-issue waits.
+__global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
@@ -1320,10 +1325,15 @@ void launch_fused(const DevParams& P, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;  // occupancy probe
-    hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds + pad, st, P);
+    // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
+    static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;
+    const int force = getenv("BROV_DEV_FUSED_WAVES") ? atoi(getenv("BROV_DEV_FUSED_WAVES")) : 0;
+    const bool w2 = force ? force == 2 : 6 * lds <= 160 * 1024;   // N <= 13
+    if (w2) hipLaunchKernelGGL(rti_fused_kernel_w2, dim3(P.B), dim3(64), lds + pad, st, P);
+    else hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds + pad, st, P);
 }
 
 }  // namespace brov

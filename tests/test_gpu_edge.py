@@ -44,6 +44,29 @@ def test_small_and_ragged_shapes(ba, oracle, golden_traj, N, B, path):
     assert np.abs(r["u0"] - ro["u0"]).max() < 1e-7 and np.abs(s.get_iterate()[0] - it[0]).max() < 1e-7
 
 
+@pytest.mark.parametrize("N", [8, 13])
+def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
+    """rti_fused_kernel (one wave per SIMD) and rti_fused_kernel_w2 (two, the default for N <= 13) are the same code under
+    two register budgets: same statuses and iteration counts, iterates equal to rounding, with active bounds in the batch"""
+    B = 96
+    x0, circ = _inputs(golden_traj, B, seed=N, big=6.0)
+    out = {}
+    for w in (1, 2):
+        monkeypatch.setenv("BROV_DEV_FUSED_WAVES", str(w))
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05, kernel_path=ba.PATH_FUSED))
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+        for k in range(2):
+            s.set_yref(circ[k:k + N + 1]); s.solve()
+        out[w] = (s.results(), s.get_iterate())
+        s.close()
+    (r1, it1), (r2, it2) = out[1], out[2]
+    assert (r1["qp_iter"] > 0).any()
+    assert np.array_equal(r1["status"], r2["status"]) and np.array_equal(r1["qp_iter"], r2["qp_iter"])
+    for a, b in zip(it1, it2):
+        assert np.abs(a - b).max() < 1e-10
+    assert np.abs(r1["u0"] - r2["u0"]).max() < 1e-10
+
+
 @pytest.mark.parametrize("N,B", [(22, 4), (24, 3), (43, 5), (64, 2), (85, 3), (128, 2)])
 def test_streaming_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B):
     """horizons that split into 2..7 linearisation chunks of unequal length (lin_wave_kernel: <= 21 intervals per wave), up to
