@@ -141,7 +141,7 @@ constexpr int kBaStride = 13;              // only the 13 non-trivial columns 3.
 constexpr int kBaStage = NX * kBaStride;  // for either image); columns 0..2 of [A B] are exactly e_c
 constexpr int kKtStage = NX * 4;          // K^T compact [12][4] per stage
 
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: rows k = rg+4r (0..11), cols c = cl
     if constexpr (LDS) {
         const lds_f64* t = I.lds_ba + i * I.ba_str;
@@ -150,7 +150,7 @@ __device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: ro
         return load_tile3(I.BA + (size_t)i * 192, I.lane);
     }
 }
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ d4 get_bat(const Inst& I, int i) {  // [A B]^T image: rows c = rg+4r (0..15), cols k = cl (< 12)
     if constexpr (LDS) {
         const lds_f64* t = I.lds_ba + i * I.bat_str;
@@ -164,7 +164,7 @@ __device__ __forceinline__ d4 get_bat(const Inst& I, int i) {  // [A B]^T image:
         return d4{in ? t[0] : 0.0, in ? t[4] : 0.0, in ? t[8] : 0.0, in ? t[12] : 0.0};
     }
 }
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ d4 get_bv(const Inst& I, int i) {  // b_i, row-replicated
     if constexpr (LDS) {
         const lds_f64* t = I.lds_bv + i * NX + I.rg;
@@ -209,6 +209,10 @@ __device__ __forceinline__ void pipelined(int count, Load load, Body body) {
     }
 }
 
+// Fused path: LDS = 1 is the one-wave-per-SIMD kernel (look-ahead of two stages), LDS = 2 the two-waves-per-SIMD kernel for
+// short horizons (one stage: the SIMD's other wave covers the rest, and the third register slot would be spilled).
+template <int LDS> constexpr int kLdsDist = LDS == 2 ? 1 : 2;
+
 struct BwdIn {
     d4 ba;          // [A B] tile, rows 0..11
     d4 bv;          // FACTOR: b_i;  else: Pb_i = P_{i+1} b_i   (row-replicated)
@@ -217,7 +221,7 @@ struct BwdIn {
     double ks, mt;        // stored factors (only !FACTOR)
 };
 
-template <bool FACTOR, bool LDS, bool STEP0 = false>
+template <bool FACTOR, int LDS, bool STEP0 = false>
 __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* gam, const double* rt) {
     BwdIn s;
     s.ba = get_ba<LDS>(I, i);
@@ -247,7 +251,7 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
 // backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
 // not positive definite.
-template <bool FACTOR, bool LDS, bool STORE_IPM = true, bool STEP0 = false>
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
 __device__ bool riccati_backward(const Inst& I) {
     const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
@@ -399,7 +403,7 @@ __device__ bool riccati_backward(const Inst& I) {
         }
     };
     if constexpr (LDS) {
-        pipelined<2, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+        pipelined<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
                             [&](int k, const BwdIn& in) { stage(N - 1 - k, in); });
     } else {
         // distance 1 here: a stage is ~2 k cycles of issue per wave (4 k with the SIMD's second wave), enough to cover the
@@ -415,7 +419,7 @@ __device__ bool riccati_backward(const Inst& I) {
 }
 
 struct FwdIn { d4 kt, bat, bb; double kf; };
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
     FwdIn s;
     if constexpr (LDS) {
@@ -432,7 +436,7 @@ __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
 
 // forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i.
 // Leaves vhat in I.vhat and the state steps in I.dxb.
-template <bool LDS>
+template <int LDS>
 __device__ void riccati_forward(const Inst& I, const d4& d0) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
@@ -440,7 +444,7 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
         // two stages ahead (see adjoint<>): the LDS reads of a stage are in flight for a whole stage before they are needed
-        pipelined<2, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
+        pipelined<kLdsDist<LDS>, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
             d4 c = {in.kf, 0, 0, 0};
             d4 v = tn<3>(in.kt, xx, c);
             I.lds_vhat[i * 4 + rg] = v[0];
@@ -465,7 +469,7 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
 }
 
 struct RollIn { d4 bat, bb; double v; };
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* varr) {
     RollIn s;
     s.bat = get_bat<LDS>(I, i);
@@ -474,14 +478,14 @@ __device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* 
     return s;
 }
 // roll the linearised dynamics out for the inputs in varr -> I.dxb
-template <bool LDS>
+template <int LDS>
 __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
     d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
-        pipelined<2, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
+        pipelined<kLdsDist<LDS>, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
             d4 z = {xx[0], xx[1], xx[2], in.v};
             xx = tn<4>(in.bat, z, in.bb);
             xx[3] = 0.0;
@@ -499,7 +503,7 @@ __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
 }
 
 struct AdjIn { d4 ba; double dx[3], xn[3], yn[3]; double v, u, ur; };
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* varr) {
     AdjIn s;
     s.ba = get_ba<LDS>(I, i);
@@ -526,7 +530,7 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
 // With COMMIT the multipliers pi are written to pi_out (the iterate).
 // LDS path: both outputs go to LDS regions that are dead at this point (g -> the feed-forward array, pi -> the K^T array,
 // 12 of its 48 doubles per stage); per-stage global stores would sit on vmcnt in front of every prefetch wait.
-template <bool COMMIT, bool LDS>
+template <bool COMMIT, int LDS>
 __device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     wave_fence();
@@ -554,7 +558,7 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
     if constexpr (LDS) {
         // two stages ahead: the LDS reads of stage i-2 are issued a full stage before they are consumed, so the wait at the
         // top of a stage never sees the ~200 cycles of LDS queue + latency that a one-stage look-ahead leaves exposed
-        pipelined<2, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
+        pipelined<kLdsDist<LDS>, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
                             [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
     } else {
         pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
@@ -577,7 +581,7 @@ struct IpmVec {
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
 #define DBG_STAMP(slot) do { if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
-template <bool LDS>
+template <int LDS>
 __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan) {
     const double* __restrict__ cst = P.cst;
     const int lane = I.lane, N = I.N, nv = I.nv;
@@ -666,7 +670,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // Fused path: the interior-point vectors (two elements per lane, nv <= 92) live in registers -- at one wave per
             // SIMD every element loop over HBM-resident vectors costs an exposed L2 round trip; only Gamma and the right-hand
             // side, which the backward sweep reads by stage, go through memory.
-            IpmVec<LDS> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
+            IpmVec<(LDS != 0)> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
                 vDLL{{0, 0}, GAM}, vDLU{{0, 0}, RT};   // dual steps: registers, or parked in GAM / RT (both rebuilt every iteration)
 #define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const int j = lane + 64 * t; j < nv)
             constexpr int kIpmT = LDS ? 2 : 8;   // streaming path: nv <= 512
@@ -1004,6 +1008,7 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 // ([A B] compact [n][12][13]), so the scattered 8-byte writes that rule this mapping out against HBM cost nothing.
 //   ba_s [n][12][13], bv_s [n][12], q_s [n+1][12] (row n: terminal gradient if the chunk ends the horizon), r_s [n][4];
 //   rec_s: scratch for the stage records, n*68 doubles.  part / nanp: this lane's share of the KKT max / NaN flag.
+template <bool TWO = true>
 __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
                                           double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
     const int N = P.N;
@@ -1108,16 +1113,30 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     //   (3) body velocities 6..8 and the pure force inputs u0, u2: closed form (sens_column_cheap).
     // L = 3 at N = 20: 2 + 1 + 2 trips costing about 1, 0.6 and 0.15 of a general one -- 2.9 trip-equivalents (was 5, then 4.3).
     // A lane whose class has run out of columns repeats the class's last column (same values stored twice).
+    if constexpr (TWO) {
 #pragma unroll 1
-    for (int q0 = j0; q0 - j0 < 6; q0 += 2 * L) {   // two general columns per trip: the Jacobian entries of a stage are shared
-        const int qa = q0 < 6 ? q0 : 5, qb = q0 + L < 6 ? q0 + L : 5;
-        const int ca = qa < 3 ? 3 + qa : 6 + qa, cb = qb < 3 ? 3 + qb : 6 + qb;
-        double acc0[NX], acc1[NX];
-        const KktOperands koa = load_kkt_operands(P, cst, b, ig, i, n, ca, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-        const KktOperands kob = load_kkt_operands(P, cst, b, ig, i, n, cb, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-        sens_column_rec2(rec, m, P.Ts, ca, cb, acc0, acc1);
-        finish(ca, koa, acc0);
-        finish(cb, kob, acc1);
+        for (int q0 = j0; q0 - j0 < 6; q0 += 2 * L) {   // two general columns per trip: the Jacobian entries of a stage are shared
+            const int qa = q0 < 6 ? q0 : 5, qb = q0 + L < 6 ? q0 + L : 5;
+            const int ca = qa < 3 ? 3 + qa : 6 + qa, cb = qb < 3 ? 3 + qb : 6 + qb;
+            double acc0[NX], acc1[NX];
+            const KktOperands koa = load_kkt_operands(P, cst, b, ig, i, n, ca, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+            const KktOperands kob = load_kkt_operands(P, cst, b, ig, i, n, cb, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+            sens_column_rec2(rec, m, P.Ts, ca, cb, acc0, acc1);
+            finish(ca, koa, acc0);
+            finish(cb, kob, acc1);
+        }
+    } else {
+        // short horizons (L >= 4 lanes per interval, two waves per SIMD): one column per trip -- a pair would mostly repeat
+        // column 11, and the second wave covers the latency the pairing is there to hide
+#pragma unroll 1
+        for (int q0 = j0; q0 - j0 < 6; q0 += L) {
+            const int qa = q0 < 6 ? q0 : 5;
+            const int ca = qa < 3 ? 3 + qa : 6 + qa;
+            double acc0[NX];
+            const KktOperands koa = load_kkt_operands(P, cst, b, ig, i, n, ca, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
+            sens_column_rec(rec, m, P.Ts, ca, acc0);
+            finish(ca, koa, acc0);
+        }
     }
     // the closed-form trips are far too short to hide the L2 round trips of their own KKT operands: requested here, under
     // the input-column trip
@@ -1238,6 +1257,7 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
 // are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
 // (interior-point) instance does not pin the LDS of three finished ones.
 constexpr int kFusedMaxN = 23;
+template <int W>
 __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
@@ -1258,7 +1278,7 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     // ---- preparation: ERK4 + sensitivities of all N intervals at once (lin_phase below)
     double part = 0.0;
     bool nanp = false;
-    lin_phase(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
+    lin_phase<W == 1>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     Inst I;
     setup_inst(P, I, b, lane);
@@ -1293,13 +1313,13 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
         for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
         I.kt_str = cl < 4 ? kKtStage : 0;
     }
-    qp_body<true>(P, I, b, part, nanp);
+    qp_body<W>(P, I, b, part, nanp);
 }
 // One wave per SIMD (up to 512 VGPRs): the variant for horizons whose LDS slice admits only four blocks per CU anyway.
-__global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fused_body(P); }
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fused_body<1>(P); }
 // Two waves per SIMD (256 VGPRs, some spilled): short horizons (N <= 13, at least six blocks per CU by LDS), where the
 // second wave fills the first one's MFMA / LDS / dependent-issue waits.
-__global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body(P); }
+__global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body<2>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
