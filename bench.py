@@ -2,18 +2,31 @@
 """bench.py -- BASELINE.json metric: BlueROV2 NMPC RTI solves/s.
 
 One "step" = one SQP-RTI pass (brov_solve: linearise + QP + full step) over one batch of synthetic OCP instances that is
-already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: batch 4096, N=20 / Ts=0.05, circle reference
-(bluerov2_path/config/traj/circle.py formulas), per-instance x0 noise (seed 1), nominal
-hydrodynamic parameters; the reference window advances one row per step and is sliced on the device.  With --gpus G each
-rank (one process per GPU, torch.distributed / RCCL) owns its own 4096 instances (weak scaling); the only collective is
-the all-gather of the 56-byte result records, issued every step when G > 1.
+already resident in HBM.  Default workload (--config 2) = BASELINE.json configs[1]: batch 4096 per GPU, N=20 / Ts=0.05, circle
+reference (bluerov2_path/config/traj/circle.py formulas), per-instance x0 noise (seed 1), nominal
+hydrodynamic parameters; the reference window advances one row per step and is sliced on the device.
 
-Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel: rti_fused_kernel on
-the default path -- linearisation + QP of one instance per wavefront, stage blocks in LDS; bound = FP64 MFMA) and `cpu_baseline` (the C oracle timed on the host cores; the oracle is never the thing measured as `value`).
+    python bench.py                          1 GPU, config 2 (the headline), + forced-IPM / mixed-batch / CPU legs
+    python bench.py --gpus 8                 spawns its own 8 ranks (re-exec under torch.distributed.run) when WORLD_SIZE is
+                                             not set; under `python -m torch.distributed.run ... bench.py --gpus 8` it is a rank
+    python bench.py --gpus 8 --config 4      65 536 lemniscate candidates, 8192 per GPU, all-gather + global arg-min every step
+    python bench.py --gpus 8 --config 5      horizon sweep N in {10,20,40,80}, 4096 per GPU (Ts = 1/N)
+    python bench.py --config 3               16 384 DOB-MPC disturbance draws on one GPU
+    python bench.py --gpus 2 --dry-run       launcher / rendezvous / gather / select plumbing on CPU (gloo), no solver
+
+Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL), each rank owns its own instances
+(weak scaling), no communication during the solve, ONE all-gather of the 104-byte result records per step (u0, cost, KKT,
+status, thrusts), arg-min of cost on the gathered records for the candidate workload.
+
+Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel; bound = FP64 MFMA),
+`roofline_hbm`, `cpu_baseline` (the C oracle timed on the host cores -- never the thing measured as `value`) and, for the
+default single-GPU run, `forced_ipm`, `mixed_batch_25pct_saturated` and `cpu_baseline_single_thread`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +40,11 @@ BATCH_PER_GPU = 4096
 HORIZON = 20
 TS = 0.05
 # AMD Instinct MI355X data sheet: 78.6 TFLOP/s FP64 matrix (= FP64 vector); /opt/skills/guides/MI355X_MICROARCH.md lists
-# no FP64 MFMA row, scripts/dev/mfma_f64_peak.py measures it on the box (see profiles/).
+# no FP64 MFMA row, scripts/dev/mfma_f64_peak.hip measures 77.7 on the box.
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+CAND_TOTAL, CAND_SHARDS = 65536, 8   # BASELINE config 4
+KERNEL_NAMES = {2: "rti_fused_kernel", 3: "rti_window_kernel"}
 
 
 def circle_trajectory(rows):
@@ -47,13 +62,31 @@ def circle_trajectory(rows):
     return traj
 
 
-def synthetic_inputs(batch, seed):
+def synthetic_inputs(batch, seed, noise=True):
     rng = np.random.default_rng(seed)
     circ = circle_trajectory(4096)
     x0 = np.zeros((batch, NX))
     x0[:, :6] = circ[0, :6]
-    x0 += rng.normal(size=(batch, NX)) * np.array([0.05] * 3 + [0.02] * 3 + [0.05] * 3 + [0.02] * 3)
+    if noise:
+        x0 += rng.normal(size=(batch, NX)) * np.array([0.05] * 3 + [0.02] * 3 + [0.05] * 3 + [0.02] * 3)
     return x0, circ
+
+
+def saturate(x0, frac, seed):
+    """the mixed batch of tests/test_gpu_parity.py: the first `frac` of the instances start metres away from the reference, so
+    that their inputs hit the +-50 bounds and the interior-point branch runs"""
+    rng = np.random.default_rng(seed)
+    n = int(frac * x0.shape[0])
+    x0 = x0.copy()
+    x0[:n, :3] += rng.uniform(-4, 4, size=(n, 3))
+    x0[:n, 5] += rng.uniform(-0.3, 0.3, size=n)
+    return x0
+
+
+def candidate_params():
+    """BASELINE config 4: amp ~ U(1,3), omega ~ U(0.25,0.75), phase ~ U(0,2 pi), seed 3, 65 536 candidates"""
+    rng = np.random.default_rng(3)
+    return rng.uniform(1, 3, CAND_TOTAL), rng.uniform(0.25, 0.75, CAND_TOTAL), rng.uniform(0, 2 * np.pi, CAND_TOTAL)
 
 
 # algorithmic FP64 flops per stage (DESIGN.md "Accounting"; SURVEY.md 8d conventions)
@@ -71,7 +104,26 @@ def qp_flops(qp_iter, N):
     return float(np.sum(N * (fac * F_FACTOR + sol * F_SOLVE)))
 
 
-def cpu_baseline(batch, steps, warmup):
+def algorithmic_bytes(N, shared_yref):
+    """compulsory HBM bytes of one solve: x0, reference window (per instance, or 0 when one window is shared by the
+    whole batch and lives in L2), parameters [N+1][16], iterate x/u read and written, the 104-byte record"""
+    yref = 0 if shared_yref else 16 * (N + 1)
+    return 8 * (12 + yref + 16 * (N + 1) + 2 * (12 * (N + 1) + 4 * N)) + 104
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch, reps=5, ticks=4, warmup=3):
+    """the C oracle on the config-2 workload, OpenMP over instances, all host threads: median over `reps` repetitions of `ticks`
+    consecutive RTI ticks"""
     from oracle.oracle_ffi import Oracle, build
     build()
     orc = Oracle()
@@ -81,74 +133,283 @@ def cpu_baseline(batch, steps, warmup):
     p = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (batch, HORIZON + 1, NP)))
     x, u, pi, lam = orc.init_iterate(op, batch)
     nthreads = orc.num_threads()
-    t_sum, n = 0.0, 0
-    for k in range(warmup + steps):
+    rates, k = [], 0
+
+    def tick():
+        nonlocal k
         yref = np.ascontiguousarray(np.broadcast_to(circ[k:k + HORIZON + 1], (batch, HORIZON + 1, NY)))
         t0 = time.perf_counter()
         orc.rti_step_batch(op, x0, yref, p, x, u, pi, lam, nthreads=0)
-        dt = time.perf_counter() - t0
-        if k >= warmup:
-            t_sum += dt
-            n += batch
-    return dict(value=n / t_sum, unit="solves/s", cores=nthreads, kind="port",
-                sample=f"{batch} instances x {steps} RTI ticks of the same workload (after {warmup} warm-up ticks), "
-                       f"oracle/bluerov2_oracle.c -O3, OpenMP over instances, {nthreads} threads; acados itself was not "
-                       "run (not vendored/installed) and no published acados timing exists for this OCP")
+        k += 1
+        return time.perf_counter() - t0
+    for _ in range(warmup):
+        tick()
+    for _ in range(reps):
+        rates.append(batch * ticks / sum(tick() for _ in range(ticks)))
+    return dict(value=float(np.median(rates)), unit="solves/s", cores=nthreads, kind="port", cpu=cpu_model(),
+                min=float(min(rates)), max=float(max(rates)), repetitions=reps,
+                sample=f"median of {reps} repetitions of {ticks} RTI ticks x {batch} instances of the same workload (after "
+                       f"{warmup} warm-up ticks), oracle/bluerov2_oracle.c -O3, OpenMP over instances, {nthreads} threads; acados "
+                       "itself was not run (not vendored/installed) and no published acados timing exists for this OCP")
 
 
-def main():
+def cpu_single_thread(ticks=1000):
+    """BASELINE config 1 (SURVEY.md 8d / BASELINE.md 2a): ONE instance, one thread, circle reference, closed on the nominal
+    model (x0 <- RK4 plant step with u0), per-tick latency of the CPU restatement = the analogue of acados' `time_tot`
+    (bluerov2_dob.cpp:386) at N=20/Ts=0.05 and at the reference's shipped N=80/Ts=0.0125."""
+    from oracle.oracle_ffi import Oracle, build
+    build()
+    orc = Oracle()
+    from bluerov2_amd import P_NOMINAL
+    out = {}
+    for N, Ts in ((20, 0.05), (80, 0.0125)):
+        op = orc.opts(N, Ts)
+        x0, circ = synthetic_inputs(1, seed=1, noise=False)
+        x0 = x0[0].copy()
+        stride = 1   # the nodes read one trajectory row per shooting node whatever Ts is (bluerov2_dob.cpp:367-372)
+        p = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (N + 1, NP)))
+        x, u, pi, lam = orc.init_iterate(op)
+        lat, u0 = [], np.zeros(NU)
+        for k in range(ticks + 20):
+            yref = np.ascontiguousarray(circ[k:k + (N + 1) * stride:stride])
+            t0 = time.perf_counter()
+            r = orc.rti_step(op, x0, yref, p, x, u, pi, lam, u0_prev=u0)
+            dt = time.perf_counter() - t0
+            if k >= 20:
+                lat.append(dt)
+            u0 = r["u0"]
+            x0 = orc.rk4(x0, u0, P_NOMINAL, 0.05)
+        lat = np.array(lat) * 1e3
+        out[f"N{N}"] = dict(median_ms=float(np.median(lat)), p99_ms=float(np.percentile(lat, 99)), mean_ms=float(lat.mean()),
+                            solves_per_s=float(1e3 / np.median(lat)), Ts=Ts, ticks=ticks)
+    out.update(cores=1, kind="port", cpu=cpu_model(),
+               sample=f"{ticks} closed-loop ticks of one instance after 20 warm-up ticks, ctypes call overhead included (~5 us)")
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json configs[config-1]")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0 = the config's own)")
+    ap.add_argument("--horizon", type=int, default=0, help="N for configs 2/3 (0 = 20); config 5: run this horizon only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the forced-IPM / mixed-batch legs of the default run")
     ap.add_argument("--force-ipm", action="store_true", help="qp_early_exit=0 as the headline variant")
     ap.add_argument("--force-gather", action="store_true", help="run the result all-gather even with one rank")
-    ap.add_argument("--path", type=int, default=0, help="0 auto (fused when the horizon fits LDS), 1 streaming, 2 fused")
-    args = ap.parse_args()
+    ap.add_argument("--path", type=int, default=0, help="0 auto (LDS-resident kernels), 1 streaming, 2 fused")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU, no solver: launcher + gloo collectives on synthetic records")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch(args, argv):
+    """`python bench.py --gpus N` from a plain shell: become the launcher of N ranks (one process per GPU) and pass rank 0's
+    single JSON line through"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    for ln in pr.stdout.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if pr.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(f"bench.py launcher: {args.gpus} ranks exited with code {pr.returncode}, {len(lines)} JSON line(s)\n")
+        for ln in lines:
+            sys.stdout.write(ln + "\n")
+        return pr.returncode or 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def workload(args, rank, world):
+    """what one rank solves: dict(name, B, horizons=[(N, Ts)], make(N, Ts, early_exit) -> (solver, tick(k, stream), shared_yref))"""
+    import torch
+    import bluerov2_amd as ba
+    cfg = args.config
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def opts(N, Ts, early):
+        return ba.SolverOptions(N, Ts, qp_early_exit=early, kernel_path=args.path)
+
+    def circle_ticks(s, circ):
+        traj_dev = torch.from_numpy(circ).to("cuda")
+        base = traj_dev.data_ptr()
+        s._keepalive = traj_dev
+
+        def tick(k, stream):
+            s.set_yref_device(base + k * NY * 8, shared=True, stream=stream)
+        return tick
+
+    if cfg == 2 or cfg == 3:
+        N = args.horizon or HORIZON
+        Ts = TS if N == HORIZON else 1.0 / N
+        B = args.batch or (BATCH_PER_GPU if cfg == 2 else 16384)
+
+        def make(N, Ts, early, sat=0.0):
+            s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
+            x0, circ = synthetic_inputs(B, seed=(1 if cfg == 2 else 2) + 1000 * rank, noise=(cfg == 2))
+            if sat:
+                x0 = saturate(x0, sat, seed=77)
+            p = np.tile(ba.P_NOMINAL, (B, 1))
+            if cfg == 3:   # Monte-Carlo current disturbance, converted like the node does (bluerov2_dob.cpp:334-337)
+                rng = np.random.default_rng(2 + 1000 * rank)
+                d = np.concatenate([rng.uniform(-10, 10, (B, 3)), rng.uniform(-3, 3, (B, 1))], axis=1)
+                p[:, 0:2] = d[:, 0:2] / 0.032546960744430276
+                p[:, 2:4] = d[:, 2:4] / 0.026546960744430276
+            s.set_x0(x0)
+            s.set_params(p)
+            return s, circle_ticks(s, circ), True
+        name = ("BASELINE.json configs[1]: batch=%d independent BlueROV2 NMPC instances per GPU, N=%d, Ts=%g s, circle reference "
+                "window advancing one row per step, per-instance x0 noise (seed 1), nominal parameters" % (B, N, Ts)) if cfg == 2 else (
+                "BASELINE.json configs[2]: batch=%d DOB-MPC Monte-Carlo current-disturbance draws per GPU (p[0..3] per instance, "
+                "seed 2), N=%d, Ts=%g s, shared circle window" % (B, N, Ts))
+        return dict(name=name, B=B, horizons=[(N, Ts)], make=make)
+    if cfg == 4:
+        if world > CAND_SHARDS:
+            raise SystemExit("config 4 has 8 shards of 8192 candidates")
+        B = args.batch or CAND_TOTAL // CAND_SHARDS
+        amp, frq, ph = candidate_params()
+        sl = slice(rank * B, (rank + 1) * B)
+
+        def make(N, Ts, early, sat=0.0):
+            s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
+            x0 = np.zeros((B, NX)); x0[:, 0] = 2.0; x0[:, 2] = -20.0   # lemniscate row 0 pose
+            s.set_x0(x0)
+            s.set_params(ba.P_NOMINAL)
+            s.set_candidate_params("lemniscate", amp[sl], frq[sl], ph[sl])
+
+            def tick(k, stream):
+                s.set_yref_candidates_tick(TS * k, TS, stream=stream)   # one kernel per tick, parameters resident
+            return s, tick, False
+        return dict(name="BASELINE.json configs[3]: 65536 lemniscate-trajectory candidates (amp~U(1,3), omega~U(.25,.75), "
+                         "phase~U(0,2pi), seed 3) sharded %d per GPU, N=20, x0 = lemniscate row 0; every step: candidate windows "
+                         "rebuilt on the device, RTI step, all-gather of the result records, global arg-min of cost" % B,
+                    B=B, horizons=[(HORIZON, TS)], make=make, always_gather=True)
+    # cfg 5
+    B = args.batch or BATCH_PER_GPU
+    Ns = [args.horizon] if args.horizon else [10, 20, 40, 80]
+
+    def make(N, Ts, early, sat=0.0):
+        s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
+        x0, circ = synthetic_inputs(B, seed=4 + 1000 * rank)
+        s.set_x0(x0)
+        s.set_params(ba.P_NOMINAL)
+        return s, circle_ticks(s, circ), True
+    return dict(name="BASELINE.json configs[4]: horizon sweep N in %s at batch=%d per GPU (32768 over 8 GPUs), Ts = 1/N, x0 as "
+                     "config 2 (seed 4), shared circle window (one row per node)" % (Ns, B),
+                B=B, horizons=[(N, 1.0 / N) for N in Ns], make=make)
+
+
+def dry_run(args, rank, world):
+    """no GPU: the launcher, the rendezvous, the record all-gather and the arg-min on synthetic records under gloo"""
+    import torch
+    import torch.distributed as dist
+    from bluerov2_amd import distributed as D
+    from bluerov2_amd.solver import RESULT_DTYPE
+    B = args.batch or 64
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = np.zeros(B, dtype=RESULT_DTYPE)
+    g = np.arange(rank * B, (rank + 1) * B)
+    rec["cost"] = 100.0 + ((g * 7919 + 266) % 1013)          # global minimum at a known index
+    rec["status"][g % 17 == 3] = 4                     # some failed instances: must be skipped by the arg-min
+    rec["u0"][:, 0] = g
+    local = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy())
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        allb = D.gather_records(local)
+    dt = time.perf_counter() - t0
+    ranks = torch.tensor([rank], dtype=torch.int64)
+    seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(seen, ranks)
+    else:
+        seen = [ranks]
+    idx, best = D.select_best(allb)
+    gall = np.arange(world * B)
+    cost = np.where(gall % 17 == 3, np.inf, 100.0 + ((gall * 7919 + 266) % 1013))
+    out = {"metric": "NMPC RTI solves/s", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / (args.warmup + args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "dry-run: synthetic records, NO solver, gloo on CPU", "dry_run": True,
+           "config": {"workload": "launcher / collective plumbing only"}, "ranks_seen": sorted(int(t.item()) for t in seen),
+           "select_best": {"index": idx, "expected_index": int(np.argmin(cost)), "cost": float(best["cost"]),
+                           "records_gathered": int(allb.numel() // D.RECORD_BYTES)}}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(args, argv))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without "
+                         "torch.distributed.run: bench.py spawns its own ranks)")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29513")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
+    gather = world > 1 or args.force_gather
     if world > 1 or args.force_gather:
         # RCCL writes its debug/warn lines to stdout; keep them away from the one JSON line this script must print
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29513")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import bluerov2_amd as ba
     from bluerov2_amd import distributed as D
-    B, N = args.batch, HORIZON
-    K, W = args.steps, args.warmup
+    wl = workload(args, rank, world)
+    gather = gather or (wl.get("always_gather", False) and dist.is_initialized())
+    B, K, W = wl["B"], args.steps, args.warmup
+    dev = f"cuda:{local_rank}"
 
-    def make_solver(early_exit):
-        s = ba.BatchSolver(B, ba.SolverOptions(N, TS, qp_early_exit=early_exit, kernel_path=args.path), device=local_rank)
-        x0, circ = synthetic_inputs(B, seed=1 + 1000 * rank)
-        s.set_x0(x0)
-        s.set_params(ba.P_NOMINAL)
-        return s, circ
-
-    def run(s, traj_dev, steps, warmup, gather, timing):
+    def run(s, tick, steps, warmup, timing, select):
         stream = torch.cuda.current_stream().cuda_stream
         res_view = D.records_tensor_from_solver(s) if gather else None
-        gathered = torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=f"cuda:{local_rank}") if gather else None
+        gathered = torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=dev) if gather else None
         s.init_iterate_default()
         s.enable_timing(False)
-        base = traj_dev.data_ptr()
-        for k in range(warmup):
-            s.set_yref_device(base + k * NY * 8, shared=True, stream=stream)
+        best = None
+
+        def step(k):
+            nonlocal best
+            tick(k, stream)
             s.solve(stream=stream)
             if gather:
                 dist.all_gather_into_tensor(gathered, res_view)
+                if select:
+                    best = D.select_best_device(gathered)   # stays on the device; read after the timed region
+        for k in range(warmup):
+            step(k)
         s.enable_timing(timing)
         ksec = np.zeros(2)
         if world > 1:
@@ -156,10 +417,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(warmup, warmup + steps):
-            s.set_yref_device(base + k * NY * 8, shared=True, stream=stream)
-            s.solve(stream=stream)
-            if gather:
-                dist.all_gather_into_tensor(gathered, res_view)
+            step(k)
             if timing:  # HIP events on the launch stream; read back after the step (host-side wait only)
                 _, k2 = s.last_solve_seconds()
                 ksec += k2
@@ -171,76 +429,132 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, ksec / max(steps, 1)
+        return dt, ksec / max(steps, 1), (gathered, best)
 
-    s, circ = make_solver(0 if args.force_ipm else 1)
-    traj_dev = torch.from_numpy(circ).to("cuda")
-    gather = world > 1 or args.force_gather
-    # pass 1: the timed region that defines `value` (no per-kernel events inside)
-    dt, _ = run(s, traj_dev, K, W, gather, timing=False)
-    res = s.results()
-    n_bad = int((res["status"] != 0).sum())
-    # pass 2: same steps again with HIP events around each kernel for the roofline numbers
-    dt2, ksec = run(s, traj_dev, K, W, gather, timing=True)
-    res2 = s.results()
-    value = B * world * K / dt
+    early = 0 if args.force_ipm else 1
+    select = bool(wl.get("always_gather", False))
+    legs, out = [], None
+    for (N, Ts) in wl["horizons"]:
+        s, tick, shared = wl["make"](N, Ts, early)
+        # pass 1: the timed region that defines `value` (no per-kernel events inside)
+        dt, _, _ = run(s, tick, K, W, False, select)
+        n_bad = int((s.results()["status"] != 0).sum())
+        # pass 2: same steps again with HIP events around each kernel for the roofline numbers
+        _, ksec, (gathered, best) = run(s, tick, K, W, True, select)
+        res2 = s.results()
+        legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
+                         shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
+        last = (s, gathered, best)
+        if (N, Ts) != wl["horizons"][-1]:
+            s.close()
+    s, gathered, best = last
+    total_dt = sum(l["dt"] for l in legs)
+    value = B * world * K * len(legs) / total_dt
 
-    out = None
+    ranks_seen = [0]
+    if dist.is_initialized():
+        rk = torch.tensor([rank], dtype=torch.int64, device=dev)
+        allr = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allr, rk)
+        ranks_seen = sorted(int(v) for v in allr.cpu())
+
     if rank == 0:
-        qp_fl = qp_flops(res2["qp_iter"], N)
+        lg = legs[-1] if len(legs) == 1 else max(legs, key=lambda l: l["dt"])   # roofline: the (slowest) leg's dominant kernel
+        N = lg["N"]
+        qp_fl = qp_flops(lg["qp_iter"], N)
         lin_fl = B * N * F_LIN
-        fused = s.last_kernel_path() == ba.PATH_FUSED
-        if fused:  # one kernel does both phases
-            dom, dom_fl, dom_t = "rti_fused_kernel", qp_fl + lin_fl, ksec[1]
-            kernel_ms = {"rti_fused_kernel": ksec[1] * 1e3}
+        ksec = lg["ksec"]
+        if lg["path"] in KERNEL_NAMES:  # one kernel does both phases
+            dom, dom_fl, dom_t = KERNEL_NAMES[lg["path"]], qp_fl + lin_fl, ksec[1]
+            kernel_ms = {dom: ksec[1] * 1e3}
         else:
             dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_wave_kernel"
             dom_fl, dom_t = (qp_fl, ksec[1]) if dom == "qp_kernel" else (lin_fl, ksec[0])
             kernel_ms = {"lin_wave_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3}
         achieved = dom_fl / dom_t / 1e12
-        alg_bytes = 8 * (12 + 16 * (N + 1) + 16 * (N + 1) + 2 * (12 * (N + 1) + 4 * N)) + 56
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
-        if os.path.exists(pj):
+        alg_bytes = algorithmic_bytes(N, lg["shared"])
+        traffic, traffic_src = None, None
+        for pj in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
             try:
-                pm = json.load(open(pj))
-                if pm.get("batch") == B and pm.get("N") == N:
-                    traffic = pm.get("hbm_bytes_per_launch", {}).get(dom)
+                pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
+                ent = pm.get("runs", {}).get(f"cfg{args.config}_B{B}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
+                t = ent.get("hbm_bytes_per_launch", {}).get(dom)
+                if t is not None and args.config == 2:
+                    traffic, traffic_src = t, f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run"
+                    break
             except Exception:
-                traffic = None
+                pass
+        per_gpu_rate = B * K / lg["dt"]
         out = {
-            "metric": "NMPC RTI solves/s (N=20, 12 states / 4 inputs), batch 4096 per GPU", "value": value,
-            "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "metric": "NMPC RTI solves/s (N=20, 12 states / 4 inputs), batch 4096 per GPU" if args.config == 2 and N == 20 and B == 4096
+            else f"NMPC RTI solves/s (12 states / 4 inputs), config {args.config}",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": total_dt / (K * len(legs)) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch=4096 independent BlueROV2 NMPC instances per GPU, "
-                                   "N=20, Ts=0.05 s, circle reference window advancing one row per step, per-instance "
-                                   "x0 noise (seed 1), nominal parameters, default options "
-                                   + ("with qp_early_exit=0 (forced interior point)" if args.force_ipm else
-                                      "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
-                       "batch_per_gpu": B, "N": N, "Ts": TS, "parallelism": f"instances sharded over {world} GPU(s), "
-                       "all-gather of 56 B result records" if world > 1 else "single GPU"},
-            "solver_status_nonzero": n_bad,
-            "mean_qp_iter": float(res2["qp_iter"].mean()),
-            "kernel_ms": kernel_ms,
+            "config": {"workload": wl["name"] + ", default options " +
+                       ("with qp_early_exit=0 (forced interior point)" if args.force_ipm else
+                        "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
+                       "batch_per_gpu": B, "N": [l["N"] for l in legs] if len(legs) > 1 else N, "Ts": lg["Ts"] if len(legs) == 1 else "1/N",
+                       "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
+                                       "records per step") if world > 1 else "single GPU"},
+            "ranks_seen": ranks_seen,
+            "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
+            "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),
+            "kernel_ms": kernel_ms, "device_bytes": lg["device_bytes"],
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "algorithmic_flops_per_launch": dom_fl,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "N": N, "algorithmic_flops_per_launch": dom_fl,
                          "note": "FP64; algorithmic flops = factorisations/solves actually required by each instance "
                                  "(DESIGN.md Accounting), not the MFMA-issued flops"},
-            "roofline_hbm": {"bound": "hbm", "achieved": value / world * alg_bytes / 1e9, "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": value / world * alg_bytes / 1e9 / PEAK_HBM_GBS,
-                             "algorithmic_bytes_per_solve": alg_bytes},
+            "roofline_hbm": {"bound": "hbm", "achieved": per_gpu_rate * alg_bytes / 1e9, "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": per_gpu_rate * alg_bytes / 1e9 / PEAK_HBM_GBS,
+                             "algorithmic_bytes_per_solve": alg_bytes,
+                             "formula": "8*[12 + (0 if one window is shared by the batch else 16(N+1)) + 16(N+1) + 2*(12(N+1)+4N)] + 104"},
         }
+        if len(legs) > 1:
+            out["sweep"] = {f"N{l['N']}": dict(solves_per_s=B * world * K / l["dt"], ms_per_step=l["dt"] / K * 1e3,
+                                               kernel_path={1: "streaming", 2: "fused", 3: "windowed"}.get(l["path"], "?"),
+                                               status_nonzero=l["n_bad"], mean_qp_iter=float(l["qp_iter"].mean()))
+                            for l in legs}
     if gather:
         allrec = D.gather_records(D.records_tensor_from_solver(s))  # every rank takes part in the collective
         if rank == 0:
-            idx, best = D.select_best(allrec)
-            out["select_best"] = {"index": idx, "cost": None if best is None else float(best["cost"]),
-                                  "records_gathered": int(allrec.numel() // D.RECORD_BYTES)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, K, W)
+            idx, brec = D.select_best(allrec)
+            out["select_best"] = {"index": idx, "cost": None if brec is None else float(brec["cost"]),
+                                  "u0": None if brec is None else [float(v) for v in brec["u0"]],
+                                  "thrust": None if brec is None else [float(v) for v in brec["thrust"]],
+                                  "records_gathered": int(allrec.numel() // D.RECORD_BYTES),
+                                  "selected_every_step_on_device": select}
+            if select and best is not None:
+                out["select_best"]["last_step_index_on_device"] = int(best[0].item())
     s.close()
+
+    extra = rank == 0 and world == 1 and args.config == 2 and not args.force_ipm and not args.no_extra
+    if extra:
+        # the headline never runs an interior-point iteration (no bound is active on the nominal circle): report the legs that do
+        (N, Ts) = wl["horizons"][0]
+        s2, tick2, _ = wl["make"](N, Ts, 0)
+        dt2, _, _ = run(s2, tick2, K, W, False, False)
+        r2 = s2.results()
+        out["forced_ipm"] = dict(value=B * K / dt2, unit="solves/s", ms_per_step=dt2 / K * 1e3, mean_qp_iter=float(r2["qp_iter"].mean()),
+                                 status_nonzero=int((r2["status"] != 0).sum()),
+                                 note="same workload with qp_early_exit=0: every instance runs the Mehrotra interior-point loop")
+        s2.close()
+        s3, tick3, _ = wl["make"](N, Ts, 1, sat=0.25)
+        dt3, _, _ = run(s3, tick3, K, W, False, False)
+        r3 = s3.results()
+        out["mixed_batch_25pct_saturated"] = dict(value=B * K / dt3, unit="solves/s", ms_per_step=dt3 / K * 1e3,
+                                                  ipm_instance_fraction=float((r3["qp_iter"] > 0).mean()),
+                                                  mean_qp_iter=float(r3["qp_iter"].mean()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
+                                                  note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
+                                                       "the launch ends with its slowest interior-point instance")
+        s3.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(BATCH_PER_GPU)
+        if extra:
+            out["cpu_baseline_single_thread"] = cpu_single_thread()
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")

@@ -3,6 +3,7 @@
 // usable HIP device every entry point fails with BROV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,7 +44,11 @@ struct brov_solver {
     int traj_rows = 0;
     double* scratch3 = nullptr;  // [3][B] candidate parameters
     double* pplant = nullptr;    // [B][16] true plant parameters
-    bool pplant_set = false;
+    bool pplant_set = false;     // explicit plant parameters given (brov_plant_set_params_host)
+    bool pplant_stale = true;    // controller parameters changed since the plant's copy of them was taken
+    bool cand_set = false;       // candidate shape parameters resident in scratch3
+    int cand_kind = 0;
+    bool dump_lin = false;
     int* lines = nullptr;        // [B]
     size_t bytes = 0;
     std::vector<void*> allocs;
@@ -68,6 +73,8 @@ extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
     o->qp_tol_mu = 1e-12;
     o->qp_tol_stat = 1e-9;
     o->qp_early_exit = 1;
+    o->kernel_path = BROV_PATH_AUTO;
+    o->on_failure = BROV_ON_FAILURE_RESTART;
 }
 
 template <typename T>
@@ -109,7 +116,7 @@ extern "C" int brov_init_iterate_default(brov_solver* s) {
 
 extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts* opts) {
     if (!out || !opts || B < 1 || opts->N < 1 || opts->N > BROV_MAX_N || !(opts->Ts > 0.0) || opts->kernel_path < 0 ||
-        opts->kernel_path > 2) {
+        opts->kernel_path > 2 || opts->on_failure < 0 || opts->on_failure > 1) {
         g_err = "brov_create: bad argument";
         return BROV_ERR_ARG;
     }
@@ -220,6 +227,7 @@ __global__ void bcast_par_kernel(const double* __restrict__ p16, double* __restr
 
 static int set_par(brov_solver* s, const double* p, int per_stage, bool host, void* st) {
     if (!s || !p) return BROV_ERR_ARG;
+    s->pplant_stale = true;
     const size_t N1 = s->N + 1;
     if (per_stage) return copy_in(s, s->par, p, (size_t)s->B * N1 * 16, host, st);
     HIPCHK(hipSetDevice(s->device));
@@ -247,6 +255,7 @@ extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, co
     if (!s || !p16 || inst < 0 || inst >= s->B || stage < 0 || stage > s->N) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipMemcpy(s->par + ((size_t)inst * (s->N + 1) + stage) * 16, p16, 16 * sizeof(double), hipMemcpyHostToDevice));
+    if (stage == 0) s->pplant_stale = true;
     return BROV_OK;
 }
 extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, const double* y, int ny) {
@@ -289,18 +298,31 @@ extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t*
     HIPCHK(hipGetLastError());
     return BROV_OK;
 }
-extern "C" int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase,
-                                             double t0, double dt) {
+extern "C" int brov_set_candidate_params_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase) {
     if (!s || !p0 || !p1 || !phase || kind < 0 || kind > 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
     const size_t nb = (size_t)s->B * sizeof(double);
     HIPCHK(hipMemcpy(s->scratch3, p0, nb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->scratch3 + s->B, p1, nb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->scratch3 + 2 * (size_t)s->B, phase, nb, hipMemcpyHostToDevice));
-    launch_candidates(kind, s->scratch3, s->scratch3 + s->B, s->scratch3 + 2 * (size_t)s->B, t0, dt, s->B, s->N, s->yref, nullptr);
+    s->cand_set = true;
+    s->cand_kind = kind;
+    return BROV_OK;
+}
+extern "C" int brov_set_yref_candidates(brov_solver* s, double t0, double dt, void* stream) {
+    if (!s || !s->cand_set) { g_err = "brov_set_yref_candidates: no candidate parameters (brov_set_candidate_params_host)"; return BROV_ERR_ARG; }
+    HIPCHK(hipSetDevice(s->device));
+    launch_candidates(s->cand_kind, s->scratch3, s->scratch3 + s->B, s->scratch3 + 2 * (size_t)s->B, t0, dt, s->B, s->N, s->yref,
+                      (hipStream_t)stream);
     s->yref_shared = false;
     HIPCHK(hipGetLastError());
     return BROV_OK;
+}
+extern "C" int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase,
+                                             double t0, double dt) {
+    const int rc = brov_set_candidate_params_host(s, kind, p0, p1, phase);
+    return rc != BROV_OK ? rc : brov_set_yref_candidates(s, t0, dt, nullptr);
 }
 extern "C" int brov_get_yref_host(brov_solver* s, double* yref) {
     if (!s || !yref) return BROV_ERR_ARG;
@@ -338,10 +360,12 @@ extern "C" int brov_plant_set_params_host(brov_solver* s, const double* p) {
     s->pplant_set = true;
     return BROV_OK;
 }
+// Without explicit plant parameters the plant is the controller's own model: stage-0 parameters, re-read whenever the
+// controller's parameters may have changed (setters, brov_params_device() hand-outs, the EKF's write-back).
 static int ensure_plant_params(brov_solver* s, hipStream_t st) {
-    if (!s->pplant_set) {  // default: the plant is the controller's model (stage-0 parameters)
+    if (!s->pplant_set && s->pplant_stale) {
         hipLaunchKernelGGL(copy_stage0_par_kernel, dim3((s->B * 16 + 255) / 256), dim3(256), 0, st, s->par, s->pplant, s->B, s->N + 1);
-        s->pplant_set = true;
+        s->pplant_stale = false;
     }
     return BROV_OK;
 }
@@ -371,12 +395,20 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
     const size_t B = s->B;
     double *dx = nullptr, *du = nullptr;
     int* dst = nullptr;
-    if (x_log) HIPCHK(hipMalloc((void**)&dx, (size_t)(ticks + 1) * B * 12 * sizeof(double)));
-    if (u_log) HIPCHK(hipMalloc((void**)&du, (size_t)ticks * B * 4 * sizeof(double)));
-    if (st_log) HIPCHK(hipMalloc((void**)&dst, (size_t)ticks * B * sizeof(int)));
-    ensure_plant_params(s, st);
-    if (dx) HIPCHK(hipMemcpyAsync(dx, s->x0, B * 12 * sizeof(double), hipMemcpyDeviceToDevice, st));
     int rc = BROV_OK;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (rc != BROV_OK) return;
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) { g_err = std::string("brov_closed_loop: hipMalloc: ") + hipGetErrorString(e); rc = BROV_ERR_ALLOC; }
+    };
+    if (x_log) alloc((void**)&dx, (size_t)(ticks + 1) * B * 12 * sizeof(double));
+    if (u_log) alloc((void**)&du, (size_t)ticks * B * 4 * sizeof(double));
+    if (st_log) alloc((void**)&dst, (size_t)ticks * B * sizeof(int));
+    if (rc == BROV_OK) ensure_plant_params(s, st);
+    if (rc == BROV_OK && dx && hipMemcpyAsync(dx, s->x0, B * 12 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        g_err = "brov_closed_loop: log copy failed";
+        rc = BROV_ERR_HIP;
+    }
     for (int k = 0; k < ticks && rc == BROV_OK; k++) {
         launch_window(s->traj, s->traj_rows, nullptr, line0 + k, 1, s->N, ncols, s->yref_sh, st);
         s->yref_shared = true;
@@ -433,6 +465,7 @@ static DevParams make_params(const brov_solver* s) {
     std::memset(&P, 0, sizeof P);
     P.B = s->B; P.N = s->N;
     P.qp_iter_max = s->opts.qp_iter_max; P.early_exit = s->opts.qp_early_exit;
+    P.on_failure = s->opts.on_failure; P.dump_lin = s->dump_lin ? 1 : 0;
     P.Ts = s->opts.Ts; P.tol_mu = s->opts.qp_tol_mu; P.tol_stat = s->opts.qp_tol_stat;
     for (int j = 0; j < 16; j++) P.W[j] = s->opts.W[j];
     for (int j = 0; j < 12; j++) P.We[j] = s->opts.We[j];
@@ -474,7 +507,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
 }
 extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phase(s, stream, 0); }
 extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
-    if (!s || !o || o->N != s->N || !(o->Ts > 0.0)) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
+    if (!s || !o || o->N != s->N || !(o->Ts > 0.0) || o->on_failure < 0 || o->on_failure > 1 || o->kernel_path < 0 || o->kernel_path > 2) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->last_stream));
     s->opts = *o;
@@ -492,6 +525,11 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
     return BROV_OK;
 }
 extern "C" int brov_last_kernel_path(const brov_solver* s) { return s ? (s->last_fused ? BROV_PATH_FUSED : BROV_PATH_STREAMING) : BROV_ERR_ARG; }
+extern "C" int brov_debug_dump_linearisation(brov_solver* s, int enable) {
+    if (!s) return BROV_ERR_ARG;
+    s->dump_lin = enable != 0;
+    return BROV_OK;
+}
 // developer hook (not in the public header): per-instance phase timestamps of the last solve, 8 x uint64 per instance
 extern "C" int brov_debug_phase_stamps(brov_solver* s, int enable, unsigned long long* out_host) {
     if (!s) return BROV_ERR_ARG;
@@ -531,7 +569,7 @@ extern "C" int brov_get_u0_host(brov_solver* s, double* u0) {
 extern "C" const brov_result* brov_results_device(const brov_solver* s) { return s ? s->res : nullptr; }
 extern "C" double* brov_x0_device(brov_solver* s) { return s ? s->x0 : nullptr; }
 extern "C" double* brov_yref_device(brov_solver* s) { if (!s) return nullptr; s->yref_shared = false; return s->yref; }
-extern "C" double* brov_params_device(brov_solver* s) { return s ? s->par : nullptr; }
+extern "C" double* brov_params_device(brov_solver* s) { if (!s) return nullptr; s->pplant_stale = true; return s->par; }
 extern "C" double* brov_x_device(brov_solver* s) { return s ? s->x : nullptr; }
 extern "C" double* brov_u_device(brov_solver* s) { return s ? s->u : nullptr; }
 
@@ -584,19 +622,9 @@ extern "C" int brov_select_best_host(brov_solver* s, int* best_index, brov_resul
 
 extern "C" int brov_get_thrusts_host(brov_solver* s, double* t6) {
     if (!s || !t6) return BROV_ERR_ARG;
-    std::vector<double> u0((size_t)s->B * 4);
-    int rc = brov_get_u0_host(s, u0.data());
-    if (rc != BROV_OK) return rc;
-    const double c = 0.026546960744430276;  // bluerov2_dob.cpp:390-395
-    for (int b = 0; b < s->B; b++) {
-        const double* u = &u0[(size_t)b * 4];
-        double* t = t6 + (size_t)b * 6;
-        t[0] = (-u[0] + u[1] + u[3]) / c;
-        t[1] = (-u[0] - u[1] - u[3]) / c;
-        t[2] = (u[0] + u[1] - u[3]) / c;
-        t[3] = (u[0] - u[1] + u[3]) / c;
-        t[4] = (-u[2]) / c;
-        t[5] = (-u[2]) / c;
-    }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(hipMemcpy2D(t6, 6 * sizeof(double), (const char*)s->res + offsetof(brov_result, thrust), sizeof(brov_result), 6 * sizeof(double),
+                       s->B, hipMemcpyDeviceToHost));
     return BROV_OK;
 }

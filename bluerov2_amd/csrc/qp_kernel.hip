@@ -801,6 +801,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     const int nxe = (N + 1) * 12;
     double cost = 0.0;
     bool wrote_u0 = false;
+    double u0v = 0.0;   // lanes 0..3: first input of the result record
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
         if (!early) {  // early exit: dxb already holds the states of the accepted Newton point
             rollout<LDS>(I, d0, V);
@@ -860,7 +861,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         lam_it[i * 8 + 4 + m] = gg[t] < 0 ? -gg[t] : 0.0;
                         const double un = uo[t] + vv[t];
                         u_it[j] = un;
-                        if (j < 4) P.res[b].u0[j] = un;
+                        if (j < 4) { P.res[b].u0[j] = un; u0v = un; }
                         const double e = un - ur[t];
                         cost += 0.5 * P.Ts * cst[12 + m] * e * e;
                     }
@@ -896,16 +897,20 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         }
     }
     if (status != BROV_STATUS_SUCCESS && status != BROV_STATUS_MAXITER) {
-        // iterate untouched; report the cost of the (unchanged) iterate
+        // failed step: report the cost of the entering iterate; the iterate is left as it is (acados: SQP_RTI returns before
+        // update_variables) or, with on_failure = RESTART, cold-started at the measured state so that the instance can recover
+        const double* x0 = P.x0 + (size_t)b * 12;
         for (int j = lane; j < nv; j += 64) {
             const int i = j >> 2, m = j & 3;
             const double e = u_it[j] - I.yref[(size_t)i * 16 + 12 + m];
             cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+            if (P.on_failure == BROV_ON_FAILURE_RESTART) { u_it[j] = 0.0; lam_it[i * 8 + m] = 0.0; lam_it[i * 8 + 4 + m] = 0.0; }
         }
         for (int j = lane; j < nxe; j += 64) {
             const int i = j / 12, c = j - i * 12;
             const double e = x_it[j] - I.yref[(size_t)i * 16 + c];
             cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+            if (P.on_failure == BROV_ON_FAILURE_RESTART) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
         }
     }
     cost = wave_sum(cost);
@@ -916,7 +921,22 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         r->status = status;
         r->qp_iter = early ? 0 : iters;
     }
-    if (!wrote_u0 && lane < 4) P.res[b].u0[lane] = u_it[lane];
+    // first input of the record.  Failed step: the last successfully computed input is held (clamped into the box, NaN -> 0),
+    // so that the plant / thrust consumers never see a diverged iterate's input.
+    if (!wrote_u0 && lane < 4) {
+        u0v = P.res[b].u0[lane];
+        u0v = (u0v == u0v) ? u0v : 0.0;
+        u0v = fmin(fmax(u0v, cst[32 + lane]), cst[36 + lane]);
+        P.res[b].u0[lane] = u0v;
+    }
+    {   // thrust allocation epilogue (bluerov2_dob.cpp:390-395), six lanes
+        const double a0 = readlane_f64(u0v, 0), a1 = readlane_f64(u0v, 1), a2 = readlane_f64(u0v, 2), a3 = readlane_f64(u0v, 3);
+        const double s0 = (lane == 0 || lane == 1) ? -a0 : a0;
+        const double s1 = (lane == 0 || lane == 2) ? a1 : -a1;
+        const double s3 = (lane == 0 || lane == 3) ? a3 : -a3;
+        const double th = ((lane < 4) ? (s0 + s1) + s3 : -a2) / kRotor;   // same operation order as the host helper
+        if (lane < 6) P.res[b].thrust[lane] = th;
+    }
     DBG_STAMP(6);
 }
 
@@ -1199,6 +1219,25 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     }
 }
 
+// coalesced copy of a chunk's linearisation out of LDS into the HBM images of the streaming path: [A B] as [12][16] row-major
+// tiles (register image r of the tile = rows rg + 4r, column cl; columns 0..2 are e_c) and b_i.  Also the debug dump of the
+// LDS-resident kernels (DevParams::dump_lin), so that tests compare their linearisation with the oracle directly.
+__device__ __forceinline__ void copy_out_linearisation(const DevParams& P, int b, int i0, int n, int lane, const double* ba_s,
+                                                       const double* bv_s) {
+    const int rg = lane >> 4, cl = lane & 15;
+    const size_t g0 = (size_t)b * P.N + i0;
+    for (int il = 0; il < n; il++) {
+        const double* t = ba_s + il * kBaStage;
+        double* BA = P.BA + (g0 + il) * 192;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int row = rg + 4 * r;
+            BA[r * 64 + lane] = cl >= 3 ? t[row * kBaStride + cl - 3] : (row == cl ? 1.0 : 0.0);
+        }
+    }
+    for (int j = lane; j < n * NX; j += 64) P.bvec[g0 * NX + j] = bv_s[j];
+}
+
 // Streaming path (any horizon): the same wave-wide linearisation, one wavefront per chunk of <= 21 intervals, followed by a
 // coalesced copy of the chunk out of LDS into the HBM images qp_kernel reads -- [A B] as [12][16] row-major tiles, b_i, and
 // one KKT partial per interval.
@@ -1223,19 +1262,8 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
     lin_phase(P, b, i0, n, lane, ba_s, bv_s, rec_s, q_s, r_s, part, nanp, false);
     part_s[lane] = nanp ? __builtin_nan("") : part;
     __syncthreads();
-    const int rg = lane >> 4, cl = lane & 15;
     const size_t g0 = (size_t)b * N + i0;
-    // [A B] tiles: register image r of the tile = rows rg + 4r, column cl; columns 0..2 are e_c
-    for (int il = 0; il < n; il++) {
-        const double* t = ba_s + il * kBaStage;
-        double* BA = P.BA + (g0 + il) * 192;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const int row = rg + 4 * r;
-            BA[r * 64 + lane] = cl >= 3 ? t[row * kBaStride + cl - 3] : (row == cl ? 1.0 : 0.0);
-        }
-    }
-    for (int j = lane; j < n * NX; j += 64) P.bvec[g0 * NX + j] = bv_s[j];
+    copy_out_linearisation(P, b, i0, n, lane, ba_s, bv_s);
     // one KKT partial per interval: max over the L lanes of its group, NaN-poisoning
     {
         const int L = n <= 4 ? 16 : 64 / n;
@@ -1280,6 +1308,7 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     bool nanp = false;
     lin_phase<W == 1>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
+    if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
     Inst I;
     setup_inst(P, I, b, lane);
     I.lds_ba = (const lds_f64*)ba_s;
@@ -1321,14 +1350,21 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fus
 // second wave fills the first one's MFMA / LDS / dependent-issue waits.
 __global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body<2>(P); }
 
+// function attributes are per device (a process may hold solvers on several GPUs): one flag per (launcher, device)
+static bool first_launch_on_device(int which) {
+    static bool done[3][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const bool first = !done[which][dev];
+    done[which][dev] = true;
+    return first;
+}
+
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
     const size_t lds = ((size_t)C * (kBaStage + NX + kRecInterval + NU) + (size_t)(C + 1) * NX + 64) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_launch_on_device(0))
         (void)hipFuncSetAttribute((const void*)lin_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(lin_wave_kernel, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
 }
 
@@ -1342,11 +1378,9 @@ bool fused_supported(int N) { return N <= kFusedMaxN; }
 
 void launch_fused(const DevParams& P, hipStream_t st) {
     const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX + 2 + 17) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_launch_on_device(1)) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
     static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;

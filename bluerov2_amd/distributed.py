@@ -1,5 +1,5 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm), OCP instances sharded
-contiguously over ranks, no communication during the solve, ONE all-gather of the 56-byte per-instance result records
+contiguously over ranks, no communication during the solve, ONE all-gather of the 104-byte per-instance result records (u0, cost, KKT, status, thrusts)
 afterwards, then an arg-min for best-candidate selection (BASELINE config 4).
 
 The functions below only move/inspect records, so the same code runs under the gloo backend on CPU tensors
@@ -10,7 +10,7 @@ import torch.distributed as dist
 
 from .solver import RESULT_DTYPE
 
-RECORD_BYTES = 56
+RECORD_BYTES = RESULT_DTYPE.itemsize  # 104
 
 
 def shard_bounds(total, rank, world):
@@ -55,16 +55,24 @@ def records_to_numpy(rec_bytes):
     return np.frombuffer(rec_bytes.detach().cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
 
 
-def select_best(rec_bytes):
-    """index and record of the successful instance with the smallest cost (ties -> lowest index), computed with torch ops on
-    the device holding the gathered records; returns (index, numpy record) or (-1, None)"""
+def select_best_device(rec_bytes):
+    """arg-min of cost over the successful records with torch ops on the device holding them, no host synchronisation:
+    returns (index tensor, cost tensor); the cost is +inf when no record qualifies"""
     n = rec_bytes.numel() // RECORD_BYTES
     rows = rec_bytes.view(n, RECORD_BYTES)
     cost = rows[:, 32:40].contiguous().view(torch.float64).view(n)
     status = rows[:, 48:52].contiguous().view(torch.int32).view(n)
     ok = (status == 0) & ~torch.isnan(cost)
-    if not bool(ok.any()):
-        return -1, None
     masked = torch.where(ok, cost, torch.full_like(cost, float("inf")))
-    idx = int(torch.argmin(masked).item())
-    return idx, records_to_numpy(rows[idx])[0]
+    idx = torch.argmin(masked)
+    return idx, masked[idx]
+
+
+def select_best(rec_bytes):
+    """index and record of the successful instance with the smallest cost (ties -> lowest index); returns (index, numpy
+    record) or (-1, None)"""
+    idx, cost = select_best_device(rec_bytes)
+    if not bool(torch.isfinite(cost)):
+        return -1, None
+    idx = int(idx.item())
+    return idx, records_to_numpy(rec_bytes.view(-1, RECORD_BYTES)[idx])[0]

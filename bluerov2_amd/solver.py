@@ -24,8 +24,10 @@ PATH_AUTO, PATH_STREAMING, PATH_FUSED = 0, 1, 2
 P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
 ROTOR_CONSTANT = 0.026546960744430276
 
-RESULT_DTYPE = np.dtype([("u0", "f8", (4,)), ("cost", "f8"), ("kkt", "f8"), ("status", "i4"), ("qp_iter", "i4")])
-assert RESULT_DTYPE.itemsize == 56
+RESULT_DTYPE = np.dtype([("u0", "f8", (4,)), ("cost", "f8"), ("kkt", "f8"), ("status", "i4"), ("qp_iter", "i4"),
+                         ("thrust", "f8", (6,))])
+assert RESULT_DTYPE.itemsize == 104
+ON_FAILURE_KEEP, ON_FAILURE_RESTART = 0, 1
 
 
 class NoDeviceError(RuntimeError):
@@ -35,7 +37,8 @@ class NoDeviceError(RuntimeError):
 class _Opts(C.Structure):
     _fields_ = [("N", C.c_int32), ("qp_iter_max", C.c_int32), ("Ts", C.c_double), ("W", C.c_double * 16),
                 ("We", C.c_double * 12), ("lbu", C.c_double * 4), ("ubu", C.c_double * 4), ("qp_tol_mu", C.c_double),
-                ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int32), ("kernel_path", C.c_int32)]
+                ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int32), ("kernel_path", C.c_int32),
+                ("on_failure", C.c_int32), ("reserved_", C.c_int32)]
 
 
 def library_path():
@@ -91,7 +94,9 @@ def _load():
         "brov_closed_loop": [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int32)],
         "brov_traj_set_host": [vp, dp, C.c_int], "brov_traj_rows": [vp], "brov_set_yref_from_traj": [vp, C.c_int, C.c_int, vp],
         "brov_set_yref_from_traj_lines_host": [vp, C.POINTER(C.c_int32), C.c_int],
-        "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
+        "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double],
+        "brov_set_candidate_params_host": [vp, C.c_int, dp, dp, dp], "brov_set_yref_candidates": [vp, C.c_double, C.c_double, vp],
+        "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
     }.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -235,6 +240,15 @@ class BatchSolver:
         a, b, c = (_arr(v, (self.B,)) for v in (p0, p1, phase))
         self._chk(self._L.brov_set_yref_candidates_host(self._h, k, _dp(a), _dp(b), _dp(c), float(t0), float(dt)), "set_yref_candidates")
 
+    def set_candidate_params(self, kind, p0, p1, phase):
+        """shape parameters stay on the device; set_yref_candidates_tick() then rebuilds the windows without host traffic"""
+        k = {"lemniscate": 0, "circle": 1}[kind]
+        a, b, c = (_arr(v, (self.B,)) for v in (p0, p1, phase))
+        self._chk(self._L.brov_set_candidate_params_host(self._h, k, _dp(a), _dp(b), _dp(c)), "set_candidate_params")
+
+    def set_yref_candidates_tick(self, t0, dt=0.05, stream=0):
+        self._chk(self._L.brov_set_yref_candidates(self._h, float(t0), float(dt), C.c_void_p(stream)), "set_yref_candidates_tick")
+
     def get_yref(self):
         y = np.empty((self.B, self.N + 1, NY))
         self._chk(self._L.brov_get_yref_host(self._h, _dp(y)), "get_yref")
@@ -313,6 +327,10 @@ class BatchSolver:
         t = np.empty((self.B, 6))
         self._chk(self._L.brov_get_thrusts_host(self._h, _dp(t)), "thrusts")
         return t
+
+    def debug_dump_linearisation(self, on=True):
+        """make the LDS-resident kernels write their [A B | b] out so that linearisation() works for them too (tests)"""
+        self._chk(self._L.brov_debug_dump_linearisation(self._h, int(on)), "debug_dump_linearisation")
 
     def linearisation(self):
         AB, b = np.empty((self.B, self.N, NX, 16)), np.empty((self.B, self.N, NX))

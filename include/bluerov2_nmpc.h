@@ -64,22 +64,36 @@ typedef struct brov_opts {
     double  qp_tol_mu;      /* IPM complementarity target (1e-12) */
     double  qp_tol_stat;    /* IPM stationarity target   (1e-9)  */
     int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
-    int32_t kernel_path;    /* BROV_PATH_AUTO (fused when the horizon fits LDS, N <= 23), _STREAMING, _FUSED */
+    int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above), _STREAMING, _FUSED */
+    int32_t on_failure;     /* what happens to an instance whose step fails (status NAN / MINSTEP / QP_FAILURE):
+                             *   BROV_ON_FAILURE_KEEP    iterate left untouched -- what acados' SQP_RTI does (it returns before
+                             *                           update_variables); a diverged iterate then fails again every tick
+                             *   BROV_ON_FAILURE_RESTART (default) cold restart at the measured state: x_i = x0 for all i, u = 0,
+                             *                           multipliers 0, so that the instance can recover on the next tick
+                             * In both cases the record's u0 is the last successfully computed input (zero-order hold), clamped
+                             * to [lbu, ubu] with NaN -> 0: plant / thrust consumers never see a diverged input. */
+    int32_t reserved_;
 } brov_opts;
 
+#define BROV_ON_FAILURE_KEEP 0
+#define BROV_ON_FAILURE_RESTART 1
+
 #define BROV_PATH_AUTO 0
-#define BROV_PATH_STREAMING 1 /* lin_kernel + qp_kernel, stage blocks streamed through HBM; any N <= BROV_MAX_N */
-#define BROV_PATH_FUSED 2     /* one kernel, one wavefront per instance, [A B | b] of the whole horizon resident in LDS */
+#define BROV_PATH_STREAMING 1 /* lin_wave_kernel + qp_kernel, stage blocks streamed through HBM; any N <= BROV_MAX_N */
+#define BROV_PATH_FUSED 2     /* one kernel, one wavefront per instance, stage blocks in LDS: the whole horizon (N <= 23) or a
+                               * window of <= 20 stages at a time with the other windows parked in a per-instance HBM image */
 
 #define BROV_MAX_N 128
 
-/* 56-byte per-instance result record; this is also the record all-gathered across GPUs */
+/* 104-byte per-instance result record; this is also the record all-gathered across GPUs ("optimal
+ * thrusts/costs for selection") */
 typedef struct brov_result {
     double  u0[BROV_NU];    /* optimal first input after the step  (ocp_nlp_out_get(..,0,"u")) */
     double  cost;           /* NLS objective at the updated iterate */
     double  kkt;            /* NLP KKT inf-norm of the iterate entering the step (-> ocp_nlp_out::inf_norm_res) */
     int32_t status;         /* BROV_STATUS_* */
     int32_t qp_iter;        /* interior-point iterations used (0 = early exit) */
+    double  thrust[6];      /* thrust allocation of u0, written by the solve kernel (bluerov2_dob.cpp:390-395) */
 } brov_result;
 
 typedef struct brov_solver brov_solver; /* opaque */
@@ -124,6 +138,10 @@ int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t* lines /*[B
  * kind 1 circle (p0 = radius, p1 = speed) */
 int brov_set_yref_candidates_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase /*[B]*/,
                                   double t0, double dt);
+/* the same in two steps for per-tick use: shape parameters uploaded once (HOST pointers), then one kernel per tick on `stream`
+ * (no host traffic) that rebuilds every instance's window at t0 + i*dt */
+int brov_set_candidate_params_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase /*[B]*/);
+int brov_set_yref_candidates(brov_solver* s, double t0, double dt, void* stream);
 /* read back the reference windows currently in force, as [B][N+1][16] (shared windows are replicated) */
 int brov_get_yref_host(brov_solver* s, double* yref);
 /* read back the model parameters currently in force, [B][N+1][16] */
@@ -133,6 +151,8 @@ int brov_get_params_host(brov_solver* s, double* par);
  * Plant = the OCP's own 12-state model (bluerov2.py:103-137) integrated with ERK4 over one control period with u0 of the
  * last solve and per-instance TRUE parameters (Monte-Carlo disturbance draws / model mismatch); the thrusters see
  * bluerov2_dob.cpp:390-395's allocation of that u0 (brov_get_thrusts_host). */
+/* Without brov_plant_set_params_host the plant uses the controller's own stage-0 parameters, re-read whenever they may have
+ * changed (any brov_set_params_* call, brov_params_device() hand-out) */
 int brov_plant_set_params_host(brov_solver* s, const double* p /*[B][16]*/);
 int brov_plant_step(brov_solver* s, double dt, int substeps, void* stream);   /* x0 <- ERK4(x0, u0, p_plant, dt) */
 /* `ticks` control ticks entirely on the device: window(line0 + k) -> RTI step -> plant step; like the nodes, the window
@@ -169,15 +189,16 @@ double* brov_yref_device(brov_solver* s);   /* [B][N+1][16] (always allocated; u
 double* brov_params_device(brov_solver* s); /* [B][N+1][16] */
 double* brov_x_device(brov_solver* s);
 double* brov_u_device(brov_solver* s);
-/* linearisation of the LAST solve that used the streaming path (row-major per stage: [A|B] as [12][16], b as [12]);
- * the fused path keeps it in LDS and never writes it out.  For tests. */
+/* linearisation of the LAST solve (row-major per stage: [A|B] as [12][16], b as [12]).  The streaming path always leaves it
+ * in HBM; the LDS-resident kernels write it out only after brov_debug_dump_linearisation(s, 1).  For tests. */
 int brov_get_linearisation_host(brov_solver* s, double* AB /*[B][N][12][16]*/, double* b /*[B][N][12]*/);
+int brov_debug_dump_linearisation(brov_solver* s, int enable);
 
 /* argmin of cost over instances with status SUCCESS (config 4 "best-trajectory select"); writes the winning index
  * and its record; runs on the GPU, result copied to HOST */
 int brov_select_best_host(brov_solver* s, int* best_index, brov_result* best);
 
-/* thrust allocation epilogue (bluerov2_dob.cpp:390-395): t[B][6] from the u0 of the last solve */
+/* thrust allocation (bluerov2_dob.cpp:390-395): t[B][6] = the `thrust` field the solve kernel wrote into every result record */
 int brov_get_thrusts_host(brov_solver* s, double* t6 /*[B][6]*/);
 
 /* timing of the last brov_solve (HIP events on its stream), seconds: total and per kernel [linearise, qp] */

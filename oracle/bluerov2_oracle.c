@@ -34,6 +34,7 @@ void orc_default_opts(orc_opts* o, int N, double Ts) {
     o->qp_tol_mu = 1e-12;
     o->qp_tol_stat = 1e-9;
     o->qp_early_exit = 1;
+    o->on_failure = 1;
 }
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -681,8 +682,25 @@ int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const 
         for (int j = 0; j < NU; j++) { double e = u[i * NU + j] - yref[i * NY + NX + j]; cost += 0.5 * o->Ts * o->W[NX + j] * e * e; }
     }
     for (int j = 0; j < NX; j++) { double e = x[N * NX + j] - yref[N * NY + j]; cost += 0.5 * o->We[j] * e * e; }
+    const int failed = !(status == 0 || status == 2);
+    if (failed && o->on_failure == 1) { /* cold restart at the measured state */
+        for (int i = 0; i <= N; i++) memcpy(x + (size_t)i * NX, x0, NX * sizeof(double));
+        memset(u, 0, (size_t)N * NU * sizeof(double));
+        memset(pi, 0, (size_t)N * NX * sizeof(double));
+        memset(lam, 0, (size_t)N * 8 * sizeof(double));
+    }
     if (res) {
-        for (int j = 0; j < NU; j++) res->u0[j] = u[j];
+        for (int j = 0; j < NU; j++) {
+            if (!failed) res->u0[j] = u[j];
+            else { /* hold the last successful input, sanitised */
+                double v = res->u0[j];
+                if (v != v) v = 0.0;
+                v = v < o->lbu[j] ? o->lbu[j] : v;
+                v = v > o->ubu[j] ? o->ubu[j] : v;
+                res->u0[j] = v;
+            }
+        }
+        orc_thrust_alloc(res->u0, res->thrust);
         res->cost = cost;
         res->kkt = kkt;
         res->status = status;

@@ -46,6 +46,9 @@ typedef struct orc_opts {
     double qp_tol_mu;     /* complementarity target */
     double qp_tol_stat;   /* stationarity target of the QP */
     int    qp_early_exit; /* 1: return the equality-constrained minimiser when it is feasible (exact) */
+    int    on_failure;    /* failed step (status 1/3/4): 0 keep the iterate (acados: SQP_RTI returns before update_variables),
+                           * 1 cold restart at the measured state (x_i = x0, u = 0, multipliers 0).  Either way the record's u0
+                           * holds the last successfully computed input, clamped to the bounds, NaN -> 0. */
 } orc_opts;
 
 void orc_default_opts(orc_opts* o, int N, double Ts);
@@ -73,17 +76,19 @@ int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const doub
                  const double* ub, double* dx, double* du, double* pi, double* lam, double* stats);
 
 /* RTI ------------------------------------------------------------------------------------------------ */
-/* per-instance result record, 56 bytes on the wire */
+/* per-instance result record, 104 bytes on the wire */
 typedef struct orc_result {
-    double u0[ORC_NU];
-    double cost;      /* NLS objective at the updated iterate */
+    double u0[ORC_NU]; /* in/out: a failed step holds the value passed in (last successful input) */
+    double cost;      /* NLS objective at the updated iterate (failed step: at the entering iterate) */
     double kkt;       /* NLP KKT inf-norm at the iterate ENTERING this step (with the stored multipliers) */
     int    status;
     int    qp_iter;
+    double thrust[6]; /* thrust allocation of u0 (bluerov2_dob.cpp:390-395) */
 } orc_result;
 
 /* One SQP-RTI step (preparation + feedback) for one OCP instance.
  * in:  x0[12], yref[(N+1)*16], p[(N+1)*16]; in/out iterate: x[(N+1)*12], u[N*4], pi[N*12], lam[N*8].
+ * res is in/out: res->u0 must hold the previously applied input (zeros at start) -- a failed step keeps it.
  * optional out (may be NULL): Aout[N*144], Bout[N*48], bout[N*12], qp_stats[4] */
 int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const double* p, double* x, double* u,
                  double* pi, double* lam, orc_result* res, double* Aout, double* Bout, double* bout,

@@ -21,16 +21,17 @@ _dp = C.POINTER(C.c_double)
 class OrcOpts(C.Structure):
     _fields_ = [("N", C.c_int), ("Ts", C.c_double), ("W", C.c_double * NY), ("We", C.c_double * NX),
                 ("lbu", C.c_double * NU), ("ubu", C.c_double * NU), ("qp_iter_max", C.c_int),
-                ("qp_tol_mu", C.c_double), ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int)]
+                ("qp_tol_mu", C.c_double), ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int), ("on_failure", C.c_int)]
 
 
 class OrcResult(C.Structure):
     _fields_ = [("u0", C.c_double * NU), ("cost", C.c_double), ("kkt", C.c_double), ("status", C.c_int),
-                ("qp_iter", C.c_int)]
+                ("qp_iter", C.c_int), ("thrust", C.c_double * 6)]
 
 
-RESULT_DTYPE = np.dtype([("u0", "f8", (4,)), ("cost", "f8"), ("kkt", "f8"), ("status", "i4"), ("qp_iter", "i4")])
-assert RESULT_DTYPE.itemsize == 56 == C.sizeof(OrcResult)
+RESULT_DTYPE = np.dtype([("u0", "f8", (4,)), ("cost", "f8"), ("kkt", "f8"), ("status", "i4"), ("qp_iter", "i4"),
+                         ("thrust", "f8", (6,))])
+assert RESULT_DTYPE.itemsize == 104 == C.sizeof(OrcResult)
 
 
 def build(force=False):
@@ -128,13 +129,17 @@ class Oracle:
         return dict(status=status, dx=dx, du=du, pi=pi, lam=lam, iters=int(st[0]), mu=st[1], res_stat=st[2],
                     early=bool(st[3]))
 
-    def rti_step(self, o, x0, yref, p, x, u, pi, lam, want_lin=False):
-        """in-place update of (x,u,pi,lam); returns dict(result fields [, A, B, b, qp_stats])"""
+    def rti_step(self, o, x0, yref, p, x, u, pi, lam, want_lin=False, u0_prev=None):
+        """in-place update of (x,u,pi,lam); returns dict(result fields [, A, B, b, qp_stats]).  u0_prev: the input a failed
+        step holds (default zeros)"""
         N = o.N
         x0, yref, p = _c(x0, (NX,)), _c(yref, (N + 1, NY)), _c(p, (N + 1, NP))
         for a, s in ((x, (N + 1, NX)), (u, (N, NU)), (pi, (N, NX)), (lam, (N, 8))):
             assert a.dtype == np.float64 and a.flags.c_contiguous and a.shape == s
         res = OrcResult()
+        if u0_prev is not None:
+            for j in range(NU):
+                res.u0[j] = float(u0_prev[j])
         st = np.zeros(4)
         A = np.empty((N, NX, NX)) if want_lin else None
         B = np.empty((N, NX, NU)) if want_lin else None
@@ -142,19 +147,20 @@ class Oracle:
         status = self.lib.orc_rti_step(C.byref(o), _p(x0), _p(yref), _p(p), _p(x), _p(u), _p(pi), _p(lam), C.byref(res),
                                        _p(A) if want_lin else None, _p(B) if want_lin else None,
                                        _p(b) if want_lin else None, _p(st))
-        out = dict(status=status, u0=np.array(res.u0[:]), cost=res.cost, kkt=res.kkt, qp_iter=res.qp_iter,
+        out = dict(status=status, u0=np.array(res.u0[:]), thrust=np.array(res.thrust[:]), cost=res.cost, kkt=res.kkt, qp_iter=res.qp_iter,
                    qp_mu=st[1], qp_res_stat=st[2], early=bool(st[3]))
         if want_lin:
             out.update(A=A, B=B, b=b)
         return out
 
-    def rti_step_batch(self, o, x0, yref, p, x, u, pi, lam, nthreads=0):
+    def rti_step_batch(self, o, x0, yref, p, x, u, pi, lam, nthreads=0, res_prev=None):
+        """res_prev: the previous tick's records (their u0 is what a failed step holds); default zeros"""
         N = o.N
         nb = x0.shape[0]
         x0, yref, p = _c(x0, (nb, NX)), _c(yref, (nb, N + 1, NY)), _c(p, (nb, N + 1, NP))
         for a, s in ((x, (nb, N + 1, NX)), (u, (nb, N, NU)), (pi, (nb, N, NX)), (lam, (nb, N, 8))):
             assert a.dtype == np.float64 and a.flags.c_contiguous and a.shape == s, (a.shape, s)
-        res = np.zeros(nb, dtype=RESULT_DTYPE)
+        res = np.zeros(nb, dtype=RESULT_DTYPE) if res_prev is None else np.array(res_prev, dtype=RESULT_DTYPE, copy=True)
         worst = self.lib.orc_rti_step_batch(C.byref(o), nb, _p(x0), _p(yref), _p(p), _p(x), _p(u), _p(pi), _p(lam),
                                             res.ctypes.data, int(nthreads))
         return worst, res

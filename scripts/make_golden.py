@@ -153,8 +153,42 @@ def scenario_list(circ, lem):
     return sc
 
 
+def solver_defaults():
+    """The options the reference's generator dumped next to the generated solver (bluerov2_dobmpc/scripts/acados_ocp.json),
+    reduced to the values brov_default_opts / orc_default_opts / brov_create have to reproduce.  Data only (numbers)."""
+    import json
+    d = json.load(open(f"{REF}/bluerov2_dobmpc/scripts/acados_ocp.json"))
+    so, c, k, dm = d["solver_options"], d["cost"], d["constraints"], d["dims"]
+    W, We = np.array(c["W"], dtype=float), np.array(c["W_e"], dtype=float)
+    assert np.array_equal(W, np.diag(np.diag(W))) and np.array_equal(We, np.diag(np.diag(We)))  # diagonal weights
+    assert np.array_equal(np.array(c["W_0"], dtype=float), W)
+    assert np.array_equal(np.array(c["Vx"], dtype=float)[:NX], np.eye(NX)) and np.array_equal(np.array(c["Vu"], dtype=float)[NX:], np.eye(NU))
+    ts = np.array(so["time_steps"], dtype=float)
+    out = dict(
+        source="bluerov2_dobmpc/scripts/acados_ocp.json",
+        N=int(dm["N"]), nx=int(dm["nx"]), nu=int(dm["nu"]), np=int(dm["np"]), ny=int(dm["ny"]), ny_e=int(dm["ny_e"]),
+        tf=float(so["tf"]), time_step=float(ts[0]), time_steps_uniform=bool(np.allclose(ts, ts[0], rtol=0, atol=1e-15)),
+        W_diag=[float(v) for v in np.diag(W)], We_diag=[float(v) for v in np.diag(We)],
+        lbu=[float(v) for v in k["lbu"]], ubu=[float(v) for v in k["ubu"]], idxbu=[int(v) for v in k["idxbu"]],
+        x0=[float(v) for v in k["lbx_0"]], x0_is_equality=bool(k["lbx_0"] == k["ubx_0"]),
+        yref=[float(v) for v in c["yref"]], yref_e=[float(v) for v in c["yref_e"]],
+        parameter_values=[float(v) for v in d["parameter_values"]],
+        qp_solver_iter_max=int(so["qp_solver_iter_max"]), qp_solver=so["qp_solver"], nlp_solver_type=so["nlp_solver_type"],
+        hessian_approx=so["hessian_approx"], integrator_type=so["integrator_type"],
+        sim_method_num_stages=int(np.array(so["sim_method_num_stages"]).ravel()[0]),
+        sim_method_num_steps=int(np.array(so["sim_method_num_steps"]).ravel()[0]),
+        globalization=so["globalization"], nlp_solver_step_length=float(so["nlp_solver_step_length"]),
+        qp_solver_warm_start=int(so["qp_solver_warm_start"]), levenberg_marquardt=float(so["levenberg_marquardt"]),
+        hpipm_mode=so["hpipm_mode"])
+    json.dump(out, open(os.path.join(OUT, "solver_defaults.json"), "w"), indent=1)
+    print("solver_defaults:", out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "defaults":   # only the options fixture (the others take minutes)
+        return solver_defaults()
+    solver_defaults()
     ref = CasadiRef()
     circ_path = f"{REF}/bluerov2_path/config/traj/circle.txt"
     lem_path = f"{REF}/bluerov2_path/config/traj/lemniscate.txt"

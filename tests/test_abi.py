@@ -26,18 +26,44 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
-def test_result_record_is_56_bytes():
+def test_result_record_layout():
+    """104-byte record = brov_result of include/bluerov2_nmpc.h = orc_result: what the all-gather carries"""
     import bluerov2_amd
-    assert bluerov2_amd.RESULT_DTYPE.itemsize == 56
+    from oracle import oracle_ffi
+    d = bluerov2_amd.RESULT_DTYPE
+    assert d.itemsize == 104 and d == oracle_ffi.RESULT_DTYPE
+    assert [d.fields[k][1] for k in ("u0", "cost", "kkt", "status", "qp_iter", "thrust")] == [0, 32, 40, 48, 52, 56]
+    from bluerov2_amd import distributed as D
+    assert D.RECORD_BYTES == 104
 
 
-def test_default_options_match_reference_generated_solver():
+def _defaults_fixture():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "solver_defaults.json")))
+
+
+def test_default_options_match_reference_generator_dump(oracle):
+    """brov_default_opts and orc_default_opts against the options the reference's generator dumped
+    (bluerov2_dobmpc/scripts/acados_ocp.json -> tests/golden/solver_defaults.json by scripts/make_golden.py), not against
+    hand-typed lists; the generated C renders the same values (acados_solver_bluerov2.c:422-481, :559-566, :668)."""
     import bluerov2_amd
-    o = bluerov2_amd.SolverOptions(80, 0.0125)
-    # c_generated_code/acados_solver_bluerov2.c:422-481 (W), :559-566 (bounds), :668 (qp_iter_max)
-    assert list(o.W) == [300, 480, 200, 10, 10, 200, 40, 40, 10, 10, 10, 10, 1, 1, 0.1, 0.05]
-    assert list(o.We) == [300, 480, 200, 10, 10, 200, 40, 40, 10, 10, 10, 10]
-    assert list(o.lbu) == [-50] * 4 and list(o.ubu) == [50] * 4 and o.qp_iter_max == 50
+    g = _defaults_fixture()
+    assert (g["nx"], g["nu"], g["np"], g["ny"], g["ny_e"]) == (12, 4, 16, 16, 12) and g["idxbu"] == [0, 1, 2, 3]
+    assert g["time_steps_uniform"] and g["x0_is_equality"] and abs(g["tf"] / g["N"] - g["time_step"]) < 1e-15
+    assert (g["nlp_solver_type"], g["qp_solver"], g["hessian_approx"], g["integrator_type"], g["globalization"]) == (
+        "SQP_RTI", "FULL_CONDENSING_HPIPM", "GAUSS_NEWTON", "ERK", "FIXED_STEP")
+    assert g["sim_method_num_stages"] == 4 and g["sim_method_num_steps"] == 1 and g["nlp_solver_step_length"] == 1.0
+    assert g["levenberg_marquardt"] == 0.0
+    o = bluerov2_amd.SolverOptions(g["N"], g["time_step"])
+    oo = oracle.opts(g["N"], g["time_step"])
+    for opt, get in ((o, lambda k: list(getattr(o, k))), (oo, lambda k: list(getattr(oo, k)))):
+        assert get("W") == g["W_diag"] and get("We") == g["We_diag"]
+        assert get("lbu") == g["lbu"] and get("ubu") == g["ubu"]
+        assert opt.qp_iter_max == g["qp_solver_iter_max"] and opt.N == g["N"] and opt.Ts == g["time_step"]
+    # create-time defaults of the iterate / reference / parameters (checked on the oracle here, on the GPU in test_gpu_edge)
+    x, u, pi, lam = oracle.init_iterate(oo)
+    assert np.array_equal(x, np.tile(g["x0"], (g["N"] + 1, 1))) and not u.any() and not pi.any() and not lam.any()
+    assert not any(g["yref"]) and not any(g["yref_e"]) and not any(g["parameter_values"])
 
 
 def test_no_cpu_fallback():

@@ -36,17 +36,18 @@ def test_tile_primitive_against_numpy(ba):
         assert np.abs(out - ref).max() < 1e-13, k4
 
 
-PATHS = [1, 2]  # BROV_PATH_STREAMING, BROV_PATH_FUSED (falls back to streaming when the horizon does not fit LDS)
+PATHS = [1, 2]  # BROV_PATH_STREAMING, BROV_PATH_FUSED (whole horizon in LDS for N <= 23, windowed above)
 
 
 def _path_for(ba, N, path):
-    return path if (path != ba.PATH_FUSED or N <= 23) else ba.PATH_STREAMING
+    return path if (path != ba.PATH_FUSED or N <= 23) else ba.PATH_STREAMING   # TODO(windowed kernel): drop the fallback
 
 
 def _gpu_run(ba, g, name, path=0, **optkw):
     N, Ts = int(g[f"{name}/N"]), float(g[f"{name}/Ts"])
     s = ba.BatchSolver(1, ba.SolverOptions(N, Ts, kernel_path=_path_for(ba, N, path), **optkw))
     s.set_iterate(x=g[f"{name}/x_init"][None], u=g[f"{name}/u_init"][None], pi=np.zeros((1, N, 12)), lam=np.zeros((1, N, 8)))
+    s.debug_dump_linearisation(True)   # the LDS-resident kernels copy their [A B | b] out of LDS for the comparison below
     s.set_x0(g[f"{name}/x0_meas"][None])
     s.set_params(g[f"{name}/p"][None])
     out = []
@@ -78,9 +79,9 @@ def test_against_oracle_every_scenario(ba, oracle, golden_rti, path):
         pi, lam = np.zeros((N, 12)), np.zeros((N, 8))
         for k, (r, (gx, gu, gpi, glam), (A, B, b)) in enumerate(_gpu_run(ba, g, name, path)):
             ro = oracle.rti_step(op, g[f"{name}/x0_meas"], g[f"{name}/yref{k}"], g[f"{name}/p"], x, u, pi, lam, want_lin=True)
-            if _path_for(ba, N, path) == ba.PATH_STREAMING:  # the fused path keeps the linearisation in LDS
-                assert _rel(A[0], ro["A"]) < TOL_LIN and _rel(B[0], ro["B"]) < TOL_LIN, (name, k)
-                assert np.abs(b[0] - ro["b"]).max() < 1e-10 * (1 + np.abs(ro["b"]).max()), (name, k)
+            # every path: the streaming kernels leave [A B | b] in HBM, the LDS-resident ones dump it on request
+            assert _rel(A[0], ro["A"]) < TOL_LIN and _rel(B[0], ro["B"]) < TOL_LIN, (name, k)
+            assert np.abs(b[0] - ro["b"]).max() < 1e-10 * (1 + np.abs(ro["b"]).max()), (name, k)
             assert r["status"] == ro["status"] == 0
             assert np.abs(gu[0] - u).max() < TOL_IT and np.abs(gx[0] - x).max() < TOL_IT, (name, k)
             assert abs(r["cost"] - ro["cost"]) < 1e-7 * (1 + abs(ro["cost"])), (name, k)
@@ -105,10 +106,24 @@ def _batch_inputs(golden_traj, N, nb, seed, sat_frac=0.0):
     return x0, circ
 
 
-def _well_posed(kkt):
-    """Full-step SQP without globalisation (the reference's choice, acados_solver_bluerov2.c:623) diverges for a few of
-    the large-error instances; their QPs are numerically meaningless (KKT 1e5..1e7) and excluded from 1e-7 comparisons."""
-    return kkt < 5e3
+def _scaled_ok(a, b, kkt, tol=TOL_IT):
+    """per instance: |a - b|_inf <= tol * max(1, kkt).  1e-7 absolute for well-posed instances; for the few large-error
+    instances whose full-step SQP iterates diverge (no globalisation, as in the reference: acados_solver_bluerov2.c:623) the
+    QP data itself is of size KKT (1e5..1e7) and the bound scales with it -- no instance is left out of the comparison."""
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    err = np.abs(a - b).max(axis=1)
+    return err <= tol * np.maximum(1.0, kkt), err
+
+
+def _f4_params(ba, nb, N, seed):
+    """AMPC-style model variation (bluerov2_ampc.cpp:337-380 writes added mass p[4..7], linear damping p[8..11] and quadratic
+    damping p[12..15] per stage): per instance AND per stage, +-30 % around the nominal values, plus disturbance draws"""
+    rng = np.random.default_rng(seed)
+    p = np.tile(ba.P_NOMINAL, (nb, N + 1, 1))
+    p[..., 4:] *= rng.uniform(0.7, 1.3, size=(nb, N + 1, 12))
+    p[..., 5] = rng.uniform(0.0, 1.0, size=(nb, N + 1))          # the nominal Y added mass is 0
+    p[..., :4] = rng.uniform(-200, 200, size=(nb, 1, 4))         # disturbance: per instance, constant over the horizon
+    return np.ascontiguousarray(p)
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -122,24 +137,30 @@ def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj, path
     op = oracle.opts(N)
     x, u, pi, lam = oracle.init_iterate(op, nb)
     pfull = np.ascontiguousarray(np.broadcast_to(p[:, None, :], (nb, N + 1, 16)))
-    n_ipm = 0
+    n_ipm, prev = 0, None
     for k in range(3):
         yref = circ[k:k + N + 1]
         s.set_yref(yref)
         s.solve()
         res = s.results()
         gx, gu, gpi, glam = s.get_iterate()
-        worst, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (nb, N + 1, 16))), pfull, x, u, pi, lam)
-        ok = _well_posed(ro["kkt"])
-        assert ok.mean() > 0.95
-        assert np.all(ro["status"][ok] == 0) and np.all(res["status"][ok] == 0)
-        assert np.abs(gu[ok] - u[ok]).max() < TOL_IT and np.abs(gx[ok] - x[ok]).max() < TOL_IT, k
-        assert np.abs(res["u0"][ok] - ro["u0"][ok]).max() < TOL_IT
-        assert np.abs(res["cost"][ok] - ro["cost"][ok]).max() < 1e-7 * (1 + np.abs(ro["cost"][ok]).max())
-        assert np.abs(res["kkt"][ok] - ro["kkt"][ok]).max() < 1e-6 * (1 + np.abs(ro["kkt"][ok]).max())
-        assert np.array_equal(res["qp_iter"][ok] == 0, ro["qp_iter"][ok] == 0)
-        n_ipm += int((res["qp_iter"][ok] > 0).sum())
+        worst, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (nb, N + 1, 16))), pfull, x, u, pi, lam,
+                                          res_prev=prev)
+        # EVERY instance is compared (status always, values to a KKT-scaled tolerance)
+        assert np.array_equal(res["status"], ro["status"]), (k, np.nonzero(res["status"] != ro["status"])[0])
+        kk = ro["kkt"]
+        assert (kk < 5e3).mean() > 0.95          # ... and for >95 % of them the scaled tolerance IS the absolute 1e-7
+        for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"])):
+            ok, err = _scaled_ok(a, b, kk)
+            assert ok.all(), (k, name, np.nonzero(~ok)[0], err[~ok], kk[~ok])
+        assert np.all(np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))
+        assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
+        well = kk < 5e3
+        assert np.array_equal(res["qp_iter"][well] == 0, ro["qp_iter"][well] == 0)
+        assert np.allclose(res["thrust"], ba.thrust_allocation(res["u0"]), rtol=1e-15, atol=0)
+        n_ipm += int((res["qp_iter"] > 0).sum())
         x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
+        prev = res.copy()
     assert n_ipm > 20  # the interior-point branch was exercised
     # batch invariance: instance 37 alone gives bit-identical output
     s1 = ba.BatchSolver(1, ba.SolverOptions(N, kernel_path=path))
@@ -147,6 +168,46 @@ def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj, path
     for k in range(3):
         s1.set_yref(circ[k:k + N + 1]); s1.solve()
     assert np.array_equal(s1.get_iterate()[1][0], gu[37])
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("N", [20, 40])
+def test_model_parameter_variation_per_instance_and_stage(ba, oracle, golden_traj, path, N):
+    """the AMPC node's parameter vector varies per tick and per stage (bluerov2_ampc.cpp:337-380).  256
+    instances, each stage of each instance with its own added mass / linear / quadratic damping, against the oracle:
+    linearisation 1e-11, iterates 1e-7, over 3 ticks with the parameters redrawn every tick."""
+    nb = 256
+    x0, circ = _batch_inputs(golden_traj, N, nb, seed=31, sat_frac=0.1)
+    s = ba.BatchSolver(nb, ba.SolverOptions(N, kernel_path=path))
+    s.debug_dump_linearisation(True)
+    s.set_x0(x0)
+    op = oracle.opts(N)
+    x, u, pi, lam = oracle.init_iterate(op, nb)
+    prev = None
+    for k in range(3):
+        p = _f4_params(ba, nb, N, seed=100 + k)
+        yref = circ[k:k + N + 1]
+        s.set_params(p); s.set_yref(yref); s.solve()
+        res = s.results()
+        gx, gu, gpi, glam = s.get_iterate()
+        A, Bm, bb = s.linearisation()
+        # the oracle's linearisation of the SAME entering iterate, instance by instance (first 16 only: python loop)
+        for b in range(16):
+            xo, uo, po, lo = x[b].copy(), u[b].copy(), pi[b].copy(), lam[b].copy()
+            r1 = oracle.rti_step(op, x0[b], yref, p[b], xo, uo, po, lo, want_lin=True)
+            assert _rel(A[b], r1["A"]) < TOL_LIN and _rel(Bm[b], r1["B"]) < TOL_LIN, (k, b)
+            assert np.abs(bb[b] - r1["b"]).max() < 1e-10 * (1 + np.abs(r1["b"]).max()), (k, b)
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (nb, N + 1, 16))), p, x, u, pi, lam, res_prev=prev)
+        assert np.array_equal(res["status"], ro["status"])
+        kk = ro["kkt"]
+        for name, a, b_ in (("u", gu, u), ("x", gx, x)):
+            ok, err = _scaled_ok(a, b_, kk)
+            assert ok.all(), (k, name, np.nonzero(~ok)[0], err[~ok], kk[~ok])
+        assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
+        x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
+        prev = res.copy()
+    # the parameters really differ per stage: stage 3 and stage 4 of instance 0 see different added mass
+    assert p[0, 3, 4] != p[0, 4, 4]
 
 
 def test_fused_and_streaming_paths_agree(ba, golden_traj):
@@ -161,17 +222,19 @@ def test_fused_and_streaming_paths_agree(ba, golden_traj):
         its.append((s.get_iterate(), s.results()))
     (xa, ua, pa, la), ra = its[0]
     (xb, ub, pb, lb), rb = its[1]
+    kk = np.maximum(1.0, ra["kkt"])   # every instance; tolerance scaled by the size of the instance's QP data
+    assert np.all(np.abs(ua - ub).reshape(nb, -1).max(axis=1) <= 1e-9 * kk) and np.all(np.abs(xa - xb).reshape(nb, -1).max(axis=1) <= 1e-9 * kk)
     ok = ra["kkt"] < 5e3
-    assert np.abs(ua[ok] - ub[ok]).max() < 1e-9 and np.abs(xa[ok] - xb[ok]).max() < 1e-9
     assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["qp_iter"][ok], rb["qp_iter"][ok])
-    assert np.abs(ra["kkt"][ok] - rb["kkt"][ok]).max() < 1e-9 * (1 + ra["kkt"][ok].max())
+    assert np.all(np.abs(ra["kkt"] - rb["kkt"]) <= 1e-9 * (1 + ra["kkt"]))
 
 
-def test_horizon_sweep_matches_oracle(ba, oracle, golden_traj):
-    for N in (10, 23, 40, 80):
+@pytest.mark.parametrize("path", [0, 1])
+def test_horizon_sweep_matches_oracle(ba, oracle, golden_traj, path):
+    for N in (1, 2, 5, 10, 13, 14, 23, 24, 40, 43, 64, 80, 128):
         nb = 64
         x0, circ = _batch_inputs(golden_traj, N, nb, seed=4, sat_frac=0.25)
-        s = ba.BatchSolver(nb, ba.SolverOptions(N))
+        s = ba.BatchSolver(nb, ba.SolverOptions(N, kernel_path=path))
         s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1])
         s.solve()
         op = oracle.opts(N)
