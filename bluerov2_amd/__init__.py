@@ -5,9 +5,9 @@ is the thin host-side mirror of that ABI; there is no CPU or PyTorch fallback --
 solver raises.
 """
 from .solver import (BatchSolver, SolverOptions, RESULT_DTYPE, P_NOMINAL, build_library, library_path,  # noqa: F401
-                     NoDeviceError, thrust_allocation, PATH_AUTO, PATH_STREAMING, PATH_FUSED)
+                     NoDeviceError, thrust_allocation, PATH_AUTO, PATH_STREAMING, PATH_FUSED, PATH_WINDOWED)
 
 from .ekf import BatchEkf, EkfParams  # noqa: F401,E402
 
 __all__ = ["BatchEkf", "EkfParams", "BatchSolver", "SolverOptions", "RESULT_DTYPE", "P_NOMINAL", "build_library", "library_path",
-           "NoDeviceError", "thrust_allocation", "PATH_AUTO", "PATH_STREAMING", "PATH_FUSED"]
+           "NoDeviceError", "thrust_allocation", "PATH_AUTO", "PATH_STREAMING", "PATH_FUSED", "PATH_WINDOWED"]

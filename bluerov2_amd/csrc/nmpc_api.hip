@@ -56,7 +56,11 @@ struct brov_solver {
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool ev_valid = false;
-    bool last_fused = false;
+    bool last_fused = false, last_windowed = false;
+    double* ws = nullptr;        // windowed kernel: per-block parking images
+    int32_t* counter = nullptr;
+    int win_blocks = 0;
+    bool force_windowed = false;
     unsigned long long* dbg = nullptr;
 };
 
@@ -160,6 +164,13 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(scratch3, 3 * Bz);
     AL(lines, Bz);
     AL(pplant, Bz * 16);
+    AL(counter, 4);
+    // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
+    s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
+    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING) {
+        s->win_blocks = windowed_blocks(opts->N, B);
+        AL(ws, (size_t)s->win_blocks * windowed_ws_doubles(opts->N));
+    }
 #undef AL
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
     // create defaults: yref = 0, p = 0, x0 = [0,0,-20,0..] (acados_solver_bluerov2.c:355-364, 405-420, 520-527)
@@ -478,6 +489,8 @@ static DevParams make_params(const brov_solver* s) {
     P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
+    P.ws = s->ws; P.ws_stride = (int64_t)windowed_ws_doubles(s->N); P.counter = s->counter;
+    P.win_L = windowed_stage_count(s->N); P.win_blocks = s->win_blocks;
     P.dbg = s->dbg;
     return P;
 }
@@ -488,12 +501,16 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     hipStream_t st = (hipStream_t)stream;
     const DevParams P = make_params(s);
     const int path = s->opts.kernel_path;
-    if (path == BROV_PATH_FUSED && !fused_supported(s->N)) { g_err = "brov_solve: horizon too long for the fused (LDS-resident) path"; return BROV_ERR_ARG; }
-    const bool fused = rti_phase == 0 && path != BROV_PATH_STREAMING && fused_supported(s->N);
+    // LDS-resident kernels (one launch): whole horizon for N <= 23, windowed above.  rti_phase 1 / 2 (preparation and feedback as
+    // separate calls) need the linearisation in HBM between the calls: streaming kernels.
+    const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING;
+    const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
+    const bool windowed = lds_path && !fused && s->ws != nullptr;
     if (s->timing) hipEventRecord(s->ev[0], st);
-    if (fused) {
+    if (fused || windowed) {
         if (s->timing) hipEventRecord(s->ev[1], st);
-        launch_fused(P, st);
+        if (fused) launch_fused(P, st);
+        else launch_windowed(P, st);   // counter reset + persistent blocks
     } else {
         if (rti_phase != 2) launch_linearise(P, st);
         if (s->timing) hipEventRecord(s->ev[1], st);
@@ -501,6 +518,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     }
     if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
     s->last_fused = fused;
+    s->last_windowed = windowed;
     s->last_stream = st;
     HIPCHK(hipGetLastError());
     return BROV_OK;
@@ -524,7 +542,9 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return BROV_OK;
 }
-extern "C" int brov_last_kernel_path(const brov_solver* s) { return s ? (s->last_fused ? BROV_PATH_FUSED : BROV_PATH_STREAMING) : BROV_ERR_ARG; }
+extern "C" int brov_last_kernel_path(const brov_solver* s) {
+    return s ? (s->last_fused ? BROV_PATH_FUSED : (s->last_windowed ? BROV_PATH_WINDOWED : BROV_PATH_STREAMING)) : BROV_ERR_ARG;
+}
 extern "C" int brov_debug_dump_linearisation(brov_solver* s, int enable) {
     if (!s) return BROV_ERR_ARG;
     s->dump_lin = enable != 0;

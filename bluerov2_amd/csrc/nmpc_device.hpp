@@ -48,6 +48,11 @@ struct DevParams {
     double* dxb;    // [B][N+1][12] QP primal step of the states
     const double* cst;  // [W16 | We12 pad4 | lbu4 | ubu4]
     brov_result* res;
+    // windowed kernel (N >= 24): per-block parking image + scratch, instance hand-out counter, stages per window
+    double* ws;
+    int64_t ws_stride;   // doubles per block
+    int32_t* counter;
+    int32_t win_L, win_blocks;
     unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
@@ -56,7 +61,12 @@ enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_
 void launch_linearise(const DevParams& P, hipStream_t st);
 void launch_qp(const DevParams& P, hipStream_t st);
 void launch_fused(const DevParams& P, hipStream_t st);  // linearise + QP in one kernel, stage blocks in LDS
-bool fused_supported(int N);
+bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
+// windowed LDS-resident kernel for longer horizons: persistent blocks (one wavefront each) that take instances from a counter
+void launch_windowed(const DevParams& P, hipStream_t st);
+int windowed_stage_count(int N);          // stages per window
+int windowed_blocks(int N, int B);        // persistent blocks that will be launched on the current device
+size_t windowed_ws_doubles(int N);        // per-block workspace
 void launch_window(const double* traj, int rows, const int* lines, int line0, int B, int N, int ncols, double* out, hipStream_t st);
 void launch_plant(double* x0, const brov_result* res, const double* pplant, int B, double dt, int substeps, double* xlog, double* ulog,
                   hipStream_t st);

@@ -23,6 +23,10 @@ namespace brov {
 
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) dbl2 lds_d2;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_cvoid;
 
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -79,7 +83,8 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 
 // everything one wave needs to know about its instance
 struct Inst {
-    int lane, rg, cl, N, nv;
+    int lane, rg, cl, N, nv;   // N = stages the sweeps run over (the whole horizon, or the resident window of it)
+    int i0, NT;                // windowed kernel: global index of the window's first stage, total horizon (else 0, N)
     const double* x;     // [N+1][12] entering iterate
     const double* u;     // [N][4]
     const double* yref;  // [N+1][16]
@@ -225,7 +230,8 @@ template <bool FACTOR, int LDS, bool STEP0 = false>
 __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* gam, const double* rt) {
     BwdIn s;
     s.ba = get_ba<LDS>(I, i);
-    s.bv = FACTOR ? get_bv<LDS>(I, i) : load_vec12(I.Pb + (size_t)i * 12, I.rg);
+    const int ig = I.i0 + i;   // HBM-resident operands are indexed by the global stage
+    s.bv = FACTOR ? get_bv<LDS>(I, i) : load_vec12(I.Pb + (size_t)ig * 12, I.rg);
     if constexpr (LDS) {
 #pragma unroll
         for (int r = 0; r < 3; r++) { s.xv[r] = I.lds_q[i * 12 + I.rg + 4 * r]; s.yv[r] = 0.0; }
@@ -240,24 +246,23 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
         else s.rtv = I.Ts * I.Wr[3] * (I.u[i * 4 + I.rg] - I.yref[(size_t)i * 16 + 12 + I.rg]);
         s.gm = 0.0;
     } else {
-        s.rtv = rt[i * 4 + I.rg];
-        s.gm = FACTOR ? gam[i * 4 + I.rg] : 0.0;
+        s.rtv = rt[ig * 4 + I.rg];
+        s.gm = FACTOR ? gam[ig * 4 + I.rg] : 0.0;
     }
-    s.ks = FACTOR ? 0.0 : I.Ks[(size_t)i * 64 + I.lane];
-    s.mt = FACTOR ? 0.0 : I.Mt[(size_t)i * 64 + I.lane];
+    s.ks = FACTOR ? 0.0 : I.Ks[(size_t)ig * 64 + I.lane];
+    s.mt = FACTOR ? 0.0 : I.Mt[(size_t)ig * 64 + I.lane];
     return s;
 }
 
 // backward Riccati sweep.  FACTOR = true: factorise with the current Gamma (ipm[GAM]) and solve for rhs ipm[RT];
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
-// not positive definite.
-template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
-__device__ bool riccati_backward(const Inst& I) {
-    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
-    const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
-    const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
-    wave_fence();
-    BwdIn nx;
+// not positive definite.  The sweep is split into bwd_init (terminal cost -> P, p) and bwd_chunk (the stages of the resident
+// window, state carried in registers) so that the windowed kernel can run it window by window.
+struct BwdState { d4 P, pv; bool ok; };
+
+template <bool FACTOR, int LDS>
+__device__ __forceinline__ void bwd_init(const Inst& I, BwdState& S) {
+    const int rg = I.rg, cl = I.cl, N = I.N;
     d4 P = {0, 0, 0, 0}, pv;
     {
         const double* xN = I.x + (size_t)N * 12;
@@ -275,7 +280,18 @@ __device__ bool riccati_backward(const Inst& I) {
             for (int r = 0; r < 3; r++) pv[r] = (cl == 0) ? pv[r] : 0.0;
         }
     }
-    bool ok = true;
+    S.P = P; S.pv = pv; S.ok = true;
+}
+
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
+__device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
+    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
+    const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
+    const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
+    BwdIn nx;
+    d4& P = S.P;
+    d4& pv = S.pv;
+    bool& ok = S.ok;
     const d4 z4 = {0, 0, 0, 0};
     const unsigned mk_col0 = cl == 0 ? ~0u : 0u;
     d4 diagm;  // stage cost diag(Ts*Wx, Ts*Wu) in tile layout
@@ -303,7 +319,7 @@ __device__ bool riccati_backward(const Inst& I) {
             for (int r = 0; r < 3; r++) ba1[r] = blend(mk_col0, in.bv[r], in.ba[r]);
             ba1[3] = 0.0;
             const d4 Pb = tn<3>(P, ba1, z4);
-            if (STORE_IPM) store_vec12(I.Pb + (size_t)i * 12, Pb, rg, cl);
+            if (STORE_IPM) store_vec12(I.Pb + (size_t)(I.i0 + i) * 12, Pb, rg, cl);
 #pragma unroll
             for (int r = 0; r < 3; r++) Y2[r] = Pb[r] + pv[r];   // pv is zero outside column 0
             Y2[3] = 0.0;
@@ -367,8 +383,8 @@ __device__ bool riccati_backward(const Inst& I) {
             d4 pn = tn1(ks, g[3], g);
             // store factors
             if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads these
-                I.Ks[(size_t)i * 64 + lane] = ks;
-                I.Mt[(size_t)i * 64 + lane] = mt;
+                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = ks;
+                I.Mt[(size_t)(I.i0 + i) * 64 + lane] = mt;
             }
             if constexpr (LDS) {
                 // K^T[k][m] = -T[m][k] is ks at lane (rg = m, cl = k): the compact LDS image [12][4] is written straight from
@@ -415,7 +431,15 @@ __device__ bool riccati_backward(const Inst& I) {
             stage(i, in);
         }
     }
-    return ok;
+}
+
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
+__device__ bool riccati_backward(const Inst& I) {
+    BwdState S;
+    wave_fence();
+    bwd_init<FACTOR, LDS>(I, S);
+    bwd_chunk<FACTOR, LDS, STORE_IPM, STEP0>(I, S);
+    return S.ok;
 }
 
 struct FwdIn { d4 kt, bat, bb; double kf; };
@@ -435,12 +459,10 @@ __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
 }
 
 // forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i.
-// Leaves vhat in I.vhat and the state steps in I.dxb.
+// Leaves vhat in I.vhat and the state steps in I.dxb.  fwd_chunk: the stages of the resident window, dx carried in xx.
 template <int LDS>
-__device__ void riccati_forward(const Inst& I, const d4& d0) {
+__device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
     const int rg = I.rg, cl = I.cl, N = I.N;
-    wave_fence();
-    d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
         // two stages ahead (see adjoint<>): the LDS reads of a stage are in flight for a whole stage before they are needed
@@ -465,6 +487,12 @@ __device__ void riccati_forward(const Inst& I, const d4& d0) {
             store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
         });
     }
+}
+template <int LDS>
+__device__ void riccati_forward(const Inst& I, const d4& d0) {
+    wave_fence();
+    d4 xx = d0;
+    fwd_chunk<LDS>(I, xx);
     wave_fence();
 }
 
@@ -479,10 +507,8 @@ __device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* 
 }
 // roll the linearised dynamics out for the inputs in varr -> I.dxb
 template <int LDS>
-__device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
+__device__ __forceinline__ void roll_chunk(const Inst& I, d4& xx, const double* varr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
-    wave_fence();
-    d4 xx = d0;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
         pipelined<kLdsDist<LDS>, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
@@ -499,6 +525,12 @@ __device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
             store_vec12(I.dxb + (size_t)(i + 1) * 12, xx, rg, cl);
         });
     }
+}
+template <int LDS>
+__device__ void rollout(const Inst& I, const d4& d0, const double* varr) {
+    wave_fence();
+    d4 xx = d0;
+    roll_chunk<LDS>(I, xx, varr);
     wave_fence();
 }
 
@@ -531,16 +563,14 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
 // LDS path: both outputs go to LDS regions that are dead at this point (g -> the feed-forward array, pi -> the K^T array,
 // 12 of its 48 doubles per stage); per-stage global stores would sit on vmcnt in front of every prefetch wait.
 template <bool COMMIT, int LDS>
-__device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
+__device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
-    wave_fence();
-    d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
     const d4 z4 = {0, 0, 0, 0};
     auto stage = [&](int i, const AdjIn& in) __attribute__((always_inline)) {
         d4 pi;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const double qd = (i + 1 == N) ? I.Wer[r] : I.Ts * I.Wr[r];
+            const double qd = (I.i0 + i + 1 == I.NT) ? I.Wer[r] : I.Ts * I.Wr[r];
             pi[r] = LDS ? qd * in.dx[r] + in.xn[r] + atpi[r] : qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
         }
         pi[3] = 0.0;
@@ -564,7 +594,154 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
         pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
                             [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
     }
+}
+template <bool COMMIT, int LDS>
+__device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
     wave_fence();
+    d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
+    adj_chunk<COMMIT, LDS>(I, atpi, varr, garr, pi_out);
+    wave_fence();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Windowed LDS residency (rti_window_kernel, horizons that do not fit the LDS slice: N >= 24).  The LDS slice holds the stage
+// blocks of ONE window of <= 20 consecutive stages in exactly the layout of the fused kernel; the windows that are not
+// resident are parked in a per-block HBM image (flat over the stages, array by array) and move as contiguous pieces:
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging, one vmcnt wait per window),
+// LDS -> HBM through registers in batches of eight 16-byte pieces per lane.  Every sweep is a loop over windows with its
+// recursion state (P, p / dx / A'pi) carried in registers; a sweep fetches only the arrays it reads and writes back only the
+// arrays it produced.  The window left resident by one sweep is the first window of the next one (sweeps alternate direction).
+enum : unsigned { WM_BA = 1, WM_BV = 2, WM_KT = 4, WM_KFF = 8, WM_DX = 16, WM_Q = 32, WM_R = 64 };
+struct Win {
+    int nc, Lc;         // number of windows, stages per window (the last one may be shorter)
+    int cur;            // resident window
+    unsigned valid;     // arrays of the resident window that are valid in LDS
+    double *ba, *bv, *kt, *kff, *vh, *dx, *q, *r;          // LDS arrays (generic pointers)
+    double *ws_ba, *ws_bv, *ws_kt, *ws_kff, *ws_q, *ws_r;  // parked image of the whole horizon (per block)
+};
+
+// nd doubles (even, 16-byte aligned on both sides), HBM -> LDS, asynchronous: wait with s_waitcnt vmcnt(0) before reading
+__device__ __forceinline__ void win_fetch(const double* g, double* l, int nd, int lane) {
+    for (int o = 0; o < nd; o += 128)
+        if (o + lane * 2 < nd) __builtin_amdgcn_global_load_lds((glb_cvoid*)(g + o + lane * 2), (lds_void*)(l + o), 16, 0, 0);
+}
+// LDS -> HBM; the LDS source may be overwritten as soon as this returns (its reads have landed in registers)
+__device__ __forceinline__ void win_flush(double* g, const double* l, int nd, int lane) {
+    const lds_d2* lv = (const lds_d2*)l;
+    for (int o0 = 0; o0 < nd; o0 += 1024) {
+        dbl2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int o = o0 + (k * 64 + lane) * 2;
+            v[k] = lv[(o < nd ? o : 0) >> 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int o = o0 + (k * 64 + lane) * 2;
+            if (o < nd) *(dbl2*)(g + o) = v[k];
+        }
+    }
+}
+__device__ __forceinline__ void win_select(Inst& I, Win& W, int c) {
+    if (c != W.cur) {
+        W.cur = c;
+        W.valid = 0;
+        I.i0 = c * W.Lc;
+        I.N = (I.NT - I.i0 < W.Lc) ? I.NT - I.i0 : W.Lc;
+    }
+}
+// make window c resident with (at least) the arrays in `mask`; vh_src != nullptr: the window's candidate inputs are fetched from
+// that flat [N][4] array (they are never trusted to be resident: forward / interior-point loop / commit use different arrays)
+__device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, const double* vh_src) {
+    win_select(I, W, c);
+    const unsigned need = mask & ~W.valid;
+    const int i0 = I.i0, n = I.N, lane = I.lane;
+    __syncthreads();   // single wave: every lane is done with the slice's previous content, earlier stores are issued
+    if (need & WM_BA) win_fetch(W.ws_ba + (size_t)i0 * kBaStage, W.ba, n * kBaStage, lane);
+    if (need & WM_BV) win_fetch(W.ws_bv + i0 * NX, W.bv, n * NX, lane);
+    if (need & WM_KT) win_fetch(W.ws_kt + i0 * kKtStage, W.kt, n * kKtStage, lane);
+    if (need & WM_KFF) win_fetch(W.ws_kff + i0 * 4, W.kff, n * 4, lane);
+    if (need & WM_Q) win_fetch(W.ws_q + i0 * NX, W.q, (n + 1) * NX, lane);      // row n: next window's first stage / terminal
+    if (need & WM_R) win_fetch(W.ws_r + i0 * 4, W.r, n * 4, lane);
+    if (need & WM_DX) win_fetch(I.dxb + i0 * NX, W.dx, (n + 1) * NX, lane);
+    if (vh_src) win_fetch(vh_src + i0 * 4, W.vh, n * 4, lane);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    W.valid |= mask;
+}
+
+template <int LDS>
+__device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0) {
+    if constexpr (LDS != 3) {
+        riccati_forward<LDS>(I, d0);
+    } else {
+        wave_fence();
+        d4 xx = d0;
+        for (int c = 0; c < W->nc; c++) {
+            win_need(I, *W, c, WM_BA | WM_BV | WM_KT | WM_KFF, nullptr);
+            fwd_chunk<3>(I, xx);
+            __syncthreads();
+            win_flush(I.vhat + I.i0 * 4, W->vh, I.N * 4, I.lane);
+            win_flush(I.dxb + I.i0 * NX, W->dx, (I.N + 1) * NX, I.lane);
+            W->valid |= WM_DX;
+        }
+        wave_fence();
+    }
+}
+template <int LDS>
+__device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const double* varr) {
+    if constexpr (LDS != 3) {
+        rollout<LDS>(I, d0, varr);
+    } else {
+        wave_fence();
+        d4 xx = d0;
+        for (int c = 0; c < W->nc; c++) {
+            win_need(I, *W, c, WM_BA | WM_BV, varr);
+            roll_chunk<3>(I, xx, varr);
+            __syncthreads();
+            win_flush(I.dxb + I.i0 * NX, W->dx, (I.N + 1) * NX, I.lane);
+            W->valid |= WM_DX;
+        }
+        wave_fence();
+    }
+}
+template <bool COMMIT, int LDS>
+__device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, double* garr, double* pi_out) {
+    if constexpr (LDS != 3) {
+        adjoint<COMMIT, LDS>(I, varr, garr, pi_out);
+    } else {
+        wave_fence();
+        d4 atpi = {0, 0, 0, 0};
+        for (int c = W->nc - 1; c >= 0; c--) {
+            win_need(I, *W, c, WM_BA | WM_DX | WM_Q | WM_R, varr);
+            adj_chunk<COMMIT, 3>(I, atpi, varr, garr, pi_out);
+            W->valid &= ~(WM_KT | WM_KFF);   // multipliers / input gradient were staged in the K^T / feed-forward areas
+            __syncthreads();
+            if (COMMIT) win_flush(pi_out + (size_t)I.i0 * NX, W->kt, I.N * NX, I.lane);
+            win_flush(garr + I.i0 * 4, W->kff, I.N * 4, I.lane);
+        }
+        wave_fence();
+    }
+}
+template <bool FACTOR, int LDS>
+__device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
+    if constexpr (LDS != 3) {
+        return riccati_backward<FACTOR, LDS>(I);
+    } else {
+        wave_fence();
+        BwdState S;
+        for (int c = W->nc - 1; c >= 0; c--) {
+            win_need(I, *W, c, FACTOR ? (WM_BA | WM_BV | WM_Q) : (WM_BA | WM_Q), nullptr);
+            if (c == W->nc - 1) bwd_init<FACTOR, 3>(I, S);
+            bwd_chunk<FACTOR, 3, true, false>(I, S);
+            __syncthreads();
+            if (FACTOR) win_flush(W->ws_kt + (size_t)I.i0 * kKtStage, W->kt, I.N * kKtStage, I.lane);
+            win_flush(W->ws_kff + I.i0 * 4, W->kff, I.N * 4, I.lane);
+            W->valid |= FACTOR ? (WM_KT | WM_KFF) : WM_KFF;
+        }
+        wave_fence();
+        return S.ok;
+    }
 }
 
 // one interior-point vector: two elements per lane in registers (fused path, nv <= 128) or an HBM array (streaming path)
@@ -581,10 +758,15 @@ struct IpmVec {
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
 #define DBG_STAMP(slot) do { if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 
+// LDS = 0 streaming kernels, 1 / 2 fused kernels (whole horizon resident; element arrays in LDS / registers: EL), 3 windowed
+// kernel (sweeps on the resident window through the sw_* wrappers, element loops on the flat HBM arrays like LDS = 0; the
+// step-0 factorisation has already run, fused with the linearisation: pre_ok)
 template <int LDS>
-__device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan) {
+__device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan, Win* W = nullptr,
+                                        bool pre_ok = true) {
+    constexpr bool EL = (LDS == 1 || LDS == 2);
     const double* __restrict__ cst = P.cst;
-    const int lane = I.lane, N = I.N, nv = I.nv;
+    const int lane = I.lane, N = I.NT, nv = I.nv;
     DBG_STAMP(1);
     const int rg = I.rg;
 
@@ -601,12 +783,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     double* RT = I.ipm + (size_t)IPM_RT * nv;
     double* DVA = I.ipm + (size_t)IPM_DVA * nv;
     // where adjoint<> leaves the input gradient g: HBM array, or (fused path) the dead feed-forward array in LDS
-    const double* GRAD = LDS ? (const double*)I.kff : (const double*)DVA;
+    const double* GRAD = EL ? (const double*)I.kff : (const double*)DVA;
     // element accessors: LDS-typed on the fused path (a generic pointer into LDS compiles to flat loads / stores)
-    auto rd_vhat = [&](int j) -> double { if constexpr (LDS) return I.lds_vhat[j]; else return I.vhat[j]; };
-    auto wr_vhat = [&](int j, double v) { if constexpr (LDS) I.lds_vhat[j] = v; else I.vhat[j] = v; };
-    auto rd_dxb = [&](int j) -> double { if constexpr (LDS) return I.lds_dxb[j]; else return I.dxb[j]; };
-    auto rd_grad = [&](int j) -> double { if constexpr (LDS) return I.lds_kff[j]; else return GRAD[j]; };
+    auto rd_vhat = [&](int j) -> double { if constexpr (EL) return I.lds_vhat[j]; else return I.vhat[j]; };
+    auto wr_vhat = [&](int j, double v) { if constexpr (EL) I.lds_vhat[j] = v; else I.vhat[j] = v; };
+    auto rd_dxb = [&](int j) -> double { if constexpr (EL) return I.lds_dxb[j]; else return I.dxb[j]; };
+    auto rd_grad = [&](int j) -> double { if constexpr (EL) return I.lds_kff[j]; else return GRAD[j]; };
 
     // d0 = x0 - x_0, row-replicated; KKT of the entering iterate = max(LIN partials, |d0|)
     d4 d0;
@@ -629,7 +811,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     // ---- step 0: equality-constrained minimiser (Gamma = 0, rhs = r) ---------------------------------------
     // fused path: this lane's share of u (needed for the bound check right after the forward sweep) is requested now
     double ureg[2] = {0.0, 0.0};
-    if constexpr (LDS) {
+    if constexpr (EL) {
 #pragma unroll
         for (int t = 0; t < 2; t++)
             if (lane + 64 * t < nv) ureg[t] = I.u[lane + 64 * t];
@@ -637,15 +819,16 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false;
-    bool ok = riccati_backward<true, LDS, false, true>(I);
+    bool ok = pre_ok;
+    if constexpr (LDS != 3) ok = riccati_backward<true, LDS, false, true>(I);
     DBG_STAMP(2);
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
-        riccati_forward<LDS>(I, d0);
+        sw_forward<LDS>(I, W, d0);
         DBG_STAMP(3);
         bool feas = true;
-        if constexpr (LDS) {  // nv <= 92: two elements per lane, u already in registers
+        if constexpr (EL) {  // nv <= 92: two elements per lane, u already in registers
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const int j = lane + 64 * t;
@@ -670,13 +853,13 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // Fused path: the interior-point vectors (two elements per lane, nv <= 92) live in registers -- at one wave per
             // SIMD every element loop over HBM-resident vectors costs an exposed L2 round trip; only Gamma and the right-hand
             // side, which the backward sweep reads by stage, go through memory.
-            IpmVec<(LDS != 0)> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
+            IpmVec<EL> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
                 vDLL{{0, 0}, GAM}, vDLU{{0, 0}, RT};   // dual steps: registers, or parked in GAM / RT (both rebuilt every iteration)
 #define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const int j = lane + 64 * t; j < nv)
-            constexpr int kIpmT = LDS ? 2 : 8;   // streaming path: nv <= 512
+            constexpr int kIpmT = EL ? 2 : 8;   // streaming path: nv <= 512
             IPM_FOR(t, j) {
                 const int m = j & 3;
-                const double uj = LDS ? ureg[t & 1] : I.u[j];
+                const double uj = EL ? ureg[t & 1] : I.u[j];
                 const double lb = cst[32 + m] - uj, ub = cst[36 + m] - uj;
                 const double wdt = ub - lb;
                 double vj = rd_vhat(j);
@@ -684,10 +867,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 vj = (vj < lo) ? lo : vj;
                 vj = (vj > hi) ? hi : vj;
                 vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
-                if constexpr (LDS) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
+                if constexpr (EL) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
             }
-            rollout<LDS>(I, d0, V);
-            adjoint<false, LDS>(I, V, DVA, nullptr);
+            sw_rollout<LDS>(I, W, d0, V);
+            sw_adjoint<false, LDS>(I, W, V, DVA, nullptr);
             double g0 = 0.0;
             for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(rd_grad(j)));
             g0 = wave_max(g0);
@@ -709,15 +892,15 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     s += ll * tl + lu * tu;
                     const double gm = ll / tl + lu / tu;
                     GAM[j] = gm;
-                    if constexpr (LDS) gam_r[t & 1] = gm;
+                    if constexpr (EL) gam_r[t & 1] = gm;
                     const int m = j & 3;
-                    const double rr = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+                    const double rr = EL ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
                     RT[j] = rr - gm * vV.get(t, j);
                 }
                 mu = wave_sum(s) * inv2nv;
-                ok = riccati_backward<true, LDS>(I);
+                ok = sw_backward<true, LDS>(I, W);
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
-                riccati_forward<LDS>(I, d0);
+                sw_forward<LDS>(I, W, d0);
                 // predictor step length and centering
                 double aaff = 1.0;
                 IPM_FOR(t, j) {
@@ -746,12 +929,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                     const double cl_ = dll * dv, cu_ = -dlu * dv;
                     const int m = j & 3;
-                    const double rr = LDS ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
-                    const double gm = LDS ? gam_r[t & 1] : GAM[j];
+                    const double rr = EL ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
+                    const double gm = EL ? gam_r[t & 1] : GAM[j];
                     RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
                 }
-                (void)riccati_backward<false, LDS>(I);
-                riccati_forward<LDS>(I, d0);
+                (void)sw_backward<false, LDS>(I, W);
+                sw_forward<LDS>(I, W, d0);
                 double amax = 1e300;
                 IPM_FOR(t, j) {
                     const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dva = vDVA.get(t, j);
@@ -787,7 +970,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if (mu <= P.tol_mu && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
             }
             // the final inputs go where the finalisation expects them: V (streaming path, already there) / the LDS copy
-            if constexpr (LDS) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
+            if constexpr (EL) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
 #undef IPM_FOR
             if (iters > P.qp_iter_max) iters = P.qp_iter_max;
         }
@@ -796,21 +979,21 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     // ---- finalise: consistent primal/dual for the final inputs, multiplier recovery, full step ---------------
     // Element loops issue all their loads before the first use (UX/UU elements per lane per chunk): at one wave per SIMD
     // every dependent global round trip is otherwise fully exposed (~2 us each).
-    constexpr int UX = LDS ? 5 : 4, UU = LDS ? 2 : 4;
-    const double* vfin = (early || LDS) ? I.vhat : V;   // fused path: the interior-point loop leaves its inputs in the LDS copy
+    constexpr int UX = EL ? 5 : 4, UU = EL ? 2 : 4;
+    const double* vfin = (early || EL) ? I.vhat : V;   // fused path: the interior-point loop leaves its inputs in the LDS copy
     const int nxe = (N + 1) * 12;
     double cost = 0.0;
     bool wrote_u0 = false;
     double u0v = 0.0;   // lanes 0..3: first input of the result record
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
         if (!early) {  // early exit: dxb already holds the states of the accepted Newton point
-            rollout<LDS>(I, d0, V);
+            sw_rollout<LDS>(I, W, d0, V);
         }
         DBG_STAMP(4);
         // fused path: the iterate and the reference of the commit loops below are requested before the adjoint sweep, which
         // hides their round trip (the single resident wave has nothing else to switch to)
         double xpre[UX], ypre[UX], urpre[UU];
-        if constexpr (LDS) {
+        if constexpr (EL) {
 #pragma unroll
             for (int t = 0; t < UX; t++) {
                 const int j = lane + 64 * t;
@@ -826,11 +1009,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 urpre[t] = I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
             }
         }
-        adjoint<true, LDS>(I, vfin, DVA, pi_it);
+        sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
         DBG_STAMP(5);
         bool nanv = false;
         for (int j = lane; j < nv; j += 64) {
-            const double vj = LDS ? rd_vhat(j) : vfin[j];
+            const double vj = EL ? rd_vhat(j) : vfin[j];
             if (!(vj == vj)) nanv = true;
         }
         for (int j = lane; j < nxe; j += 64) {
@@ -847,10 +1030,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const int j = j0 + 64 * t;
                     const bool in = j < nv;
                     const int jj = in ? j : 0;
-                    uo[t] = (LDS && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
-                    vv[t] = LDS ? rd_vhat(jj) : vfin[jj];
+                    uo[t] = (EL && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
+                    vv[t] = EL ? rd_vhat(jj) : vfin[jj];
                     gg[t] = early ? 0.0 : rd_grad(jj);
-                    ur[t] = (LDS && j0 == lane) ? urpre[t] : I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
+                    ur[t] = (EL && j0 == lane) ? urpre[t] : I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
                 }
 #pragma unroll
                 for (int t = 0; t < UU; t++) {
@@ -868,7 +1051,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
             wrote_u0 = true;
-            if constexpr (LDS) {  // multipliers staged in LDS by adjoint<>: [N][12] at the head of the K^T array
+            if constexpr (EL) {  // multipliers staged in LDS by adjoint<>: [N][12] at the head of the K^T array
                 for (int j = lane; j < N * 12; j += 64) pi_it[j] = I.lds_kt[j];
             }
             for (int j0 = lane; j0 < nxe; j0 += 64 * UX) {
@@ -878,9 +1061,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const int j = j0 + 64 * t;
                     const int jj = j < nxe ? j : 0;
                     const int i = jj / 12, c = jj - i * 12;
-                    xo[t] = (LDS && j0 == lane) ? xpre[t] : x_it[jj];
+                    xo[t] = (EL && j0 == lane) ? xpre[t] : x_it[jj];
                     dj[t] = rd_dxb(jj);
-                    yr[t] = (LDS && j0 == lane) ? ypre[t] : I.yref[(size_t)i * 16 + c];
+                    yr[t] = (EL && j0 == lane) ? ypre[t] : I.yref[(size_t)i * 16 + c];
                 }
 #pragma unroll
                 for (int t = 0; t < UX; t++) {
@@ -900,17 +1083,20 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         // failed step: report the cost of the entering iterate; the iterate is left as it is (acados: SQP_RTI returns before
         // update_variables) or, with on_failure = RESTART, cold-started at the measured state so that the instance can recover
         const double* x0 = P.x0 + (size_t)b * 12;
+        // a restart needs a usable measurement: with a non-finite x0 (sensor glitch) the iterate is kept for the next tick
+        const double xl = x0[lane < 12 ? lane : 0];
+        const bool restart = P.on_failure == BROV_ON_FAILURE_RESTART && __ballot(!(fabs(xl) < 1e300)) == 0ull;
         for (int j = lane; j < nv; j += 64) {
             const int i = j >> 2, m = j & 3;
             const double e = u_it[j] - I.yref[(size_t)i * 16 + 12 + m];
             cost += 0.5 * P.Ts * cst[12 + m] * e * e;
-            if (P.on_failure == BROV_ON_FAILURE_RESTART) { u_it[j] = 0.0; lam_it[i * 8 + m] = 0.0; lam_it[i * 8 + 4 + m] = 0.0; }
+            if (restart) { u_it[j] = 0.0; lam_it[i * 8 + m] = 0.0; lam_it[i * 8 + 4 + m] = 0.0; }
         }
         for (int j = lane; j < nxe; j += 64) {
             const int i = j / 12, c = j - i * 12;
             const double e = x_it[j] - I.yref[(size_t)i * 16 + c];
             cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
-            if (P.on_failure == BROV_ON_FAILURE_RESTART) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
+            if (restart) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
         }
     }
     cost = wave_sum(cost);
@@ -945,6 +1131,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     const int N = P.N, nv = 4 * N;
     const double* __restrict__ cst = P.cst;
     I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
+    I.i0 = 0; I.NT = N;
     I.x = P.x + (size_t)b * (N + 1) * 12;
     I.u = P.u + (size_t)b * N * 4;
     I.yref = P.yref + (size_t)b * P.yref_stride;
@@ -1003,8 +1190,6 @@ __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
 
 // coalesced global -> LDS staging of one instance's contiguous input arrays (16 bytes per lane per request).  All requests
 // of all arrays are issued before the first LDS write so that they overlap; nd = number of doubles (even).
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) dbl2 lds_d2;
 template <int MAXC>
 __device__ __forceinline__ void stage_issue(const double* __restrict__ g, int nd, int lane, dbl2 (&v)[MAXC]) {
 #pragma unroll
@@ -1360,6 +1545,129 @@ static bool first_launch_on_device(int which) {
     return first;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Windowed kernel: horizons that do not fit the LDS slice (N >= 24; the reference ships N = 80, generate_c_code.py:17,24).
+// Same algorithm and the same sweep code as rti_fused_kernel, run window by window (Win above).  Pass 1 walks the windows from
+// the end of the horizon to its start: linearise the window's intervals into LDS, run the factor sweep over them (P, p carried
+// in registers), park the window.  qp_body<3> then runs forward / adjoint (and interior-point) sweeps as loops over windows.
+// Persistent blocks: the grid is what fits the chip (one wavefront per SIMD), each block owns one parking image in HBM and
+// takes instances from an atomic counter -- the parked working set is (blocks x horizon), not (batch x horizon), and stays
+// hot in L2 / Infinity Cache.
+constexpr int kWinMaxStages = 20;
+__host__ __device__ inline int win_chunks(int N) { return (N + kWinMaxStages - 1) / kWinMaxStages; }
+__host__ __device__ inline int win_len(int N) { const int nc = win_chunks(N); return (N + nc - 1) / nc; }
+__host__ __device__ inline size_t win_ws_doubles(int N) {
+    return (size_t)N * (kBaStage + NX + kKtStage + 4) + (size_t)(N + 1) * NX + (size_t)N * 4   // ba bv kt kff | q | r
+           + (size_t)N * 4 + (size_t)(N + 1) * NX                                              // vhat, dx
+           + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N;                            // Ks Mt Pb | interior-point vectors
+}
+__global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane0 = threadIdx.x;
+    const int N = P.N, Lc = P.win_L, nc = (N + Lc - 1) / Lc;
+    double* ba_s = smem;                           // [Lc][12][13]
+    double* bv_s = ba_s + (size_t)Lc * kBaStage;   // [Lc][12]
+    double* kt_s = bv_s + (size_t)Lc * NX;         // [Lc][12][4]
+    double* kff_s = kt_s + (size_t)Lc * kKtStage;  // [Lc][4]
+    double* vh_s = kff_s + (size_t)Lc * 4;         // [Lc][4]
+    double* dx_s = vh_s + (size_t)Lc * 4;          // [Lc+1][12]
+    double* q_s = dx_s + (size_t)(Lc + 1) * NX;    // [Lc+1][12]
+    double* r_s = q_s + (size_t)(Lc + 1) * NX;     // [Lc][4]
+    double* const_s = r_s + (size_t)Lc * 4;        // {0.0, 1.0} + 17 doubles of transposition scratch
+    if (lane0 == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
+    double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
+    Win W;
+    W.nc = nc; W.Lc = Lc; W.cur = -1; W.valid = 0;
+    W.ba = ba_s; W.bv = bv_s; W.kt = kt_s; W.kff = kff_s; W.vh = vh_s; W.dx = dx_s; W.q = q_s; W.r = r_s;
+    W.ws_ba = ws;
+    W.ws_bv = W.ws_ba + (size_t)N * kBaStage;
+    W.ws_kt = W.ws_bv + (size_t)N * NX;
+    W.ws_kff = W.ws_kt + (size_t)N * kKtStage;
+    W.ws_q = W.ws_kff + (size_t)N * 4;
+    W.ws_r = W.ws_q + (size_t)(N + 1) * NX;
+    double* ws_vhat = W.ws_r + (size_t)N * 4;
+    double* ws_dxb = ws_vhat + (size_t)N * 4;
+    double* ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
+    double* ws_Mt = ws_Ks + (size_t)N * 64;
+    double* ws_Pb = ws_Mt + (size_t)N * 64;
+    double* ws_ipm = ws_Pb + (size_t)N * NX;
+    for (;;) {
+        // the lane index is re-derived behind an opaque move in every iteration: nothing lane-dependent is hoisted out of the
+        // instance loop (such loop invariants otherwise sit in VGPRs across lin_phase and push the kernel into scratch)
+        int lane;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
+        int b = 0;
+        if (lane == 0) b = atomicAdd(P.counter, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= P.B) break;
+        // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
+        // lin_phase (which needs the whole architectural register file)
+        auto setup = [&](Inst& I) __attribute__((always_inline)) {
+        setup_inst(P, I, b, lane);
+            I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
+            I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr;
+            I.lds_ba = (const lds_f64*)ba_s;
+            I.lds_bv = (const lds_f64*)bv_s;
+            I.lds_kt = (lds_f64*)kt_s;
+            I.lds_q = (const lds_f64*)q_s;
+            I.lds_r = (const lds_f64*)r_s;
+            I.lds_kff = (lds_f64*)kff_s;
+            I.lds_vhat = (lds_f64*)vh_s;
+            I.lds_dxb = (lds_f64*)dx_s;
+            I.lds_zero = (lds_f64*)const_s;
+            I.lds_tr = (lds_f64*)const_s + 2;
+            {
+                const int rg = I.rg, cl = I.cl;
+                const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
+                for (int r = 0; r < 3; r++) I.ba_off[r] = cl >= 3 ? (rg + 4 * r) * kBaStride + cl - 3 : ((r == 0 && rg == cl) ? one : zero);
+                I.ba_str = cl >= 3 ? kBaStage : 0;
+                for (int r = 0; r < 4; r++) {
+                    const int c = rg + 4 * r;
+                    I.bat_off[r] = cl >= NX ? zero : (c >= 3 ? cl * kBaStride + c - 3 : (c == cl ? one : zero));
+                }
+                I.bat_str = cl >= NX ? 0 : kBaStage;
+                I.bat_str0 = (cl < NX && rg == 3) ? kBaStage : 0;
+                for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
+                I.kt_str = cl < 4 ? kKtStage : 0;
+            }
+        };
+        // ---- pass 1: linearisation + step-0 factor sweep, last window first
+        double part = 0.0;
+        bool nanp = false;
+        BwdState S;
+        W.cur = -1;
+        for (int c = nc - 1; c >= 0; c--) {
+            const int i0 = c * Lc, n = (N - i0 < Lc) ? N - i0 : Lc;
+            __syncthreads();
+            lin_phase<true>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+            __syncthreads();
+            if (P.dump_lin) copy_out_linearisation(P, b, i0, n, lane, ba_s, bv_s);
+            Inst I;
+            setup(I);
+            win_select(I, W, c);
+            if (c == nc - 1) bwd_init<true, 3>(I, S);
+            bwd_chunk<true, 3, false, true>(I, S);
+            __syncthreads();
+            win_flush(W.ws_ba + (size_t)i0 * kBaStage, ba_s, n * kBaStage, lane);
+            win_flush(W.ws_bv + i0 * NX, bv_s, n * NX, lane);
+            win_flush(W.ws_kt + (size_t)i0 * kKtStage, kt_s, n * kKtStage, lane);
+            win_flush(W.ws_kff + i0 * 4, kff_s, n * 4, lane);
+            win_flush(W.ws_q + i0 * NX, q_s, (c == nc - 1 ? n + 1 : n) * NX, lane);   // the last window also owns the terminal row
+            win_flush(W.ws_r + i0 * 4, r_s, n * 4, lane);
+        }
+        W.valid = WM_BA | WM_BV | WM_KT | WM_KFF | WM_R;   // window 0; its q image lacks row n (the next window's first stage)
+        Inst I;
+        setup(I);
+        W.cur = -1;
+        win_select(I, W, 0);
+        W.valid = WM_BA | WM_BV | WM_KT | WM_KFF | WM_R;
+#if !defined(BROV_WIN_EXP) || BROV_WIN_EXP != 1
+        qp_body<3>(P, I, b, part, nanp, &W, S.ok);
+#endif
+        __syncthreads();
+    }
+}
+
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
     const size_t lds = ((size_t)C * (kBaStage + NX + kRecInterval + NU) + (size_t)(C + 1) * NX + 64) * sizeof(double);
@@ -1375,6 +1683,29 @@ void launch_qp(const DevParams& P, hipStream_t st) {
 }
 
 bool fused_supported(int N) { return N <= kFusedMaxN; }
+
+int windowed_stage_count(int N) { return win_len(N); }
+size_t windowed_ws_doubles(int N) { return win_ws_doubles(N); }
+static size_t windowed_lds_bytes(int N) {
+    const int L = win_len(N);
+    return ((size_t)L * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(L + 1) * NX + 2 + 17) * sizeof(double);
+}
+int windowed_blocks(int N, int B) {
+    if (first_launch_on_device(2))
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, cus = 256, per_cu = 4;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rti_window_kernel, 64, windowed_lds_bytes(N)) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    const long long fit = (long long)cus * per_cu;
+    return (int)(B < fit ? B : fit);
+}
+void launch_windowed(const DevParams& P, hipStream_t st) {
+    (void)hipMemsetAsync(P.counter, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.N), st, P);
+}
+
 
 void launch_fused(const DevParams& P, hipStream_t st) {
     const size_t lds = ((size_t)P.N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(P.N + 1) * NX + 2 + 17) * sizeof(double);

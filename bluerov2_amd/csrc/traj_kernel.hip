@@ -81,7 +81,7 @@ void launch_candidates(int kind, const double* p0, const double* p1, const doubl
 #include "bluerov2_model.hpp"
 namespace brov {
 
-__global__ void plant_kernel(double* __restrict__ x0, const brov_result* __restrict__ res, const double* __restrict__ pplant, int B,
+__global__ __launch_bounds__(128) void plant_kernel(double* __restrict__ x0, const brov_result* __restrict__ res, const double* __restrict__ pplant, int B,
                              double dt, int substeps, double* __restrict__ xlog, double* __restrict__ ulog) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;

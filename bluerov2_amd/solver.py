@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(HERE, "lib", "libbluerov2_nmpc.so")
 NX, NU, NP, NY = 12, 4, 16, 16
 MAX_N = 128
-PATH_AUTO, PATH_STREAMING, PATH_FUSED = 0, 1, 2
+PATH_AUTO, PATH_STREAMING, PATH_FUSED, PATH_WINDOWED = 0, 1, 2, 3
 
 # nominal hydrodynamic parameters the nodes pass every tick (bluerov2_dob.cpp:340-353); p[0:4] = disturbance
 P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])

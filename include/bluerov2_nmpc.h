@@ -68,7 +68,7 @@ typedef struct brov_opts {
     int32_t on_failure;     /* what happens to an instance whose step fails (status NAN / MINSTEP / QP_FAILURE):
                              *   BROV_ON_FAILURE_KEEP    iterate left untouched -- what acados' SQP_RTI does (it returns before
                              *                           update_variables); a diverged iterate then fails again every tick
-                             *   BROV_ON_FAILURE_RESTART (default) cold restart at the measured state: x_i = x0 for all i, u = 0,
+                             *   BROV_ON_FAILURE_RESTART (default) cold restart at the measured state (if x0 is finite): x_i = x0 for all i, u = 0,
                              *                           multipliers 0, so that the instance can recover on the next tick
                              * In both cases the record's u0 is the last successfully computed input (zero-order hold), clamped
                              * to [lbu, ubu] with NaN -> 0: plant / thrust consumers never see a diverged input. */
@@ -82,6 +82,8 @@ typedef struct brov_opts {
 #define BROV_PATH_STREAMING 1 /* lin_wave_kernel + qp_kernel, stage blocks streamed through HBM; any N <= BROV_MAX_N */
 #define BROV_PATH_FUSED 2     /* one kernel, one wavefront per instance, stage blocks in LDS: the whole horizon (N <= 23) or a
                                * window of <= 20 stages at a time with the other windows parked in a per-instance HBM image */
+
+#define BROV_PATH_WINDOWED 3  /* reported by brov_last_kernel_path only: the windowed flavour of BROV_PATH_FUSED / _AUTO (N >= 24) */
 
 #define BROV_MAX_N 128
 
@@ -204,7 +206,7 @@ int brov_get_thrusts_host(brov_solver* s, double* t6 /*[B][6]*/);
 /* timing of the last brov_solve (HIP events on its stream), seconds: total and per kernel [linearise, qp] */
 int brov_last_solve_seconds(brov_solver* s, double* total, double* kernels2);
 int brov_enable_timing(brov_solver* s, int on);
-/* which kernels the last brov_solve launched: BROV_PATH_FUSED or BROV_PATH_STREAMING */
+/* which kernels the last brov_solve launched: BROV_PATH_FUSED, BROV_PATH_WINDOWED or BROV_PATH_STREAMING */
 int brov_last_kernel_path(const brov_solver* s);
 
 /* ---------------------------------------------------------------------------------------------------------------------

@@ -683,7 +683,9 @@ int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const 
     }
     for (int j = 0; j < NX; j++) { double e = x[N * NX + j] - yref[N * NY + j]; cost += 0.5 * o->We[j] * e * e; }
     const int failed = !(status == 0 || status == 2);
-    if (failed && o->on_failure == 1) { /* cold restart at the measured state */
+    int x0_ok = 1; /* a restart needs a usable measurement */
+    for (int j = 0; j < NX; j++) if (!(fabs(x0[j]) < 1e300)) x0_ok = 0;
+    if (failed && o->on_failure == 1 && x0_ok) { /* cold restart at the measured state */
         for (int i = 0; i <= N; i++) memcpy(x + (size_t)i * NX, x0, NX * sizeof(double));
         memset(u, 0, (size_t)N * NU * sizeof(double));
         memset(pi, 0, (size_t)N * NX * sizeof(double));

@@ -47,7 +47,7 @@ typedef struct orc_opts {
     double qp_tol_stat;   /* stationarity target of the QP */
     int    qp_early_exit; /* 1: return the equality-constrained minimiser when it is feasible (exact) */
     int    on_failure;    /* failed step (status 1/3/4): 0 keep the iterate (acados: SQP_RTI returns before update_variables),
-                           * 1 cold restart at the measured state (x_i = x0, u = 0, multipliers 0).  Either way the record's u0
+                           * 1 cold restart at the measured state if it is finite (x_i = x0, u = 0, multipliers 0).  Either way the record's u0
                            * holds the last successfully computed input, clamped to the bounds, NaN -> 0. */
 } orc_opts;
 

@@ -68,21 +68,22 @@ def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
     assert np.abs(r1["u0"] - r2["u0"]).max() < 1e-8
 
 
-@pytest.mark.parametrize("N,B", [(22, 4), (24, 3), (43, 5), (64, 2), (85, 3), (128, 2)])
-def test_streaming_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B):
-    """horizons that split into 2..7 linearisation chunks of unequal length (lin_wave_kernel: <= 21 intervals per wave), up to
-    the shim's maximum N = 128; two RTI ticks so that the second one linearises at a non-trivial iterate with multipliers"""
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("N,B", [(22, 4), (24, 3), (41, 3), (43, 5), (64, 2), (85, 3), (128, 2)])
+def test_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B, path):
+    """horizons that split into 2..7 windows / linearisation chunks of unequal length (windowed kernel: <= 20 stages per
+    window, lin_wave_kernel: <= 21 intervals per wave), up to the shim's maximum N = 128; two RTI ticks so that the second one
+    linearises at a non-trivial iterate with multipliers"""
     x0, circ = _inputs(golden_traj, B, seed=N, big=1.0)
     Ts = 2.0 / N
-    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
-    assert s.opts.kernel_path == ba.PATH_AUTO
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, kernel_path=path))
     s.set_x0(x0); s.set_params(ba.P_NOMINAL)
     op = oracle.opts(N, Ts)
     it = oracle.init_iterate(op, B)
     win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])[:N + 2]   # the golden head is short: pad like the reference
     for k in range(2):
         s.set_yref(win[k:k + N + 1]); s.solve()
-        assert s.last_kernel_path() == (ba.PATH_FUSED if N <= 23 else ba.PATH_STREAMING)
+        assert s.last_kernel_path() == (ba.PATH_STREAMING if path == 1 else (ba.PATH_FUSED if N <= 23 else ba.PATH_WINDOWED))
         worst, ro = _oracle_step(oracle, op, x0, win[k:k + N + 1], ba.P_NOMINAL, it)
         r = s.results()
         assert np.array_equal(r["status"], ro["status"])
@@ -93,11 +94,14 @@ def test_streaming_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj,
 
 
 @pytest.mark.parametrize("path", [1, 2])
-def test_nan_input_is_contained(ba, oracle, golden_traj, path):
-    N, B = 20, 8
+@pytest.mark.parametrize("N,on_failure", [(20, 1), (20, 0), (40, 1)])
+def test_nan_input_is_contained(ba, oracle, golden_traj, path, N, on_failure):
+    """a NaN in one instance's measured state: that instance fails (status 1), its iterate is left alone under either
+    on_failure policy (a restart needs a finite x0), its record holds a finite input; the neighbours are unaffected"""
+    B = 8
     x0, circ = _inputs(golden_traj, B, seed=2)
     x0[3, 4] = np.nan
-    s = ba.BatchSolver(B, ba.SolverOptions(N, kernel_path=path))
+    s = ba.BatchSolver(B, ba.SolverOptions(N, kernel_path=path, on_failure=on_failure))
     s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1])
     before = s.get_iterate()
     s.solve()
@@ -105,8 +109,8 @@ def test_nan_input_is_contained(ba, oracle, golden_traj, path):
     after = s.get_iterate()
     assert r["status"][3] != 0 and np.all(np.delete(r["status"], 3) == 0)
     assert np.array_equal(after[0][3], before[0][3]) and np.array_equal(after[1][3], before[1][3])  # failed instance: iterate untouched
-    assert np.isfinite(np.delete(r["u0"], 3, axis=0)).all() and np.isnan(r["kkt"][3])
-    op = oracle.opts(N)
+    assert np.isfinite(r["u0"]).all() and np.isfinite(r["thrust"]).all() and np.isnan(r["kkt"][3])
+    op = oracle.opts(N, on_failure=on_failure)
     it = oracle.init_iterate(op, B)
     _, ro = _oracle_step(oracle, op, x0, circ[:N + 1], ba.P_NOMINAL, it)
     assert ro["status"][3] != 0
