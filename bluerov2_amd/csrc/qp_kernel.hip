@@ -611,14 +611,30 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
 // LDS -> HBM through registers in batches of eight 16-byte pieces per lane.  Every sweep is a loop over windows with its
 // recursion state (P, p / dx / A'pi) carried in registers; a sweep fetches only the arrays it reads and writes back only the
 // arrays it produced.  The window left resident by one sweep is the first window of the next one (sweeps alternate direction).
-enum : unsigned { WM_BA = 1, WM_BV = 2, WM_KT = 4, WM_KFF = 8, WM_DX = 16, WM_Q = 32, WM_R = 64 };
+// LDS slice of the windowed kernel (L = stages per window), in this order:
+//     [A B] L x 156 | b L x 12 | q (L+1) x 12 | r L x 4 | K^T L x 48 | kff L x 4 | vhat L x 4 | dx (L+1) x 12 | constants
+// The first 236 L + 12 doubles (everything up to and including kff) are what a window parks in HBM: ONE contiguous image per
+// window, a verbatim copy of the slice, so that parking and fetching are single contiguous transfers.  WM_LIN = the prefix
+// [A B] | b | q | r (184 L + 12 doubles; what the backward, roll-out and adjoint sweeps read), WM_GAIN = K^T | kff (the rest;
+// what the forward sweep reads in addition), WM_DX = the state steps (flat array of the whole horizon in HBM).
+enum : unsigned { WM_LIN = 1, WM_GAIN = 2, WM_DX = 4 };
 struct Win {
     int nc, Lc;         // number of windows, stages per window (the last one may be shorter)
     int cur;            // resident window
-    unsigned valid;     // arrays of the resident window that are valid in LDS
-    double *ba, *bv, *kt, *kff, *vh, *dx, *q, *r;          // LDS arrays (generic pointers)
-    double *ws_ba, *ws_bv, *ws_kt, *ws_kff, *ws_q, *ws_r;  // parked image of the whole horizon (per block)
+    unsigned valid;     // parts of the resident window that are valid in LDS
+    double* lds;        // slice base (generic pointer)
+    double* img;        // parked images of this block: nc x img_doubles(Lc)
 };
+__host__ __device__ constexpr int win_lin_doubles(int L) { return 184 * L + 12; }
+__host__ __device__ constexpr int win_img_doubles(int L) { return 236 * L + 12; }
+__host__ __device__ constexpr int win_off_bv(int L) { return 156 * L; }
+__host__ __device__ constexpr int win_off_q(int L) { return 168 * L; }
+__host__ __device__ constexpr int win_off_r(int L) { return 180 * L + 12; }
+__host__ __device__ constexpr int win_off_kt(int L) { return 184 * L + 12; }
+__host__ __device__ constexpr int win_off_kff(int L) { return 232 * L + 12; }
+__host__ __device__ constexpr int win_off_vh(int L) { return 236 * L + 12; }
+__host__ __device__ constexpr int win_off_dx(int L) { return 240 * L + 12; }
+__host__ __device__ constexpr int win_off_const(int L) { return 252 * L + 24; }   // {0.0, 1.0} + 17 doubles of transposition scratch
 
 // nd doubles (even, 16-byte aligned on both sides), HBM -> LDS, asynchronous: wait with s_waitcnt vmcnt(0) before reading
 __device__ __forceinline__ void win_fetch(const double* g, double* l, int nd, int lane) {
@@ -650,21 +666,19 @@ __device__ __forceinline__ void win_select(Inst& I, Win& W, int c) {
         I.N = (I.NT - I.i0 < W.Lc) ? I.NT - I.i0 : W.Lc;
     }
 }
-// make window c resident with (at least) the arrays in `mask`; vh_src != nullptr: the window's candidate inputs are fetched from
+// make window c resident with (at least) the parts in `mask`; vh_src != nullptr: the window's candidate inputs are fetched from
 // that flat [N][4] array (they are never trusted to be resident: forward / interior-point loop / commit use different arrays)
 __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, const double* vh_src) {
     win_select(I, W, c);
     const unsigned need = mask & ~W.valid;
-    const int i0 = I.i0, n = I.N, lane = I.lane;
+    const int i0 = I.i0, n = I.N, lane = I.lane, L = W.Lc;
+    const double* img = W.img + (size_t)c * win_img_doubles(L);
     __syncthreads();   // single wave: every lane is done with the slice's previous content, earlier stores are issued
-    if (need & WM_BA) win_fetch(W.ws_ba + (size_t)i0 * kBaStage, W.ba, n * kBaStage, lane);
-    if (need & WM_BV) win_fetch(W.ws_bv + i0 * NX, W.bv, n * NX, lane);
-    if (need & WM_KT) win_fetch(W.ws_kt + i0 * kKtStage, W.kt, n * kKtStage, lane);
-    if (need & WM_KFF) win_fetch(W.ws_kff + i0 * 4, W.kff, n * 4, lane);
-    if (need & WM_Q) win_fetch(W.ws_q + i0 * NX, W.q, (n + 1) * NX, lane);      // row n: next window's first stage / terminal
-    if (need & WM_R) win_fetch(W.ws_r + i0 * 4, W.r, n * 4, lane);
-    if (need & WM_DX) win_fetch(I.dxb + i0 * NX, W.dx, (n + 1) * NX, lane);
-    if (vh_src) win_fetch(vh_src + i0 * 4, W.vh, n * 4, lane);
+    if ((need & (WM_LIN | WM_GAIN)) == (WM_LIN | WM_GAIN)) win_fetch(img, W.lds, win_img_doubles(L), lane);
+    else if (need & WM_LIN) win_fetch(img, W.lds, win_lin_doubles(L), lane);
+    else if (need & WM_GAIN) win_fetch(img + win_off_kt(L), W.lds + win_off_kt(L), 52 * L, lane);
+    if (need & WM_DX) win_fetch(I.dxb + i0 * NX, W.lds + win_off_dx(L), (n + 1) * NX, lane);
+    if (vh_src) win_fetch(vh_src + i0 * 4, W.lds + win_off_vh(L), n * 4, lane);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     W.valid |= mask;
@@ -678,11 +692,11 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0) {
         wave_fence();
         d4 xx = d0;
         for (int c = 0; c < W->nc; c++) {
-            win_need(I, *W, c, WM_BA | WM_BV | WM_KT | WM_KFF, nullptr);
+            win_need(I, *W, c, WM_LIN | WM_GAIN, nullptr);
             fwd_chunk<3>(I, xx);
             __syncthreads();
-            win_flush(I.vhat + I.i0 * 4, W->vh, I.N * 4, I.lane);
-            win_flush(I.dxb + I.i0 * NX, W->dx, (I.N + 1) * NX, I.lane);
+            win_flush(I.vhat + I.i0 * 4, W->lds + win_off_vh(W->Lc), I.N * 4, I.lane);
+            win_flush(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
         }
         wave_fence();
@@ -696,10 +710,10 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
         wave_fence();
         d4 xx = d0;
         for (int c = 0; c < W->nc; c++) {
-            win_need(I, *W, c, WM_BA | WM_BV, varr);
+            win_need(I, *W, c, WM_LIN, varr);
             roll_chunk<3>(I, xx, varr);
             __syncthreads();
-            win_flush(I.dxb + I.i0 * NX, W->dx, (I.N + 1) * NX, I.lane);
+            win_flush(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
         }
         wave_fence();
@@ -713,12 +727,12 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
         wave_fence();
         d4 atpi = {0, 0, 0, 0};
         for (int c = W->nc - 1; c >= 0; c--) {
-            win_need(I, *W, c, WM_BA | WM_DX | WM_Q | WM_R, varr);
+            win_need(I, *W, c, WM_LIN | WM_DX, varr);
             adj_chunk<COMMIT, 3>(I, atpi, varr, garr, pi_out);
-            W->valid &= ~(WM_KT | WM_KFF);   // multipliers / input gradient were staged in the K^T / feed-forward areas
+            W->valid &= ~WM_GAIN;   // multipliers / input gradient were staged in the K^T / feed-forward areas
             __syncthreads();
-            if (COMMIT) win_flush(pi_out + (size_t)I.i0 * NX, W->kt, I.N * NX, I.lane);
-            win_flush(garr + I.i0 * 4, W->kff, I.N * 4, I.lane);
+            if (COMMIT) win_flush(pi_out + (size_t)I.i0 * NX, W->lds + win_off_kt(W->Lc), I.N * NX, I.lane);
+            win_flush(garr + I.i0 * 4, W->lds + win_off_kff(W->Lc), I.N * 4, I.lane);
         }
         wave_fence();
     }
@@ -731,13 +745,16 @@ __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
         wave_fence();
         BwdState S;
         for (int c = W->nc - 1; c >= 0; c--) {
-            win_need(I, *W, c, FACTOR ? (WM_BA | WM_BV | WM_Q) : (WM_BA | WM_Q), nullptr);
+            win_need(I, *W, c, WM_LIN, nullptr);
             if (c == W->nc - 1) bwd_init<FACTOR, 3>(I, S);
             bwd_chunk<FACTOR, 3, true, false>(I, S);
             __syncthreads();
-            if (FACTOR) win_flush(W->ws_kt + (size_t)I.i0 * kKtStage, W->kt, I.N * kKtStage, I.lane);
-            win_flush(W->ws_kff + I.i0 * 4, W->kff, I.N * 4, I.lane);
-            W->valid |= FACTOR ? (WM_KT | WM_KFF) : WM_KFF;
+            // park what the sweep produced: K^T | kff (contiguous), or kff alone after a solve-only sweep.  The resident K^T stays
+            // valid in both cases (a solve-only sweep does not touch it) unless an adjoint sweep has overwritten the area since.
+            double* img = W->img + (size_t)c * win_img_doubles(W->Lc);
+            if (FACTOR) win_flush(img + win_off_kt(W->Lc), W->lds + win_off_kt(W->Lc), 52 * W->Lc, I.lane);
+            else win_flush(img + win_off_kff(W->Lc), W->lds + win_off_kff(W->Lc), 4 * W->Lc, I.lane);
+            if (FACTOR) W->valid |= WM_GAIN;
         }
         wave_fence();
         return S.ok;
@@ -1557,35 +1574,30 @@ constexpr int kWinMaxStages = 20;
 __host__ __device__ inline int win_chunks(int N) { return (N + kWinMaxStages - 1) / kWinMaxStages; }
 __host__ __device__ inline int win_len(int N) { const int nc = win_chunks(N); return (N + nc - 1) / nc; }
 __host__ __device__ inline size_t win_ws_doubles(int N) {
-    return (size_t)N * (kBaStage + NX + kKtStage + 4) + (size_t)(N + 1) * NX + (size_t)N * 4   // ba bv kt kff | q | r
-           + (size_t)N * 4 + (size_t)(N + 1) * NX                                              // vhat, dx
-           + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N;                            // Ks Mt Pb | interior-point vectors
+    return (size_t)win_chunks(N) * win_img_doubles(win_len(N))            // parked window images
+           + (size_t)N * 4 + (size_t)(N + 1) * NX                          // vhat, dx (flat over the horizon)
+           + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N;        // Ks Mt Pb | interior-point vectors
 }
 __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x;
     const int N = P.N, Lc = P.win_L, nc = (N + Lc - 1) / Lc;
-    double* ba_s = smem;                           // [Lc][12][13]
-    double* bv_s = ba_s + (size_t)Lc * kBaStage;   // [Lc][12]
-    double* kt_s = bv_s + (size_t)Lc * NX;         // [Lc][12][4]
-    double* kff_s = kt_s + (size_t)Lc * kKtStage;  // [Lc][4]
-    double* vh_s = kff_s + (size_t)Lc * 4;         // [Lc][4]
-    double* dx_s = vh_s + (size_t)Lc * 4;          // [Lc+1][12]
-    double* q_s = dx_s + (size_t)(Lc + 1) * NX;    // [Lc+1][12]
-    double* r_s = q_s + (size_t)(Lc + 1) * NX;     // [Lc][4]
-    double* const_s = r_s + (size_t)Lc * 4;        // {0.0, 1.0} + 17 doubles of transposition scratch
+    double* ba_s = smem;                      // [Lc][12][13]
+    double* bv_s = smem + win_off_bv(Lc);     // [Lc][12]
+    double* q_s = smem + win_off_q(Lc);       // [Lc+1][12]
+    double* r_s = smem + win_off_r(Lc);       // [Lc][4]
+    double* kt_s = smem + win_off_kt(Lc);     // [Lc][12][4]   (kt .. dx double as the linearisation's stage-record scratch)
+    double* kff_s = smem + win_off_kff(Lc);   // [Lc][4]
+    double* vh_s = smem + win_off_vh(Lc);     // [Lc][4]
+    double* dx_s = smem + win_off_dx(Lc);     // [Lc+1][12]
+    double* const_s = smem + win_off_const(Lc);
     if (lane0 == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
     double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
     Win W;
     W.nc = nc; W.Lc = Lc; W.cur = -1; W.valid = 0;
-    W.ba = ba_s; W.bv = bv_s; W.kt = kt_s; W.kff = kff_s; W.vh = vh_s; W.dx = dx_s; W.q = q_s; W.r = r_s;
-    W.ws_ba = ws;
-    W.ws_bv = W.ws_ba + (size_t)N * kBaStage;
-    W.ws_kt = W.ws_bv + (size_t)N * NX;
-    W.ws_kff = W.ws_kt + (size_t)N * kKtStage;
-    W.ws_q = W.ws_kff + (size_t)N * 4;
-    W.ws_r = W.ws_q + (size_t)(N + 1) * NX;
-    double* ws_vhat = W.ws_r + (size_t)N * 4;
+    W.lds = smem;
+    W.img = ws;
+    double* ws_vhat = ws + (size_t)nc * win_img_doubles(Lc);
     double* ws_dxb = ws_vhat + (size_t)N * 4;
     double* ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
     double* ws_Mt = ws_Ks + (size_t)N * 64;
@@ -1603,7 +1615,7 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
         // lin_phase (which needs the whole architectural register file)
         auto setup = [&](Inst& I) __attribute__((always_inline)) {
-        setup_inst(P, I, b, lane);
+            setup_inst(P, I, b, lane);
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
             I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr;
             I.lds_ba = (const lds_f64*)ba_s;
@@ -1631,36 +1643,46 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
                 I.kt_str = cl < 4 ? kKtStage : 0;
             }
         };
+        DBG_STAMP(0);
         // ---- pass 1: linearisation + step-0 factor sweep, last window first
         double part = 0.0;
         bool nanp = false;
         BwdState S;
         W.cur = -1;
+        unsigned long long t_lin = 0, t_bwd = 0, t_fl = 0;   // developer instrumentation (P.dbg): pass-1 split, slot 7
         for (int c = nc - 1; c >= 0; c--) {
             const int i0 = c * Lc, n = (N - i0 < Lc) ? N - i0 : Lc;
+            const unsigned long long t0 = P.dbg ? __builtin_readcyclecounter() : 0;
+            // cost gradient of the stage after the window (row n of the window's q array; the adjoint sweep reads it): requested
+            // here, written after the linearisation.  The last window gets its row n (terminal gradient) from lin_phase.
+            double xq = 0.0, yq = 0.0, wq = 0.0;
+            if (c < nc - 1 && lane < NX) {
+                xq = P.x[((size_t)b * (N + 1) + i0 + n) * NX + lane];
+                yq = P.yref[(size_t)b * P.yref_stride + (size_t)(i0 + n) * NY + lane];
+                wq = P.cst[lane];
+            }
             __syncthreads();
             lin_phase<true>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+            if (c < nc - 1 && lane < NX) q_s[n * NX + lane] = P.Ts * wq * (xq - yq);
             __syncthreads();
             if (P.dump_lin) copy_out_linearisation(P, b, i0, n, lane, ba_s, bv_s);
+            const unsigned long long t1 = P.dbg ? __builtin_readcyclecounter() : 0;
             Inst I;
             setup(I);
             win_select(I, W, c);
             if (c == nc - 1) bwd_init<true, 3>(I, S);
             bwd_chunk<true, 3, false, true>(I, S);
             __syncthreads();
-            win_flush(W.ws_ba + (size_t)i0 * kBaStage, ba_s, n * kBaStage, lane);
-            win_flush(W.ws_bv + i0 * NX, bv_s, n * NX, lane);
-            win_flush(W.ws_kt + (size_t)i0 * kKtStage, kt_s, n * kKtStage, lane);
-            win_flush(W.ws_kff + i0 * 4, kff_s, n * 4, lane);
-            win_flush(W.ws_q + i0 * NX, q_s, (c == nc - 1 ? n + 1 : n) * NX, lane);   // the last window also owns the terminal row
-            win_flush(W.ws_r + i0 * 4, r_s, n * 4, lane);
+            const unsigned long long t2 = P.dbg ? __builtin_readcyclecounter() : 0;
+            win_flush(W.img + (size_t)c * win_img_doubles(Lc), smem, win_img_doubles(Lc), lane);   // park the window: one contiguous image
+            if (P.dbg) { const unsigned long long t3 = __builtin_readcyclecounter(); t_lin += t1 - t0; t_bwd += t2 - t1; t_fl += t3 - t2; }
         }
-        W.valid = WM_BA | WM_BV | WM_KT | WM_KFF | WM_R;   // window 0; its q image lacks row n (the next window's first stage)
+        if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + 7] = (t_lin & 0xFFFFF) | ((t_bwd & 0xFFFFF) << 20) | ((t_fl & 0xFFFFF) << 40);
         Inst I;
         setup(I);
         W.cur = -1;
         win_select(I, W, 0);
-        W.valid = WM_BA | WM_BV | WM_KT | WM_KFF | WM_R;
+        W.valid = WM_LIN | WM_GAIN;   // window 0 is resident, complete
 #if !defined(BROV_WIN_EXP) || BROV_WIN_EXP != 1
         qp_body<3>(P, I, b, part, nanp, &W, S.ok);
 #endif
@@ -1687,8 +1709,7 @@ bool fused_supported(int N) { return N <= kFusedMaxN; }
 int windowed_stage_count(int N) { return win_len(N); }
 size_t windowed_ws_doubles(int N) { return win_ws_doubles(N); }
 static size_t windowed_lds_bytes(int N) {
-    const int L = win_len(N);
-    return ((size_t)L * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(L + 1) * NX + 2 + 17) * sizeof(double);
+    return ((size_t)win_off_const(win_len(N)) + 2 + 17) * sizeof(double);
 }
 int windowed_blocks(int N, int B) {
     if (first_launch_on_device(2))

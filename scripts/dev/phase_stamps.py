@@ -26,5 +26,9 @@ for n, col in zip(names, d.T):
     print(f"  {n:14s} {int(np.median(col)):8d}  ({100*np.median(col)/np.median(tot):.1f} %)")
 
 w = st[:, 7]
-print("lin detail: cost gradients (incl. load wait)", int(np.median(w & 0xFFFFF)), " state integration", int(np.median((w >> 20) & 0xFFFFF)),
+if s.last_kernel_path() == 3:
+    print("windowed pass 1: linearisation", int(np.median(w & 0xFFFFF)), " setup + factor sweep", int(np.median((w >> 20) & 0xFFFFF)),
+          " parking (flush)", int(np.median((w >> 40) & 0xFFFFF)))
+else:
+  print("lin detail: cost gradients (incl. load wait)", int(np.median(w & 0xFFFFF)), " state integration", int(np.median((w >> 20) & 0xFFFFF)),
       " records + gap", int(np.median((w >> 40) & 0xFFFFF)))
