@@ -624,6 +624,8 @@ struct Win {
     unsigned valid;     // parts of the resident window that are valid in LDS
     double* lds;        // slice base (generic pointer)
     double* img;        // parked images of this block: nc x img_doubles(Lc)
+    bool nan, feas;     // set by the forward / roll-out wrappers: a NaN among the inputs / state steps they produced; all inputs of
+                        // the last forward sweep inside their bounds (wave-uniform)
 };
 __host__ __device__ constexpr int win_lin_doubles(int L) { return 184 * L + 12; }
 __host__ __device__ constexpr int win_img_doubles(int L) { return 236 * L + 12; }
@@ -658,6 +660,16 @@ __device__ __forceinline__ void win_flush(double* g, const double* l, int nd, in
         }
     }
 }
+// the same for short pieces (a few hundred doubles): batches of two 16-byte pieces per lane, no wasted predicated slots
+__device__ __forceinline__ void win_flush_small(double* g, const double* l, int nd, int lane) {
+    const lds_d2* lv = (const lds_d2*)l;
+    for (int o0 = 0; o0 < nd; o0 += 256) {
+        const int oa = o0 + lane * 2, ob = oa + 128;
+        const dbl2 va = lv[(oa < nd ? oa : 0) >> 1], vb = lv[(ob < nd ? ob : 0) >> 1];
+        if (oa < nd) *(dbl2*)(g + oa) = va;
+        if (ob < nd) *(dbl2*)(g + ob) = vb;
+    }
+}
 __device__ __forceinline__ void win_select(Inst& I, Win& W, int c) {
     if (c != W.cur) {
         W.cur = c;
@@ -684,21 +696,70 @@ __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, 
     W.valid |= mask;
 }
 
+// NaN among the window's candidate inputs / state steps (checked where they are produced, on the LDS copy)
+__device__ __forceinline__ bool win_nan_check(const Inst& I, const Win& W, bool first) {
+    const lds_f64* vh = (const lds_f64*)(W.lds + win_off_vh(W.Lc));
+    const lds_f64* dx = (const lds_f64*)(W.lds + win_off_dx(W.Lc));
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int j = I.lane + 64 * t;
+        const double v = vh[j < I.N * 4 ? j : 0];
+        if (!(v == v)) bad = true;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int j = I.lane + 64 * t + (first ? 0 : NX);   // row 0 belongs to the previous window (d0 for the first one)
+        const double v = dx[j < (I.N + 1) * NX ? j : NX];
+        if (!(v == v)) bad = true;
+    }
+    return bad;
+}
 template <int LDS>
-__device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0) {
+__device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const double* cst = nullptr) {
     if constexpr (LDS != 3) {
         riccati_forward<LDS>(I, d0);
     } else {
         wave_fence();
         d4 xx = d0;
+        bool bad = false, infeas = false;
+        // bound check of the candidate inputs, window by window on the LDS copy: this lane's elements j = lane + 64 t of a
+        // window all belong to input m = lane & 3; the iterate's inputs of window c + 1 are requested before window c is swept
+        const double lbm = cst ? cst[32 + (I.lane & 3)] : 0.0, ubm = cst ? cst[36 + (I.lane & 3)] : 0.0;
+        auto load_u = [&](int c, double (&uw)[2]) __attribute__((always_inline)) {
+            const int i0 = c * W->Lc, n = (I.NT - i0 < W->Lc) ? I.NT - i0 : W->Lc;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int j = I.lane + 64 * t;
+                uw[t] = I.u[i0 * 4 + (j < n * 4 ? j : 0)];
+            }
+        };
+        double uw[2] = {0.0, 0.0}, un[2] = {0.0, 0.0};
+        if (cst) load_u(0, uw);
         for (int c = 0; c < W->nc; c++) {
             win_need(I, *W, c, WM_LIN | WM_GAIN, nullptr);
+            if (cst && c + 1 < W->nc) load_u(c + 1, un);
             fwd_chunk<3>(I, xx);
             __syncthreads();
-            win_flush(I.vhat + I.i0 * 4, W->lds + win_off_vh(W->Lc), I.N * 4, I.lane);
-            win_flush(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
+            win_flush_small(I.vhat + I.i0 * 4, W->lds + win_off_vh(W->Lc), I.N * 4, I.lane);
+            win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
+            bad = bad || win_nan_check(I, *W, c == 0);
+            if (cst) {
+                const lds_f64* vh = (const lds_f64*)(W->lds + win_off_vh(W->Lc));
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int j = I.lane + 64 * t;
+                    if (j < I.N * 4) {
+                        const double vj = vh[j], lb = lbm - uw[t], ub = ubm - uw[t];
+                        if (!(vj >= lb && vj <= ub)) infeas = true;
+                    }
+                }
+                uw[0] = un[0]; uw[1] = un[1];
+            }
         }
+        W->nan = __ballot(bad) != 0ull;
+        W->feas = __ballot(infeas) == 0ull;
         wave_fence();
     }
 }
@@ -709,13 +770,16 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
     } else {
         wave_fence();
         d4 xx = d0;
+        bool bad = false;
         for (int c = 0; c < W->nc; c++) {
             win_need(I, *W, c, WM_LIN, varr);
             roll_chunk<3>(I, xx, varr);
             __syncthreads();
-            win_flush(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
+            win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
+            bad = bad || win_nan_check(I, *W, c == 0);
         }
+        W->nan = __ballot(bad) != 0ull;
         wave_fence();
     }
 }
@@ -737,6 +801,77 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
         wave_fence();
     }
 }
+// Windowed kernel: final adjoint sweep and the full step in one pass over the windows.  While a window is resident its state
+// steps, inputs, input gradient and multipliers are all in LDS; the iterate rows and the reference of the window are requested
+// before the window is fetched and swept, so the step costs no exposed HBM round trip.  cost: this lane's share of the NLS
+// objective at the updated iterate; u0v: lanes 0..3 the new first input.
+__device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, Win& W, int b, const double* vfin, bool early,
+                                                   double& cost, double& u0v) {
+    const int lane = I.lane, NT = I.NT, L = W.Lc;
+    const double* __restrict__ cst = P.cst;
+    double* x_it = P.x + (size_t)b * (NT + 1) * 12;
+    double* u_it = P.u + (size_t)b * NT * 4;
+    double* pi_it = P.pi + (size_t)b * NT * 12;
+    double* lam_it = P.lam + (size_t)b * NT * 8;
+    const lds_f64* vh = (const lds_f64*)(W.lds + win_off_vh(L));
+    const lds_f64* gl = (const lds_f64*)(W.lds + win_off_kff(L));
+    const lds_f64* dx = (const lds_f64*)(W.lds + win_off_dx(L));
+    wave_fence();
+    d4 atpi = {0, 0, 0, 0};
+    for (int c = W.nc - 1; c >= 0; c--) {
+        win_select(I, W, c);
+        const int i0 = I.i0, n = I.N;
+        const int nu = n * 4, nxr = (c == W.nc - 1 ? n + 1 : n) * NX;   // the last window also commits the terminal node
+        double uo[2], ur[2], wu[2], xo[4], yr[4], wx[4];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t, jj = j < nu ? j : 0;
+            uo[t] = u_it[i0 * 4 + jj];
+            ur[t] = I.yref[(size_t)(i0 + (jj >> 2)) * 16 + 12 + (jj & 3)];
+            wu[t] = cst[12 + (jj & 3)];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = lane + 64 * t, jj = j < nxr ? j : 0;
+            const int i = jj / 12, cc = jj - i * 12;
+            xo[t] = x_it[i0 * 12 + jj];
+            yr[t] = I.yref[(size_t)(i0 + i) * 16 + cc];
+            wx[t] = (i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc];
+        }
+        win_need(I, W, c, WM_LIN | WM_DX, vfin);
+        adj_chunk<true, 3>(I, atpi, vfin, nullptr, nullptr);
+        W.valid &= ~WM_GAIN;   // multipliers / input gradient are staged in the K^T / feed-forward areas
+        __syncthreads();
+        win_flush_small(pi_it + (size_t)i0 * NX, W.lds + win_off_kt(L), n * NX, lane);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t;
+            if (j < nu) {
+                const int i = j >> 2, m = j & 3;
+                const double gg = early ? 0.0 : (double)gl[j];
+                lam_it[(size_t)(i0 + i) * 8 + m] = gg > 0 ? gg : 0.0;
+                lam_it[(size_t)(i0 + i) * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
+                const double un = uo[t] + vh[j];
+                u_it[i0 * 4 + j] = un;
+                if (i0 == 0 && j < 4) { P.res[b].u0[j] = un; u0v = un; }
+                const double e = un - ur[t];
+                cost += 0.5 * P.Ts * wu[t] * e * e;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = lane + 64 * t;
+            if (j < nxr) {
+                const double xn = xo[t] + dx[j];
+                x_it[i0 * 12 + j] = xn;
+                const double e = xn - yr[t];
+                cost += 0.5 * wx[t] * e * e;
+            }
+        }
+    }
+    wave_fence();
+}
+
 template <bool FACTOR, int LDS>
 __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
     if constexpr (LDS != 3) {
@@ -842,10 +977,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
-        sw_forward<LDS>(I, W, d0);
+        sw_forward<LDS>(I, W, d0, cst);
         DBG_STAMP(3);
         bool feas = true;
-        if constexpr (EL) {  // nv <= 92: two elements per lane, u already in registers
+        if constexpr (LDS == 3) {
+            feas = W->feas;   // checked window by window inside the sweep wrapper
+        } else if constexpr (EL) {  // nv <= 92: two elements per lane, u already in registers
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const int j = lane + 64 * t;
@@ -1009,6 +1146,15 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         DBG_STAMP(4);
         // fused path: the iterate and the reference of the commit loops below are requested before the adjoint sweep, which
         // hides their round trip (the single resident wave has nothing else to switch to)
+        if constexpr (LDS == 3) {
+            if (W->nan) {
+                status = BROV_STATUS_NAN;
+            } else {
+                win_adjoint_commit(P, I, *W, b, vfin, early, cost, u0v);
+                wrote_u0 = true;
+            }
+            DBG_STAMP(5);
+        } else {
         double xpre[UX], ypre[UX], urpre[UU];
         if constexpr (EL) {
 #pragma unroll
@@ -1095,6 +1241,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
         }
+        }   // LDS != 3
     }
     if (status != BROV_STATUS_SUCCESS && status != BROV_STATUS_MAXITER) {
         // failed step: report the cost of the entering iterate; the iterate is left as it is (acados: SQP_RTI returns before
