@@ -555,8 +555,9 @@ extern "C" int brov_debug_phase_stamps(brov_solver* s, int enable, unsigned long
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->last_stream));
-    if (enable && !s->dbg) { HIPCHK(hipMalloc((void**)&s->dbg, (size_t)s->B * 8 * sizeof(unsigned long long))); HIPCHK(hipMemset(s->dbg, 0, (size_t)s->B * 64)); }
-    if (out_host && s->dbg) HIPCHK(hipMemcpy(out_host, s->dbg, (size_t)s->B * 64, hipMemcpyDeviceToHost));
+    // [B][8] phase stamps followed by [B][8] interior-point phase totals (the latter only filled by a -DBROV_DBG_IPM build)
+    if (enable && !s->dbg) { HIPCHK(hipMalloc((void**)&s->dbg, (size_t)s->B * 128)); HIPCHK(hipMemset(s->dbg, 0, (size_t)s->B * 128)); }
+    if (out_host && s->dbg) HIPCHK(hipMemcpy(out_host, s->dbg, (size_t)s->B * (enable == 2 ? 128 : 64), hipMemcpyDeviceToHost));
     if (!enable && s->dbg) { hipFree(s->dbg); s->dbg = nullptr; }
     return BROV_OK;
 }

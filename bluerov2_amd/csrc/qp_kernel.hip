@@ -909,6 +909,13 @@ struct IpmVec {
 // lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
 #define DBG_STAMP(slot) do { if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+// development build only (make EXTRA=-DBROV_DBG_IPM=1, scripts/dev/ipm_phases.py): cycle totals of the interior-point loop's
+// phases in a second array, 8 slots per instance: init, element loops, factor sweep, forward, solve-only sweep, forward, iterations
+#ifdef BROV_DBG_IPM
+#define IPM_T(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); ipm_t[k] += t_ - ipm_last; ipm_last = t_; } while (0)
+#else
+#define IPM_T(k) do { } while (0)
+#endif
 
 // LDS = 0 streaming kernels, 1 / 2 fused kernels (whole horizon resident; element arrays in LDS / registers: EL), 3 windowed
 // kernel (sweeps on the resident window through the sw_* wrappers, element loops on the flat HBM arrays like LDS = 0; the
@@ -1007,6 +1014,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // Fused path: the interior-point vectors (two elements per lane, nv <= 92) live in registers -- at one wave per
             // SIMD every element loop over HBM-resident vectors costs an exposed L2 round trip; only Gamma and the right-hand
             // side, which the backward sweep reads by stage, go through memory.
+#ifdef BROV_DBG_IPM
+            unsigned long long ipm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipm_last = __builtin_readcyclecounter();
+#endif
             IpmVec<EL> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
                 vDLL{{0, 0}, GAM}, vDLU{{0, 0}, RT};   // dual steps: registers, or parked in GAM / RT (both rebuilt every iteration)
 #define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const int j = lane + 64 * t; j < nv)
@@ -1038,6 +1048,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             rho = wave_max(r0);
             status = BROV_STATUS_MAXITER;
             const double inv2nv = 1.0 / (2.0 * nv);
+            IPM_T(0);
             for (iters = 1; iters <= P.qp_iter_max; iters++) {
                 double s = 0.0;
                 double gam_r[2] = {0.0, 0.0};
@@ -1052,9 +1063,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     RT[j] = rr - gm * vV.get(t, j);
                 }
                 mu = wave_sum(s) * inv2nv;
+                IPM_T(1);
                 ok = sw_backward<true, LDS>(I, W);
+                IPM_T(2);
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
                 sw_forward<LDS>(I, W, d0);
+                IPM_T(3);
                 // predictor step length and centering
                 double aaff = 1.0;
                 IPM_FOR(t, j) {
@@ -1087,8 +1101,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const double gm = EL ? gam_r[t & 1] : GAM[j];
                     RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
                 }
+                IPM_T(1);
                 (void)sw_backward<false, LDS>(I, W);
+                IPM_T(4);
                 sw_forward<LDS>(I, W, d0);
+                IPM_T(5);
                 double amax = 1e300;
                 IPM_FOR(t, j) {
                     const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dva = vDVA.get(t, j);
@@ -1121,8 +1138,15 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if (__ballot(bad) != 0ull) { status = BROV_STATUS_NAN; break; }
                 rho *= (1.0 - alpha);
                 mu = wave_sum(s2) * inv2nv;
+                IPM_T(1);
                 if (mu <= P.tol_mu && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
             }
+#ifdef BROV_DBG_IPM
+            if (P.dbg && lane == 0) {
+                ipm_t[6] = iters;
+                for (int k = 0; k < 7; k++) P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + k] = ipm_t[k];
+            }
+#endif
             // the final inputs go where the finalisation expects them: V (streaming path, already there) / the LDS copy
             if constexpr (EL) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
 #undef IPM_FOR

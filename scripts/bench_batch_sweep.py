@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json's metric is quoted "at batch=1..65536": kernel time and solves/s of one RTI step (N=20, circle reference,
-x0 noise, default options) over the batch size, for the fused path, plus the streaming path at the reference's own N=80.
-Writes gpurun_out/<tag>_batch_sweep.json.  Run on the GPU box:  python scripts/bench_batch_sweep.py r1"""
+x0 noise, default options) over the batch size, for the fused kernel, plus the windowed kernel at the reference's own N=80.
+Prints one JSON line (scripts/profile_round.sh stores it).  Run on the GPU box:  python scripts/bench_batch_sweep.py"""
 import json
 import os
 import sys
@@ -29,7 +29,7 @@ def run(B, N, ticks=12, warm=4):
     r = s.results()
     t = float(np.median(ks))
     out = dict(batch=B, N=N, kernel_ms=t * 1e3, solves_per_s=B / t, status_nonzero=int((r["status"] != 0).sum()),
-               kernel_path="fused" if s.last_kernel_path() == ba.PATH_FUSED else "streaming")
+               kernel_path={1: "streaming", 2: "fused", 3: "windowed"}[s.last_kernel_path()], device_bytes=s.device_bytes)
     s.close()
     return out
 
@@ -37,11 +37,7 @@ def run(B, N, ticks=12, warm=4):
 def main(tag):
     out = {"N20": [run(B, 20) for B in (1, 16, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536)],
            "N80": [run(B, 80) for B in (1, 256, 1024, 4096, 16384)]}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_batch_sweep.json"), "w"), indent=1)
-    for k, rows in out.items():
-        for r in rows:
-            print(k, r)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
