@@ -78,8 +78,12 @@ __device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, [](
 // workgroup-scope fence (= s_waitcnt, no cache maintenance) orders the two phases.
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-#define IPM_TAU0 0.1   /* interior push of the start point (fraction of the box width) */
-#define IPM_FTB 0.995  /* fraction to the boundary */
+// Start and step rule of the interior-point loop (the oracle uses the same three numbers; oracle/bluerov2_oracle.c says how they
+// were chosen): a start close to the box (0.3 % of its width inside) with a small complementarity target needs 2 iterations
+// where no bound is active and 4-5 where inputs saturate, instead of 4 and 7 with the textbook 0.1 / 0.995 / mu0 = g0.
+#define IPM_TAU0 0.003  /* interior push of the start point (fraction of the box width) */
+#define IPM_FTB 0.9999  /* fraction to the boundary */
+#define IPM_MU0F 0.1    /* mu0 = IPM_MU0F * stationarity residual of the clamped point */
 
 // everything one wave needs to know about its instance
 struct Inst {
@@ -1038,7 +1042,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             double g0 = 0.0;
             for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(rd_grad(j)));
             g0 = wave_max(g0);
-            const double mu0 = fmax(g0, 1e-4);
+            const double mu0 = fmax(IPM_MU0F * g0, 1e-4);
             double r0 = 0.0;
             IPM_FOR(t, j) {
                 const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);

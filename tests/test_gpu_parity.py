@@ -226,7 +226,8 @@ def test_fused_and_streaming_paths_agree(ba, golden_traj):
     kk = np.maximum(1.0, ra["kkt"])   # every instance; tolerance scaled by the size of the instance's QP data
     assert np.all(np.abs(ua - ub).reshape(nb, -1).max(axis=1) <= 1e-9 * kk) and np.all(np.abs(xa - xb).reshape(nb, -1).max(axis=1) <= 1e-9 * kk)
     ok = ra["kkt"] < 5e3
-    assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["qp_iter"][ok], rb["qp_iter"][ok])
+    assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["qp_iter"][ok] == 0, rb["qp_iter"][ok] == 0)
+    assert np.abs(ra["qp_iter"][ok] - rb["qp_iter"][ok]).max() <= 1   # the stopping test can fall on either side of mu = 1e-12
     assert np.all(np.abs(ra["kkt"] - rb["kkt"]) <= 1e-9 * (1 + ra["kkt"]))
 
 
