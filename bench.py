@@ -392,10 +392,18 @@ def main(argv=None):
     B, K, W = wl["B"], args.steps, args.warmup
     dev = f"cuda:{local_rank}"
 
+    side = torch.cuda.Stream(device=dev) if gather else None
+
     def run(s, tick, steps, warmup, timing, select):
-        stream = torch.cuda.current_stream().cuda_stream
+        """`steps` timed RTI steps.  With more than one rank every step's result records are all-gathered -- on a side stream,
+        from a staging copy, so that the collective of step k (one small latency-bound ring all-gather over xGMI) overlaps the solve
+        of step k + 1; the timed region ends when the last gather has landed on every rank."""
+        main = torch.cuda.current_stream()
+        stream = main.cuda_stream
         res_view = D.records_tensor_from_solver(s) if gather else None
-        gathered = torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=dev) if gather else None
+        stage = [torch.empty_like(res_view) for _ in range(2)] if gather else None
+        gathered = [torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
+        done = [None, None]
         s.init_iterate_default()
         s.enable_timing(False)
         best = None
@@ -405,13 +413,24 @@ def main(argv=None):
             tick(k, stream)
             s.solve(stream=stream)
             if gather:
-                dist.all_gather_into_tensor(gathered, res_view)
-                if select:
-                    best = D.select_best_device(gathered)   # stays on the device; read after the timed region
+                j = k & 1
+                if done[j] is not None:
+                    main.wait_event(done[j])          # the gather that last read this staging buffer has finished
+                stage[j].copy_(res_view, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    dist.all_gather_into_tensor(gathered[j], stage[j])
+                    if select:
+                        best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
+                    done[j] = torch.cuda.Event()
+                    done[j].record(side)
         for k in range(warmup):
             step(k)
         s.enable_timing(timing)
         ksec = np.zeros(2)
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -429,7 +448,7 @@ def main(argv=None):
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, ksec / max(steps, 1), (gathered, best)
+        return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best)
 
     early = 0 if args.force_ipm else 1
     select = bool(wl.get("always_gather", False))
@@ -477,9 +496,9 @@ def main(argv=None):
         for pj in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
-                ent = pm.get("runs", {}).get(f"cfg{args.config}_B{B}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
-                t = ent.get("hbm_bytes_per_launch", {}).get(dom)
-                if t is not None and args.config == 2:
+                ent = pm.get("runs", {}).get(f"cfg{args.config}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
+                t = ent.get("hbm_bytes_per_launch", {}).get(dom) if B == BATCH_PER_GPU and not args.force_ipm and args.path == 0 else None
+                if t is not None:
                     traffic, traffic_src = t, f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run"
                     break
             except Exception:
@@ -496,7 +515,7 @@ def main(argv=None):
                         "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
                        "batch_per_gpu": B, "N": [l["N"] for l in legs] if len(legs) > 1 else N, "Ts": lg["Ts"] if len(legs) == 1 else "1/N",
                        "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
-                                       "records per step") if world > 1 else "single GPU"},
+                                       "records per step (side stream, overlapped with the next step's solve)") if world > 1 else "single GPU"},
             "ranks_seen": ranks_seen,
             "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
             "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),

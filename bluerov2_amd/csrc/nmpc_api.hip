@@ -14,6 +14,8 @@
 
 using namespace brov;
 
+#define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N >= 24: up to this many instances run on the streaming kernels */
+
 static thread_local std::string g_err;
 extern "C" const char* brov_last_error(void) { return g_err.c_str(); }
 
@@ -167,7 +169,11 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(counter, 4);
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
     s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
-    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING) {
+    // BROV_PATH_AUTO at long horizons: the windowed kernel solves an instance on ONE wavefront, the streaming pair spreads its
+    // linearisation over several -- for a handful of instances (the ROS node's batch of one: 164 vs 187 us at N = 80) the
+    // streaming pair has the shorter latency, from a few dozen instances on the windowed kernel wins (profiles/r2_batch_sweep.json)
+    const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed;
+    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few) {
         s->win_blocks = windowed_blocks(opts->N, B);
         AL(ws, (size_t)s->win_blocks * windowed_ws_doubles(opts->N));
     }

@@ -64,7 +64,8 @@ typedef struct brov_opts {
     double  qp_tol_mu;      /* IPM complementarity target (1e-12) */
     double  qp_tol_stat;    /* IPM stationarity target   (1e-9)  */
     int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
-    int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above), _STREAMING, _FUSED */
+    int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above -- except for batches of
+                             * <= 8 instances at N >= 24, where the streaming pair has the shorter latency), _STREAMING, _FUSED */
     int32_t on_failure;     /* what happens to an instance whose step fails (status NAN / MINSTEP / QP_FAILURE):
                              *   BROV_ON_FAILURE_KEEP    iterate left untouched -- what acados' SQP_RTI does (it returns before
                              *                           update_variables); a diverged iterate then fails again every tick

@@ -70,7 +70,20 @@ def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
     assert np.abs(r1["u0"] - r2["u0"]).max() < 1e-8
 
 
-@pytest.mark.parametrize("path", [0, 1])
+def test_auto_path_selection(ba, golden_traj):
+    """BROV_PATH_AUTO: fused for N <= 23; at longer horizons the windowed kernel, except for a handful of instances (<= 8, e.g.
+    the ROS node's batch of one), where the streaming pair has the shorter latency"""
+    for N, B, want in ((20, 1, ba.PATH_FUSED), (23, 300, ba.PATH_FUSED), (24, 8, ba.PATH_STREAMING), (80, 1, ba.PATH_STREAMING),
+                       (24, 9, ba.PATH_WINDOWED), (80, 64, ba.PATH_WINDOWED)):
+        x0, circ = _inputs(golden_traj, B, seed=N)
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1]); s.solve()
+        assert s.last_kernel_path() == want, (N, B)
+        assert not s.results()["status"].any()
+        s.close()
+
+
+@pytest.mark.parametrize("path", [2, 1])
 @pytest.mark.parametrize("N,B", [(22, 4), (24, 3), (41, 3), (43, 5), (64, 2), (85, 3), (128, 2)])
 def test_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B, path):
     """horizons that split into 2..7 windows / linearisation chunks of unequal length (windowed kernel: <= 20 stages per
