@@ -290,12 +290,29 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
     if (!std::strcmp(field, "W")) {  // column-major ny x ny, diagonal (:422-481)
         const int ny = stage == s->N ? 12 : 16;
         double* dst = stage == s->N ? s->opts.We : s->opts.W;
+        // the generated solver gives every stage 0..N-1 the same W (:422-481) and so does this solver: a stage weight that differs
+        // from the one in force changes ALL stages -- said once, loudly, because acados itself would keep them apart
+        bool differs = false;
+        for (int j = 0; j < ny; j++) differs = differs || dst[j] != v[j + ny * j];
+        static bool warned = false;
+        if (differs && stage > 0 && stage < s->N && !warned) {
+            std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): \"W\" of stage %d differs from the shared stage weight; this "
+                                 "solver keeps ONE stage weight, it now applies to stages 0..N-1\n", stage);
+            warned = true;
+        }
         for (int j = 0; j < ny; j++) dst[j] = v[j + ny * j];
         s->dirty_opts = true;
         return 0;
     }
-    if (!std::strcmp(field, "scaling")) {  // :393: stage cost scaling = Ts
-        if (stage < s->N) { s->opts.Ts = v[0]; s->dirty_opts = true; }
+    if (!std::strcmp(field, "scaling")) {
+        // :393 sets the stage cost scaling to the time step, and this solver has ONE number for both (brov_opts::Ts is the ERK4
+        // step and the cost scaling).  Re-stating the current value is accepted; a scaling that differs from the integrator's step
+        // is refused instead of silently changing the discretisation (use ocp_nlp_in_set "Ts" / update_time_steps for that).
+        if (stage < s->N && std::fabs(v[0] - s->opts.Ts) > 1e-12 * std::fabs(s->opts.Ts)) {
+            std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): cost scaling %g differs from the time step %g; the two are one "
+                                 "parameter here -- refused\n", v[0], s->opts.Ts);
+            return 1;
+        }
         return 0;
     }
     std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): unsupported field '%s'\n", field);

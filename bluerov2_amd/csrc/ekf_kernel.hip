@@ -468,6 +468,44 @@ __device__ __forceinline__ void gemm_dpp(Rows& C, const Rows& B, AP ap, AS as) {
         gemm_block<0, 2, true, CORNER>(C, B, r0, r1);
     }
 }
+// Symmetric result computed with CORNER = true: rows 16, 17 (secondary set of lanes 0, 1), columns 0..15, are columns 16, 17 of
+// the primary rows -- lane 0 / 1 gathers them with 2 x 16 row broadcasts instead of 2 x 16 x 18 fmacs issued for two lanes.
+__device__ __forceinline__ void fill_secondary_from_symmetry(Rows& C, int l) {
+    for_k(std::make_integer_sequence<int, 16>{}, [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const double t16 = bcast<J>(C.p[16]), t17 = bcast<J>(C.p[17]);
+        C.s[J] = (l == 0) ? t16 : ((l == 1) ? t17 : 0.0);
+    });
+}
+// C += A B for a SYMMETRIC right operand B, secondary rows of C done the cheap way: C[16+r][j] = sum_k A[16+r][k] B[k][j] and
+// B[k][j] = B[j][k] is element k of the row lane j owns, so lane j computes C[16][j] and C[17][j] with 2 x 18 fmacs on its own
+// registers (a16(k), a17(k): rows 16, 17 of A, identical for the 16 lanes of a filter), then lanes 0 / 1 gather their rows with
+// row broadcasts.  Columns 16, 17 of those rows use B's secondary rows (lanes 0, 1).  init16 / init17: C[16][j], C[17][j] to add to.
+template <class AP, class A16, class A17>
+__device__ __forceinline__ void gemm_dpp_symB(Rows& C, const Rows& B, AP ap, A16 a16, A17 a17, int l) {
+    gemm_dpp<true>(C, B, ap, [&](int) { return 0.0; });     // primary rows; the secondary set is rebuilt below
+    double c16 = 0.0, c17 = 0.0, d16[2] = {0.0, 0.0}, d17[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < EN; k++) {
+        const double x16 = a16(k), x17 = a17(k);
+        c16 = fma(x16, B.p[k], c16);          // lane j < 16: column j of rows 16 / 17
+        c17 = fma(x17, B.p[k], c17);
+        // columns 16, 17: B[k][16 + m] = B[16 + m][k] = B.s[k] of lane m
+        d16[0] = fma(x16, B.s[k], d16[0]);    // valid in lanes 0 (column 16) and 1 (column 17)
+        d17[0] = fma(x17, B.s[k], d17[0]);
+    }
+    for_k(std::make_integer_sequence<int, 16>{}, [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        const double t16 = bcast<J>(c16), t17 = bcast<J>(c17);
+        C.s[J] = (l == 0) ? t16 : ((l == 1) ? t17 : 0.0);
+    });
+    {   // corner: lane 0 needs C[16][16] (its own d16), C[16][17] (lane 1's d16); lane 1 needs C[17][16] (lane 0's d17), C[17][17]
+        const double e16_0 = bcast<0>(d16[0]), e16_1 = bcast<1>(d16[0]), e17_0 = bcast<0>(d17[0]), e17_1 = bcast<1>(d17[0]);
+        C.s[16] = (l == 0) ? e16_0 : ((l == 1) ? e17_0 : 0.0);
+        C.s[17] = (l == 0) ? e16_1 : ((l == 1) ? e17_1 : 0.0);
+    }
+    (void)d16[1]; (void)d17[1];
+}
 __device__ __forceinline__ void zero_rows(Rows& R) {
 #pragma unroll
     for (int j = 0; j < EN; j++) { R.p[j] = 0.0; R.s[j] = 0.0; }
@@ -576,7 +614,8 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     Rows Pq;
 #pragma unroll
     for (int j = 0; j < EN; j++) { Pq.p[j] = (j == l) ? c.Q[j] : 0.0; Pq.s[j] = (sec && j == 16 + l) ? c.Q[j] : 0.0; }
-    gemm_dpp(Pq, G, [&](int k) { return bufC[k * EN + l]; }, [&](int k) { const double t = bufC[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    gemm_dpp<true>(Pq, G, [&](int k) { return bufC[k * EN + l]; }, [&](int k) { const double t = bufC[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    fill_secondary_from_symmetry(Pq, l);    // P_pred is symmetric: only the 2x2 corner of rows 16, 17 was accumulated
     store_rows(bufB, Pq, l);                // P_pred stays in bufB (right operand of V = J P_pred)
     // ---- H^T by forward differences of h at x_pred, innovation
     Rows Ht;
@@ -604,14 +643,15 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     // W = H P_pred  (= (P_pred H^T)^T; right operand: P_pred, still in registers)
     Rows W;
     zero_rows(W);
-    gemm_dpp(W, Pq, [&](int k) { return bufC[k * EN + l]; }, [&](int k) { const double t = bufC[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    gemm_dpp_symB(W, Pq, [&](int k) { return bufC[k * EN + l]; }, [&](int k) { return bufC[k * EN + 16]; }, [&](int k) { return bufC[k * EN + 17]; }, l);
     store_rows(bufA, W, l);                 // P is dead
     __syncthreads();
     // S = W H^T + R
     Rows S;
 #pragma unroll
     for (int j = 0; j < EN; j++) { S.p[j] = (j == l) ? c.R : 0.0; S.s[j] = (sec && j == 16 + l) ? c.R : 0.0; }
-    gemm_dpp(S, Ht, [&](int k) { return bufA[l * EN + k]; }, [&](int k) { const double t = bufA[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    gemm_dpp<true>(S, Ht, [&](int k) { return bufA[l * EN + k]; }, [&](int k) { const double t = bufA[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    fill_secondary_from_symmetry(S, l);     // S is symmetric
     // ---- K^T = S^-1 W by Gauss-Jordan on [S | W] without pivoting (S is SPD); the pivot row is broadcast with DPP.
     // Secondary rows of lanes >= 2 are zero and stay zero (their factor is 0).
     Rows T;
@@ -682,7 +722,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
         Rows Pr;
         load_rows(bufB, Pr, l);
         zero_rows(V);
-        gemm_dpp(V, Pr, [&](int k) { return bufC[l * EN + k]; }, [&](int k) { const double t = bufC[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+        gemm_dpp_symB(V, Pr, [&](int k) { return bufC[l * EN + k]; }, [&](int k) { return bufC[16 * EN + k]; }, [&](int k) { return bufC[17 * EN + k]; }, l);
     }
     __syncthreads();                        // reads of bufB (P_pred) are done
     store_rows(bufB, V, l);
