@@ -1319,7 +1319,22 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
 }
 
 
-__device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane) {
+// weights and bounds of the lane's rows (cst = [W16 | We12 pad4 | lbu4 | ubu4]).  The LDS-resident kernels request them BEFORE
+// the linearisation and hand them to setup_inst afterwards: requested there, the loads would be an exposed L2 round trip
+// (the single resident wave has nothing else to run)
+struct LaneCst { double Wr[4], Wer[3], lbm, ubm; };
+__device__ __forceinline__ LaneCst load_lane_cst(const double* __restrict__ cst, int lane) {
+    const int rg = lane >> 4;
+    LaneCst c;
+#pragma unroll
+    for (int r = 0; r < 4; r++) c.Wr[r] = cst[rg + 4 * r];
+#pragma unroll
+    for (int r = 0; r < 3; r++) c.Wer[r] = cst[16 + rg + 4 * r];
+    c.lbm = cst[32 + rg];
+    c.ubm = cst[36 + rg];
+    return c;
+}
+__device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane, const LaneCst* pre = nullptr) {
     const int N = P.N, nv = 4 * N;
     const double* __restrict__ cst = P.cst;
     I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
@@ -1348,13 +1363,13 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.lds_dxb = nullptr;
     I.lds_zero = nullptr;
     I.lds_tr = nullptr;
-    // cst = [W16 | We12 pad4 | lbu4 | ubu4]
+    const LaneCst c = pre ? *pre : load_lane_cst(cst, lane);
 #pragma unroll
-    for (int r = 0; r < 4; r++) I.Wr[r] = cst[I.rg + 4 * r];
+    for (int r = 0; r < 4; r++) I.Wr[r] = c.Wr[r];
 #pragma unroll
-    for (int r = 0; r < 3; r++) I.Wer[r] = cst[16 + I.rg + 4 * r];
-    I.lbm = cst[32 + I.rg];
-    I.ubm = cst[36 + I.rg];
+    for (int r = 0; r < 3; r++) I.Wer[r] = c.Wer[r];
+    I.lbm = c.lbm;
+    I.ubm = c.ubm;
 }
 
 #ifndef BROV_QP_WAVES
@@ -1683,11 +1698,13 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     // ---- preparation: ERK4 + sensitivities of all N intervals at once (lin_phase below)
     double part = 0.0;
     bool nanp = false;
+    LaneCst lc;
+    if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
     lin_phase<W == 1>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
     Inst I;
-    setup_inst(P, I, b, lane);
+    setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr);
     I.lds_ba = (const lds_f64*)ba_s;
     I.lds_bv = (const lds_f64*)bv_s;
     I.lds_kt = (lds_f64*)kt_s;
@@ -1789,8 +1806,9 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
         if (b >= P.B) break;
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
         // lin_phase (which needs the whole architectural register file)
+        const LaneCst lc = load_lane_cst(P.cst, lane);
         auto setup = [&](Inst& I) __attribute__((always_inline)) {
-            setup_inst(P, I, b, lane);
+            setup_inst(P, I, b, lane, &lc);
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
             I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr;
             I.lds_ba = (const lds_f64*)ba_s;
