@@ -953,22 +953,13 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     auto rd_dxb = [&](int j) -> double { if constexpr (EL) return I.lds_dxb[j]; else return I.dxb[j]; };
     auto rd_grad = [&](int j) -> double { if constexpr (EL) return I.lds_kff[j]; else return GRAD[j]; };
 
-    // d0 = x0 - x_0, row-replicated; KKT of the entering iterate = max(LIN partials, |d0|)
-    d4 d0;
-    double kkt = 0.0;
+    // d0 = x0 - x_0, row-replicated; KKT of the entering iterate = max(LIN partials, |d0|).  The six loads are requested here and
+    // consumed after the step-0 backward sweep: waited for at once they are an exposed L2 / HBM round trip of the single wave
+    double x0v[3], xiv[3];
     {
         const double* x0 = P.x0 + (size_t)b * 12;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            d0[r] = x0[rg + 4 * r] - I.x[rg + 4 * r];
-            kkt_upd(kkt, d0[r]);  // NaN-poisoning max (lin_device.hpp)
-        }
-        d0[3] = 0.0;
-        double part = lin_part;
-        bool nanp = lin_nan;
-        if (kkt != kkt) nanp = true;
-        kkt = wave_max(fmax(part, (kkt != kkt) ? 0.0 : kkt));
-        if (__ballot(nanp) != 0ull) kkt = __builtin_nan("");
+        for (int r = 0; r < 3; r++) { x0v[r] = x0[rg + 4 * r]; xiv[r] = I.x[rg + 4 * r]; }
     }
 
     // ---- step 0: equality-constrained minimiser (Gamma = 0, rhs = r) ---------------------------------------
@@ -984,7 +975,25 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     bool early = false;
     bool ok = pre_ok;
     if constexpr (LDS != 3) ok = riccati_backward<true, LDS, false, true>(I);
+    d4 d0;
+    double kkt = 0.0;
+    {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            d0[r] = x0v[r] - xiv[r];
+            kkt_upd(kkt, d0[r]);  // NaN-poisoning max (lin_device.hpp)
+        }
+        d0[3] = 0.0;
+        double part = lin_part;
+        bool nanp = lin_nan;
+        if (kkt != kkt) nanp = true;
+        kkt = wave_max(fmax(part, (kkt != kkt) ? 0.0 : kkt));
+        if (__ballot(nanp) != 0ull) kkt = __builtin_nan("");
+    }
     DBG_STAMP(2);
+    // bounds of this lane's elements of the check below (element j = lane + 64 t belongs to input lane & 3): requested before
+    // the forward sweep, not after it
+    const double lbc = EL ? cst[32 + (lane & 3)] : 0.0, ubc = EL ? cst[36 + (lane & 3)] : 0.0;
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
@@ -998,8 +1007,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             for (int t = 0; t < 2; t++) {
                 const int j = lane + 64 * t;
                 if (j < nv) {
-                    const int m = j & 3;
-                    const double vj = rd_vhat(j), lb = cst[32 + m] - ureg[t], ub = cst[36 + m] - ureg[t];
+                    const double vj = rd_vhat(j), lb = lbc - ureg[t], ub = ubc - ureg[t];
                     if (!(vj >= lb && vj <= ub)) feas = false;
                 }
             }
@@ -1184,6 +1192,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             DBG_STAMP(5);
         } else {
         double xpre[UX], ypre[UX], urpre[UU];
+        // one-wave fused kernel: the cost weights of those elements too (the two-wave variant has no registers for them)
+        double wxpre[LDS == 1 ? UX : 1], wupre[LDS == 1 ? UU : 1];
         if constexpr (EL) {
 #pragma unroll
             for (int t = 0; t < UX; t++) {
@@ -1192,12 +1202,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 const int i = jj / 12, c = jj - i * 12;
                 xpre[t] = x_it[jj];
                 ypre[t] = I.yref[(size_t)i * 16 + c];
+                if constexpr (LDS == 1) wxpre[t] = cst[(i == N) ? 16 + c : c];
             }
 #pragma unroll
             for (int t = 0; t < UU; t++) {
                 const int j = lane + 64 * t;
                 const int jj = j < nv ? j : 0;
                 urpre[t] = I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
+                if constexpr (LDS == 1) wupre[t] = cst[12 + (jj & 3)];
             }
         }
         sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
@@ -1237,7 +1249,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         u_it[j] = un;
                         if (j < 4) { P.res[b].u0[j] = un; u0v = un; }
                         const double e = un - ur[t];
-                        cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+                        const double wgt = (LDS == 1 && j0 == lane) ? wupre[LDS == 1 ? t : 0] : cst[12 + m];
+                        cost += 0.5 * P.Ts * wgt * e * e;
                     }
                 }
             }
@@ -1264,7 +1277,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         const double xn = xo[t] + dj[t];
                         x_it[j] = xn;
                         const double e = xn - yr[t];
-                        cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+                        const double wgt = (LDS == 1 && j0 == lane) ? wxpre[LDS == 1 ? t : 0] : cst[(i == N) ? 16 + c : c];
+                        cost += 0.5 * ((i == N) ? wgt : P.Ts * wgt) * e * e;
                     }
                 }
             }
