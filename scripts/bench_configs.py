@@ -29,7 +29,7 @@ def run(s, set_ref, ticks=TICKS, warm=WARM):
     r = s.results()
     return dict(solves_per_s=s.B * ticks / dt, ms_per_step=dt / ticks * 1e3, mean_qp_iter=float(r["qp_iter"].mean()),
                 frac_ipm=float((r["qp_iter"] > 0).mean()), status_nonzero=int((r["status"] != 0).sum()),
-                kernel_path="fused" if s.last_kernel_path() == ba.PATH_FUSED else "streaming",
+                kernel_path={1: "streaming", 2: "fused", 3: "windowed"}[s.last_kernel_path()],
                 hbm_state_bytes=s.device_bytes)
 
 
@@ -85,7 +85,8 @@ def main(tag):
     amp, frq, ph = rng.uniform(1, 3, B), rng.uniform(0.25, 0.75, B), rng.uniform(0, 2 * np.pi, B)
     x0 = np.zeros((B, 12)); x0[:, 0] = 2.0; x0[:, 2] = -20.0
     s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05)); s.set_x0(x0); s.set_params(ba.P_NOMINAL)
-    r4 = run(s, lambda k: s.set_yref_candidates("lemniscate", amp, frq, ph, t0=0.05 * k, dt=0.05))
+    s.set_candidate_params("lemniscate", amp, frq, ph)      # shape parameters stay on the device; one kernel per tick rebuilds the windows
+    r4 = run(s, lambda k: s.set_yref_candidates_tick(0.05 * k, 0.05))
     idx, best = s.select_best()
     r4["select_best"] = dict(index=int(idx), cost=float(best["cost"]))
     out["cfg4_shard_B8192_N20_lemniscate_candidates"] = r4
@@ -96,7 +97,9 @@ def main(tag):
         x0, circ = synthetic_inputs(B, 4)
         s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
         r5 = run(s, lambda k: s.set_yref_from_trajectory(k))
-        r5["lds_bytes_per_instance"] = int((N * (12 * 13 + 12 + 48 + 4 + 4 + 4) + 2 * (N + 1) * 12) * 8) if r5["kernel_path"] == "fused" else 0
+        L = N if N <= 23 else -(-N // -(-N // 20))             # stages resident in LDS: whole horizon, or one window
+        r5["lds_resident_stages"] = L
+        r5["lds_bytes_per_wave"] = int((L * (12 * 13 + 12 + 48 + 4 + 4 + 4) + 2 * (L + 1) * 12) * 8) if r5["kernel_path"] != "streaming" else 0
         out[f"cfg5_shard_B4096_N{N}"] = r5
         s.close()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
