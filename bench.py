@@ -404,6 +404,10 @@ def main(argv=None):
         stage = [torch.empty_like(res_view) for _ in range(2)] if gather else None
         gathered = [torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
         done = [None, None]
+        if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered[0], stage[0])
+            torch.cuda.synchronize()
         s.init_iterate_default()
         s.enable_timing(False)
         best = None
