@@ -111,6 +111,7 @@ struct Inst {
     double Ts;
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
     double Wer[3];  // We[row]
+    double Wq, Weq, Wuq;  // VALU sweeps (lane = (row c, column group)): W[c], We[c] for c = min(lane >> 2, 11); W[12 + (lane >> 2 & 3)]
     double lbm, ubm;  // bounds of input m = rg
 };
 
@@ -464,21 +465,93 @@ __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
 
 // forward sweep of the closed loop: vhat_i = K_i dx_i + kff_i, dx_{i+1} = A dx_i + B vhat_i + b_i.
 // Leaves vhat in I.vhat and the state steps in I.dxb.  fwd_chunk: the stages of the resident window, dx carried in xx.
+// ---- vector recursions on the VALU (LDS-resident kernels) ---------------------------------------------------------------
+// The forward, roll-out and adjoint sweeps are matrix-VECTOR recursions.  Round 1 ran them through the 16x16x4 MFMA with the vector
+// row-replicated (no cross-lane movement, but 15 of the tile's 16 columns wasted: 7 MFMAs = 448 issue cycles per forward stage for
+// 240 multiply-adds).  Here a 16-row x 16-column stage matrix is spread over the wave as lane (k, q) = (lane >> 2, lane & 3) <->
+// row k, columns 4q..4q+3: four fmas per lane, a two-step DPP quad reduction, and the result vector goes through LDS (where the
+// sweeps store it anyway) to come back as "four elements per lane".  A forward stage is ~60 VALU instructions + two LDS round trips.
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+// per-lane LDS offsets of the forward stage's operands, computed once per sweep (every load of a stage is then base + stage
+// stride + constant: one address add per array and stage)
+struct FwdOff { int a, a3, b4, kk, bk, kf; };
+struct FwdV { double a[4], kk[4], b4[4], bk, kf; };
+__device__ __forceinline__ FwdOff fwd_offsets(const Inst& I) {
+    const int k = I.lane >> 2, q = I.lane & 3;
+    const int ka = k < NX ? k : NX - 1, km = k < 4 ? k : 3, q3 = q < 3 ? q : 2;
+    FwdOff o;
+    const int c0 = 4 * q3 - 3;                 // first stored column of the lane's group (columns 0..2 are e_c: not stored)
+    o.a = ka * kBaStride + (c0 > 0 ? c0 : 0);  // q == 0: elements 0..2 are the structural e_c, overridden in the stage
+    o.a3 = ka * kBaStride + c0 + 3;            // last column of the group (column 3 for q == 0)
+    o.b4 = ka * kBaStride + 9;                 // B row k: columns 12..15
+    o.kk = 16 * q3 + km;                       // K[m][4q+t] = K^T[4q+t][m] at [(4q+t)*4 + m]
+    o.bk = ka;
+    o.kf = km;
+    return o;
+}
+__device__ __forceinline__ FwdV load_fwd_v(const Inst& I, const FwdOff& o, int i) {
+    FwdV s;
+    const lds_f64* ba = I.lds_ba + i * kBaStage;
+#pragma unroll
+    for (int t = 0; t < 3; t++) s.a[t] = ba[o.a + t];
+    s.a[3] = ba[o.a3];
+#pragma unroll
+    for (int t = 0; t < 4; t++) s.b4[t] = ba[o.b4 + t];
+    const lds_f64* kt = I.lds_kt + i * kKtStage + o.kk;
+#pragma unroll
+    for (int t = 0; t < 4; t++) s.kk[t] = kt[t * 4];
+    s.bk = I.lds_bv[i * NX + o.bk];
+    s.kf = I.lds_kff[i * 4 + o.kf];
+    return s;
+}
 template <int LDS>
 __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
-        // two stages ahead (see adjoint<>): the LDS reads of a stage are in flight for a whole stage before they are needed
-        pipelined<kLdsDist<LDS>, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
-            d4 c = {in.kf, 0, 0, 0};
-            d4 v = tn<3>(in.kt, xx, c);
-            I.lds_vhat[i * 4 + rg] = v[0];
-            d4 z = {xx[0], xx[1], xx[2], v[0]};
-            xx = tn<4>(in.bat, z, in.bb);
-            xx[3] = 0.0;
-            store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl);
+        // Lane (k, q): row k, column group q.  Phase 1: partials of K x (quads k < 4) and A x; the inputs v = K x + kff go through
+        // LDS (where they are stored anyway) to all lanes; phase 2: x+ = A x + B v + b.  Two LDS round trips per stage; a variant
+        // with one (closed-loop partials, row rotations of the K x partials) measured the same: the DPP moves cost what the second
+        // round trip costs.
+        const int k = I.lane >> 2, q = I.lane & 3;
+        const bool rowx = k < NX, rowv = k < 4, colx = q < 3;
+        const int q3 = colx ? q : 2;
+        const double e0 = (k == 0) ? 1.0 : 0.0, e1 = (k == 1) ? 1.0 : 0.0, e2 = (k == 2) ? 1.0 : 0.0;
+        const FwdOff off = fwd_offsets(I);
+        lds_f64* vpark = rowv ? I.lds_vhat + k : I.lds_tr + (I.lane & 15);   // idle lanes: 16 distinct scratch slots, not one
+        const int vstr = rowv ? 4 : 0;
+        lds_f64* xpark = rowx ? I.lds_dxb + NX + k : I.lds_tr + (I.lane & 15);
+        const int xstr = rowx ? NX : 0;
+        // the state step of the stage is requested at the END of the previous stage, right behind the store it depends on and
+        // AHEAD of the operand prefetch of the next iteration: LDS returns in order, so a read queued behind the prefetch reads
+        // would wait for all of them
+        const lds_f64* xr0 = I.lds_dxb + 4 * q3;
+        double x0 = xr0[0], x1 = xr0[1], x2 = xr0[2], x3 = xr0[3];
+        pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(I, off, kk); }, [&](int i, const FwdV& in) {
+            const double a0 = q == 0 ? e0 : in.a[0], a1 = q == 0 ? e1 : in.a[1], a2 = q == 0 ? e2 : in.a[2];
+            double pv = in.kk[0] * x0;
+            pv = fma(in.kk[1], x1, pv); pv = fma(in.kk[2], x2, pv); pv = fma(in.kk[3], x3, pv);
+            double pa = a0 * x0;
+            pa = fma(a1, x1, pa); pa = fma(a2, x2, pa); pa = fma(in.a[3], x3, pa);
+            pv = colx ? pv : 0.0;
+            pa = colx ? pa : 0.0;
+            const double v = quad_sum(pv) + in.kf;
+            vpark[i * vstr] = rowv ? v : 0.0;
+            const lds_f64* vr = I.lds_vhat + i * 4;
+            const double v0 = vr[0], v1 = vr[1], v2 = vr[2], v3 = vr[3];
+            double xn = quad_sum(pa) + in.bk;                      // under the LDS round trip of v
+            xn = fma(in.b4[0], v0, xn); xn = fma(in.b4[1], v1, xn); xn = fma(in.b4[2], v2, xn); xn = fma(in.b4[3], v3, xn);
+            xpark[i * xstr] = rowx ? xn : 0.0;
+            const lds_f64* xr = xr0 + (i + 1) * NX;
+            x0 = xr[0]; x1 = xr[1]; x2 = xr[2]; x3 = xr[3];
         });
+        // the last state step back into the row-replicated form the callers carry between windows
+        const lds_f64* xl = I.lds_dxb + N * NX + rg;
+        xx = d4{xl[0], xl[4], xl[8], 0.0};
     }
     if constexpr (!LDS) {
         pipelined<2, FwdIn>(N, [&](int k) { return load_fwd<LDS>(I, k); }, [&](int i, const FwdIn& in) {
@@ -510,17 +583,44 @@ __device__ __forceinline__ RollIn load_roll(const Inst& I, int i, const double* 
     return s;
 }
 // roll the linearised dynamics out for the inputs in varr -> I.dxb
+struct RollV { double a[4], bk; };
+__device__ __forceinline__ RollV load_roll_v(const Inst& I, int oa, int oa3, int ob, int i) {
+    RollV s;
+    const lds_f64* ba = I.lds_ba + i * kBaStage;
+#pragma unroll
+    for (int t = 0; t < 3; t++) s.a[t] = ba[oa + t];
+    s.a[3] = ba[oa3];
+    s.bk = I.lds_bv[i * NX + ob];
+    return s;
+}
 template <int LDS>
 __device__ __forceinline__ void roll_chunk(const Inst& I, d4& xx, const double* varr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
-    if constexpr (LDS) {
-        pipelined<kLdsDist<LDS>, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
-            d4 z = {xx[0], xx[1], xx[2], in.v};
-            xx = tn<4>(in.bat, z, in.bb);
-            xx[3] = 0.0;
-            store_vec12_lds(I.lds_dxb + (i + 1) * 12, xx, rg, cl);
+    if constexpr (LDS) {   // VALU form (see fwd_chunk): x+ = [A B] [x; v] + b with the inputs v staged in the LDS copy of vhat
+        const int k = I.lane >> 2, q = I.lane & 3;
+        const bool rowx = k < NX;
+        const double e0 = (q == 0 && k == 0) ? 1.0 : 0.0, e1 = (q == 0 && k == 1) ? 1.0 : 0.0, e2 = (q == 0 && k == 2) ? 1.0 : 0.0;
+        lds_f64* xpark = rowx ? I.lds_dxb + NX + k : I.lds_tr + (I.lane & 15);
+        const int xstr = rowx ? NX : 0;
+        const int ka = rowx ? k : NX - 1, c0 = 4 * q - 3;
+        const int oa = ka * kBaStride + (c0 > 0 ? c0 : 0), oa3 = ka * kBaStride + c0 + 3, ob = ka;
+        // z = [dx_i ; v_i]: column group q < 3 from the state-step row, q == 3 from the inputs; requested behind the store of the
+        // previous stage and ahead of the operand prefetch (see fwd_chunk)
+        const lds_f64* zr0 = q < 3 ? I.lds_dxb + 4 * q : I.lds_vhat;
+        const int zstr = q < 3 ? NX : 4;
+        double z0 = zr0[0], z1 = zr0[1], z2 = zr0[2], z3 = zr0[3];
+        pipelined<kLdsDist<LDS>, RollV>(N, [&](int kk) { return load_roll_v(I, oa, oa3, ob, kk); }, [&](int i, const RollV& in) {
+            const double a0 = q == 0 ? e0 : in.a[0], a1 = q == 0 ? e1 : in.a[1], a2 = q == 0 ? e2 : in.a[2];
+            double pa = a0 * z0;
+            pa = fma(a1, z1, pa); pa = fma(a2, z2, pa); pa = fma(in.a[3], z3, pa);
+            const double xn = quad_sum(pa) + in.bk;
+            xpark[i * xstr] = rowx ? xn : 0.0;
+            const lds_f64* zr = zr0 + (i + 1 < N ? i + 1 : i) * zstr;
+            z0 = zr[0]; z1 = zr[1]; z2 = zr[2]; z3 = zr[3];
         });
+        const lds_f64* xl = I.lds_dxb + N * NX + rg;
+        xx = d4{xl[0], xl[4], xl[8], 0.0};
     } else {
         pipelined<3, RollIn>(N, [&](int k) { return load_roll<LDS>(I, k, varr); }, [&](int i, const RollIn& in) {
             d4 z = {xx[0], xx[1], xx[2], in.v};
@@ -566,38 +666,82 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
 // With COMMIT the multipliers pi are written to pi_out (the iterate).
 // LDS path: both outputs go to LDS regions that are dead at this point (g -> the feed-forward array, pi -> the K^T array,
 // 12 of its 48 doubles per stage); per-stage global stores would sit on vmcnt in front of every prefetch wait.
+struct AdjV { double m[4], dxc, qc, vm, rm; };
+__device__ __forceinline__ AdjV load_adj_v(const Inst& I, int om, int ox, int ou, int i) {
+    AdjV s;
+    // column c of [A_i B_i], rows 4q..4q+3 (columns 0..2 are e_c: not stored)
+    const lds_f64* col = I.lds_ba + i * kBaStage + om;
+#pragma unroll
+    for (int t = 0; t < 4; t++) s.m[t] = col[t * kBaStride];
+    s.dxc = I.lds_dxb[(i + 1) * NX + ox];
+    s.qc = I.lds_q[(i + 1) * NX + ox];
+    s.vm = I.lds_vhat[i * 4 + ou];
+    s.rm = I.lds_r[i * 4 + ou];
+    return s;
+}
 template <bool COMMIT, int LDS>
 __device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
+    if constexpr (LDS) {
+        // VALU form (see fwd_chunk): lane (c, q) = (lane >> 2, lane & 3) <-> column c of [A B], rows 4q..4q+3 (q < 3).
+        //   pi_i[c] = Qd dx_{i+1}[c] + q_{i+1}[c] + (A_{i+1}' pi_{i+1})[c]     by the quad that owns c, through LDS to every lane,
+        //   G = [A_i B_i]' pi_i: rows 0..11 feed the next stage, rows 12..15 are the input gradient.
+        // The multipliers' LDS buffer is the K^T area (dead in every adjoint sweep; with COMMIT it is what the caller parks).
+        const int c = I.lane >> 2, q = I.lane & 3;
+        const bool rowx = c < NX, colx = q < 3;
+        const int q3 = colx ? q : 2;
+        const double e0 = (colx && 4 * q == c) ? 1.0 : 0.0, e1 = (colx && 4 * q + 1 == c) ? 1.0 : 0.0, e2 = (colx && 4 * q + 2 == c) ? 1.0 : 0.0,
+                     e3 = (colx && 4 * q + 3 == c) ? 1.0 : 0.0;
+        const bool ecol = c < 3;
+        const int om = (4 * q3) * kBaStride + (c >= 3 ? c - 3 : 0), ox = rowx ? c : NX - 1, ou = c & 3;
+        // A'pi of the stage after this window: row-replicated -> the quad that owns the row (through the transposition scratch)
+        store_vec12_lds(I.lds_tr, atpi, rg, cl);
+        double gq = I.lds_tr[rowx ? c : 0];
+        lds_f64* ppark = rowx ? I.lds_kt + c : I.lds_tr + (I.lane & 15);
+        const int pstr = rowx ? NX : 0;
+        lds_f64* gpark = rowx ? I.lds_tr + (I.lane & 15) : I.lds_kff + (c - NX);
+        const int gstr = rowx ? 0 : 4;
+        const double rd = I.Ts * I.Wuq;
+        pipelined<kLdsDist<LDS>, AdjV>(N, [&](int kk) { return load_adj_v(I, om, ox, ou, N - 1 - kk); }, [&](int kk, const AdjV& in) {
+            const int i = N - 1 - kk;
+            const double qd = (I.i0 + i + 1 == I.NT) ? I.Weq : I.Ts * I.Wq;
+            const double pic = fma(qd, in.dxc, in.qc + gq);
+            ppark[i * pstr] = rowx ? pic : 0.0;
+            const lds_f64* pr = I.lds_kt + i * NX + 4 * q3;
+            const double p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+            __builtin_amdgcn_sched_barrier(0);
+            const double m0 = ecol ? e0 : in.m[0], m1 = ecol ? e1 : in.m[1], m2 = ecol ? e2 : in.m[2], m3 = ecol ? e3 : in.m[3];
+            double acc = m0 * p0;
+            acc = fma(m1, p1, acc); acc = fma(m2, p2, acc); acc = fma(m3, p3, acc);
+            acc = colx ? acc : 0.0;
+            const double G = quad_sum(acc);
+            gpark[i * gstr] = rowx ? 0.0 : fma(rd, in.vm, in.rm + G);
+            gq = G;
+        });
+        // hand A'pi of this window's first stage on, row-replicated
+        lds_f64* tpark = rowx ? I.lds_tr + c : I.lds_tr + 16;
+        *tpark = gq;
+        const lds_f64* tl = I.lds_tr + rg;
+        atpi = d4{tl[0], tl[4], tl[8], 0.0};
+        return;
+    }
     const d4 z4 = {0, 0, 0, 0};
     auto stage = [&](int i, const AdjIn& in) __attribute__((always_inline)) {
         d4 pi;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const double qd = (I.i0 + i + 1 == I.NT) ? I.Wer[r] : I.Ts * I.Wr[r];
-            pi[r] = LDS ? qd * in.dx[r] + in.xn[r] + atpi[r] : qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
+            pi[r] = qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
         }
         pi[3] = 0.0;
-        if constexpr (LDS) {
-            if (COMMIT) store_vec12_lds(I.lds_kt + i * 12, pi, rg, cl);
-        } else {
-            if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
-        }
+        if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
         d4 G = tn<3>(in.ba, pi, z4);
         const double rd = I.Ts * I.Wr[3];
-        if constexpr (LDS) I.lds_kff[i * 4 + rg] = rd * in.v + in.u + G[3];
-        else if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
+        if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
         atpi = G;
     };
-    if constexpr (LDS) {
-        // two stages ahead: the LDS reads of stage i-2 are issued a full stage before they are consumed, so the wait at the
-        // top of a stage never sees the ~200 cycles of LDS queue + latency that a one-stage look-ahead leaves exposed
-        pipelined<kLdsDist<LDS>, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
-                            [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
-    } else {
-        pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
-                            [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
-    }
+    pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
+                        [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
 }
 template <bool COMMIT, int LDS>
 __device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
@@ -1336,7 +1480,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
 // weights and bounds of the lane's rows (cst = [W16 | We12 pad4 | lbu4 | ubu4]).  The LDS-resident kernels request them BEFORE
 // the linearisation and hand them to setup_inst afterwards: requested there, the loads would be an exposed L2 round trip
 // (the single resident wave has nothing else to run)
-struct LaneCst { double Wr[4], Wer[3], lbm, ubm; };
+struct LaneCst { double Wr[4], Wer[3], lbm, ubm, Wq, Weq, Wuq; };
 __device__ __forceinline__ LaneCst load_lane_cst(const double* __restrict__ cst, int lane) {
     const int rg = lane >> 4;
     LaneCst c;
@@ -1346,6 +1490,10 @@ __device__ __forceinline__ LaneCst load_lane_cst(const double* __restrict__ cst,
     for (int r = 0; r < 3; r++) c.Wer[r] = cst[16 + rg + 4 * r];
     c.lbm = cst[32 + rg];
     c.ubm = cst[36 + rg];
+    const int cq = (lane >> 2) < NX ? (lane >> 2) : NX - 1;
+    c.Wq = cst[cq];
+    c.Weq = cst[16 + cq];
+    c.Wuq = cst[12 + ((lane >> 2) & 3)];
     return c;
 }
 __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane, const LaneCst* pre = nullptr) {
@@ -1384,6 +1532,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     for (int r = 0; r < 3; r++) I.Wer[r] = c.Wer[r];
     I.lbm = c.lbm;
     I.ubm = c.ubm;
+    I.Wq = c.Wq; I.Weq = c.Weq; I.Wuq = c.Wuq;
 }
 
 #ifndef BROV_QP_WAVES
