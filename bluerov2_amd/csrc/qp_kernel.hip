@@ -111,7 +111,7 @@ struct Inst {
     double Ts;
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
     double Wer[3];  // We[row]
-    double Wq, Weq, Wuq;  // VALU sweeps (lane = (row c, column group)): W[c], We[c] for c = min(lane >> 2, 11); W[12 + (lane >> 2 & 3)]
+    double Wq, Weq, Wuq;  // adjoint sweep (lane = (column c, row group)): W[c], We[c] for c = min(lane >> 2, 11); W[12 + (lane >> 2 & 3)]
     double lbm, ubm;  // bounds of input m = rg
 };
 
@@ -394,7 +394,8 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             if constexpr (LDS) {
                 // K^T[k][m] = -T[m][k] is ks at lane (rg = m, cl = k): the compact LDS image [12][4] is written straight from
                 // that register (no transposing MFMA); lanes cl >= 12 are parked on the constant-zero slot
-                lds_f64* t = (cl < NX) ? I.lds_kt + i * kKtStage + cl * 4 + rg : I.lds_zero;
+                // ... as the gain itself, row-major [4][12] (what the VALU forward sweep reads: row m contiguous)
+                lds_f64* t = (cl < NX) ? I.lds_kt + i * kKtStage + rg * NX + cl : I.lds_zero;
                 *t = (cl < NX) ? ks : 0.0;
             } else {
                 d4 KtT = tn1(H[3], -mt, z4);
@@ -476,36 +477,21 @@ __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
     return v;
 }
-// per-lane LDS offsets of the forward stage's operands, computed once per sweep (every load of a stage is then base + stage
-// stride + constant: one address add per array and stage)
-struct FwdOff { int a, a3, b4, kk, bk, kf; };
-struct FwdV { double a[4], kk[4], b4[4], bk, kf; };
-__device__ __forceinline__ FwdOff fwd_offsets(const Inst& I) {
-    const int k = I.lane >> 2, q = I.lane & 3;
-    const int ka = k < NX ? k : NX - 1, km = k < 4 ? k : 3, q3 = q < 3 ? q : 2;
-    FwdOff o;
-    const int c0 = 4 * q3 - 3;                 // first stored column of the lane's group (columns 0..2 are e_c: not stored)
-    o.a = ka * kBaStride + (c0 > 0 ? c0 : 0);  // q == 0: elements 0..2 are the structural e_c, overridden in the stage
-    o.a3 = ka * kBaStride + c0 + 3;            // last column of the group (column 3 for q == 0)
-    o.b4 = ka * kBaStride + 9;                 // B row k: columns 12..15
-    o.kk = 16 * q3 + km;                       // K[m][4q+t] = K^T[4q+t][m] at [(4q+t)*4 + m]
-    o.bk = ka;
-    o.kf = km;
-    return o;
-}
-__device__ __forceinline__ FwdV load_fwd_v(const Inst& I, const FwdOff& o, int i) {
+// "Vector in scalar registers" form of the recursions: lane k (of every 16-lane row: the four rows of the wave do the same work)
+// owns ROW k of the stage matrix -- rows 0..11 = [A_i B_i] rows (x+), rows 12..15 = rows of the gain K_i (inputs) -- and forms the
+// whole 12-term dot product itself against the state step held in SGPRs (v_fma with a scalar operand); the result vector goes
+// back into SGPRs with v_readlane.  No cross-lane reduction, no LDS round trip on the chain: 12 + 4 fmas and 32 v_readlane per
+// forward stage.
+struct FwdV { double m[12], b4[4], cv; };
+__device__ __forceinline__ FwdV load_fwd_v(const lds_f64* mrow, const lds_f64* klo, const lds_f64* brow, const lds_f64* cvec) {
     FwdV s;
-    const lds_f64* ba = I.lds_ba + i * kBaStage;
 #pragma unroll
-    for (int t = 0; t < 3; t++) s.a[t] = ba[o.a + t];
-    s.a[3] = ba[o.a3];
+    for (int c = 0; c < 3; c++) s.m[c] = klo[c];      // columns 0..2: real data only for the gain rows (A rows: structural e_c)
 #pragma unroll
-    for (int t = 0; t < 4; t++) s.b4[t] = ba[o.b4 + t];
-    const lds_f64* kt = I.lds_kt + i * kKtStage + o.kk;
+    for (int c = 3; c < 12; c++) s.m[c] = mrow[c];
 #pragma unroll
-    for (int t = 0; t < 4; t++) s.kk[t] = kt[t * 4];
-    s.bk = I.lds_bv[i * NX + o.bk];
-    s.kf = I.lds_kff[i * 4 + o.kf];
+    for (int t = 0; t < 4; t++) s.b4[t] = brow[t];
+    s.cv = *cvec;
     return s;
 }
 template <int LDS>
@@ -513,41 +499,37 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
-        // Lane (k, q): row k, column group q.  Phase 1: partials of K x (quads k < 4) and A x; the inputs v = K x + kff go through
-        // LDS (where they are stored anyway) to all lanes; phase 2: x+ = A x + B v + b.  Two LDS round trips per stage; a variant
-        // with one (closed-loop partials, row rotations of the K x partials) measured the same: the DPP moves cost what the second
-        // round trip costs.
-        const int k = I.lane >> 2, q = I.lane & 3;
-        const bool rowx = k < NX, rowv = k < 4, colx = q < 3;
-        const int q3 = colx ? q : 2;
+        const int k = I.lane & 15;
+        const bool rowx = k < NX;
+        const int ka = rowx ? k : NX - 1, km = rowx ? 0 : k - NX;
+        // row k of [A_i | K_i]: A row k = ba[k*13 + c - 3] (columns 0..2 structural, overridden below), K row m = kt[m*12 + c]
+        const lds_f64* mrow0 = rowx ? I.lds_ba + ka * kBaStride - 3 : I.lds_kt + km * NX;
+        const int mstr = rowx ? kBaStage : kKtStage;
+        const lds_f64* klo0 = I.lds_kt + km * NX;                              // always a valid address (A rows: value unused)
+        const lds_f64* brow0 = I.lds_ba + ka * kBaStride + 9;                  // B row k (rows 12..15: unused)
+        const lds_f64* cvec0 = rowx ? I.lds_bv + k : I.lds_kff + km;          // b_k / kff_m
+        const int cstr = rowx ? NX : 4;
+        lds_f64* out0 = rowx ? I.lds_dxb + NX + k : I.lds_vhat + km;          // x+_k -> state-step row i+1, v_m -> inputs of stage i
+        const int ostr = rowx ? NX : 4;
         const double e0 = (k == 0) ? 1.0 : 0.0, e1 = (k == 1) ? 1.0 : 0.0, e2 = (k == 2) ? 1.0 : 0.0;
-        const FwdOff off = fwd_offsets(I);
-        lds_f64* vpark = rowv ? I.lds_vhat + k : I.lds_tr + (I.lane & 15);   // idle lanes: 16 distinct scratch slots, not one
-        const int vstr = rowv ? 4 : 0;
-        lds_f64* xpark = rowx ? I.lds_dxb + NX + k : I.lds_tr + (I.lane & 15);
-        const int xstr = rowx ? NX : 0;
-        // the state step of the stage is requested at the END of the previous stage, right behind the store it depends on and
-        // AHEAD of the operand prefetch of the next iteration: LDS returns in order, so a read queued behind the prefetch reads
-        // would wait for all of them
-        const lds_f64* xr0 = I.lds_dxb + 4 * q3;
-        double x0 = xr0[0], x1 = xr0[1], x2 = xr0[2], x3 = xr0[3];
-        pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(I, off, kk); }, [&](int i, const FwdV& in) {
-            const double a0 = q == 0 ? e0 : in.a[0], a1 = q == 0 ? e1 : in.a[1], a2 = q == 0 ? e2 : in.a[2];
-            double pv = in.kk[0] * x0;
-            pv = fma(in.kk[1], x1, pv); pv = fma(in.kk[2], x2, pv); pv = fma(in.kk[3], x3, pv);
-            double pa = a0 * x0;
-            pa = fma(a1, x1, pa); pa = fma(a2, x2, pa); pa = fma(in.a[3], x3, pa);
-            pv = colx ? pv : 0.0;
-            pa = colx ? pa : 0.0;
-            const double v = quad_sum(pv) + in.kf;
-            vpark[i * vstr] = rowv ? v : 0.0;
-            const lds_f64* vr = I.lds_vhat + i * 4;
-            const double v0 = vr[0], v1 = vr[1], v2 = vr[2], v3 = vr[3];
-            double xn = quad_sum(pa) + in.bk;                      // under the LDS round trip of v
-            xn = fma(in.b4[0], v0, xn); xn = fma(in.b4[1], v1, xn); xn = fma(in.b4[2], v2, xn); xn = fma(in.b4[3], v3, xn);
-            xpark[i * xstr] = rowx ? xn : 0.0;
-            const lds_f64* xr = xr0 + (i + 1) * NX;
-            x0 = xr[0]; x1 = xr[1]; x2 = xr[2]; x3 = xr[3];
+        // state step of the first stage: row-replicated -> SGPRs (row r*4 + rg' sits in register r of the lanes with rg == rg')
+        double xs[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) xs[c] = readlane_f64(xx[c >> 2], 16 * (c & 3));
+        pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(mrow0 + kk * mstr, klo0 + kk * kKtStage, brow0 + kk * kBaStage, cvec0 + kk * cstr); },
+                                       [&](int i, const FwdV& in) {
+            const double m0 = rowx ? e0 : in.m[0], m1 = rowx ? e1 : in.m[1], m2 = rowx ? e2 : in.m[2];
+            double d0 = fma(m0, xs[0], in.cv), d1 = m1 * xs[1], d2 = m2 * xs[2];
+            d0 = fma(in.m[3], xs[3], d0); d1 = fma(in.m[4], xs[4], d1); d2 = fma(in.m[5], xs[5], d2);
+            d0 = fma(in.m[6], xs[6], d0); d1 = fma(in.m[7], xs[7], d1); d2 = fma(in.m[8], xs[8], d2);
+            d0 = fma(in.m[9], xs[9], d0); d1 = fma(in.m[10], xs[10], d1); d2 = fma(in.m[11], xs[11], d2);
+            const double dot = d0 + (d1 + d2);          // rows 12..15: v_m = K x + kff; rows 0..11: A x + b
+            const double v0 = readlane_f64(dot, 12), v1 = readlane_f64(dot, 13), v2 = readlane_f64(dot, 14), v3 = readlane_f64(dot, 15);
+            double xn = fma(in.b4[0], v0, dot);
+            xn = fma(in.b4[1], v1, xn); xn = fma(in.b4[2], v2, xn); xn = fma(in.b4[3], v3, xn);
+            out0[i * ostr] = rowx ? xn : dot;
+#pragma unroll
+            for (int c = 0; c < 12; c++) xs[c] = readlane_f64(xn, c);
         });
         // the last state step back into the row-replicated form the callers carry between windows
         const lds_f64* xl = I.lds_dxb + N * NX + rg;
