@@ -255,7 +255,7 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
         s.gm = FACTOR ? gam[ig * 4 + I.rg] : 0.0;
     }
     s.ks = FACTOR ? 0.0 : I.Ks[(size_t)ig * 64 + I.lane];
-    s.mt = FACTOR ? 0.0 : I.Mt[(size_t)ig * 64 + I.lane];
+    s.mt = 0.0;   // M rides in columns 12..15 of the stored gain operand
     return s;
 }
 
@@ -365,16 +365,17 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             const double m00 = e00 - (m20 * x00 + m30 * x01), m10 = e01 - (m20 * x10 + m30 * x11);
             const double m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
             if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
-            // Mtile: lane (rg = m, cl = n < 4) = M[m][n]
-            double mt = 0.0;
+            // Mtile: lane (rg = m, cl = n < 4) = M[m][n]; msel: the same element for every column n = cl & 3
+            double mt = 0.0, msel;
             {
-                const int a = rg > cl ? rg : cl, c = rg > cl ? cl : rg;  // (max, min)
+                const int cq = cl & 3;
+                const int a = rg > cq ? rg : cq, c = rg > cq ? cq : rg;  // (max, min)
                 const double r0 = m00;
                 const double r1 = (c == 0) ? m10 : m11;
                 const double r2 = (c == 0) ? m20 : ((c == 1) ? m21 : m22);
                 const double r3 = (c == 0) ? m30 : ((c == 1) ? m31 : ((c == 2) ? m32 : m33));
-                const double sel = (a == 0) ? r0 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
-                mt = (cl < 4) ? sel : 0.0;
+                msel = (a == 0) ? r0 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
+                mt = (cl < 4) ? msel : 0.0;
             }
             H[0] = blend(mk_col0, lane == 0 ? P[0] + diagm[0] : t0, H[0]);   // H[0][0] = (P e_0)[0] + Ts W_0
             H[1] = blend(mk_col0, t1, H[1]);
@@ -384,12 +385,23 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             d4 T = tn1(mt, H[3], z4);
             const double ks = -T[0];
             d4 S = tn1(H[3], ks, H);
-            d4 kf = tn1(mt, g[3], z4);
-            d4 pn = tn1(ks, g[3], g);
+            // kff = -M gu and p = gx + K^T gu in ONE product: the operand carries the gain in columns 0..11 and M in columns
+            // 12..15, so rows 0..11 of the result are p and rows 12..15 are M gu (M is symmetric)
+            // (windowed kernel.  In the fused kernels the separate M gu product is what fills the issue slot behind T while S and
+            // p wait for the gain: merged, the stage measured 110 cycles SLOWER there and 125 cycles faster in the windowed kernel.)
+            const double xt2 = (cl < NX) ? ks : msel;
+            d4 pn;
+            if constexpr (LDS == 3) {
+                const d4 gC = {g[0], g[1], g[2], 0.0};
+                pn = tn1(xt2, g[3], gC);
+            } else {
+                const d4 kf = tn1(mt, g[3], z4);
+                pn = tn1(ks, g[3], g);
+                pn[3] = kf[0];
+            }
             // store factors
-            if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads these
-                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = ks;
-                I.Mt[(size_t)(I.i0 + i) * 64 + lane] = mt;
+            if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads this: gain | M as one operand tile
+                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = xt2;
             }
             if constexpr (LDS) {
                 // K^T[k][m] = -T[m][k] is ks at lane (rg = m, cl = k): the compact LDS image [12][4] is written straight from
@@ -402,11 +414,11 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
                 double* kt = I.Kt + (size_t)i * 192;
                 kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
             }
-            if constexpr (LDS) {  // only column 0 of kf is M gu: the other lanes are parked on the constant-zero slot
+            if constexpr (LDS) {  // only column 0 of rows 12..15 is M gu: the other lanes are parked on the constant-zero slot
                 lds_f64* kp = (cl == 0) ? I.lds_kff + i * 4 + rg : I.lds_zero;
-                *kp = (cl == 0) ? -kf[0] : 0.0;
+                *kp = (cl == 0) ? -pn[3] : 0.0;
             } else if (cl == 0) {
-                I.kff[i * 4 + rg] = -kf[0];
+                I.kff[i * 4 + rg] = -pn[3];
             }
             P = S;
 #pragma unroll
@@ -417,9 +429,9 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
 #pragma unroll
             for (int r = 0; r < 4; r++) l[r] = in.bv[r] + pv[r];
             d4 g = tn<3>(in.ba, l, qr);
-            d4 kf = tn1(in.mt, g[3], z4);
-            d4 pn = tn1(in.ks, g[3], g);
-            if constexpr (LDS) I.lds_kff[i * 4 + rg] = -kf[0]; else if (cl == 0) I.kff[i * 4 + rg] = -kf[0];
+            const d4 gC = {g[0], g[1], g[2], 0.0};
+            d4 pn = tn1(in.ks, g[3], gC);      // stored operand = gain | M: rows 0..11 p, rows 12..15 M gu
+            if constexpr (LDS) I.lds_kff[i * 4 + rg] = -pn[3]; else if (cl == 0) I.kff[i * 4 + rg] = -pn[3];
             pv = pn;
             pv[3] = 0.0;
         }
