@@ -34,6 +34,7 @@ struct brov_solver {
     int device = 0, B = 0, N = 0;
     brov_opts opts{};
     bool yref_shared = false;
+    const double* yref_view = nullptr;   // shared window = rows of the resident trajectory table, used in place (no copy)
     // device buffers
     double *x0 = nullptr, *yref = nullptr, *yref_sh = nullptr, *par = nullptr;
     double *x = nullptr, *u = nullptr, *pi = nullptr, *lam = nullptr;
@@ -225,8 +226,11 @@ static int copy_in(brov_solver* s, double* dst, const double* src, size_t n, boo
 extern "C" int brov_set_x0_host(brov_solver* s, const double* x0) { return copy_in(s, s ? s->x0 : nullptr, x0, s ? (size_t)s->B * 12 : 0, true, nullptr); }
 extern "C" int brov_set_x0_device(brov_solver* s, const double* x0, void* st) { return copy_in(s, s ? s->x0 : nullptr, x0, s ? (size_t)s->B * 12 : 0, false, st); }
 
+static const double* shared_window(const brov_solver* s) { return s->yref_view ? s->yref_view : s->yref_sh; }
+
 static int set_yref(brov_solver* s, const double* y, int shared, bool host, void* st) {
     if (!s) return BROV_ERR_ARG;
+    s->yref_view = nullptr;
     s->yref_shared = shared != 0;
     const size_t n = (size_t)(s->N + 1) * 16;
     return shared ? copy_in(s, s->yref_sh, y, n, host, st) : copy_in(s, s->yref, y, n * s->B, host, st);
@@ -280,8 +284,9 @@ extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, con
     HIPCHK(hipSetDevice(s->device));
     if (s->yref_shared) {  // materialise the shared window per instance first
         for (int b = 0; b < s->B; b++)
-            HIPCHK(hipMemcpy(s->yref + (size_t)b * (s->N + 1) * 16, s->yref_sh, (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(s->yref + (size_t)b * (s->N + 1) * 16, shared_window(s), (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
         s->yref_shared = false;
+        s->yref_view = nullptr;
     }
     HIPCHK(hipMemcpy(s->yref + ((size_t)inst * (s->N + 1) + stage) * 16, y, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
     return BROV_OK;
@@ -291,6 +296,10 @@ extern "C" int brov_traj_set_host(brov_solver* s, const double* traj, int rows) 
     if (!s || !traj || rows < 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (s->yref_view) {   // the window in force is a view into the table that is about to go: keep a copy
+        HIPCHK(hipMemcpy(s->yref_sh, s->yref_view, (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
+        s->yref_view = nullptr;
+    }
     if (s->traj) { hipFree(s->traj); s->traj = nullptr; }
     HIPCHK(hipMalloc((void**)&s->traj, (size_t)rows * 16 * sizeof(double)));
     HIPCHK(hipMemcpy(s->traj, traj, (size_t)rows * 16 * sizeof(double), hipMemcpyHostToDevice));
@@ -301,7 +310,13 @@ extern "C" int brov_traj_rows(const brov_solver* s) { return s ? s->traj_rows : 
 extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void* stream) {
     if (!s || !s->traj || (ncols != 12 && ncols != 16)) { g_err = "brov_set_yref_from_traj: no trajectory or bad ncols"; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
-    launch_window(s->traj, s->traj_rows, nullptr, line, 1, s->N, ncols, s->yref_sh, (hipStream_t)stream);
+    if (ncols == 16 && line >= 0 && line + s->N <= s->traj_rows - 1) {
+        // the window is N+1 consecutive whole rows of the resident table: use them where they lie (no kernel, no copy)
+        s->yref_view = s->traj + (size_t)line * 16;
+    } else {
+        s->yref_view = nullptr;
+        launch_window(s->traj, s->traj_rows, nullptr, line, 1, s->N, ncols, s->yref_sh, (hipStream_t)stream);
+    }
     s->yref_shared = true;
     HIPCHK(hipGetLastError());
     return BROV_OK;
@@ -312,6 +327,7 @@ extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t*
     HIPCHK(hipMemcpy(s->lines, lines, (size_t)s->B * sizeof(int), hipMemcpyHostToDevice));
     launch_window(s->traj, s->traj_rows, s->lines, 0, s->B, s->N, ncols, s->yref, nullptr);
     s->yref_shared = false;
+    s->yref_view = nullptr;
     HIPCHK(hipGetLastError());
     return BROV_OK;
 }
@@ -333,6 +349,7 @@ extern "C" int brov_set_yref_candidates(brov_solver* s, double t0, double dt, vo
     launch_candidates(s->cand_kind, s->scratch3, s->scratch3 + s->B, s->scratch3 + 2 * (size_t)s->B, t0, dt, s->B, s->N, s->yref,
                       (hipStream_t)stream);
     s->yref_shared = false;
+    s->yref_view = nullptr;
     HIPCHK(hipGetLastError());
     return BROV_OK;
 }
@@ -347,7 +364,7 @@ extern "C" int brov_get_yref_host(brov_solver* s, double* yref) {
     HIPCHK(hipDeviceSynchronize());
     const size_t per = (size_t)(s->N + 1) * 16;
     if (s->yref_shared) {
-        for (int b = 0; b < s->B; b++) HIPCHK(hipMemcpy(yref + (size_t)b * per, s->yref_sh, per * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < s->B; b++) HIPCHK(hipMemcpy(yref + (size_t)b * per, shared_window(s), per * sizeof(double), hipMemcpyDeviceToHost));
     } else {
         HIPCHK(hipMemcpy(yref, s->yref, per * s->B * sizeof(double), hipMemcpyDeviceToHost));
     }
@@ -427,6 +444,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
         rc = BROV_ERR_HIP;
     }
     for (int k = 0; k < ticks && rc == BROV_OK; k++) {
+        s->yref_view = nullptr;
         launch_window(s->traj, s->traj_rows, nullptr, line0 + k, 1, s->N, ncols, s->yref_sh, st);
         s->yref_shared = true;
         rc = brov_solve_phase(s, st, 0);
@@ -488,7 +506,7 @@ static DevParams make_params(const brov_solver* s) {
     for (int j = 0; j < 12; j++) P.We[j] = s->opts.We[j];
     for (int j = 0; j < 4; j++) { P.lbu[j] = s->opts.lbu[j]; P.ubu[j] = s->opts.ubu[j]; }
     P.x0 = s->x0;
-    P.yref = s->yref_shared ? s->yref_sh : s->yref;
+    P.yref = s->yref_shared ? shared_window(s) : s->yref;
     P.yref_stride = s->yref_shared ? 0 : (int64_t)(s->N + 1) * 16;
     P.par = s->par;
     P.x = s->x; P.u = s->u; P.pi = s->pi; P.lam = s->lam;
@@ -595,7 +613,7 @@ extern "C" int brov_get_u0_host(brov_solver* s, double* u0) {
 }
 extern "C" const brov_result* brov_results_device(const brov_solver* s) { return s ? s->res : nullptr; }
 extern "C" double* brov_x0_device(brov_solver* s) { return s ? s->x0 : nullptr; }
-extern "C" double* brov_yref_device(brov_solver* s) { if (!s) return nullptr; s->yref_shared = false; return s->yref; }
+extern "C" double* brov_yref_device(brov_solver* s) { if (!s) return nullptr; s->yref_shared = false; s->yref_view = nullptr; return s->yref; }
 extern "C" double* brov_params_device(brov_solver* s) { if (!s) return nullptr; s->pplant_stale = true; return s->par; }
 extern "C" double* brov_x_device(brov_solver* s) { return s ? s->x : nullptr; }
 extern "C" double* brov_u_device(brov_solver* s) { return s ? s->u : nullptr; }

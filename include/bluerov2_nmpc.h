@@ -134,7 +134,8 @@ int brov_set_yref_stage_host(brov_solver* s, int instance, int stage, const doub
  * node, ctrller/mpc.cpp:242-262). */
 int brov_traj_set_host(brov_solver* s, const double* traj /*[rows][16]*/, int rows);
 int brov_traj_rows(const brov_solver* s);
-int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void* stream);                       /* one shared window */
+/* one shared window; with ncols = 16 and the window inside the table its rows are used where they lie (no copy, no kernel) */
+int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void* stream);
 int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t* lines /*[B]*/, int ncols);     /* per instance      */
 /* analytic per-instance candidate windows (bluerov2_path/config/traj/lemniscate.py:18-39, circle.py:22-56 evaluated at
  * t0 + i*dt with per-instance shape parameters and phase): kind 0 lemniscate (p0 = amplitude, p1 = frequency),
