@@ -16,6 +16,14 @@
 // with [x;u] ordering so that the input block Hu = [Hux Huu] is rows 12..15 = register 3 of the H tile.
 // Vectors are carried "row-replicated" (lane holds v[row] for every column), which makes every matrix-vector
 // product the same tn<> call.  The 4x4 pivot block is inverted redundantly by all lanes from v_readlane values.
+// That is how the factor sweep works in every kernel and how ALL sweeps work in the streaming kernel.  In the LDS-resident
+// kernels (rti_fused_kernel*, rti_window_kernel) the pure matrix-VECTOR recursions -- forward, roll-out, adjoint -- run on the
+// VALU instead (fwd_chunk / roll_chunk / adj_chunk): a matrix-vector product fills one sixteenth of a 16x16x4 tile.
+//
+// File map: tile primitives, per-stage operand access -> sweeps (bwd_* / fwd_* / roll_* / adj_*, each split into an
+// initialisation and a "stages of the resident window" part) -> window manager of the windowed kernel (Win, win_*, sw_*) ->
+// qp_body (QP solve, multiplier recovery, full step; shared by all kernels) -> lin_phase (wave-wide linearisation) -> kernels
+// (qp_kernel + lin_wave_kernel streaming pair, rti_fused_kernel / _w2, rti_window_kernel) and their launchers.
 #include "lin_device.hpp"
 #include "nmpc_device.hpp"
 
