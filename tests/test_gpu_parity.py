@@ -172,11 +172,13 @@ def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj, path
 
 
 @pytest.mark.parametrize("path", PATHS)
-@pytest.mark.parametrize("N", [20, 40])
+@pytest.mark.parametrize("N", [10, 20, 40])
 def test_model_parameter_variation_per_instance_and_stage(ba, oracle, golden_traj, path, N):
     """the AMPC node's parameter vector varies per tick and per stage (bluerov2_ampc.cpp:337-380).  256
     instances, each stage of each instance with its own added mass / linear / quadratic damping, against the oracle:
-    linearisation 1e-11, iterates 1e-7, over 3 ticks with the parameters redrawn every tick."""
+    linearisation 1e-11, iterates 1e-7, over 3 ticks with the parameters redrawn every tick.  With path = fused the three
+    horizons are the three LDS-resident kernels: two waves per SIMD (N = 10), one wave (20), windowed (40) -- each dumps the
+    [A B | b] it keeps in LDS for the comparison."""
     nb = 256
     x0, circ = _batch_inputs(golden_traj, N, nb, seed=31, sat_frac=0.1)
     s = ba.BatchSolver(nb, ba.SolverOptions(N, kernel_path=path))
