@@ -180,11 +180,13 @@ def test_model_parameter_variation_per_instance_and_stage(ba, oracle, golden_tra
     horizons are the three LDS-resident kernels: two waves per SIMD (N = 10), one wave (20), windowed (40) -- each dumps the
     [A B | b] it keeps in LDS for the comparison."""
     nb = 256
+    Ts = 1.0 / max(N, 20)   # N = 10: the reference's 0.05 s step (a 0.1 s step with +-30 % model scatter makes a tenth of the
+                            # saturated instances diverge, which is not what this test is about)
     x0, circ = _batch_inputs(golden_traj, N, nb, seed=31, sat_frac=0.1)
-    s = ba.BatchSolver(nb, ba.SolverOptions(N, kernel_path=path))
+    s = ba.BatchSolver(nb, ba.SolverOptions(N, Ts, kernel_path=path))
     s.debug_dump_linearisation(True)
     s.set_x0(x0)
-    op = oracle.opts(N)
+    op = oracle.opts(N, Ts)
     x, u, pi, lam = oracle.init_iterate(op, nb)
     prev = None
     for k in range(3):
