@@ -1046,13 +1046,30 @@ __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
     }
 }
 
-// one interior-point vector: two elements per lane in registers (fused path, nv <= 128) or an HBM array (streaming path)
-template <bool REG>
+// one interior-point vector.  MODE 1 (fused kernels, nv <= 128): two elements per lane, in registers for the whole loop.
+// MODE 0 (streaming kernel): an HBM array, read and written element by element.  MODE 2 (windowed kernel): an HBM array with a
+// register copy of the lane's T elements that lives for one group of element loops -- fetch() at the head of the group (all the
+// group's loads are requested back to back, ahead of its first store: written element by element the compiler has to keep every
+// load behind the previous element's stores, which may alias, and the single resident wave then sits through one L2 / HBM
+// round trip per element instead of one per group), flush() at its end.  Between groups (across the sweeps) only HBM holds it.
+template <int MODE, int T>
 struct IpmVec {
-    double r[2];
+    double r[T];
     double* g;
-    __device__ __forceinline__ double get(int t, int j) const { return REG ? r[t & 1] : g[j]; }
-    __device__ __forceinline__ void set(int t, int j, double v) { if (REG) r[t & 1] = v; else g[j] = v; }
+    __device__ __forceinline__ double get(int t, int j) const { return MODE ? r[t % T] : g[j]; }
+    __device__ __forceinline__ void set(int t, int j, double v) { if (MODE) r[t % T] = v; else g[j] = v; }
+    __device__ __forceinline__ void fetch(int lane, int nv) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < T; t++) { const int j = lane + 64 * t; r[t] = g[j < nv ? j : 0]; }
+        }
+    }
+    __device__ __forceinline__ void flush(int lane, int nv) const {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < T; t++) { const int j = lane + 64 * t; if (j < nv) g[j] = r[t]; }
+        }
+    }
 };
 
 // everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
@@ -1175,50 +1192,78 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
 #ifdef BROV_DBG_IPM
             unsigned long long ipm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipm_last = __builtin_readcyclecounter();
 #endif
-            IpmVec<EL> vV{{0, 0}, V}, vTL{{0, 0}, TL}, vTU{{0, 0}, TU}, vLL{{0, 0}, LL}, vLU{{0, 0}, LU}, vDVA{{0, 0}, DVA},
-                vDLL{{0, 0}, GAM}, vDLU{{0, 0}, RT};   // dual steps: registers, or parked in GAM / RT (both rebuilt every iteration)
+            constexpr bool CACHE = (LDS == 3);   // windowed kernel: register copies per loop group (IpmVec MODE 2)
+            constexpr int kIpmT = EL ? 2 : 8;    // elements per lane; streaming / windowed path: nv <= 512
+            using Vec = IpmVec<EL ? 1 : (CACHE ? 2 : 0), kIpmT>;
+            Vec vV{{}, V}, vTL{{}, TL}, vTU{{}, TU}, vLL{{}, LL}, vLU{{}, LU}, vDVA{{}, DVA},
+                vDLL{{}, GAM}, vDLU{{}, RT};   // dual steps: registers, or (streaming) parked in GAM / RT, both rebuilt every iteration
 #define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const int j = lane + 64 * t; j < nv)
-            constexpr int kIpmT = EL ? 2 : 8;   // streaming path: nv <= 512
-            IPM_FOR(t, j) {
-                const int m = j & 3;
-                const double uj = EL ? ureg[t & 1] : I.u[j];
-                const double lb = cst[32 + m] - uj, ub = cst[36 + m] - uj;
-                const double wdt = ub - lb;
-                double vj = rd_vhat(j);
-                const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
-                vj = (vj < lo) ? lo : vj;
-                vj = (vj > hi) ? hi : vj;
-                vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
-                if constexpr (EL) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
+            // MODE 2: the group's other operands (inputs, references, Newton point ...), requested with the fetches
+#define IPM_PRE(arr, expr)                                                                     \
+            double arr[CACHE ? kIpmT : 1];                                                         \
+            if constexpr (CACHE) {                                                                 \
+                _Pragma("unroll") for (int t = 0; t < kIpmT; t++) {                                \
+                    const int j = (lane + 64 * t < nv) ? lane + 64 * t : 0;                        \
+                    arr[t] = (expr);                                                               \
+                }                                                                                  \
+            }
+            const int mI = lane & 3;   // input index of every element of this lane (j = lane + 64 t)
+            {
+                IPM_PRE(up, I.u[j]);
+                IPM_PRE(vh, I.vhat[j]);
+                IPM_FOR(t, j) {
+                    const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
+                    const double lb = cst[32 + mI] - uj, ub = cst[36 + mI] - uj;
+                    const double wdt = ub - lb;
+                    double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
+                    const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
+                    vj = (vj < lo) ? lo : vj;
+                    vj = (vj > hi) ? hi : vj;
+                    vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
+                    if constexpr (EL) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
+                }
+                vV.flush(lane, nv); vTL.flush(lane, nv); vTU.flush(lane, nv);
             }
             sw_rollout<LDS>(I, W, d0, V);
             sw_adjoint<false, LDS>(I, W, V, DVA, nullptr);
-            double g0 = 0.0;
-            for (int j = lane; j < nv; j += 64) g0 = fmax(g0, fabs(rd_grad(j)));
-            g0 = wave_max(g0);
-            const double mu0 = fmax(IPM_MU0F * g0, 1e-4);
-            double r0 = 0.0;
-            IPM_FOR(t, j) {
-                const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
-                vLL.set(t, j, ll); vLU.set(t, j, lu);
-                r0 = fmax(r0, fabs(rd_grad(j) - ll + lu));
+            double mu0;
+            {
+                vTL.fetch(lane, nv); vTU.fetch(lane, nv);
+                IPM_PRE(gr, GRAD[j]);
+                double g0 = 0.0;
+                IPM_FOR(t, j) g0 = fmax(g0, fabs(CACHE ? gr[CACHE ? t : 0] : rd_grad(j)));
+                g0 = wave_max(g0);
+                mu0 = fmax(IPM_MU0F * g0, 1e-4);
+                double r0 = 0.0;
+                IPM_FOR(t, j) {
+                    const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
+                    vLL.set(t, j, ll); vLU.set(t, j, lu);
+                    r0 = fmax(r0, fabs((CACHE ? gr[CACHE ? t : 0] : rd_grad(j)) - ll + lu));
+                }
+                rho = wave_max(r0);
+                vLL.flush(lane, nv); vLU.flush(lane, nv);
             }
-            rho = wave_max(r0);
             status = BROV_STATUS_MAXITER;
             const double inv2nv = 1.0 / (2.0 * nv);
             IPM_T(0);
             for (iters = 1; iters <= P.qp_iter_max; iters++) {
                 double s = 0.0;
                 double gam_r[2] = {0.0, 0.0};
-                IPM_FOR(t, j) {
-                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
-                    s += ll * tl + lu * tu;
-                    const double gm = ll / tl + lu / tu;
-                    GAM[j] = gm;
-                    if constexpr (EL) gam_r[t & 1] = gm;
-                    const int m = j & 3;
-                    const double rr = EL ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
-                    RT[j] = rr - gm * vV.get(t, j);
+                {   // group A: Gamma and the predictor's right-hand side
+                    vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
+                    IPM_PRE(up, I.u[j]);
+                    IPM_PRE(yr, I.yref[(size_t)(j >> 2) * 16 + 12 + (j & 3)]);
+                    IPM_FOR(t, j) {
+                        const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
+                        s += ll * tl + lu * tu;
+                        const double gm = ll / tl + lu / tu;
+                        GAM[j] = gm;
+                        if constexpr (EL) gam_r[t & 1] = gm;
+                        const double rr = EL ? (double)I.lds_r[j]
+                                             : P.Ts * cst[12 + mI] * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                                                           : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
+                        RT[j] = rr - gm * vV.get(t, j);
+                    }
                 }
                 mu = wave_sum(s) * inv2nv;
                 IPM_T(1);
@@ -1227,71 +1272,86 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
                 sw_forward<LDS>(I, W, d0);
                 IPM_T(3);
-                // predictor step length and centering
-                double aaff = 1.0;
-                IPM_FOR(t, j) {
-                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
-                    const double dv = rd_vhat(j) - vV.get(t, j);
-                    vDVA.set(t, j, dv);
-                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
-                    if (dv < 0) aaff = fmin(aaff, -tl / dv);
-                    if (dv > 0) aaff = fmin(aaff, tu / dv);
-                    if (dll < 0) aaff = fmin(aaff, -ll / dll);
-                    if (dlu < 0) aaff = fmin(aaff, -lu / dlu);
-                }
-                aaff = wave_min(aaff);
-                double sa = 0.0;
-                IPM_FOR(t, j) {
-                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dv = vDVA.get(t, j);
-                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
-                    sa += (ll + aaff * dll) * (tl + aaff * dv) + (lu + aaff * dlu) * (tu - aaff * dv);
-                }
-                const double muaff = wave_sum(sa) * inv2nv;
-                double sigma = muaff / mu;
-                sigma = sigma * sigma * sigma;
-                const double smu = sigma * mu;
-                IPM_FOR(t, j) {
-                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dv = vDVA.get(t, j);
-                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
-                    const double cl_ = dll * dv, cu_ = -dlu * dv;
-                    const int m = j & 3;
-                    const double rr = EL ? (double)I.lds_r[j] : P.Ts * cst[12 + m] * (I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + m]);
-                    const double gm = EL ? gam_r[t & 1] : GAM[j];
-                    RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
+                double smu;
+                {   // group B: predictor step length, centering, corrector right-hand side
+                    vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
+                    IPM_PRE(vh, I.vhat[j]);
+                    IPM_PRE(up, I.u[j]);
+                    IPM_PRE(yr, I.yref[(size_t)(j >> 2) * 16 + 12 + (j & 3)]);
+                    IPM_PRE(gmp, GAM[j]);
+                    double aaff = 1.0;
+                    IPM_FOR(t, j) {
+                        const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
+                        const double dv = (CACHE ? vh[CACHE ? t : 0] : rd_vhat(j)) - vV.get(t, j);
+                        vDVA.set(t, j, dv);
+                        const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                        if (dv < 0) aaff = fmin(aaff, -tl / dv);
+                        if (dv > 0) aaff = fmin(aaff, tu / dv);
+                        if (dll < 0) aaff = fmin(aaff, -ll / dll);
+                        if (dlu < 0) aaff = fmin(aaff, -lu / dlu);
+                    }
+                    aaff = wave_min(aaff);
+                    double sa = 0.0;
+                    IPM_FOR(t, j) {
+                        const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dv = vDVA.get(t, j);
+                        const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                        sa += (ll + aaff * dll) * (tl + aaff * dv) + (lu + aaff * dlu) * (tu - aaff * dv);
+                    }
+                    const double muaff = wave_sum(sa) * inv2nv;
+                    double sigma = muaff / mu;
+                    sigma = sigma * sigma * sigma;
+                    smu = sigma * mu;
+                    IPM_FOR(t, j) {
+                        const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dv = vDVA.get(t, j);
+                        const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                        const double cl_ = dll * dv, cu_ = -dlu * dv;
+                        const double rr = EL ? (double)I.lds_r[j]
+                                             : P.Ts * cst[12 + mI] * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                                                           : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
+                        const double gm = EL ? gam_r[t & 1] : (CACHE ? gmp[CACHE ? t : 0] : GAM[j]);
+                        RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
+                    }
+                    vDVA.flush(lane, nv);
                 }
                 IPM_T(1);
                 (void)sw_backward<false, LDS>(I, W);
                 IPM_T(4);
                 sw_forward<LDS>(I, W, d0);
                 IPM_T(5);
-                double amax = 1e300;
-                IPM_FOR(t, j) {
-                    const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dva = vDVA.get(t, j);
-                    const double dlla = -ll - ll / tl * dva, dlua = -lu + lu / tu * dva;
-                    const double cl_ = dlla * dva, cu_ = -dlua * dva;
-                    const double dv = rd_vhat(j) - vV.get(t, j);
-                    const double dll = (smu - cl_) / tl - ll - ll / tl * dv;
-                    const double dlu = (smu - cu_) / tu - lu + lu / tu * dv;
-                    if (dv < 0) amax = fmin(amax, -tl / dv);
-                    if (dv > 0) amax = fmin(amax, tu / dv);
-                    if (dll < 0) amax = fmin(amax, -ll / dll);
-                    if (dlu < 0) amax = fmin(amax, -lu / dlu);
-                    vDLL.set(t, j, dll);
-                    vDLU.set(t, j, dlu);
-                }
-                amax = wave_min(amax);
-                double alpha = IPM_FTB * amax;
-                alpha = alpha > 1.0 ? 1.0 : alpha;
                 bool bad = false;
-                double s2 = 0.0;
-                IPM_FOR(t, j) {
-                    const double dv = rd_vhat(j) - vV.get(t, j);
-                    const double vj = vV.get(t, j) + alpha * dv;
-                    const double tl = vTL.get(t, j) + alpha * dv, tu = vTU.get(t, j) - alpha * dv;
-                    const double ll = vLL.get(t, j) + alpha * vDLL.get(t, j), lu = vLU.get(t, j) + alpha * vDLU.get(t, j);
-                    vV.set(t, j, vj); vTL.set(t, j, tl); vTU.set(t, j, tu); vLL.set(t, j, ll); vLU.set(t, j, lu);
-                    if (!(vj == vj)) bad = true;
-                    s2 += ll * tl + lu * tu;
+                double s2 = 0.0, alpha;
+                {   // group C: step length of the combined direction, update
+                    vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
+                    vDVA.fetch(lane, nv);
+                    IPM_PRE(vh, I.vhat[j]);
+                    double amax = 1e300;
+                    IPM_FOR(t, j) {
+                        const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j), dva = vDVA.get(t, j);
+                        const double dlla = -ll - ll / tl * dva, dlua = -lu + lu / tu * dva;
+                        const double cl_ = dlla * dva, cu_ = -dlua * dva;
+                        const double dv = (CACHE ? vh[CACHE ? t : 0] : rd_vhat(j)) - vV.get(t, j);
+                        const double dll = (smu - cl_) / tl - ll - ll / tl * dv;
+                        const double dlu = (smu - cu_) / tu - lu + lu / tu * dv;
+                        if (dv < 0) amax = fmin(amax, -tl / dv);
+                        if (dv > 0) amax = fmin(amax, tu / dv);
+                        if (dll < 0) amax = fmin(amax, -ll / dll);
+                        if (dlu < 0) amax = fmin(amax, -lu / dlu);
+                        vDLL.set(t, j, dll);
+                        vDLU.set(t, j, dlu);
+                    }
+                    amax = wave_min(amax);
+                    alpha = IPM_FTB * amax;
+                    alpha = alpha > 1.0 ? 1.0 : alpha;
+                    IPM_FOR(t, j) {
+                        const double dv = (CACHE ? vh[CACHE ? t : 0] : rd_vhat(j)) - vV.get(t, j);
+                        const double vj = vV.get(t, j) + alpha * dv;
+                        const double tl = vTL.get(t, j) + alpha * dv, tu = vTU.get(t, j) - alpha * dv;
+                        const double ll = vLL.get(t, j) + alpha * vDLL.get(t, j), lu = vLU.get(t, j) + alpha * vDLU.get(t, j);
+                        vV.set(t, j, vj); vTL.set(t, j, tl); vTU.set(t, j, tu); vLL.set(t, j, ll); vLU.set(t, j, lu);
+                        if (!(vj == vj)) bad = true;
+                        s2 += ll * tl + lu * tu;
+                    }
+                    vV.flush(lane, nv); vTL.flush(lane, nv); vTU.flush(lane, nv); vLL.flush(lane, nv); vLU.flush(lane, nv);
                 }
                 if (__ballot(bad) != 0ull) { status = BROV_STATUS_NAN; break; }
                 rho *= (1.0 - alpha);
@@ -1308,6 +1368,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // the final inputs go where the finalisation expects them: V (streaming path, already there) / the LDS copy
             if constexpr (EL) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
 #undef IPM_FOR
+#undef IPM_PRE
             if (iters > P.qp_iter_max) iters = P.qp_iter_max;
         }
     }
