@@ -90,7 +90,8 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 // were chosen): a start close to the box (0.3 % of its width inside) with a small complementarity target needs 2 iterations
 // where no bound is active and 4-5 where inputs saturate, instead of 4 and 7 with the textbook 0.1 / 0.995 / mu0 = g0.
 #define IPM_TAU0 0.003  /* interior push of the start point (fraction of the box width) */
-#define IPM_FTB 0.9999  /* fraction to the boundary */
+#define IPM_FTB 0.9999  /* fraction to the boundary of a (nearly) full step */
+#define IPM_FTBLO 0.9   /* ... of a blocked step: alpha = a ((1 - a) FTBLO + a FTB), a = min(1, step to the boundary); see the oracle */
 #define IPM_MU0F 0.1    /* mu0 = IPM_MU0F * stationarity residual of the clamped point */
 
 // everything one wave needs to know about its instance
@@ -1075,7 +1076,14 @@ struct IpmVec {
 // everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
 // lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
-#define DBG_STAMP(slot) do { if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+// slots 0 / 6 (first and last) also record the 100 MHz real-time counter, which -- unlike the per-XCD cycle counters -- is one
+// clock for the whole device: second array, slots 7 (start) and 6 (end), and where the wave ran (slot 5: XCC_ID << 32 | HW_ID); scripts/dev/phase_stamps.py
+// draws the launch timeline
+#define DBG_STAMP(slot) do { if (P.dbg && lane == 0) {                                                                          \
+        P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter();                                                           \
+        if ((slot) == 0) P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 7] = __builtin_amdgcn_s_memrealtime();                        \
+        if ((slot) == 0) P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+        if ((slot) == 6) P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 // development build only (make EXTRA=-DBROV_DBG_IPM=1, scripts/dev/ipm_phases.py): cycle totals of the interior-point loop's
 // phases in a second array, 8 slots per instance: init, element loops, factor sweep, forward, solve-only sweep, forward, iterations
 #ifdef BROV_DBG_IPM
@@ -1226,7 +1234,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             }
             sw_rollout<LDS>(I, W, d0, V);
             sw_adjoint<false, LDS>(I, W, V, DVA, nullptr);
-            double mu0;
+            double mu0, gscale;
             {
                 vTL.fetch(lane, nv); vTU.fetch(lane, nv);
                 IPM_PRE(gr, GRAD[j]);
@@ -1234,6 +1242,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 IPM_FOR(t, j) g0 = fmax(g0, fabs(CACHE ? gr[CACHE ? t : 0] : rd_grad(j)));
                 g0 = wave_max(g0);
                 mu0 = fmax(IPM_MU0F * g0, 1e-4);
+                gscale = fmax(g0, 1.0);   // the tolerances are relative to the QP's gradient scale
                 double r0 = 0.0;
                 IPM_FOR(t, j) {
                     const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
@@ -1340,8 +1349,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         vDLU.set(t, j, dlu);
                     }
                     amax = wave_min(amax);
-                    alpha = IPM_FTB * amax;
-                    alpha = alpha > 1.0 ? 1.0 : alpha;
+                    {   // a blocked step stops 10 % short of the boundary, a (nearly) full one goes 99.99 % of the way
+                        const double a = amax < 1.0 ? amax : 1.0;
+                        alpha = (IPM_FTB * amax >= 1.0) ? 1.0 : a * ((1.0 - a) * IPM_FTBLO + a * IPM_FTB);
+                    }
                     IPM_FOR(t, j) {
                         const double dv = (CACHE ? vh[CACHE ? t : 0] : rd_vhat(j)) - vV.get(t, j);
                         const double vj = vV.get(t, j) + alpha * dv;
@@ -1357,7 +1368,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 rho *= (1.0 - alpha);
                 mu = wave_sum(s2) * inv2nv;
                 IPM_T(1);
-                if (mu <= P.tol_mu && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
+                if (mu <= P.tol_mu * gscale && rho <= P.tol_stat * gscale) { status = BROV_STATUS_SUCCESS; break; }
             }
 #ifdef BROV_DBG_IPM
             if (P.dbg && lane == 0) {

@@ -60,3 +60,15 @@ def status_agreement(r_status, o_status, o_kkt, max_ambiguous=4):
     assert np.all((o_kkt[mism] > 1e6) | ~np.isfinite(o_kkt[mism])), (np.nonzero(mism)[0], r_status[mism], o_status[mism], o_kkt[mism])
     assert mism.sum() <= max_ambiguous, (np.nonzero(mism)[0], r_status[mism], o_status[mism])
     return ~mism
+
+
+def values_agree(ok, kkt, what, max_diverged=4):
+    """Value parity rule shared by the batch tests: `ok` is the per-instance verdict of a KKT-scaled comparison
+    (|gpu - oracle| <= 1e-7 max(1, KKT)).  Every instance whose step is numerically meaningful (entering KKT <= 1e6) must pass.
+    A diverged instance (KKT > 1e6, see status_agreement) may miss even the scaled tolerance -- its QP is conditioned beyond what
+    FP64 resolves, and both sides may well report success with different garbage -- but there may be at most `max_diverged` of
+    them per tick."""
+    ok, kkt = np.asarray(ok), np.asarray(kkt)
+    bad = ~ok
+    assert not np.any(bad & ~(kkt > 1e6)), (what, np.nonzero(bad & ~(kkt > 1e6))[0][:8], kkt[bad][:8])
+    assert bad.sum() <= max_diverged, (what, np.nonzero(bad)[0][:8], kkt[bad][:8])

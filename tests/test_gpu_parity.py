@@ -7,7 +7,7 @@ cond ~1e5)."""
 import numpy as np
 import pytest
 
-from conftest import scenario_names, scenario_ticks, status_agreement
+from conftest import scenario_names, scenario_ticks, status_agreement, values_agree
 
 pytestmark = pytest.mark.gpu
 TOL_LIN = 1e-11
@@ -325,3 +325,52 @@ def test_full_size_batch_properties(ba, golden_traj):
     for f in ("u0", "cost", "kkt", "qp_iter"):
         assert np.array_equal(r2[f], r[f][pick]), f
     s.close(); s2.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_options_against_oracle(ba, oracle, golden_traj, seed):
+    """Fuzz over what a caller can configure (everything brov_opts carries): horizon 1..96 (all three LDS-resident kernel families
+    and, for seeds 9..11, the streaming pair), step size (a horizon of 0.25..1 s; beyond Ts = 0.05 s the explicit RK4 step is
+    unstable in the stiff roll channel and every QP is conditioned past FP64), stage / terminal weights, asymmetric input boxes, some
+    of which do not contain 0,
+    failure policy, early exit on / off, per-stage model parameters, a share of far-off initial states (interior point).  Three
+    ticks, every instance compared with the oracle: status rule of conftest.status_agreement, iterates to the KKT-scaled 1e-7."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([1, 3, 7, 12, 13, 14, 19, 20, 23, 24, 31, 40, 57, 80, 96]))
+    Ts = float(rng.uniform(0.25, 1.0) / max(N, 20))
+    W = ba.SolverOptions(N).W * rng.uniform(0.3, 3.0, size=16)
+    We = ba.SolverOptions(N).We * rng.uniform(0.3, 3.0, size=12)
+    lbu = -rng.uniform(5.0, 60.0, size=4)
+    ubu = rng.uniform(5.0, 60.0, size=4)
+    if seed % 3 == 0:   # a box that excludes 0: the default iterate u = 0 starts infeasible
+        lbu[1], ubu[1] = 2.0, 30.0
+    kw = dict(W=list(W), We=list(We), lbu=list(lbu), ubu=list(ubu), on_failure=int(seed % 2), qp_early_exit=int(seed % 4 != 1))
+    path = ba.PATH_STREAMING if seed >= 9 else ba.PATH_AUTO
+    nb = 96
+    x0, circ = _batch_inputs(golden_traj, N, nb, seed=2000 + seed, sat_frac=0.3)
+    s = ba.BatchSolver(nb, ba.SolverOptions(N, Ts, kernel_path=path, **kw))
+    op = oracle.opts(N, Ts, **kw)
+    x, u, pi, lam = oracle.init_iterate(op, nb)
+    s.set_x0(x0)
+    prev, n_ipm = None, 0
+    for k in range(3):
+        p = _f4_params(ba, nb, N, seed=3000 + 10 * seed + k)
+        yref = circ[2 * k:2 * k + N + 1]
+        s.set_params(p); s.set_yref(yref); s.solve()
+        res = s.results()
+        gx, gu, gpi, glam = s.get_iterate()
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (nb, N + 1, 16))), p, x, u, pi, lam, res_prev=prev)
+        kk = ro["kkt"]
+        cmp = status_agreement(res["status"], ro["status"], kk)
+        for name, a, b_ in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi), ("lam", glam, lam)):
+            ok, err = _scaled_ok(a[cmp], b_[cmp], kk[cmp], tol=1e-6 if name in ("pi", "lam") else TOL_IT)
+            values_agree(ok, kk[cmp], (seed, N, k, name))
+        fin = np.isfinite(kk)
+        assert np.all(np.abs(res["kkt"][fin] - kk[fin]) <= 1e-6 * (1 + kk[fin]))
+        okst = (res["status"] == 0) | (res["status"] == 2)
+        assert np.all(res["u0"][okst & cmp] >= lbu - 1e-9) and np.all(res["u0"][okst & cmp] <= ubu + 1e-9)
+        n_ipm += int((res["qp_iter"] > 0).sum())
+        x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
+        prev = res.copy()
+    assert n_ipm > 0
+    s.close()
