@@ -1,0 +1,57 @@
+"""The multi-GPU path on hardware, through the same command line the driver uses.
+
+`python bench.py --gpus N` spawns one process per GPU (torch.distributed.run, backend nccl = RCCL), every rank solves its own
+shard, the 104-byte result records are all-gathered on a side stream and the best candidate is selected.  On a box with one GPU
+the RCCL leg runs with a single rank (communicator set-up, all_gather_into_tensor, device-side arg-min: the same code, world
+size 1); with two or more GPUs visible the two-rank test runs as well.  tests/test_distributed_cpu.py drives the same launcher
+with world size 2 under gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                        env=env, timeout=600)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert pr.returncode == 0 and len(lines) == 1, (pr.returncode, pr.stdout[-2000:], pr.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_rccl_gather_and_select_single_rank_under_the_launcher():
+    """config 4 (lemniscate candidates, gather + arg-min every step) launched as the driver launches N > 1, with one rank"""
+    import torch
+    assert torch.cuda.is_available()
+    env_cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "4", "--batch", "1024", "--steps", "4",
+               "--warmup", "2", "--no-cpu-baseline", "--force-gather"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pr = subprocess.run(env_cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert pr.returncode == 0 and len(lines) == 1, (pr.returncode, pr.stdout[-2000:], pr.stderr[-2000:])
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 1 and o["ranks_seen"] == [0] and o["value"] > 0
+    sb = o["select_best"]
+    assert sb["selected_every_step_on_device"] and sb["index"] == sb["last_step_index_on_device"]
+
+
+def test_two_rank_rccl_run():
+    """two GPUs visible: the real thing -- two processes, RCCL all-gather over xGMI, global arg-min"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-rank RCCL run needs two (the launcher itself is covered under gloo on CPU)")
+    o = _bench("--gpus", "2", "--config", "4", "--batch", "2048", "--steps", "4", "--warmup", "2", "--no-cpu-baseline")
+    assert o["n_gpus"] == 2 and o["ranks_seen"] == [0, 1] and o["value"] > 0
+    sb = o["select_best"]
+    assert sb["selected_every_step_on_device"] and sb["index"] == sb["last_step_index_on_device"]
+    single = _bench("--gpus", "1", "--config", "4", "--batch", "2048", "--steps", "4", "--warmup", "2", "--no-cpu-baseline")
+    assert o["value"] > 1.2 * single["value"]   # weak scaling: two shards in (about) the time of one
