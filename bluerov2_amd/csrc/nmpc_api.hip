@@ -84,6 +84,26 @@ extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
     o->on_failure = BROV_ON_FAILURE_RESTART;
 }
 
+// what is wrong with a set of options (nullptr = nothing).  The QP must be strictly convex in the inputs (R > 0), the box must
+// have an interior (the interior-point start divides by its width), limits and tolerances must be usable.
+static const char* opts_problem(const brov_opts* o) {
+    if (o->N < 1 || o->N > BROV_MAX_N) return "N out of range";
+    if (!(o->Ts > 0.0) || !(o->Ts < 1e6)) return "Ts must be positive and finite";
+    if (o->kernel_path < 0 || o->kernel_path > 2) return "kernel_path must be BROV_PATH_AUTO / _STREAMING / _FUSED";
+    if (o->on_failure < 0 || o->on_failure > 1) return "on_failure must be BROV_ON_FAILURE_KEEP / _RESTART";
+    for (int j = 0; j < 16; j++)
+        if (!(o->W[j] >= 0.0) || !(o->W[j] < 1e300)) return "stage weights must be finite and >= 0";
+    for (int j = 12; j < 16; j++)
+        if (!(o->W[j] > 0.0)) return "input weights W[12..15] must be > 0 (strictly convex QP)";
+    for (int j = 0; j < 12; j++)
+        if (!(o->We[j] >= 0.0) || !(o->We[j] < 1e300)) return "terminal weights must be finite and >= 0";
+    for (int j = 0; j < 4; j++)
+        if (!(o->lbu[j] < o->ubu[j]) || !(o->lbu[j] > -1e300) || !(o->ubu[j] < 1e300)) return "input bounds need lbu < ubu, both finite";
+    if (o->qp_iter_max < 1) return "qp_iter_max must be >= 1";
+    if (!(o->qp_tol_mu > 0.0) || !(o->qp_tol_stat > 0.0)) return "qp tolerances must be > 0";
+    return nullptr;
+}
+
 template <typename T>
 static int dalloc(brov_solver* s, T** p, size_t n) {
     void* q = nullptr;
@@ -122,9 +142,12 @@ extern "C" int brov_init_iterate_default(brov_solver* s) {
 }
 
 extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts* opts) {
-    if (!out || !opts || B < 1 || opts->N < 1 || opts->N > BROV_MAX_N || !(opts->Ts > 0.0) || opts->kernel_path < 0 ||
-        opts->kernel_path > 2 || opts->on_failure < 0 || opts->on_failure > 1) {
+    if (!out || !opts || B < 1) {
         g_err = "brov_create: bad argument";
+        return BROV_ERR_ARG;
+    }
+    if (const char* why = opts_problem(opts)) {
+        g_err = std::string("brov_create: ") + why;
         return BROV_ERR_ARG;
     }
     int ndev = 0;
@@ -203,6 +226,7 @@ extern "C" void brov_destroy(brov_solver* s) {
     hipSetDevice(s->device);
     for (void* p : s->allocs) hipFree(p);
     if (s->traj) hipFree(s->traj);
+    if (s->dbg) hipFree(s->dbg);
     for (int k = 0; k < 3; k++)
         if (s->ev[k]) hipEventDestroy(s->ev[k]);
     delete s;
@@ -549,7 +573,8 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
 }
 extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phase(s, stream, 0); }
 extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
-    if (!s || !o || o->N != s->N || !(o->Ts > 0.0) || o->on_failure < 0 || o->on_failure > 1 || o->kernel_path < 0 || o->kernel_path > 2) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
+    if (!s || !o || o->N != s->N) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
+    if (const char* why = opts_problem(o)) { g_err = std::string("brov_set_opts: ") + why; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->last_stream));
     s->opts = *o;

@@ -85,6 +85,7 @@ def _load():
         "brov_set_param_stage_host": [vp, C.c_int, C.c_int, dp],
         "brov_set_yref_stage_host": [vp, C.c_int, C.c_int, dp, C.c_int],
         "brov_set_iterate_host": [vp, dp, dp, dp, dp], "brov_get_iterate_host": [vp, dp, dp, dp, dp],
+        "brov_set_opts": [vp, vp], "brov_get_opts": [vp, vp],
         "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_last_kernel_path": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
         "brov_get_results_host": [vp, vp], "brov_get_u0_host": [vp, dp],
         "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
@@ -182,6 +183,11 @@ class BatchSolver:
     def _chk(self, rc, what):
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self._L.brov_last_error().decode()}")
+
+    def set_options(self, opts):
+        """change weights / bounds / limits / policies at run time (brov_set_opts; the horizon is fixed at create)"""
+        self._chk(self._L.brov_set_opts(self._h, C.byref(opts._o)), "set_opts")
+        self.opts = opts
 
     @property
     def device_bytes(self):

@@ -219,3 +219,28 @@ def test_setters_reject_bad_shapes(ba):
         s.set_yref(np.zeros((3, 10, 16)))
     with pytest.raises(RuntimeError):
         ba.BatchSolver(1, ba.SolverOptions(200))  # N > BROV_MAX_N
+
+
+@pytest.mark.parametrize("kw,what", [
+    (dict(lbu=[-50, 5, -50, -50], ubu=[50, 5, 50, 50]), "lbu < ubu"),          # empty interior: the interior-point start divides by the width
+    (dict(W=[300, 480, 200, 10, 10, 200, 40, 40, 10, 10, 10, 10, 1, 0, 0.1, 0.05]), "input weights"),   # R not positive definite
+    (dict(W=[-1] + [1] * 15), "stage weights"),
+    (dict(We=[float("nan")] + [1] * 11), "terminal weights"),
+    (dict(qp_iter_max=0), "qp_iter_max"),
+    (dict(qp_tol_mu=0.0), "tolerances"),
+    (dict(Ts_=float("inf")), "Ts"),
+])
+def test_unusable_options_are_rejected_with_a_reason(ba, kw, what):
+    """brov_create / brov_set_opts refuse options the solver cannot work with, and brov_last_error says which"""
+    kw = dict(kw)
+    Ts = kw.pop("Ts_", 0.05)
+    with pytest.raises(RuntimeError) as e:
+        ba.BatchSolver(2, ba.SolverOptions(10, Ts, **kw))
+    assert what in str(e.value), str(e.value)
+    s = ba.BatchSolver(2, ba.SolverOptions(10, 0.05))
+    with pytest.raises(RuntimeError) as e2:
+        s.set_options(ba.SolverOptions(10, Ts, **kw))
+    assert what in str(e2.value)
+    s.set_x0(np.zeros((2, 12))); s.solve()          # the solver is still usable with its old options
+    assert np.all(s.results()["status"] == 0)
+    s.close()
