@@ -240,6 +240,9 @@ static int copy_in(brov_solver* s, double* dst, const double* src, size_t n, boo
     if (!s || !src) { g_err = "null argument"; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
     if (host) {
+        // a solve may still be running on the caller's (possibly non-blocking) stream: the blocking copy on the null stream does not
+        // wait for such a stream by itself
+        HIPCHK(hipStreamSynchronize(s->last_stream));
         HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
     } else {
         HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -279,6 +282,7 @@ static int set_par(brov_solver* s, const double* p, int per_stage, bool host, vo
     const double* src = p;
     double* tmp = nullptr;
     if (host) {
+        HIPCHK(hipStreamSynchronize(s->last_stream));
         HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 16 * sizeof(double)));
         hipError_t e = hipMemcpy(tmp, p, (size_t)s->B * 16 * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { hipFree(tmp); g_err = hipGetErrorString(e); return BROV_ERR_HIP; }
@@ -299,6 +303,7 @@ extern "C" int brov_set_params_device(brov_solver* s, const double* p, int per_s
 extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, const double* p16) {
     if (!s || !p16 || inst < 0 || inst >= s->B || stage < 0 || stage > s->N) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
     HIPCHK(hipMemcpy(s->par + ((size_t)inst * (s->N + 1) + stage) * 16, p16, 16 * sizeof(double), hipMemcpyHostToDevice));
     if (stage == 0) s->pplant_stale = true;
     return BROV_OK;
@@ -306,6 +311,7 @@ extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, co
 extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, const double* y, int ny) {
     if (!s || !y || inst < 0 || inst >= s->B || stage < 0 || stage > s->N || ny < 1 || ny > 16) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
     if (s->yref_shared) {  // materialise the shared window per instance first
         for (int b = 0; b < s->B; b++)
             HIPCHK(hipMemcpy(s->yref + (size_t)b * (s->N + 1) * 16, shared_window(s), (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
@@ -348,6 +354,7 @@ extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void
 extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t* lines, int ncols) {
     if (!s || !s->traj || !lines || (ncols != 12 && ncols != 16)) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
     HIPCHK(hipMemcpy(s->lines, lines, (size_t)s->B * sizeof(int), hipMemcpyHostToDevice));
     launch_window(s->traj, s->traj_rows, s->lines, 0, s->B, s->N, ncols, s->yref, nullptr);
     s->yref_shared = false;
