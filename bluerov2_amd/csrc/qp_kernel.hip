@@ -1092,6 +1092,14 @@ struct IpmVec {
 #define IPM_T(k) do { } while (0)
 #endif
 
+// development build only (make EXTRA=-DBROV_DBG_LIN=1, scripts/dev/lin_phases.py): cycle split of the linearisation; the scheduling
+// barriers keep the compiler from moving work across the stamps (which also makes this build slower than the product)
+#ifdef BROV_DBG_LIN
+#define LIN_T(k) do { __builtin_amdgcn_sched_barrier(0); lin_t[k] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LIN_T(k) do { } while (0)
+#endif
+
 // LDS = 0 streaming kernels, 1 / 2 fused kernels (whole horizon resident; element arrays in LDS / registers: EL), 3 windowed
 // kernel (sweeps on the resident window through the sw_* wrappers, element loops on the flat HBM arrays like LDS = 0; the
 // step-0 factorisation has already run, fused with the linearisation: pre_ok)
@@ -1660,6 +1668,9 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 template <bool TWO = true>
 __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
                                           double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
+#ifdef BROV_DBG_LIN
+    unsigned long long lin_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const int N = P.N;
     const double* __restrict__ cst = P.cst;
     const int L = n <= 4 ? 16 : 64 / n;
@@ -1705,6 +1716,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
 #pragma unroll
     for (int j = 0; j < 3; j++) pm1[j] = pim1[j];
     const unsigned long long tA = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
+    LIN_T(0);
     const bool last = ig == N - 1;
     double yrn[NX];
 #pragma unroll
@@ -1731,10 +1743,12 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
         }
     }
     const unsigned long long tB = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
+    LIN_T(1);
     StagePoint sp[4];
     double xn[NX];
     rk4_state(x0r, w, m, P.Ts, sp, xn);
     const unsigned long long tC = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
+    LIN_T(2);
     double* tb = ba_s + i * kBaStage;
     // stage records: 4*17 doubles per interval (in the fused kernel they overlay the gain / step arrays, which are dead
     // until the QP phase: 4*17 <= 48+4+4+12)
@@ -1751,6 +1765,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     // developer instrumentation, slot 7: loads issued -> cost gradients -> state integrated -> column loop entered
     if (stamp && P.dbg && lane == 0)
         P.dbg[(size_t)b * 8 + 7] = ((tB - tA) & 0xFFFFF) | (((tC - tB) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - tC) & 0xFFFFF) << 40);
+    LIN_T(3);
     auto finish = [&](int c, const KktOperands& ko, const double (&acc)[NX]) __attribute__((always_inline)) {
         lin_kkt_col(ka, ko, N, ig, c, pir, acc);
 #pragma unroll
@@ -1787,6 +1802,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             finish(ca, koa, acc0);
         }
     }
+    LIN_T(4);
     // the closed-form trips are far too short to hide the L2 round trips of their own KKT operands: requested here, under
     // the input-column trip
     constexpr int kCheapTrips = 3;   // ceil(5 / L) <= 3 for L >= 2
@@ -1811,6 +1827,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
         sens_column_rec_u(rec, m, P.Ts, jc, acc);
         finish(c, ko, acc);
     }
+    LIN_T(5);
     // all closed-form columns of the lane first (independent chains, interleaved by the compiler), then their KKT rows / stores
     double cv[kCheapTrips][4];
 #pragma unroll
@@ -1824,6 +1841,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             sens_column_cheap(rec, P.Ts, j, input, kbv, cv[t]);
         }
     }
+    LIN_T(6);
 #pragma unroll
     for (int t = 0; t < kCheapTrips; t++) {
         if (t < nC) {
@@ -1842,6 +1860,11 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             for (int k = 0; k < NX; k++) tb[k * kBaStride + (c - 3)] = acc[k];
         }
     }
+    LIN_T(7);
+#ifdef BROV_DBG_LIN
+    if (stamp && P.dbg && lane == 0)
+        for (int k = 0; k < 7; k++) P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + (k == 6 ? 7 : k)] = lin_t[k + 1] - lin_t[k];
+#endif
     if (active) {
         if (ka.nan) nanp = true;
         part = fmax(part, ka.mx);
