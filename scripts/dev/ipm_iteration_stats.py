@@ -57,7 +57,7 @@ for seed in range(int(os.environ.get("NSEED", "24"))):
     nb = 96; x0, circ = _batch_inputs(gt, N, nb, seed=2000 + seed, sat_frac=0.3)
     op = oracle.opts(N, Ts, **kw)
     allr += run(op, nb, x0, lambda k: np.ascontiguousarray(np.broadcast_to(circ[2*k:2*k+N+1], (nb, N+1, 16))), lambda k: _f4_params(BA, nb, N, seed=3000 + 10 * seed + k), 3)
-stats("D fuzz 24 seeds", allr)
+stats(f"D fuzz {os.environ.get('NSEED', '24')} seeds", allr)
 if os.environ.get("DETAIL"):
     k = 0
     for seed in range(int(os.environ.get("NSEED", "24"))):
