@@ -13,7 +13,8 @@ Sources of truth, all independent of the build's own solver code (oracle/bluerov
 acados itself is not available: these are known answers of the same mathematical problem, not acados
 output -- solver-level parity stays "unpinned".
 
-    python scripts/make_golden.py        # rewrites tests/golden/*.npz
+    python scripts/make_golden.py            # rewrites tests/golden/*.npz
+    python scripts/make_golden.py options    # only rti_known_answers_options.npz   (defaults: only solver_defaults.json)
 """
 import hashlib
 import os
@@ -69,13 +70,14 @@ def model_vectors(ref, n=128, n_rk=64, seed=0):
     return dict(x=X, u=U, p=P, f=F, A=A, B=B, h=hs, xn=XN, Ad=AD, Bd=BD)
 
 
-def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU):
+def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU, Wed=None):
     """one SQP-RTI step: linearise with the reference model, condense, solve the box QP by BVLS, full step."""
+    Wed = Wd[:NX] if Wed is None else Wed
     A, B, b = np.zeros((N, NX, NX)), np.zeros((N, NX, NU)), np.zeros((N, NX))
     for i in range(N):
         xn, A[i], B[i] = ref.rk4_sens(x[i], u[i], p[i], Ts)
         b[i] = xn - x[i + 1]
-    Qd = np.concatenate([np.tile(Ts * Wd[:NX], (N, 1)), Wd[None, :NX]])
+    Qd = np.concatenate([np.tile(Ts * Wd[:NX], (N, 1)), Wed[None, :]])
     q = Qd * (x - yref[:, :NX])
     Rd = np.tile(Ts * Wd[NX:], (N, 1))
     r = Rd * (u - yref[:N, NX:])
@@ -153,6 +155,61 @@ def scenario_list(circ, lem):
     return sc
 
 
+def option_scenarios(circ):
+    """Known answers away from the shipped options: scaled weights, tight / asymmetric / offset input boxes, scattered per-stage model
+    parameters, far-off initial states -- the regime in which the randomised-options test found the interior-point defects
+    (DESIGN.md section 2).  Same independent recipe; the options travel with the fixture."""
+    rng = np.random.default_rng(20260928)
+    x0c = np.zeros(NX); x0c[:6] = circ[0, :6]
+    x_def = np.zeros(NX); x_def[2] = -20
+    x0s = np.array([3.0, -4.0, -17.0, 0.05, -0.05, 1.0, 0.2, -0.1, 0.1, 0, 0, 0.1])
+
+    def scattered(N):
+        p = np.tile(P_NOMINAL, (N + 1, 1))
+        p[:, 4:] *= rng.uniform(0.7, 1.3, size=(N + 1, 12))
+        p[:, 5] = rng.uniform(0.0, 1.0, size=N + 1)
+        p[:, :4] = rng.uniform(-200, 200, size=4)
+        return p
+
+    def ref_rows(N, stride=1):
+        return lambda k: circ[stride * k:stride * k + N + 1].copy()
+
+    sc = []
+    sc.append(dict(name="tightbox_N14", N=14, Ts=0.043, ticks=3, x0=x0s, yref=ref_rows(14, 2), p=scattered(14), xi=x_def, ui=np.zeros(NU),
+                   W=W * rng.uniform(0.3, 3.0, size=16), We=W[:NX] * rng.uniform(0.3, 3.0, size=12),
+                   lbu=np.array([-55.8, -11.2, -28.2, -52.9]), ubu=np.array([18.3, 7.5, 54.0, 8.7])))
+    sc.append(dict(name="offsetbox_N20", N=20, Ts=0.05, ticks=3, x0=x0c + np.array([0.5, -0.3, 0.2, 0, 0, 0.1, 0, 0, 0, 0, 0, 0]),
+                   yref=ref_rows(20), p=scattered(20), xi=x_def, ui=np.array([0.0, 5.0, 0.0, 0.0]),
+                   W=W * rng.uniform(0.5, 2.0, size=16), We=W[:NX] * rng.uniform(0.5, 2.0, size=12),
+                   lbu=np.array([-15.6, 2.0, -40.4, -32.8]), ubu=np.array([15.0, 30.0, 22.0, 18.9])))   # the box of input 1 excludes 0
+    sc.append(dict(name="tightbox_N40", N=40, Ts=0.02, ticks=2, x0=x0s, yref=ref_rows(40), p=scattered(40), xi=x_def, ui=np.zeros(NU),
+                   W=W.copy(), We=W[:NX].copy(), lbu=-8.0 * np.ones(NU), ubu=8.0 * np.ones(NU)))
+    sc.append(dict(name="asymbox_N80", N=80, Ts=0.0125, ticks=2, x0=x0s, yref=ref_rows(80), p=np.tile(P_NOMINAL, (81, 1)), xi=x_def,
+                   ui=np.zeros(NU), W=W * rng.uniform(0.5, 2.0, size=16), We=W[:NX] * rng.uniform(0.5, 2.0, size=12),
+                   lbu=np.array([-30.0, -10.0, -20.0, -5.0]), ubu=np.array([12.0, 25.0, 8.0, 15.0])))
+    return sc
+
+
+def write_option_scenarios(ref, circ):
+    out = {}
+    for sc in option_scenarios(circ):
+        N, Ts, name = sc["N"], sc["Ts"], sc["name"]
+        x = np.tile(sc["xi"], (N + 1, 1))
+        u = np.tile(sc["ui"], (N, 1))
+        for key, val in (("N", np.array(N)), ("Ts", np.array(Ts)), ("x0_meas", sc["x0"]), ("p", sc["p"]), ("x_init", x.copy()),
+                         ("u_init", u.copy()), ("W", sc["W"]), ("We", sc["We"]), ("lbu", sc["lbu"]), ("ubu", sc["ubu"])):
+            out[f"{name}/{key}"] = val
+        for k in range(sc["ticks"]):
+            yref = sc["yref"](k)
+            x, u, info = rti_step_independent(ref, N, Ts, sc["x0"], yref, sc["p"], x, u, Wd=sc["W"], lbu=sc["lbu"], ubu=sc["ubu"], Wed=sc["We"])
+            out[f"{name}/yref{k}"] = yref
+            out[f"{name}/x{k}"] = x.copy()
+            out[f"{name}/u{k}"] = u.copy()
+            out[f"{name}/info{k}"] = np.array([info["nact"], info["qp_kkt"], info["cond"]])
+            print(f"{name} tick {k}: u0={u[0]}, active={info['nact']}/{N * NU}, qp_kkt={info['qp_kkt']:.2e}, cond={info['cond']:.1e}")
+    np.savez_compressed(os.path.join(OUT, "rti_known_answers_options.npz"), **out)
+
+
 def solver_defaults():
     """The options the reference's generator dumped next to the generated solver (bluerov2_dobmpc/scripts/acados_ocp.json),
     reduced to the values brov_default_opts / orc_default_opts / brov_create have to reproduce.  Data only (numbers)."""
@@ -188,6 +245,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "defaults":   # only the options fixture (the others take minutes)
         return solver_defaults()
+    if len(sys.argv) > 1 and sys.argv[1] == "options":    # only the known answers with non-default options
+        return write_option_scenarios(CasadiRef(), np.loadtxt(f"{REF}/bluerov2_path/config/traj/circle.txt"))
     solver_defaults()
     ref = CasadiRef()
     circ_path = f"{REF}/bluerov2_path/config/traj/circle.txt"
@@ -227,6 +286,7 @@ def main():
             out[f"{name}/info{k}"] = np.array([info["nact"], info["qp_kkt"], info["cond"]])
             print(f"{name} tick {k}: u0={u[0]}, active={info['nact']}/{N * NU}, qp_kkt={info['qp_kkt']:.2e}, cond={info['cond']:.1e}")
     np.savez_compressed(os.path.join(OUT, "rti_known_answers.npz"), **out)
+    write_option_scenarios(ref, circ)
 
 
 if __name__ == "__main__":

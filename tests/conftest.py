@@ -32,6 +32,17 @@ def golden_rti():
 
 
 @pytest.fixture(scope="session")
+def golden_rti_options():
+    """known answers with non-default weights / boxes / per-stage parameters (scripts/make_golden.py options)"""
+    return np.load(os.path.join(GOLDEN, "rti_known_answers_options.npz"))
+
+
+def scenario_options(g, name):
+    """the solver options a fixture scenario carries (empty for the shipped-options fixture)"""
+    return {k: list(g[f"{name}/{k}"]) for k in ("W", "We", "lbu", "ubu") if f"{name}/{k}" in g.files}
+
+
+@pytest.fixture(scope="session")
 def golden_traj():
     return np.load(os.path.join(GOLDEN, "traj_head.npz"))
 

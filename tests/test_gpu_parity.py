@@ -7,7 +7,7 @@ cond ~1e5)."""
 import numpy as np
 import pytest
 
-from conftest import scenario_names, scenario_ticks, status_agreement, values_agree
+from conftest import scenario_names, scenario_options, scenario_ticks, status_agreement, values_agree
 
 pytestmark = pytest.mark.gpu
 TOL_LIN = 1e-11
@@ -67,6 +67,21 @@ def test_known_answers_every_scenario(ba, golden_rti, path):
             assert np.abs(u[0] - g[f"{name}/u{k}"]).max() < 1e-6, (name, k)
             assert np.abs(x[0] - g[f"{name}/x{k}"]).max() < 1e-6, (name, k)
             assert np.array_equal(r["u0"], u[0, 0])
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_known_answers_with_non_default_options(ba, golden_rti_options, path):
+    """the kernels against answers computed without any build code (reference CasADi model + numpy condensing + scipy BVLS) for
+    scaled weights, tight / asymmetric / offset boxes and scattered per-stage parameters: N = 14 / 20 (fused), 40 / 80 (windowed),
+    and the streaming pair; every QP has active bounds, i.e. every step runs the interior-point loop"""
+    g = golden_rti_options
+    for name in scenario_names(g):
+        kw = scenario_options(g, name)
+        for k, (r, (x, u, pi, lam), _) in enumerate(_gpu_run(ba, g, name, path, **kw)):
+            assert r["status"] == 0 and 0 < r["qp_iter"] < 40, (name, k, r)
+            assert np.abs(u[0] - g[f"{name}/u{k}"]).max() < 1e-6, (name, k)
+            assert np.abs(x[0] - g[f"{name}/x{k}"]).max() < 1e-6, (name, k)
+            assert np.all(u[0] >= np.array(kw["lbu"]) - 1e-9) and np.all(u[0] <= np.array(kw["ubu"]) + 1e-9)
 
 
 @pytest.mark.parametrize("path", PATHS)

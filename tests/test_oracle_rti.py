@@ -5,7 +5,7 @@ at the solver level, see oracle/bluerov2_oracle.h)."""
 import numpy as np
 import pytest
 
-from conftest import scenario_names, scenario_ticks
+from conftest import scenario_names, scenario_options, scenario_ticks
 
 # tolerance on the iterate after each RTI step; the north star asks 1e-5 on u*, the oracle is held to 1e-6
 TOL_U = 1e-6
@@ -31,6 +31,22 @@ def test_known_answers(oracle, golden_rti):
             assert np.abs(u - g[f"{name}/u{k}"]).max() < TOL_U, (name, k)
             assert np.abs(x - g[f"{name}/x{k}"]).max() < TOL_U, (name, k)
             assert np.allclose(r["u0"], u[0])
+
+
+def test_known_answers_with_non_default_options(oracle, golden_rti_options):
+    """scaled weights, tight / asymmetric / offset input boxes, scattered per-stage parameters, far-off states: the regime of the
+    randomised-options test, here against answers computed without any build code; with and without the early exit"""
+    g = golden_rti_options
+    assert set(scenario_names(g)) == {"tightbox_N14", "offsetbox_N20", "tightbox_N40", "asymbox_N80"}
+    for name in scenario_names(g):
+        for early in (1, 0):
+            for k, (r, x, u, _, _) in enumerate(_run(oracle, g, name, qp_early_exit=early, **scenario_options(g, name))):
+                assert r["status"] == 0 and r["qp_iter"] > 0 and r["qp_iter"] < 40, (name, k, r)   # every one of these QPs has active bounds
+                assert np.abs(u - g[f"{name}/u{k}"]).max() < TOL_U, (name, k)
+                assert np.abs(x - g[f"{name}/x{k}"]).max() < TOL_U, (name, k)
+                lb, ub = np.array(scenario_options(g, name)["lbu"]), np.array(scenario_options(g, name)["ubu"])
+                assert np.all(u >= lb - 1e-9) and np.all(u <= ub + 1e-9)
+                assert int(g[f"{name}/info{k}"][0]) > 0
 
 
 def test_survey_appendix_d_values(oracle, golden_rti):
