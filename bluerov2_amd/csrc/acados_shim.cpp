@@ -67,7 +67,10 @@ int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N
     brov_shim_state* s = new brov_shim_state();
     s->N = N;
     brov_default_opts(&s->opts, N, Ts);
-    int rc = brov_create(&s->solver, 0, 1, &s->opts);
+    // which GPU: the reference has no such notion; BROV_DEVICE selects one on a multi-GPU host (default 0)
+    const char* dev_env = std::getenv("BROV_DEVICE");
+    const int device = dev_env ? std::atoi(dev_env) : 0;
+    int rc = brov_create(&s->solver, device, 1, &s->opts);
     if (rc != BROV_OK) {
         std::fprintf(stderr, "bluerov2_acados_create: MI355X solver unavailable (%d): %s\n", rc, brov_last_error());
         delete s;
