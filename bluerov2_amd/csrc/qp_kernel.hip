@@ -308,6 +308,8 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
     bool& ok = S.ok;
     const d4 z4 = {0, 0, 0, 0};
     const unsigned mk_col0 = cl == 0 ? ~0u : 0u;
+    constexpr bool kMaskPvAtUse = (LDS == 1 || LDS == 2);
+    const double col0f = cl == 0 ? 1.0 : 0.0;
     d4 diagm;  // stage cost diag(Ts*Wx, Ts*Wu) in tile layout
 #pragma unroll
     for (int r = 0; r < 3; r++) diagm[r] = (rg + 4 * r == cl) ? I.Ts * I.Wr[r] : 0.0;
@@ -335,7 +337,13 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             const d4 Pb = tn<3>(P, ba1, z4);
             if (STORE_IPM) store_vec12(I.Pb + (size_t)(I.i0 + i) * 12, Pb, rg, cl);
 #pragma unroll
-            for (int r = 0; r < 3; r++) Y2[r] = Pb[r] + pv[r];   // pv is zero outside column 0
+            for (int r = 0; r < 3; r++) {
+                // only column 0 of pv is the gradient.  Fused kernels: pv arrives unmasked (finite don't-care values of the previous
+                // stage's product elsewhere) and is masked by the multiplication -- 47 cycles per stage less than blending it to zero
+                // when it is produced; in the windowed and streaming kernels that form measured slower / spilled, they keep the blend
+                if constexpr (kMaskPvAtUse) Y2[r] = fma(pv[r], col0f, Pb[r]);
+                else Y2[r] = Pb[r] + pv[r];
+            }
             Y2[3] = 0.0;
             d4 H = tn<3>(in.ba, Y2, z4);
             d4 g;
@@ -431,7 +439,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             }
             P = S;
 #pragma unroll
-            for (int r = 0; r < 3; r++) pv[r] = blend(mk_col0, pn[r], 0.0);
+            for (int r = 0; r < 3; r++) pv[r] = kMaskPvAtUse ? pn[r] : blend(mk_col0, pn[r], 0.0);
             pv[3] = 0.0;
         } else {
             d4 l;

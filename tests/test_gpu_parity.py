@@ -168,8 +168,8 @@ def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj, path
         assert (kk < 5e3).mean() > 0.95          # ... and for >95 % of them the scaled tolerance IS the absolute 1e-7
         for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"])):
             ok, err = _scaled_ok(a[cmp], b[cmp], kk[cmp])
-            assert ok.all(), (k, name, np.nonzero(cmp)[0][~ok], err[~ok], kk[cmp][~ok])
-        assert np.all((np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))[cmp])
+            values_agree(ok, kk[cmp], (k, name))
+        values_agree((np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))[cmp], kk[cmp], (k, "cost"))
         assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
         well = (kk < 5e3) & cmp
         assert np.array_equal(res["qp_iter"][well] == 0, ro["qp_iter"][well] == 0)
