@@ -511,6 +511,18 @@ __device__ __forceinline__ double quad_sum(double v) {
 // whole 12-term dot product itself against the state step held in SGPRs (v_fma with a scalar operand); the result vector goes
 // back into SGPRs with v_readlane.  No cross-lane reduction, no LDS round trip on the chain: 12 + 4 fmas and 32 v_readlane per
 // forward stage.
+// acc += a * (src of lane K of this lane's 16-lane row): v_fmac_f64_dpp with row_newbcast, the one DPP control gfx950 has for
+// 64-bit operands.  The broadcast costs nothing beyond the FMA (5.3 cycles against 4.9, scripts/dev/dpp_fmac_rate.hip) -- a
+// v_readlane pair into SGPRs costs 8 plus the SGPR hazard.  FIRST = the source register was written by the previous VALU
+// instruction: a DPP read needs two wait states behind a VALU write, and the compiler does not see into inline assembly.
+template <int K, bool FIRST = false>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double a) {
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
+}
+
 struct FwdV { double m[12], b4[4], cv; };
 __device__ __forceinline__ FwdV load_fwd_v(const lds_f64* mrow, const lds_f64* klo, const lds_f64* brow, const lds_f64* cvec) {
     FwdV s;
@@ -541,24 +553,27 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
         lds_f64* out0 = rowx ? I.lds_dxb + NX + k : I.lds_vhat + km;          // x+_k -> state-step row i+1, v_m -> inputs of stage i
         const int ostr = rowx ? NX : 4;
         const double e0 = (k == 0) ? 1.0 : 0.0, e1 = (k == 1) ? 1.0 : 0.0, e2 = (k == 2) ? 1.0 : 0.0;
-        // state step of the first stage: row-replicated -> SGPRs (row r*4 + rg' sits in register r of the lanes with rg == rg')
-        double xs[12];
-#pragma unroll
-        for (int c = 0; c < 12; c++) xs[c] = readlane_f64(xx[c >> 2], 16 * (c & 3));
+        // The state step lives in ONE register, lane k (< 12) of a 16-lane row holding element k; the products take element c
+        // straight out of lane c by DPP row broadcast (round 2 kept the vector in SGPRs: 32 v_readlane per stage).  First stage:
+        // out of the LDS copy just written (one wave, LDS executes in order).
+        // ONE 16-lane row runs the sweep.  Every row would compute the same thing, and every row's LDS reads cost LDS clocks: a
+        // 64-lane ds_read_b64 occupies the CU's LDS (shared by the four resident waves, all of them in the same phase) for 4
+        // clocks, a 16-lane one for 1 -- with 17 reads per stage that is the difference between 9.2 k and 7.7 k cycles per sweep.
+        double xcur = I.lds_dxb[rowx ? k : 0];
+        if (I.lane < 16)
         pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(mrow0 + kk * mstr, klo0 + kk * kKtStage, brow0 + kk * kBaStage, cvec0 + kk * cstr); },
                                        [&](int i, const FwdV& in) {
             const double m0 = rowx ? e0 : in.m[0], m1 = rowx ? e1 : in.m[1], m2 = rowx ? e2 : in.m[2];
-            double d0 = fma(m0, xs[0], in.cv), d1 = m1 * xs[1], d2 = m2 * xs[2];
-            d0 = fma(in.m[3], xs[3], d0); d1 = fma(in.m[4], xs[4], d1); d2 = fma(in.m[5], xs[5], d2);
-            d0 = fma(in.m[6], xs[6], d0); d1 = fma(in.m[7], xs[7], d1); d2 = fma(in.m[8], xs[8], d2);
-            d0 = fma(in.m[9], xs[9], d0); d1 = fma(in.m[10], xs[10], d1); d2 = fma(in.m[11], xs[11], d2);
+            double d0 = in.cv, d1 = 0.0, d2 = 0.0;   // three interleaved chains, the summation order of the round-2 form (bit-identical)
+            fmac_bc<0, true>(d0, xcur, m0); fmac_bc<1>(d1, xcur, m1); fmac_bc<2>(d2, xcur, m2);
+            fmac_bc<3>(d0, xcur, in.m[3]); fmac_bc<4>(d1, xcur, in.m[4]); fmac_bc<5>(d2, xcur, in.m[5]);
+            fmac_bc<6>(d0, xcur, in.m[6]); fmac_bc<7>(d1, xcur, in.m[7]); fmac_bc<8>(d2, xcur, in.m[8]);
+            fmac_bc<9>(d0, xcur, in.m[9]); fmac_bc<10>(d1, xcur, in.m[10]); fmac_bc<11>(d2, xcur, in.m[11]);
             const double dot = d0 + (d1 + d2);          // rows 12..15: v_m = K x + kff; rows 0..11: A x + b
-            const double v0 = readlane_f64(dot, 12), v1 = readlane_f64(dot, 13), v2 = readlane_f64(dot, 14), v3 = readlane_f64(dot, 15);
-            double xn = fma(in.b4[0], v0, dot);
-            xn = fma(in.b4[1], v1, xn); xn = fma(in.b4[2], v2, xn); xn = fma(in.b4[3], v3, xn);
+            double xn = dot;                            // + B v, the inputs v_m out of lanes 12..15 of the same register
+            fmac_bc<12, true>(xn, dot, in.b4[0]); fmac_bc<13>(xn, dot, in.b4[1]); fmac_bc<14>(xn, dot, in.b4[2]); fmac_bc<15>(xn, dot, in.b4[3]);
             out0[i * ostr] = rowx ? xn : dot;
-#pragma unroll
-            for (int c = 0; c < 12; c++) xs[c] = readlane_f64(xn, c);
+            xcur = xn;
         });
         // the last state step back into the row-replicated form the callers carry between windows
         const lds_f64* xl = I.lds_dxb + N * NX + rg;
