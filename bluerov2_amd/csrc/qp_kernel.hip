@@ -564,14 +564,18 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
         pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(mrow0 + kk * mstr, klo0 + kk * kKtStage, brow0 + kk * kBaStage, cvec0 + kk * cstr); },
                                        [&](int i, const FwdV& in) {
             const double m0 = rowx ? e0 : in.m[0], m1 = rowx ? e1 : in.m[1], m2 = rowx ? e2 : in.m[2];
-            double d0 = in.cv, d1 = 0.0, d2 = 0.0;   // three interleaved chains, the summation order of the round-2 form (bit-identical)
-            fmac_bc<0, true>(d0, xcur, m0); fmac_bc<1>(d1, xcur, m1); fmac_bc<2>(d2, xcur, m2);
-            fmac_bc<3>(d0, xcur, in.m[3]); fmac_bc<4>(d1, xcur, in.m[4]); fmac_bc<5>(d2, xcur, in.m[5]);
-            fmac_bc<6>(d0, xcur, in.m[6]); fmac_bc<7>(d1, xcur, in.m[7]); fmac_bc<8>(d2, xcur, in.m[8]);
-            fmac_bc<9>(d0, xcur, in.m[9]); fmac_bc<10>(d1, xcur, in.m[10]); fmac_bc<11>(d2, xcur, in.m[11]);
-            const double dot = d0 + (d1 + d2);          // rows 12..15: v_m = K x + kff; rows 0..11: A x + b
-            double xn = dot;                            // + B v, the inputs v_m out of lanes 12..15 of the same register
-            fmac_bc<12, true>(xn, dot, in.b4[0]); fmac_bc<13>(xn, dot, in.b4[1]); fmac_bc<14>(xn, dot, in.b4[2]); fmac_bc<15>(xn, dot, in.b4[3]);
+            // The sweep is a recurrence on one wave: a dependent FP64 DPP operation issues ~13 cycles behind its producer
+            // (measured: 65 cycles per stage for the B v chain), an independent one after ~5.  Four chains of three for the 12-term
+            // products, a two-level sum, two chains of two for B v: 8 operations deep (three chains of four + serial B v: 10).
+            double d0 = in.cv, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+            fmac_bc<0, true>(d0, xcur, m0); fmac_bc<1>(d1, xcur, m1); fmac_bc<2>(d2, xcur, m2); fmac_bc<3>(d3, xcur, in.m[3]);
+            fmac_bc<4>(d0, xcur, in.m[4]); fmac_bc<5>(d1, xcur, in.m[5]); fmac_bc<6>(d2, xcur, in.m[6]); fmac_bc<7>(d3, xcur, in.m[7]);
+            fmac_bc<8>(d0, xcur, in.m[8]); fmac_bc<9>(d1, xcur, in.m[9]); fmac_bc<10>(d2, xcur, in.m[10]); fmac_bc<11>(d3, xcur, in.m[11]);
+            const double dot = (d0 + d1) + (d2 + d3);   // rows 12..15: v_m = K x + kff; rows 0..11: A x + b
+            double xa = dot, xb = 0.0;                  // + B v, the inputs v_m out of lanes 12..15 of the same register
+            fmac_bc<12, true>(xa, dot, in.b4[0]); fmac_bc<14>(xb, dot, in.b4[2]);
+            fmac_bc<13>(xa, dot, in.b4[1]); fmac_bc<15>(xb, dot, in.b4[3]);
+            const double xn = xa + xb;
             out0[i * ostr] = rowx ? xn : dot;
             xcur = xn;
         });
