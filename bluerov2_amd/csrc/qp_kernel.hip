@@ -203,6 +203,18 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return fma(y, e, y);
 }
 
+// acc += a * (src of lane K of this lane's 16-lane row): v_fmac_f64_dpp with row_newbcast, the one DPP control gfx950 has for
+// 64-bit operands.  The broadcast costs nothing beyond the FMA (5.3 cycles against 4.9, scripts/dev/dpp_fmac_rate.hip) -- a
+// v_readlane pair into SGPRs costs 8 plus the SGPR hazard.  FIRST = the source register was written by the previous VALU
+// instruction: a DPP read needs two wait states behind a VALU write, and the compiler does not see into inline assembly.
+template <int K, bool FIRST = false>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double a) {
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Sweeps.  Every sweep is software-pipelined by hand: all global operands of stage i+-1 are requested (plain loads into
 // a second register set) before stage i is computed, so that HBM/L2 latency overlaps the MFMA chain of the current
@@ -297,8 +309,68 @@ __device__ __forceinline__ void bwd_init(const Inst& I, BwdState& S) {
     S.P = P; S.pv = pv; S.ok = true;
 }
 
+// Solve-only backward sweep (the corrector solve of an interior-point iteration: stored factors, new right-hand side) of the
+// LDS-resident kernels, on the VALU.  It is a pure vector recursion,
+//     l = P b + p,   g = [A B]' l + [q; rtilde],   kff = -M g_u,   p <- g_x + K' g_u,
+// which round 2 ran as four MFMA tile products per stage (of which 15 of 16 columns are wasted).  Here lane k of ONE 16-lane row
+// owns element k of the 16-vector g (12 state rows, 4 input rows) and of p; a product takes the element it needs out of the
+// lane that holds it by DPP row broadcast (fmac_bc, see fwd_chunk): 12 fmacs for [A B]' l, 4 for the gain / M column k of the
+// stored tile (element (m, k) = K[m][k] for k < 12, M[m][k-12] above: the same address for every lane).  16 lanes = a quarter
+// of the LDS clocks of a full-wave read.
+struct SolveV { double m[12], ks[4], pb, q, rt; };
+template <int LDS>
+__device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
+    static_assert(LDS != 0, "LDS-resident kernels only");
+    const int rg = I.rg, cl = I.cl, N = I.N;
+    const int k = I.lane & 15;
+    const bool rowx = k < NX, ecol = k < 3;
+    const int oc = k >= 3 ? k - 3 : 0, kx = rowx ? k : NX - 1, ku = k & 3;
+    const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
+    // p of the stage after this window: row-replicated -> lane k (through the transposition scratch; one wave, LDS in order)
+    store_vec12_lds(I.lds_tr, S.pv, rg, cl);
+    double pcur = I.lds_tr[kx];
+    if (I.lane < 16)
+    pipelined<kLdsDist<LDS>, SolveV>(N, [&](int kk) {
+        const int i = N - 1 - kk, ig = I.i0 + i;
+        SolveV s;
+        const lds_f64* col = I.lds_ba + i * kBaStage + oc;   // column k of [A_i B_i] (columns 0..2 are e_k: loaded, never used)
+#pragma unroll
+        for (int r = 0; r < 12; r++) s.m[r] = col[r * kBaStride];
+        const double* kt = I.Ks + (size_t)ig * 64 + k;        // column k of the stored gain | M tile
+#pragma unroll
+        for (int t = 0; t < 4; t++) s.ks[t] = kt[16 * t];
+        s.pb = I.Pb[(size_t)ig * 12 + kx];
+        s.q = I.lds_q[i * 12 + kx];      // both requested by every lane and selected in the body: a load under a divergent
+        s.rt = rt[ig * 4 + ku];          // branch is waited for where it is issued
+        return s; },
+                                     [&](int kk, const SolveV& in) {
+        const int i = N - 1 - kk;
+        const double l = in.pb + pcur;                        // lanes 12..15: a finite don't-care value, never broadcast
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+        fmac_bc<0, true>(d0, l, in.m[0]); fmac_bc<1>(d1, l, in.m[1]); fmac_bc<2>(d2, l, in.m[2]); fmac_bc<3>(d3, l, in.m[3]);
+        fmac_bc<4>(d0, l, in.m[4]); fmac_bc<5>(d1, l, in.m[5]); fmac_bc<6>(d2, l, in.m[6]); fmac_bc<7>(d3, l, in.m[7]);
+        fmac_bc<8>(d0, l, in.m[8]); fmac_bc<9>(d1, l, in.m[9]); fmac_bc<10>(d2, l, in.m[10]); fmac_bc<11>(d3, l, in.m[11]);
+        const double g = (ecol ? l : (d0 + d1) + (d2 + d3)) + (rowx ? in.q : in.rt);   // columns 0..2 of [A B] are e_k
+        double t0 = 0.0, t1 = 0.0;                            // column k of (gain | M) against g_u = lanes 12..15 of g
+        fmac_bc<12, true>(t0, g, in.ks[0]); fmac_bc<13>(t1, g, in.ks[1]); fmac_bc<14>(t0, g, in.ks[2]); fmac_bc<15>(t1, g, in.ks[3]);
+        const double t = t0 + t1;
+        lds_f64* kp = rowx ? I.lds_tr + 16 : I.lds_kff + i * 4 + ku;   // rows 12..15: M g_u -> kff = -M g_u; the others park
+        *kp = -t;
+        pcur = g + t;
+    });
+    // hand p of this window's first stage on, row-replicated
+    lds_f64* tp = (rowx && I.lane < 16) ? I.lds_tr + k : I.lds_tr + 16;
+    *tp = pcur;
+    const lds_f64* tl = I.lds_tr + rg;
+    S.pv = d4{tl[0], tl[4], tl[8], 0.0};
+}
+
 template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
 __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
+    if constexpr (!FACTOR && (LDS == 1 || LDS == 2)) {   // the windowed kernel has no registers left for it (it went into scratch)
+        bwd_solve_v<LDS>(I, S);
+        return;
+    }
     const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
@@ -511,18 +583,6 @@ __device__ __forceinline__ double quad_sum(double v) {
 // whole 12-term dot product itself against the state step held in SGPRs (v_fma with a scalar operand); the result vector goes
 // back into SGPRs with v_readlane.  No cross-lane reduction, no LDS round trip on the chain: 12 + 4 fmas and 32 v_readlane per
 // forward stage.
-// acc += a * (src of lane K of this lane's 16-lane row): v_fmac_f64_dpp with row_newbcast, the one DPP control gfx950 has for
-// 64-bit operands.  The broadcast costs nothing beyond the FMA (5.3 cycles against 4.9, scripts/dev/dpp_fmac_rate.hip) -- a
-// v_readlane pair into SGPRs costs 8 plus the SGPR hazard.  FIRST = the source register was written by the previous VALU
-// instruction: a DPP read needs two wait states behind a VALU write, and the compiler does not see into inline assembly.
-template <int K, bool FIRST = false>
-__device__ __forceinline__ void fmac_bc(double& acc, double src, double a) {
-    if constexpr (FIRST)
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
-    else
-        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
-}
-
 struct FwdV { double m[12], b4[4], cv; };
 __device__ __forceinline__ FwdV load_fwd_v(const lds_f64* mrow, const lds_f64* klo, const lds_f64* brow, const lds_f64* cvec) {
     FwdV s;
