@@ -330,7 +330,7 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
     store_vec12_lds(I.lds_tr, S.pv, rg, cl);
     double pcur = I.lds_tr[kx];
     if (I.lane < 16)
-    pipelined<kLdsDist<LDS>, SolveV>(N, [&](int kk) {
+    pipelined<(LDS == 3 ? 3 : kLdsDist<LDS>), SolveV>(N, [&](int kk) {   // windowed kernel: the stored factors come out of L2 / HBM
         const int i = N - 1 - kk, ig = I.i0 + i;
         SolveV s;
         const lds_f64* col = I.lds_ba + i * kBaStage + oc;   // column k of [A_i B_i] (columns 0..2 are e_k: loaded, never used)
@@ -367,7 +367,7 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
 
 template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
 __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
-    if constexpr (!FACTOR && (LDS == 1 || LDS == 2)) {   // the windowed kernel has no registers left for it (it went into scratch)
+    if constexpr (!FACTOR && LDS != 0) {
         bwd_solve_v<LDS>(I, S);
         return;
     }
@@ -1440,8 +1440,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         if (dv > 0) amax = fmin(amax, tu / dv);
                         if (dll < 0) amax = fmin(amax, -ll / dll);
                         if (dlu < 0) amax = fmin(amax, -lu / dlu);
-                        vDLL.set(t, j, dll);
-                        vDLU.set(t, j, dlu);
+                        if constexpr (!CACHE) { vDLL.set(t, j, dll); vDLU.set(t, j, dlu); }
                     }
                     amax = wave_min(amax);
                     {   // a blocked step stops 10 % short of the boundary, a (nearly) full one goes 99.99 % of the way
@@ -1452,7 +1451,18 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         const double dv = (CACHE ? vh[CACHE ? t : 0] : rd_vhat(j)) - vV.get(t, j);
                         const double vj = vV.get(t, j) + alpha * dv;
                         const double tl = vTL.get(t, j) + alpha * dv, tu = vTU.get(t, j) - alpha * dv;
-                        const double ll = vLL.get(t, j) + alpha * vDLL.get(t, j), lu = vLU.get(t, j) + alpha * vDLU.get(t, j);
+                        double dll, dlu;
+                        if constexpr (CACHE) {
+                            // windowed kernel: the dual steps are recomputed (a dozen operations per element) instead of held in 32
+                            // more registers across the reduction -- the kernel has none to spare
+                            const double l0 = vLL.get(t, j), u0_ = vLU.get(t, j), t0_ = vTL.get(t, j), t1_ = vTU.get(t, j), dva = vDVA.get(t, j);
+                            const double dlla = -l0 - l0 / t0_ * dva, dlua = -u0_ + u0_ / t1_ * dva;
+                            dll = (smu - dlla * dva) / t0_ - l0 - l0 / t0_ * dv;
+                            dlu = (smu + dlua * dva) / t1_ - u0_ + u0_ / t1_ * dv;
+                        } else {
+                            dll = vDLL.get(t, j); dlu = vDLU.get(t, j);
+                        }
+                        const double ll = vLL.get(t, j) + alpha * dll, lu = vLU.get(t, j) + alpha * dlu;
                         vV.set(t, j, vj); vTL.set(t, j, tl); vTU.set(t, j, tu); vLL.set(t, j, ll); vLU.set(t, j, lu);
                         if (!(vj == vj)) bad = true;
                         s2 += ll * tl + lu * tu;
@@ -1807,7 +1817,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     const bool last = ig == N - 1;
     double yrn[NX];
 #pragma unroll
-    for (int j = 0; j < NX; j++) yrn[j] = last ? yr[NY + j] : 0.0;
+    for (int j = 0; j < NX; j++) yrn[j] = yr[NY + j];   // row i+1 of the staged reference: valid for every interval, used by the last one
     const ModelPar m = make_par(pp);
     const Wrench w = make_wrench(uu);
     // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps, and the
