@@ -1538,13 +1538,28 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
         DBG_STAMP(5);
         bool nanv = false;
-        for (int j = lane; j < nv; j += 64) {
-            const double vj = EL ? rd_vhat(j) : vfin[j];
-            if (!(vj == vj)) nanv = true;
-        }
-        for (int j = lane; j < nxe; j += 64) {
-            const double dj = rd_dxb(j);
-            if (!(dj == dj)) nanv = true;
+        // fused kernels: the lane's elements of the accepted inputs and state steps (all of them: nv <= 128, nxe <= 320) are read
+        // once, back to back with clamped indices, checked here and reused by the update loops below -- written as guarded
+        // element loops every read sits in its own exec-masked block with an LDS wait inside
+        double vvp[EL ? UU : 1], djp[EL ? UX : 1];
+        if constexpr (EL) {
+#pragma unroll
+            for (int t = 0; t < UU; t++) vvp[t] = rd_vhat(lane + 64 * t < nv ? lane + 64 * t : 0);
+#pragma unroll
+            for (int t = 0; t < UX; t++) djp[t] = rd_dxb(lane + 64 * t < nxe ? lane + 64 * t : 0);
+#pragma unroll
+            for (int t = 0; t < UU; t++) nanv = nanv || !(vvp[t] == vvp[t]);   // clamped slots repeat element 0: same verdict
+#pragma unroll
+            for (int t = 0; t < UX; t++) nanv = nanv || !(djp[t] == djp[t]);
+        } else {
+            for (int j = lane; j < nv; j += 64) {
+                const double vj = vfin[j];
+                if (!(vj == vj)) nanv = true;
+            }
+            for (int j = lane; j < nxe; j += 64) {
+                const double dj = rd_dxb(j);
+                if (!(dj == dj)) nanv = true;
+            }
         }
         if (__ballot(nanv) != 0ull) {
             status = BROV_STATUS_NAN;
@@ -1557,7 +1572,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const bool in = j < nv;
                     const int jj = in ? j : 0;
                     uo[t] = (EL && j0 == lane && t < 2) ? ureg[t] : u_it[jj];
-                    vv[t] = EL ? rd_vhat(jj) : vfin[jj];
+                    vv[t] = EL ? ((j0 == lane) ? vvp[EL ? t : 0] : rd_vhat(jj)) : vfin[jj];
                     gg[t] = early ? 0.0 : rd_grad(jj);
                     ur[t] = (EL && j0 == lane) ? urpre[t] : I.yref[(size_t)(jj >> 2) * 16 + 12 + (jj & 3)];
                 }
@@ -1589,7 +1604,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     const int jj = j < nxe ? j : 0;
                     const int i = jj / 12, c = jj - i * 12;
                     xo[t] = (EL && j0 == lane) ? xpre[t] : x_it[jj];
-                    dj[t] = rd_dxb(jj);
+                    dj[t] = (EL && j0 == lane) ? djp[EL ? t : 0] : rd_dxb(jj);
                     yr[t] = (EL && j0 == lane) ? ypre[t] : I.yref[(size_t)i * 16 + c];
                 }
 #pragma unroll
@@ -1762,7 +1777,7 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 // ([A B] compact [n][12][13]), so the scattered 8-byte writes that rule this mapping out against HBM cost nothing.
 //   ba_s [n][12][13], bv_s [n][12], q_s [n+1][12] (row n: terminal gradient if the chunk ends the horizon), r_s [n][4];
 //   rec_s: scratch for the stage records, n*68 doubles.  part / nanp: this lane's share of the KKT max / NaN flag.
-template <bool TWO = true>
+template <bool TWO = true, bool FUSED = false>
 __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
                                           double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
 #ifdef BROV_DBG_LIN
@@ -1935,7 +1950,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             const int j = input ? (q == 3 ? 0 : 2) : q;       // velocity row 6 + j
             constexpr double ir = 1.0 / kRotor;
             const double kbv = !input ? 0.0 : (j == 0 ? (-4.0 * 0.707) * ir * m.imx : -2.0 * ir * m.imz);   // model_bcol rows 6 / 8
-            sens_column_cheap(rec, P.Ts, j, input, kbv, cv[t]);
+            sens_column_cheap<FUSED>(rec, P.Ts, j, input, kbv, cv[t]);
         }
     }
     LIN_T(6);
@@ -2057,7 +2072,7 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     bool nanp = false;
     LaneCst lc;
     if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
-    lin_phase<W == 1>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
+    lin_phase<W == 1, true>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
     Inst I;
