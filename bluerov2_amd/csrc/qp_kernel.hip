@@ -938,19 +938,22 @@ __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, 
 __device__ __forceinline__ bool win_nan_check(const Inst& I, const Win& W, bool first) {
     const lds_f64* vh = (const lds_f64*)(W.lds + win_off_vh(W.Lc));
     const lds_f64* dx = (const lds_f64*)(W.lds + win_off_dx(W.Lc));
-    bool bad = false;
+    // all six elements requested back to back, compared afterwards (and the caller must not short-circuit the call: under a
+    // per-lane condition the whole body becomes an exec-masked block with one LDS wait per element)
+    double v[6];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int j = I.lane + 64 * t;
-        const double v = vh[j < I.N * 4 ? j : 0];
-        if (!(v == v)) bad = true;
+        v[t] = vh[j < I.N * 4 ? j : 0];
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int j = I.lane + 64 * t + (first ? 0 : NX);   // row 0 belongs to the previous window (d0 for the first one)
-        const double v = dx[j < (I.N + 1) * NX ? j : NX];
-        if (!(v == v)) bad = true;
+        v[2 + t] = dx[j < (I.N + 1) * NX ? j : NX];
     }
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 6; t++) bad = bad | !(v[t] == v[t]);
     return bad;
 }
 template <int LDS>
@@ -982,16 +985,14 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
             win_flush_small(I.vhat + I.i0 * 4, W->lds + win_off_vh(W->Lc), I.N * 4, I.lane);
             win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
-            bad = bad || win_nan_check(I, *W, c == 0);
+            bad = bad | win_nan_check(I, *W, c == 0);
             if (cst) {
                 const lds_f64* vh = (const lds_f64*)(W->lds + win_off_vh(W->Lc));
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const int j = I.lane + 64 * t;
-                    if (j < I.N * 4) {
-                        const double vj = vh[j], lb = lbm - uw[t], ub = ubm - uw[t];
-                        if (!(vj >= lb && vj <= ub)) infeas = true;
-                    }
+                    const double vj = vh[j < I.N * 4 ? j : 0], lb = lbm - uw[t], ub = ubm - uw[t];   // read unconditionally (clamped)
+                    infeas = infeas | ((j < I.N * 4) & !(vj >= lb && vj <= ub));
                 }
                 uw[0] = un[0]; uw[1] = un[1];
             }
@@ -1015,7 +1016,7 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
             __syncthreads();
             win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
-            bad = bad || win_nan_check(I, *W, c == 0);
+            bad = bad | win_nan_check(I, *W, c == 0);
         }
         W->nan = __ballot(bad) != 0ull;
         wave_fence();
