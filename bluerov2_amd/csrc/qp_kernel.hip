@@ -1312,12 +1312,16 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }                                                                                  \
             }
             const int mI = lane & 3;   // input index of every element of this lane (j = lane + 64 t)
+            // bounds and weight of that input: loaded once and made opaque, so that the compiler cannot sink the (re-)loads into
+            // the guarded element blocks below, where every one of them would be waited for under the exec mask
+            double lbI = cst[32 + mI], ubI = cst[36 + mI], wuI = cst[12 + mI];
+            asm volatile("" : "+v"(lbI), "+v"(ubI), "+v"(wuI));
             {
                 IPM_PRE(up, I.u[j]);
                 IPM_PRE(vh, I.vhat[j]);
                 IPM_FOR(t, j) {
                     const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
-                    const double lb = cst[32 + mI] - uj, ub = cst[36 + mI] - uj;
+                    const double lb = lbI - uj, ub = ubI - uj;
                     const double wdt = ub - lb;
                     double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
                     const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
@@ -1365,7 +1369,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         GAM[j] = gm;
                         if constexpr (EL) gam_r[t & 1] = gm;
                         const double rr = EL ? (double)I.lds_r[j]
-                                             : P.Ts * cst[12 + mI] * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                             : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
                                                                            : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
                         RT[j] = rr - gm * vV.get(t, j);
                     }
@@ -1411,7 +1415,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                         const double cl_ = dll * dv, cu_ = -dlu * dv;
                         const double rr = EL ? (double)I.lds_r[j]
-                                             : P.Ts * cst[12 + mI] * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                             : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
                                                                            : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
                         const double gm = EL ? gam_r[t & 1] : (CACHE ? gmp[CACHE ? t : 0] : GAM[j]);
                         RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
