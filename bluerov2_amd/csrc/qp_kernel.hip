@@ -891,6 +891,10 @@ __device__ __forceinline__ void win_flush(double* g, const double* l, int nd, in
             const int o = o0 + (k * 64 + lane) * 2;
             v[k] = lv[(o < nd ? o : 0) >> 1];
         }
+        // opaque from here on: left alone the compiler re-reads each piece inside its store's guard (read, wait, store, eight times
+        // over) instead of using the eight reads it has just issued back to back
+#pragma unroll
+        for (int k = 0; k < 8; k++) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int o = o0 + (k * 64 + lane) * 2;
@@ -903,7 +907,8 @@ __device__ __forceinline__ void win_flush_small(double* g, const double* l, int 
     const lds_d2* lv = (const lds_d2*)l;
     for (int o0 = 0; o0 < nd; o0 += 256) {
         const int oa = o0 + lane * 2, ob = oa + 128;
-        const dbl2 va = lv[(oa < nd ? oa : 0) >> 1], vb = lv[(ob < nd ? ob : 0) >> 1];
+        dbl2 va = lv[(oa < nd ? oa : 0) >> 1], vb = lv[(ob < nd ? ob : 0) >> 1];
+        asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(vb.x), "+v"(vb.y));   // see win_flush
         if (oa < nd) *(dbl2*)(g + oa) = va;
         if (ob < nd) *(dbl2*)(g + ob) = vb;
     }
