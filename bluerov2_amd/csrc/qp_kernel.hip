@@ -240,6 +240,24 @@ __device__ __forceinline__ void pipelined(int count, Load load, Body body) {
     }
 }
 
+// The same pipeline with the request for step k + D issued from INSIDE step k: the body calls `issue()` where it has issue slots
+// to spare (behind a chain of MFMAs whose result it has to wait for anyway) instead of ahead of its first instruction.
+template <int D, class In, class Load, class Body>
+__device__ __forceinline__ void pipelined_mid(int count, Load load, Body body) {
+    constexpr int S = D + 1;
+    In slot[S];
+#pragma unroll
+    for (int d = 0; d < D; d++) slot[d] = load(d < count ? d : count - 1);
+    for (int k = 0; k < count; k += S) {
+#pragma unroll
+        for (int d = 0; d < S; d++) {
+            const int kn = k + d + D;
+            auto issue = [&]() __attribute__((always_inline)) { slot[(d + D) % S] = load(kn < count ? kn : count - 1); };
+            if (k + d < count) body(k + d, slot[d], issue); else issue();
+        }
+    }
+}
+
 // Fused path: LDS = 1 is the one-wave-per-SIMD kernel (look-ahead of two stages), LDS = 2 the two-waves-per-SIMD kernel for
 // short horizons (one stage: the SIMD's other wave covers the rest, and the third register slot would be spilled).
 template <int LDS> constexpr int kLdsDist = LDS == 2 ? 1 : 2;
@@ -386,7 +404,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
 #pragma unroll
     for (int r = 0; r < 3; r++) diagm[r] = (rg + 4 * r == cl) ? I.Ts * I.Wr[r] : 0.0;
     diagm[3] = (12 + rg == cl) ? I.Ts * I.Wr[3] : 0.0;
-    auto stage = [&](int i, const BwdIn& in) __attribute__((always_inline)) {
+    auto stage = [&](int i, const BwdIn& in, auto&& mid) __attribute__((always_inline)) {
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
 #pragma unroll
@@ -407,6 +425,10 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             for (int r = 0; r < 3; r++) ba1[r] = blend(mk_col0, in.bv[r], in.ba[r]);
             ba1[3] = 0.0;
             const d4 Pb = tn<3>(P, ba1, z4);
+            // the operand requests of stage i - 2 go here, into the wait for the product (18 idle cycles otherwise)
+            __builtin_amdgcn_sched_barrier(0);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
             if (STORE_IPM) store_vec12(I.Pb + (size_t)(I.i0 + i) * 12, Pb, rg, cl);
 #pragma unroll
             for (int r = 0; r < 3; r++) {
@@ -514,6 +536,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             for (int r = 0; r < 3; r++) pv[r] = kMaskPvAtUse ? pn[r] : blend(mk_col0, pn[r], 0.0);
             pv[3] = 0.0;
         } else {
+            mid();
             d4 l;
 #pragma unroll
             for (int r = 0; r < 4; r++) l[r] = in.bv[r] + pv[r];
@@ -526,8 +549,14 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
         }
     };
     if constexpr (LDS) {
-        pipelined<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
-                            [&](int k, const BwdIn& in) { stage(N - 1 - k, in); });
+        if constexpr (LDS != 1) {   // two-wave kernel: the other wave fills those slots, and the variant below costs it registers it does not
+                                    // have; windowed kernel: it answers the change with a wrong linearisation (toolchain)
+            pipelined<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+                                [&](int k, const BwdIn& in) { stage(N - 1 - k, in, [] {}); });
+        } else {
+            pipelined_mid<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+                                [&](int k, const BwdIn& in, auto&& issue) { stage(N - 1 - k, in, issue); });
+        }
     } else {
         // distance 1 here: a stage is ~2 k cycles of issue per wave (4 k with the SIMD's second wave), enough to cover the
         // round trip, and a second stage in flight (36 VGPRs) pushes the kernel into scratch
@@ -535,7 +564,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
         for (int i = N - 1; i >= 0; i--) {
             const BwdIn in = nx;
             if (i > 0) nx = load_bwd<FACTOR, LDS, STEP0>(I, i - 1, gam, rt);
-            stage(i, in);
+            stage(i, in, [] {});
         }
     }
 }
