@@ -1633,7 +1633,15 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             }
             wrote_u0 = true;
             if constexpr (EL) {  // multipliers staged in LDS by adjoint<>: [N][12] at the head of the K^T array
-                for (int j = lane; j < N * 12; j += 64) pi_it[j] = I.lds_kt[j];
+                // N * 12 <= 276 elements: five per lane, read back to back, then stored (a guarded copy loop waits for LDS once per element)
+                double pv5[5];
+#pragma unroll
+                for (int t = 0; t < 5; t++) pv5[t] = I.lds_kt[lane + 64 * t < N * 12 ? lane + 64 * t : 0];
+#pragma unroll
+                for (int t = 0; t < 5; t++) asm volatile("" : "+v"(pv5[t]));
+#pragma unroll
+                for (int t = 0; t < 5; t++)
+                    if (lane + 64 * t < N * 12) pi_it[lane + 64 * t] = pv5[t];
             }
             for (int j0 = lane; j0 < nxe; j0 += 64 * UX) {
                 double xo[UX], dj[UX], yr[UX];
