@@ -304,7 +304,6 @@ __device__ __forceinline__ void sens_column_rec_u(const lds_f64* rec, const Mode
 // RK stage maps the scalar sigma = s[r] to k = [R_st(:, j) sigma; d_st sigma + kb]: ~25 operations per stage instead of the
 // ~125 of the general Jacobian-vector product.  acc = the full column (rows other than 0..2 and r are e_c resp. 0).
 // out = {S[0][c], S[1][c], S[2][c], S[6+j][c]}; expand_cheap() builds the full column
-template <bool IDXDD = false>
 __device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, int j, bool input, double kbv, double (&out)[4]) {
     // all four stage records first (one LDS wait instead of one per stage): the six trig values and this row's damping entry
     double tr[4][6], dd[4];
@@ -313,15 +312,8 @@ __device__ __forceinline__ void sens_column_cheap(const lds_f64* rec, double h, 
         const lds_f64* r = rec + st * kRecStage;
 #pragma unroll
         for (int k = 0; k < 6; k++) tr[st][k] = r[k];
-        if constexpr (IDXDD) {
-            dd[st] = r[13 + j];   // one load with a per-lane address: as a select of three loads the compiler branches on j and waits
-                                  // for the LDS queue inside each branch (four lgkmcnt(0) stalls per column: 1 k cycles per solve)
-        } else {
-            // windowed / streaming kernels: with the indexed form rti_window_kernel reads garbage here (another instance of this
-            // toolchain's trouble with that kernel) -- they keep the select
-            const double d0 = r[13], d1 = r[14], d2 = r[15];
-            dd[st] = (j == 0) ? d0 : ((j == 1) ? d1 : d2);
-        }
+        dd[st] = r[13 + j];   // one load with a per-lane address: as a select of three loads the compiler branches on j and waits
+                              // for the LDS queue inside each branch (four lgkmcnt(0) stalls per column: 1 k cycles per solve)
     }
     const double s0 = input ? 0.0 : 1.0;   // seed: e_c for a state column, 0 for an input column
     double sig = s0, ar = s0, a0 = 0.0, a1 = 0.0, a2 = 0.0;

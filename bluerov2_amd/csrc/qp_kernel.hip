@@ -549,8 +549,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
         }
     };
     if constexpr (LDS) {
-        if constexpr (LDS != 1) {   // two-wave kernel: the other wave fills those slots, and the variant below costs it registers it does not
-                                    // have; windowed kernel: it answers the change with a wrong linearisation (toolchain)
+        if constexpr (LDS == 2) {   // two-wave kernel: the other wave fills those slots, and the variant below costs it registers it does not have
             pipelined<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
                                 [&](int k, const BwdIn& in) { stage(N - 1 - k, in, [] {}); });
         } else {
@@ -1824,7 +1823,7 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 // ([A B] compact [n][12][13]), so the scattered 8-byte writes that rule this mapping out against HBM cost nothing.
 //   ba_s [n][12][13], bv_s [n][12], q_s [n+1][12] (row n: terminal gradient if the chunk ends the horizon), r_s [n][4];
 //   rec_s: scratch for the stage records, n*68 doubles.  part / nanp: this lane's share of the KKT max / NaN flag.
-template <bool TWO = true, bool FUSED = false>
+template <bool TWO = true>
 __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
                                           double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
 #ifdef BROV_DBG_LIN
@@ -1997,7 +1996,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             const int j = input ? (q == 3 ? 0 : 2) : q;       // velocity row 6 + j
             constexpr double ir = 1.0 / kRotor;
             const double kbv = !input ? 0.0 : (j == 0 ? (-4.0 * 0.707) * ir * m.imx : -2.0 * ir * m.imz);   // model_bcol rows 6 / 8
-            sens_column_cheap<FUSED>(rec, P.Ts, j, input, kbv, cv[t]);
+            sens_column_cheap(rec, P.Ts, j, input, kbv, cv[t]);
         }
     }
     LIN_T(6);
@@ -2043,7 +2042,11 @@ __device__ __forceinline__ void copy_out_linearisation(const DevParams& P, int b
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const int row = rg + 4 * r;
-            BA[r * 64 + lane] = cl >= 3 ? t[row * kBaStride + cl - 3] : (row == cl ? 1.0 : 0.0);
+            // every lane reads (clamped to a stored column), then arithmetic instead of a select: written as
+            // `cl >= 3 ? t[..] : constant` some builds of the windowed kernel stored the loaded value in the structural columns too
+            const double v = t[row * kBaStride + (cl >= 3 ? cl - 3 : 0)];
+            const double m = cl >= 3 ? 1.0 : 0.0, c0 = (cl < 3 && row == cl) ? 1.0 : 0.0;
+            BA[r * 64 + lane] = fma(m, v, c0);
         }
     }
     for (int j = lane; j < n * NX; j += 64) P.bvec[g0 * NX + j] = bv_s[j];
@@ -2119,7 +2122,7 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     bool nanp = false;
     LaneCst lc;
     if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
-    lin_phase<W == 1, true>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
+    lin_phase<W == 1>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
     Inst I;
