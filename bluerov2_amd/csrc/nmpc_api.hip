@@ -77,7 +77,7 @@ extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
     for (int j = 0; j < 12; j++) o->We[j] = W[j];
     for (int j = 0; j < 4; j++) { o->lbu[j] = -50.0; o->ubu[j] = 50.0; }
     o->qp_iter_max = 50;
-    o->qp_tol_mu = 1e-12;
+    o->qp_tol_mu = 1e-7;
     o->qp_tol_stat = 1e-9;
     o->qp_early_exit = 1;
     o->kernel_path = BROV_PATH_AUTO;

@@ -93,6 +93,8 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 #define IPM_FTB 0.9999  /* fraction to the boundary of a (nearly) full step */
 #define IPM_FTBLO 0.9   /* ... of a blocked step: alpha = a ((1 - a) FTBLO + a FTB), a = min(1, step to the boundary); see the oracle */
 #define IPM_MU0F 0.1    /* mu0 = IPM_MU0F * stationarity residual of the clamped point */
+#define IPM_STALL_MU 1e-10   /* floor detection: mu below this fraction of the gradient scale ... */
+#define IPM_STALL_RATIO 0.3  /* ... and not cut to less than this fraction of its previous value (see the oracle) */
 
 // everything one wave needs to know about its instance
 struct Inst {
@@ -1349,6 +1351,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // the guarded element blocks below, where every one of them would be waited for under the exec mask
             double lbI = cst[32 + mI], ubI = cst[36 + mI], wuI = cst[12 + mI];
             asm volatile("" : "+v"(lbI), "+v"(ubI), "+v"(wuI));
+            const double rdI = P.Ts * wuI;   // the input's own Hessian entry
             {
                 IPM_PRE(up, I.u[j]);
                 IPM_PRE(vh, I.vhat[j]);
@@ -1387,6 +1390,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             }
             status = BROV_STATUS_MAXITER;
             const double inv2nv = 1.0 / (2.0 * nv);
+            double mu_prev = 1e300;
             IPM_T(0);
             for (iters = 1; iters <= P.qp_iter_max; iters++) {
                 double s = 0.0;
@@ -1461,7 +1465,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 sw_forward<LDS>(I, W, d0);
                 IPM_T(5);
                 bool bad = false;
-                double s2 = 0.0, alpha;
+                double s2 = 0.0, alpha, unres = 0.0;
                 {   // group C: step length of the combined direction, update
                     vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
                     vDVA.fetch(lane, nv);
@@ -1504,6 +1508,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         vV.set(t, j, vj); vTL.set(t, j, tl); vTU.set(t, j, tu); vLL.set(t, j, ll); vLU.set(t, j, lu);
                         if (!(vj == vj)) bad = true;
                         s2 += ll * tl + lu * tu;
+                        // how far this element's bounds are from resolved: min(distance to the bound, multiplier / input weight)
+                        unres = fmax(unres, fmax(fmin(tl, ll / rdI), fmin(tu, lu / rdI)));
                     }
                     vV.flush(lane, nv); vTL.flush(lane, nv); vTU.flush(lane, nv); vLL.flush(lane, nv); vLU.flush(lane, nv);
                 }
@@ -1511,7 +1517,13 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 rho *= (1.0 - alpha);
                 mu = wave_sum(s2) * inv2nv;
                 IPM_T(1);
-                if (mu <= P.tol_mu * gscale && rho <= P.tol_stat * gscale) { status = BROV_STATUS_SUCCESS; break; }
+                // termination (same rule as the oracle, bluerov2_oracle.c): every bound resolved to tol_mu -- the input within that
+                // distance of it, or its multiplier too small to move the input that far -- and the tracked stationarity residual
+                // below tol_stat; escape when mu has reached the floor of what FP64 resolves for this QP (tiny and no longer falling)
+                unres = wave_max(unres);
+                const bool stalled = mu <= IPM_STALL_MU * gscale && mu > IPM_STALL_RATIO * mu_prev;
+                mu_prev = mu;
+                if ((unres <= P.tol_mu || stalled) && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
             }
 #ifdef BROV_DBG_IPM
             if (P.dbg && lane == 0) {

@@ -61,8 +61,9 @@ typedef struct brov_opts {
     double  We[BROV_NX];    /* diagonal terminal weight */
     double  lbu[BROV_NU];
     double  ubu[BROV_NU];
-    double  qp_tol_mu;      /* IPM complementarity target (1e-12), relative to the QP's gradient scale max(1, |g|_inf) */
-    double  qp_tol_stat;    /* IPM stationarity target   (1e-9), same scaling */
+    double  qp_tol_mu;      /* interior point, bound resolution (1e-7): at termination every input is within this distance of a bound or
+                             * the bound's multiplier divided by the input's weight is below it */
+    double  qp_tol_stat;    /* interior point, stationarity target (1e-9, tracked residual, absolute) */
     int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
     int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above -- except for batches of
                              * <= 8 instances at N >= 24, where the streaming pair has the shorter latency), _STREAMING, _FUSED */

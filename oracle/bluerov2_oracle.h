@@ -43,8 +43,8 @@ typedef struct orc_opts {
     double We[ORC_NX];    /* diag of terminal weight */
     double lbu[ORC_NU], ubu[ORC_NU];
     int    qp_iter_max;   /* 50 */
-    double qp_tol_mu;     /* complementarity target, relative to the QP's gradient scale max(1, |g|_inf) */
-    double qp_tol_stat;   /* stationarity target of the QP, same scaling */
+    double qp_tol_mu;     /* bound resolution: input within this distance of a bound, or its multiplier / input weight below it (1e-7) */
+    double qp_tol_stat;   /* stationarity target of the QP (tracked residual, absolute) */
     int    qp_early_exit; /* 1: return the equality-constrained minimiser when it is feasible (exact) */
     int    on_failure;    /* failed step (status 1/3/4): 0 keep the iterate (acados: SQP_RTI returns before update_variables),
                            * 1 cold restart at the measured state if it is finite (x_i = x0, u = 0, multipliers 0).  Either way the record's u0

@@ -73,7 +73,7 @@ def status_agreement(r_status, o_status, o_kkt, max_ambiguous=4):
     return ~mism
 
 
-def values_agree(ok, kkt, what, max_diverged=4):
+def values_agree(ok, kkt, what, max_diverged=4, err=None, degenerate_tol=1e-4, max_degenerate=2):
     """Value parity rule shared by the batch tests: `ok` is the per-instance verdict of a KKT-scaled comparison
     (|gpu - oracle| <= 1e-7 max(1, KKT)).  Every instance whose step is numerically meaningful (entering KKT <= 1e6) must pass.
     A diverged instance (KKT > 1e6, see status_agreement) may miss even the scaled tolerance -- its QP is conditioned beyond what
@@ -81,5 +81,15 @@ def values_agree(ok, kkt, what, max_diverged=4):
     them per tick."""
     ok, kkt = np.asarray(ok), np.asarray(kkt)
     bad = ~ok
+    if err is not None:
+        # Degenerate bounds.  Where a bound is active with a vanishing multiplier (strict complementarity fails) an interior-point
+        # method converges like sqrt(mu), and mu has a floor in FP64: the minimiser is then resolved to ~1e-5 at best, by ANY
+        # implementation.  Measured against the independent BVLS answer (scripts/dev/fuzz_truth.py, seed 1 / instance 88: N = 80,
+        # 92 active bounds): kernel 1.9e-6, oracle 3.0e-5 away, both stopped by the stall rule at mu ~ 5e-15.  At most
+        # `max_degenerate` instances per tick may miss the scaled tolerance while agreeing to `degenerate_tol` (the north star
+        # asks 1e-5 on u0; this is over all stages).
+        soft = bad & (np.asarray(err) <= degenerate_tol) & ~(kkt > 1e6)
+        assert soft.sum() <= max_degenerate, (what, "degenerate", np.nonzero(soft)[0][:8], np.asarray(err)[soft][:8])
+        bad = bad & ~soft
     assert not np.any(bad & ~(kkt > 1e6)), (what, np.nonzero(bad & ~(kkt > 1e6))[0][:8], kkt[bad][:8])
     assert bad.sum() <= max_diverged, (what, np.nonzero(bad)[0][:8], kkt[bad][:8])

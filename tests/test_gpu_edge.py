@@ -49,8 +49,9 @@ def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
     """rti_fused_kernel (one wave per SIMD) and rti_fused_kernel_w2 (two, the default for N <= 13) differ only in how the
     linearisation groups sensitivity columns and in the prefetch distance of the sweeps: same statuses, same early-exit
     decisions, iteration counts equal for > 95 % of the instances (the step-length rule with fraction-to-boundary 0.9999 turns
-    last-bit differences into one to three iterations more or less on a few far-off instances); iterates equal to rounding
-    carried through the interior-point iterations (1e-8), with active bounds in the batch"""
+    last-bit differences into one to three iterations more or less on a few far-off instances); iterates equal to what the
+    interior-point termination resolves (qp_tol_mu = 1e-7: both variants are that close to the same minimiser), with active
+    bounds in the batch"""
     B = 96
     x0, circ = _inputs(golden_traj, B, seed=N, big=6.0)
     out = {}
@@ -66,9 +67,11 @@ def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
     assert (r1["qp_iter"] > 0).any()
     assert np.array_equal(r1["status"], r2["status"]) and np.array_equal(r1["qp_iter"] == 0, r2["qp_iter"] == 0)
     assert (r1["qp_iter"] != r2["qp_iter"]).mean() < 0.05
-    for a, b in zip(it1, it2):
-        assert np.abs(a - b).max() < 1e-8
-    assert np.abs(r1["u0"] - r2["u0"]).max() < 1e-8
+    for a, b in zip(it1[:2], it2[:2]):   # x, u
+        assert np.abs(a - b).max() < 2e-7
+    for a, b in zip(it1[2:], it2[2:]):   # multipliers: scaled by the weights (up to 480)
+        assert np.abs(a - b).max() < 1e-5 * (1 + np.abs(a).max())
+    assert np.abs(r1["u0"] - r2["u0"]).max() < 2e-7
 
 
 def test_auto_path_selection(ba, golden_traj):

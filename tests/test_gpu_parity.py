@@ -379,7 +379,7 @@ def test_randomised_options_against_oracle(ba, oracle, golden_traj, seed):
         cmp = status_agreement(res["status"], ro["status"], kk)
         for name, a, b_ in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi), ("lam", glam, lam)):
             ok, err = _scaled_ok(a[cmp], b_[cmp], kk[cmp], tol=1e-6 if name in ("pi", "lam") else TOL_IT)
-            values_agree(ok, kk[cmp], (seed, N, k, name))
+            values_agree(ok, kk[cmp], (seed, N, k, name), err=err if name in ("u", "x", "u0") else None)
         fin = np.isfinite(kk)
         assert np.all(np.abs(res["kkt"][fin] - kk[fin]) <= 1e-6 * (1 + kk[fin]))
         okst = (res["status"] == 0) | (res["status"] == 2)
