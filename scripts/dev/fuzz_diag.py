@@ -16,7 +16,7 @@ for seed in [int(a) for a in sys.argv[1:]] or range(12):
     if seed % 3 == 0:
         lbu[1], ubu[1] = 2.0, 30.0
     kw = dict(W=list(W), We=list(We), lbu=list(lbu), ubu=list(ubu), on_failure=int(seed % 2), qp_early_exit=int(seed % 4 != 1))
-    path = ba.PATH_STREAMING if seed >= 9 else ba.PATH_AUTO
+    path = ba.PATH_STREAMING if (seed >= 9 and seed % 2) else ba.PATH_AUTO
     nb = 96
     x0, circ = _batch_inputs(gt, N, nb, seed=2000 + seed, sat_frac=0.3)
     s = ba.BatchSolver(nb, ba.SolverOptions(N, Ts, kernel_path=path, **kw))
