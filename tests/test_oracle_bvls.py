@@ -1,0 +1,67 @@
+"""The oracle's QP layer against answers computed without any build code, on RANDOM problems: reference CasADi model (oracle/_ref,
+compiled from the reference's generated C) -> textbook RK4 + numpy condensing -> scipy BVLS (scripts/make_golden.py's recipe).
+The committed golden scenarios pin a dozen fixed cases; this test draws options the way the GPU fuzz test does (horizon, step,
+weights, asymmetric / offset boxes, scattered per-stage parameters, far-off states) and holds the interior-point termination rule
+ to the accuracy it was chosen for: an earlier, relative complementarity target passed every fixed case and
+was 2e-4 .. 7e-4 off on problems like these."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.fixture(scope="module")
+def recipe():
+    import oracle.oracle_ffi as F
+    if not os.path.exists(F.REF_SO):
+        pytest.skip("oracle/_ref (the reference's CasADi C, built where /root/reference is present) is not here")
+    import make_golden as G
+    return G, F.CasadiRef()
+
+
+def _draw(G, rng, N, Ts, t, golden_traj):
+    circ = golden_traj["circle"]
+    W = G.W * rng.uniform(0.3, 3.0, size=16)
+    We = G.W[:12] * rng.uniform(0.3, 3.0, size=12)
+    lbu, ubu = -rng.uniform(5, 60, size=4), rng.uniform(5, 60, size=4)
+    if t % 3 == 0:
+        lbu[1], ubu[1] = 2.0, 30.0          # a box that excludes 0
+    x0 = np.zeros(12); x0[:6] = circ[0, :6]; x0 += rng.normal(size=12) * 0.05
+    if t % 2 == 0:
+        x0[:3] += rng.uniform(-4, 4, size=3); x0[5] += rng.uniform(-0.3, 0.3)
+    p = np.tile(G.P_NOMINAL, (N + 1, 1))
+    p[:, 4:] *= rng.uniform(0.7, 1.3, size=(N + 1, 12)); p[:, 5] = rng.uniform(0, 1, size=N + 1); p[:, :4] = rng.uniform(-200, 200, size=4)
+    x = np.tile([0, 0, -20.0] + [0] * 9, (N + 1, 1)).astype(float)
+    u = np.zeros((N, 4))
+    if t % 3 == 0:
+        u[:, 1] = 5.0
+    return W, We, lbu, ubu, x0, p, x, u, circ
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_random_qps_against_independent_answers(oracle, recipe, golden_traj, hard):
+    G, ref = recipe
+    rng = np.random.default_rng(11 if hard else 7)
+    worst, n_active = 0.0, 0
+    for t in range(4 if hard else 24):
+        if hard:   # long horizons over a short time: many active bounds, weakly active ones among them
+            N = int(rng.choice([57, 80])); Ts = float(rng.uniform(0.2, 0.5) / N)
+        else:
+            N = int(rng.choice([3, 7, 12, 14, 20, 23, 24, 31, 40])); Ts = float(rng.uniform(0.25, 1.0) / max(N, 20))
+        W, We, lbu, ubu, x0, p, x, u, circ = _draw(G, rng, N, Ts, t, golden_traj)
+        op = oracle.opts(N, Ts, W=list(W), We=list(We), lbu=list(lbu), ubu=list(ubu))
+        xo, uo, pi, lam = x.copy(), u.copy(), np.zeros((N, 12)), np.zeros((N, 8))
+        for k in range(2):
+            yref = circ[2 * k:2 * k + N + 1].copy()
+            x, u, info = G.rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=lbu, ubu=ubu, Wed=We)
+            r = oracle.rti_step(op, x0, yref, p, xo, uo, pi, lam)
+            assert r["status"] == 0 and info["qp_kkt"] < 1e-9, (t, k, r, info)
+            e = np.abs(uo - u).max()
+            assert e < 2e-6, (t, k, N, Ts, e, info)
+            worst, n_active = max(worst, e), n_active + info["nact"]
+            xo, uo = x.copy(), u.copy()    # both continue from the independent iterate
+    assert n_active > (400 if hard else 300)   # the draws do contain active bounds (interior-point solves)
