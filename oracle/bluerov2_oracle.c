@@ -52,7 +52,11 @@ static inline void thrust_wrench(const double* u, double* Kt0, double* Kt1, doub
     *Kt5 = 0.167 * t0 - 0.167 * t1 - 0.175 * t2 + 0.175 * t3;
 }
 
-void orc_f(const double* x, const double* u, const double* p, double* f) {
+void orc_f6(const double* x, const double* u, const double* p, const double* drp, double* f);
+void orc_f(const double* x, const double* u, const double* p, double* f) { orc_f6(x, u, p, NULL, f); }
+/* drp != NULL: the 6-disturbance variant -- the roll / pitch disturbance moments the reference carries as commented-out symbols
+ * (bluerov2.py:37-38) enter dp, dq the way the other four enter their rows (:123-128): + d_phi / Ix, + d_theta / Iy */
+void orc_f6(const double* x, const double* u, const double* p, const double* drp, double* f) {
     const double ph = x[3], th = x[4], ps = x[5], vu = x[6], vv = x[7], vw = x[8], wp = x[9], wq = x[10], wr = x[11];
     const double sph = sin(ph), cph = cos(ph), sth = sin(th), cth = cos(th), sps = sin(ps), cps = cos(ps);
     double Kt0, Kt1, Kt2, Kt5;
@@ -66,8 +70,8 @@ void orc_f(const double* x, const double* u, const double* p, double* f) {
     f[6] = (Kt0 - BOUY * sth + p[0] + p[8] * vu + p[12] * fabs(vu) * vu) / (M_ + p[4]);
     f[7] = (Kt1 + BOUY * cth * sph + p[1] + p[9] * vv + p[13] * fabs(vv) * vv) / (M_ + p[5]);
     f[8] = (Kt2 + BOUY * cth * cph + p[2] + p[10] * vw + p[14] * fabs(vw) * vw) / (M_ + p[6]);
-    f[9] = ((IY - IZ) * wq * wr - M_ * ZG * GR * cth * sph) / IX;
-    f[10] = ((IZ - IX) * wp * wr - M_ * ZG * GR * sth) / IY;
+    f[9] = ((IY - IZ) * wq * wr - M_ * ZG * GR * cth * sph + (drp ? drp[0] : 0.0)) / IX;
+    f[10] = ((IZ - IX) * wp * wr - M_ * ZG * GR * sth + (drp ? drp[1] : 0.0)) / IY;
     f[11] = (Kt5 - (IY - IX) * wp * wq + p[3] + p[11] * wr + p[15] * fabs(wr) * wr) / (IZ + p[7]);
 }
 
@@ -155,6 +159,10 @@ void orc_jac(const double* x, const double* u, const double* p, double* A, doubl
  * variational equation = bluerov2_expl_vde_forw (Sx' = A Sx, Su' = A Su + B), seeds Sx = I, Su = 0.
  * ------------------------------------------------------------------------------------------------------- */
 void orc_rk4_sens(const double* x, const double* u, const double* p, double h, double* xn, double* Aout, double* Bout) {
+    orc_rk4_sens6(x, u, p, NULL, h, xn, Aout, Bout);
+}
+void orc_rk4_sens6(const double* x, const double* u, const double* p, const double* drp, double h, double* xn, double* Aout,
+                   double* Bout) {
     static const double ca[4] = {0.0, 0.5, 0.5, 1.0}, cb[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
     double S0[NX * NXU], Sacc[NX * NXU], Ks[NX * NXU], Ss[NX * NXU];
     double xs[NX], k[NX], xacc[NX], Ac[NX * NX], Bc[NX * NU];
@@ -167,7 +175,7 @@ void orc_rk4_sens(const double* x, const double* u, const double* p, double h, d
     for (int s = 0; s < 4; s++) {
         for (int i = 0; i < NX; i++) xs[i] = x[i] + h * ca[s] * k[i];
         for (int i = 0; i < NX * NXU; i++) Ss[i] = S0[i] + h * ca[s] * Ks[i];
-        orc_f(xs, u, p, k);
+        orc_f6(xs, u, p, drp, k);
         orc_jac(xs, u, p, Ac, Bc);
         for (int r = 0; r < NX; r++)
             for (int c = 0; c < NXU; c++) {
@@ -185,15 +193,16 @@ void orc_rk4_sens(const double* x, const double* u, const double* p, double h, d
     }
 }
 
-void orc_rk4(const double* x, const double* u, const double* p, double h, double* xn) {
+void orc_rk4(const double* x, const double* u, const double* p, double h, double* xn) { orc_rk4_6(x, u, p, NULL, h, xn); }
+void orc_rk4_6(const double* x, const double* u, const double* p, const double* drp, double h, double* xn) {
     double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
-    orc_f(x, u, p, k1);
+    orc_f6(x, u, p, drp, k1);
     for (int i = 0; i < NX; i++) xs[i] = x[i] + 0.5 * h * k1[i];
-    orc_f(xs, u, p, k2);
+    orc_f6(xs, u, p, drp, k2);
     for (int i = 0; i < NX; i++) xs[i] = x[i] + 0.5 * h * k2[i];
-    orc_f(xs, u, p, k3);
+    orc_f6(xs, u, p, drp, k3);
     for (int i = 0; i < NX; i++) xs[i] = x[i] + h * k3[i];
-    orc_f(xs, u, p, k4);
+    orc_f6(xs, u, p, drp, k4);
     for (int i = 0; i < NX; i++) xn[i] = x[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
 }
 
@@ -424,33 +433,88 @@ static double rollout_adjoint(int N, const double* A, const double* B, const dou
 #define IPM_FTB 0.9999   /* fraction to the boundary of a (nearly) full step */
 #define IPM_FTBLO 0.9    /* ... of a blocked step: alpha = a ((1 - a) FTBLO + a FTB), a = min(1, step to the boundary) */
 #define IPM_MU0F 0.1     /* initial complementarity target = IPM_MU0F * stationarity residual of the clamped point */
-#define IPM_STALL_MU 1e-10   /* floor detection: mu below this fraction of the gradient scale ... */
-#define IPM_STALL_RATIO 0.3  /* ... and not cut to less than this fraction of its previous value */
-/* Safeguards found with the randomised-options test (tests/test_gpu_parity.py::test_randomised_options_against_oracle: tight
- * asymmetric boxes, 30 % far-off states, scattered model parameters).  Without them 122 of 31 000 such QPs ran into the
- * iteration limit with a meaningless point (status 2) although the entering iterate was fine (KKT < 1e5):
+/* Safeguards found with the randomised-options test (tests/test_gpu_parity.py::test_randomised_options_against_oracle):
  *  - a blocked step that goes 99.99 % of the way to the boundary leaves complementarity products 1e-5 of the average behind;
- *    the next predictor is then blocked at once and plain Mehrotra falls into a limit cycle (mu 1.1 -> 4.1 -> 2.5 -> 5.3 -> 1.1
- *    observed).  A short step now stops 10 % short of the boundary, a (nearly) full one still takes 99.99 % (the same idea as
- *    HPIPM's step-length dependent fraction to the boundary).  No effect on the iteration counts of the standard workloads;
- *  - an absolute complementarity target mu <= 1e-12 is below what FP64 can resolve when the multipliers are 1e4..1e6: the loop
- *    jittered at mu ~ 1e-11 until the iteration limit.  A target relative to the gradient scale fixed that but stopped too early
- *    for weakly active bounds (200 random QPs against independent BVLS answers: worst |du| 2e-4) and, applied to the stationarity
- *    residual as well, far too early on ill-conditioned QPs.  The rule below (every bound resolved to qp_tol_mu, absolute
- *    stationarity target, stall of mu at the FP64 floor as escape) is within 2e-7 of the BVLS answers on the same 200 QPs and
- *    within 8e-7 on 80 harder ones (N = 57 / 80, horizon 0.2..0.5 s, up to 230 active bounds; the relative rule: 7e-4), with as
- *    many or fewer iterations on the standard workloads (1 instead of 2 where no bound is active), none at the limit in the
- *    fuzz seeds. */
+ *    the next predictor is then blocked at once and plain Mehrotra falls into a limit cycle.  A short step now stops 10 % short
+ *    of the boundary, a (nearly) full one still takes 99.99 % (the same idea as HPIPM's step-length dependent fraction);
+ *  - the interior-point loop ends when every bound is resolved to qp_tol_mu (the input within that distance of it, or its
+ *    multiplier too small to move the input that far) and the tracked stationarity residual is below qp_tol_stat.
+ *
+ * ACTIVE-SET POLISH (round 3).  An interior-point method approaches a degenerate bound (active, vanishing multiplier) like
+ * sqrt(mu), and mu has a floor in FP64: round 2 stopped such QPs through a "stall" escape 1e-6 .. 3e-5 away from the minimiser
+ * and called that success.  The QP is strictly convex with box constraints only, so its minimiser is characterised exactly by
+ * its active set: pin the inputs of a guessed active set at their bounds, solve the remaining EQUALITY-constrained QP with one
+ * Riccati factorisation (pinning = a 1e30 entry on the input's Hessian diagonal: the same code path as an interior-point Newton
+ * system), and check the two conditions that make the result THE minimiser: free inputs inside the box, multipliers of pinned
+ * inputs of the right sign.  A wrong guess is repaired the primal-dual active-set way (violating free inputs are pinned, pinned
+ * inputs with a wrong-signed multiplier are released).  Schedule:
+ *   - a first round of at most POL_FIRST tries straight from the equality-constrained minimiser (guess: the inputs that violate
+ *     their bounds) -- on the standard workloads this finishes 90 % of the QPs with ONE factorisation and the rest with two or
+ *     three.  A round ends early when a try had to repair more than POL_NCHG inputs or more than the try before it (measured on
+ *     8000 QPs: converging guesses repair 1..9 inputs, fewer each time; hopeless ones 40..120 every time);
+ *   - then interior-point iterations from the last active-set point, followed by a round of at most POL_LOOP tries from the
+ *     iterate's classification (lambda / R > t <=> active) -- after a failed round only once mu has been halved again.  The
+ *     interior-point loop remains the globally convergent fallback, and may still end by its own rule; the stall escape is gone
+ *     (a QP that exhausts qp_iter_max Newton systems returns status 2).
+ * Against independent BVLS answers (scripts/dev/polish_eval.py): 4e-12 on 48 random QPs, 2e-11 on the hard ones (N = 57 / 80,
+ * hundreds of active bounds); the interior-point rule alone: 9e-8 and 1.1e-6.  stats[0] counts Newton systems (interior-point
+ * iterations + active-set tries). */
+#define POL_BIG 1e30      /* Hessian entry that pins an input */
+#define POL_FIRST 5       /* active-set tries before the first interior-point iteration (at most) */
+#define POL_LOOP 3        /* ... per round after an interior-point iteration (at most) */
+#define POL_NCHG 8        /* a round ends when a try repairs more than this many inputs, or more than the try before it */
+#define POL_MU_GATE 0.5   /* after a failed round the next one waits until the interior-point loop has cut mu by this factor */
+#define POL_TOL_FEAS 1e-9 /* a free input may leave the box by this much (it is clamped) */
+#define POL_TOL_G 1e-9    /* wrong-signed multiplier of a pinned input: tolerated up to POL_TOL_G * R (+ POL_TOL_GREL * |g|max) */
+#define POL_TOL_GREL 1e-13
 
-int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const double* b, const double* Qd, const double* q,
-                 const double* Rd, const double* r, const double* d0, const double* lb, const double* ub, double* dx,
-                 double* du, double* pi, double* lam, double* stats) {
+size_t orc_ws_doubles(int N) {
+    const size_t nv = (size_t)N * NU;
+    return /* qp */ (size_t)(N + 1) * 144 + (size_t)N * 48 + (size_t)N * 16 + (size_t)(N + 1) * NX + (size_t)N * NU +
+           (size_t)(N + 1) * NX + (size_t)N * NU + (size_t)N * NX + 13 * nv + (size_t)N * 8 +
+           /* rti */ (size_t)N * 144 + (size_t)N * 48 + (size_t)N * NX + 2 * (size_t)(N + 1) * NX + 4 * (size_t)N * NU +
+           (size_t)(N + 1) * NX + (size_t)N * NU + (size_t)N * NX + (size_t)N * 8 + 64;
+}
+
+/* one equality-constrained solve with the inputs act[j] != 0 pinned at their bounds (-1 lower, +1 upper).  Returns 1 when the
+ * result is the QP's minimiser (-> vp, with xs / pis / g of that point), 0 when the guess was wrong (act_new = repaired guess,
+ * vp = the point clamped into the box), -4 / -1 on a factorisation failure / NaN. */
+static int polish_try(qp_ws* w, const double* A, const double* B, const double* b, const double* Qd, const double* q,
+                      const double* Rd, const double* r, const double* d0, const double* lb, const double* ub, const double* act,
+                      double* gam, double* rt, double* vp, double* xs, double* pis, double* g, double* act_new, const double* lamz) {
+    const int N = w->N, nv = N * NU;
+    for (int j = 0; j < nv; j++) {
+        gam[j] = act[j] != 0.0 ? POL_BIG : 0.0;
+        rt[j] = r[j] - gam[j] * (act[j] < 0.0 ? lb[j] : ub[j]);
+    }
+    if (ric_factor(w, A, B, Qd, Rd, gam)) return -4;
+    ric_solve(w, A, B, b, q, rt, d0);
+    int ok = 1;
+    for (int j = 0; j < nv; j++) {
+        act_new[j] = act[j];
+        double vj = w->vs[j];
+        if (!(vj == vj)) return -1;
+        if (act[j] != 0.0) { vp[j] = act[j] < 0.0 ? lb[j] : ub[j]; continue; }
+        if (vj < lb[j]) { if (lb[j] - vj > POL_TOL_FEAS) { ok = 0; act_new[j] = -1.0; } vj = lb[j]; }
+        if (vj > ub[j]) { if (vj - ub[j] > POL_TOL_FEAS) { ok = 0; act_new[j] = 1.0; } vj = ub[j]; }
+        vp[j] = vj;
+    }
+    (void)rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, vp, lamz, xs, pis, g);
+    double gmax = 0.0;
+    for (int j = 0; j < nv; j++) if (fabs(g[j]) > gmax) gmax = fabs(g[j]);
+    for (int j = 0; j < nv; j++) {
+        const double tolg = POL_TOL_G * Rd[j] + POL_TOL_GREL * gmax;
+        if ((act[j] < 0.0 && g[j] < -tolg) || (act[j] > 0.0 && g[j] > tolg)) { ok = 0; act_new[j] = 0.0; }
+    }
+    return ok;
+}
+
+int orc_qp_solve_ws(const orc_opts* o, const double* A, const double* B, const double* b, const double* Qd, const double* q,
+                    const double* Rd, const double* r, const double* d0, const double* lb, const double* ub, double* dx,
+                    double* du, double* pi, double* lam, double* stats, double* mem) {
     const int N = o->N, nv = N * NU;
     qp_ws w;
     w.N = N;
-    size_t tot = (size_t)(N + 1) * 144 + (size_t)N * 48 + (size_t)N * 16 + (size_t)(N + 1) * NX + (size_t)N * NU +
-                 (size_t)(N + 1) * NX + (size_t)N * NU + (size_t)N * NX + 8 * (size_t)nv;
-    double* mem = (double*)malloc(tot * sizeof(double));
     double* m = mem;
     w.P = m; m += (size_t)(N + 1) * 144;
     w.K = m; m += (size_t)N * 48;
@@ -468,8 +532,14 @@ int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const doub
     double* ll = m; m += nv;
     double* lu = m; m += nv;
     double* dva = m; m += nv;
-    int status = 0, iters = 0, early = 0;
-    double mu = 0.0, rho = 0.0, gscale = 1.0, mu_prev = 1e300;
+    double* vp = m; m += nv;
+    double* gp = m; m += nv;
+    double* act = m; m += nv;
+    double* act_new = m; m += nv;
+    double* lamz = m; m += (size_t)N * 8;
+    int status = 0, nsys = 0, early = 0, ipm_on = 0, converged = 0, round_k = 0, round_cap = 0, nchg_prev = nv + 1;
+    double mu = 0.0, rho = 0.0, mu_gate = 1e300;
+    memset(lamz, 0, (size_t)N * 8 * sizeof(double));
 
     /* step 0: equality-constrained minimiser (Gamma = 0) */
     memset(gam, 0, nv * sizeof(double));
@@ -477,8 +547,11 @@ int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const doub
     ric_solve(&w, A, B, b, q, r, d0);
     {
         int feas = 1;
-        for (int j = 0; j < nv; j++)
+        for (int j = 0; j < nv; j++) {
             if (!(w.vs[j] >= lb[j] && w.vs[j] <= ub[j])) feas = 0;
+            act[j] = w.vs[j] < lb[j] ? -1.0 : (w.vs[j] > ub[j] ? 1.0 : 0.0);   /* first active-set guess */
+            vp[j] = w.vs[j];
+        }
         if (feas && o->qp_early_exit) {
             memcpy(du, w.vs, nv * sizeof(double));
             memcpy(dx, w.xs, (size_t)(N + 1) * NX * sizeof(double));
@@ -488,34 +561,49 @@ int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const doub
             goto done;
         }
     }
-    /* interior start: clamp into the box, multipliers from mu0 */
-    {
-        double viol = 0.0;
-        for (int j = 0; j < nv; j++) {
-            const double wdt = ub[j] - lb[j];
-            double vj = w.vs[j];
-            const double lo = lb[j] + IPM_TAU0 * wdt, hi = ub[j] - IPM_TAU0 * wdt;
-            if (vj < lo) { if (lo - vj > viol) viol = lo - vj; vj = lo; }
-            if (vj > hi) { if (vj - hi > viol) viol = vj - hi; vj = hi; }
-            v[j] = vj;
-            tl[j] = vj - lb[j];
-            tu[j] = ub[j] - vj;
-        }
-        /* multiplier scale: stationarity residual of the clamped point without multipliers */
-        double* lam0 = dva;
-        (void)lam0;
-        memset(lam, 0, (size_t)N * 8 * sizeof(double));
-        double g0 = rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lam, w.xs, w.pis, NULL);
-        double mu0 = IPM_MU0F * g0;
-        if (mu0 < 1e-4) mu0 = 1e-4;
-        gscale = g0 > 1.0 ? g0 : 1.0;
-        for (int j = 0; j < nv; j++) { ll[j] = mu0 / tl[j]; lu[j] = mu0 / tu[j]; }
-        for (int i = 0; i < N; i++)
-            for (int c = 0; c < NU; c++) { lam[i * 8 + c] = ll[i * NU + c]; lam[i * 8 + 4 + c] = lu[i * NU + c]; }
-        rho = rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lam, w.xs, w.pis, NULL);
-    }
     status = 2;
-    for (iters = 1; iters <= o->qp_iter_max; iters++) {
+    round_cap = POL_FIRST;
+    while (nsys < o->qp_iter_max) {
+        if (round_k < round_cap) {   /* ---- active-set try */
+            nsys++;
+            round_k++;
+            const int pr = polish_try(&w, A, B, b, Qd, q, Rd, r, d0, lb, ub, act, gam, rt, vp, w.xs, w.pis, gp, act_new, lamz);
+            if (pr < 0) { status = -pr; break; }
+            if (pr) { memcpy(v, vp, nv * sizeof(double)); status = 0; break; }
+            /* repaired guess; the round goes on while the repairs are few and do not grow (a guess that is converging) */
+            int nchg = 0;
+            for (int j = 0; j < nv; j++) { nchg += act[j] != act_new[j]; act[j] = act_new[j]; }
+            if (nchg > POL_NCHG || nchg > nchg_prev) round_cap = 0;
+            nchg_prev = nchg;
+            if (round_k >= round_cap) {   /* the round has failed: the next one waits for the interior-point loop to halve mu */
+                mu_gate = mu;
+                if (converged) break;
+            }
+            continue;
+        }
+        if (!ipm_on) {   /* ---- interior start at the last active-set point: clamp into the box, multipliers from mu0 */
+            ipm_on = 1;
+            for (int j = 0; j < nv; j++) {
+                const double wdt = ub[j] - lb[j];
+                double vj = vp[j];
+                const double lo = lb[j] + IPM_TAU0 * wdt, hi = ub[j] - IPM_TAU0 * wdt;
+                if (vj < lo) vj = lo;
+                if (vj > hi) vj = hi;
+                v[j] = vj;
+                tl[j] = vj - lb[j];
+                tu[j] = ub[j] - vj;
+            }
+            /* multiplier scale: stationarity residual of the clamped point without multipliers */
+            double g0 = rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lamz, w.xs, w.pis, NULL);
+            double mu0 = IPM_MU0F * g0;
+            if (mu0 < 1e-4) mu0 = 1e-4;
+            for (int j = 0; j < nv; j++) { ll[j] = mu0 / tl[j]; lu[j] = mu0 / tu[j]; }
+            for (int i = 0; i < N; i++)
+                for (int c = 0; c < NU; c++) { lam[i * 8 + c] = ll[i * NU + c]; lam[i * 8 + 4 + c] = lu[i * NU + c]; }
+            rho = rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lam, w.xs, w.pis, NULL);
+        }
+        /* ---- interior-point iteration (Mehrotra predictor-corrector) */
+        nsys++;
         mu = 0.0;
         for (int j = 0; j < nv; j++) mu += ll[j] * tl[j] + lu[j] * tu[j];
         mu /= (2.0 * nv);
@@ -583,29 +671,31 @@ int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const doub
         mu = 0.0;
         for (int j = 0; j < nv; j++) mu += ll[j] * tl[j] + lu[j] * tu[j];
         mu /= (2.0 * nv);
-        /* termination: every bound is resolved -- either the input is within qp_tol_mu of it, or its multiplier is too small to move
-         * the input by qp_tol_mu (lambda / R, R = the input's own weight, a lower bound of the curvature) -- and the tracked
-         * stationarity residual is below qp_tol_stat.  This bounds the distance to the minimiser directly (what a complementarity
-         * target mu <= eps cannot: a weakly active bound, lambda* ~ 1e-3, is approached to t = mu / lambda*).  Escape: the loop
-         * has reached what FP64 resolves for this QP -- mu is tiny against the gradient scale and has stopped falling (a healthy
-         * iteration cuts it tenfold or more; at the floor it jitters). */
+        /* the loop's own termination: every bound is resolved -- either the input is within qp_tol_mu of it, or its multiplier is
+         * too small to move the input by qp_tol_mu (lambda / R, R = the input's own weight, a lower bound of the curvature) -- and
+         * the tracked stationarity residual is below qp_tol_stat.  The same two quantities classify the bounds for the next
+         * active-set tries: active <=> the multiplier could move the input further than it is away from the bound. */
         double unres = 0.0;
         for (int j = 0; j < nv; j++) {
-            const double a = ll[j] / Rd[j] < tl[j] ? ll[j] / Rd[j] : tl[j], c = lu[j] / Rd[j] < tu[j] ? lu[j] / Rd[j] : tu[j];
-            if (a > unres) unres = a;
-            if (c > unres) unres = c;
+            const double al = ll[j] / Rd[j], au = lu[j] / Rd[j];
+            const double a_ = al < tl[j] ? al : tl[j], c_ = au < tu[j] ? au : tu[j];
+            if (a_ > unres) unres = a_;
+            if (c_ > unres) unres = c_;
+            act[j] = al > tl[j] ? -1.0 : (au > tu[j] ? 1.0 : 0.0);
+            vp[j] = v[j];
         }
-        const int stalled = mu <= IPM_STALL_MU * gscale && mu > IPM_STALL_RATIO * mu_prev;
-        mu_prev = mu;
-        if ((unres <= o->qp_tol_mu || stalled) && rho <= o->qp_tol_stat) { status = 0; break; }
+        /* the loop's own rule is met: one more round for the exact answer; if that fails too the iterate is the answer (to qp_tol_mu) */
+        if (unres <= o->qp_tol_mu && rho <= o->qp_tol_stat) converged = 1;
+        if (converged || mu <= POL_MU_GATE * mu_gate) { round_k = 0; round_cap = POL_LOOP; nchg_prev = nv + 1; }
     }
-    if (iters > o->qp_iter_max) iters = o->qp_iter_max;
     /* consistent primal/dual output for the final inputs.  The IPM multipliers carry an absolute error ~ eps*Gamma*|v|
      * on active bounds (Gamma = lam/t -> 1e12+), so the multipliers are recovered from the gradient instead:
      * g = Rd v + r + B'pi, lam_l = max(g,0), lam_u = max(-g,0)  (stationarity then holds exactly; what is left of the
      * KKT error shows up as complementarity, reported in stats[2]) */
-    memset(lam, 0, (size_t)N * 8 * sizeof(double));
-    (void)rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lam, dx, pi, gam);
+    if (status == 4 || status == 1) goto done;
+    if (converged && status == 2) status = 0;
+    if (status == 2 && !ipm_on) memcpy(v, vp, nv * sizeof(double));   /* limit reached before the first interior-point iteration */
+    (void)rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lamz, dx, pi, gam);
     rho = 0.0;
     for (int i = 0; i < N; i++)
         for (int c = 0; c < NU; c++) {
@@ -619,21 +709,27 @@ int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const doub
         }
     memcpy(du, v, nv * sizeof(double));
 done:
-    if (stats) { stats[0] = iters; stats[1] = mu; stats[2] = rho; stats[3] = early; }
-    free(mem);
+    if (stats) { stats[0] = nsys; stats[1] = mu; stats[2] = rho; stats[3] = early; }
     return status;
+}
+
+int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const double* b, const double* Qd, const double* q,
+                 const double* Rd, const double* r, const double* d0, const double* lb, const double* ub, double* dx,
+                 double* du, double* pi, double* lam, double* stats) {
+    double* mem = (double*)malloc(orc_ws_doubles(o->N) * sizeof(double));
+    const int st = orc_qp_solve_ws(o, A, B, b, Qd, q, Rd, r, d0, lb, ub, dx, du, pi, lam, stats, mem);
+    free(mem);
+    return st;
 }
 
 /* ---------------------------------------------------------------------------------------------------------
  * SQP_RTI step: preparation (linearise) + feedback (QP, full step): acados_solver_bluerov2.c:623-672,945-951.
  * Cost scaling Ts on stages 0..N-1 (:393), terminal unscaled.  Iterate is not shifted between calls.
  * ------------------------------------------------------------------------------------------------------- */
-int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const double* p, double* x, double* u, double* pi,
-                 double* lam, orc_result* res, double* Aout, double* Bout, double* bout, double* qp_stats) {
+int orc_rti_step_ws(const orc_opts* o, const double* x0, const double* yref, const double* p, const double* drp, double* x,
+                    double* u, double* pi, double* lam, orc_result* res, double* Aout, double* Bout, double* bout,
+                    double* qp_stats, double* mem) {
     const int N = o->N;
-    size_t tot = (size_t)N * 144 + (size_t)N * 48 + (size_t)N * NX + 2 * (size_t)(N + 1) * NX + 2 * (size_t)N * NU +
-                 2 * (size_t)N * NU + (size_t)(N + 1) * NX + (size_t)N * NU + (size_t)N * NX + (size_t)N * 8;
-    double* mem = (double*)malloc(tot * sizeof(double));
     double* m = mem;
     double* A = m; m += (size_t)N * 144;
     double* B = m; m += (size_t)N * 48;
@@ -648,12 +744,14 @@ int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const 
     double* du = m; m += (size_t)N * NU;
     double* pin = m; m += (size_t)N * NX;
     double* lamn = m; m += (size_t)N * 8;
+    m += (8 - ((m - mem) & 7)) & 7;   /* the QP's share of the workspace, 64-byte aligned */
     double d0[NX];
 
     /* preparation: ERK4 + sensitivities on every interval */
     for (int i = 0; i < N; i++) {
         double xn[NX];
-        orc_rk4_sens(x + (size_t)i * NX, u + (size_t)i * NU, p + (size_t)i * NP, o->Ts, xn, A + (size_t)i * 144, B + (size_t)i * 48);
+        orc_rk4_sens6(x + (size_t)i * NX, u + (size_t)i * NU, p + (size_t)i * NP, drp ? drp + (size_t)i * 2 : NULL, o->Ts, xn,
+                      A + (size_t)i * 144, B + (size_t)i * 48);
         for (int j = 0; j < NX; j++) b[i * NX + j] = xn[j] - x[(i + 1) * NX + j];
     }
     /* Gauss-Newton LS cost: y = [x;u], J = I, Hess = s W, grad = s W (y - yref) */
@@ -701,7 +799,7 @@ int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const 
 #undef UPD
 
     double st[4] = {0, 0, 0, 0};
-    int status = orc_qp_solve(o, A, B, b, Qd, q, Rd, r, d0, lb, ub, dx, du, pin, lamn, st);
+    int status = orc_qp_solve_ws(o, A, B, b, Qd, q, Rd, r, d0, lb, ub, dx, du, pin, lamn, st, m);
     if (status == 0 || status == 2) {
         int nan = 0;
         for (int j = 0; j < (N + 1) * NX; j++) if (dx[j] != dx[j]) nan = 1;
@@ -750,8 +848,24 @@ int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const 
     if (Bout) memcpy(Bout, B, (size_t)N * 48 * sizeof(double));
     if (bout) memcpy(bout, b, (size_t)N * NX * sizeof(double));
     if (qp_stats) memcpy(qp_stats, st, sizeof st);
-    free(mem);
     return status;
+}
+
+int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const double* p, double* x, double* u, double* pi,
+                 double* lam, orc_result* res, double* Aout, double* Bout, double* bout, double* qp_stats) {
+    double* mem = (double*)malloc(orc_ws_doubles(o->N) * sizeof(double));
+    const int st = orc_rti_step_ws(o, x0, yref, p, NULL, x, u, pi, lam, res, Aout, Bout, bout, qp_stats, mem);
+    free(mem);
+    return st;
+}
+
+/* the 6-disturbance model variant: drp[(N+1)*2] = per-stage roll / pitch disturbance moments */
+int orc_rti_step6(const orc_opts* o, const double* x0, const double* yref, const double* p, const double* drp, double* x,
+                  double* u, double* pi, double* lam, orc_result* res, double* qp_stats) {
+    double* mem = (double*)malloc(orc_ws_doubles(o->N) * sizeof(double));
+    const int st = orc_rti_step_ws(o, x0, yref, p, drp, x, u, pi, lam, res, NULL, NULL, NULL, qp_stats, mem);
+    free(mem);
+    return st;
 }
 
 int orc_num_threads(void) {
@@ -762,23 +876,45 @@ int orc_num_threads(void) {
 #endif
 }
 
-int orc_rti_step_batch(const orc_opts* o, int nb, const double* x0, const double* yref, const double* p, double* x, double* u,
-                       double* pi, double* lam, orc_result* res, int nthreads) {
+/* OpenMP over instances.  One preallocated workspace per thread (round 2 did two malloc / free of > 128 KB per instance and step:
+ * mmap / munmap and page faults under the process' mmap lock -- 4 % parallel efficiency on 128 threads), static schedule. */
+int orc_rti_step_batch6(const orc_opts* o, int nb, const double* x0, const double* yref, const double* p, const double* drp,
+                        double* x, double* u, double* pi, double* lam, orc_result* res, int nthreads) {
     const int N = o->N;
     int worst = 0;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads) reduction(max : worst)
+    if (nthreads > nb) nthreads = nb > 0 ? nb : 1;
+#pragma omp parallel num_threads(nthreads) reduction(max : worst)
 #else
     (void)nthreads;
 #endif
-    for (int k = 0; k < nb; k++) {
-        int st = orc_rti_step(o, x0 + (size_t)k * NX, yref + (size_t)k * (N + 1) * NY, p + (size_t)k * (N + 1) * NP,
-                              x + (size_t)k * (N + 1) * NX, u + (size_t)k * N * NU, pi + (size_t)k * N * NX,
-                              lam + (size_t)k * N * 8, res + k, NULL, NULL, NULL, NULL);
-        if (st > worst) worst = st;
+    {
+        static __thread double* tls_mem = NULL;
+        static __thread size_t tls_n = 0;
+        const size_t need = orc_ws_doubles(N);
+        if (tls_n < need) {
+            free(tls_mem);
+            tls_mem = (double*)malloc(need * sizeof(double));
+            tls_n = need;
+        }
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int k = 0; k < nb; k++) {
+            int st = orc_rti_step_ws(o, x0 + (size_t)k * NX, yref + (size_t)k * (N + 1) * NY, p + (size_t)k * (N + 1) * NP,
+                                     drp ? drp + (size_t)k * (N + 1) * 2 : NULL, x + (size_t)k * (N + 1) * NX,
+                                     u + (size_t)k * N * NU, pi + (size_t)k * N * NX, lam + (size_t)k * N * 8, res + k, NULL, NULL,
+                                     NULL, NULL, tls_mem);
+            if (st > worst) worst = st;
+        }
     }
     return worst;
+}
+
+int orc_rti_step_batch(const orc_opts* o, int nb, const double* x0, const double* yref, const double* p, double* x, double* u,
+                       double* pi, double* lam, orc_result* res, int nthreads) {
+    return orc_rti_step_batch6(o, nb, x0, yref, p, NULL, x, u, pi, lam, res, nthreads);
 }
 
 void orc_init_iterate(const orc_opts* o, double* x, double* u, double* pi, double* lam) {

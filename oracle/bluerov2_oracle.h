@@ -25,6 +25,8 @@
 #ifndef BLUEROV2_ORACLE_H_
 #define BLUEROV2_ORACLE_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -62,6 +64,12 @@ void orc_jac(const double* x, const double* u, const double* p, double* A, doubl
 void orc_rk4_sens(const double* x, const double* u, const double* p, double h, double* xn, double* A, double* B);
 /* RK4 step without sensitivities (plant simulation) */
 void orc_rk4(const double* x, const double* u, const double* p, double h, double* xn);
+/* the 6-disturbance model variant (bluerov2.py:37-38 carries the two symbols commented out, the EKF estimates all
+ * six, bluerov2_dob.h:200-205): drp = {d_phi, d_theta} roll / pitch disturbance moments, entering dp += d_phi / Ix, dq += d_theta / Iy
+ * the way the other four enter their rows (bluerov2.py:123-128).  drp == NULL is the shipped np = 16 model. */
+void orc_f6(const double* x, const double* u, const double* p, const double* drp, double* xdot);
+void orc_rk4_sens6(const double* x, const double* u, const double* p, const double* drp, double h, double* xn, double* A, double* B);
+void orc_rk4_6(const double* x, const double* u, const double* p, const double* drp, double h, double* xn);
 
 /* QP ------------------------------------------------------------------------------------------------- */
 /* box-constrained OCP QP (diagonal cost) in delta variables:
@@ -69,11 +77,17 @@ void orc_rk4(const double* x, const double* u, const double* p, double h, double
  *   s.t. dx_{i+1} = A_i dx_i + B_i du_i + b_i, dx_0 = d0, lb_i <= du_i <= ub_i
  * Solved by a primal-dual interior point method whose Newton systems are solved by a Riccati sweep.
  * Outputs dx[(N+1)*12], du[N*4], pi[N*12] (multiplier of the i-th dynamics equation), lam[N*8] ([lower4, upper4]).
- * stats[0]=ipm iterations, [1]=final mu, [2]=QP complementarity residual (after multiplier recovery), [3]=1 if early exit.
+ * stats[0]=Newton systems solved (interior-point iterations + active-set tries), [1]=final mu, [2]=QP complementarity residual (after multiplier recovery), [3]=1 if early exit.
  * returns 0 ok, 2 max iter, 1 NaN, 4 factorisation failure  (acados status codes) */
 int orc_qp_solve(const orc_opts* o, const double* A, const double* B, const double* b, const double* Qd,
                  const double* q, const double* Rd, const double* r, const double* d0, const double* lb,
                  const double* ub, double* dx, double* du, double* pi, double* lam, double* stats);
+
+/* doubles of scratch orc_qp_solve_ws / orc_rti_step_ws need for horizon N */
+size_t orc_ws_doubles(int N);
+int orc_qp_solve_ws(const orc_opts* o, const double* A, const double* B, const double* b, const double* Qd,
+                    const double* q, const double* Rd, const double* r, const double* d0, const double* lb,
+                    const double* ub, double* dx, double* du, double* pi, double* lam, double* stats, double* mem);
 
 /* RTI ------------------------------------------------------------------------------------------------ */
 /* per-instance result record, 104 bytes on the wire */
@@ -93,6 +107,15 @@ typedef struct orc_result {
 int orc_rti_step(const orc_opts* o, const double* x0, const double* yref, const double* p, double* x, double* u,
                  double* pi, double* lam, orc_result* res, double* Aout, double* Bout, double* bout,
                  double* qp_stats);
+
+/* the same with a caller-provided workspace (orc_ws_doubles(N) doubles) and the optional roll / pitch disturbances drp[(N+1)*2] */
+int orc_rti_step_ws(const orc_opts* o, const double* x0, const double* yref, const double* p, const double* drp, double* x,
+                    double* u, double* pi, double* lam, orc_result* res, double* Aout, double* Bout, double* bout,
+                    double* qp_stats, double* mem);
+int orc_rti_step6(const orc_opts* o, const double* x0, const double* yref, const double* p, const double* drp, double* x,
+                  double* u, double* pi, double* lam, orc_result* res, double* qp_stats);
+int orc_rti_step_batch6(const orc_opts* o, int nb, const double* x0, const double* yref, const double* p, const double* drp,
+                        double* x, double* u, double* pi, double* lam, orc_result* res, int nthreads);
 
 /* nb independent instances, instance-major contiguous arrays; nthreads<=0 -> all cores (OpenMP) */
 int orc_rti_step_batch(const orc_opts* o, int nb, const double* x0, const double* yref, const double* p,

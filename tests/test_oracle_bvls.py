@@ -3,7 +3,8 @@ compiled from the reference's generated C) -> textbook RK4 + numpy condensing ->
 The committed golden scenarios pin a dozen fixed cases; this test draws options the way the GPU fuzz test does (horizon, step,
 weights, asymmetric / offset boxes, scattered per-stage parameters, far-off states) and holds the interior-point termination rule
  to the accuracy it was chosen for: an earlier, relative complementarity target passed every fixed case and
-was 2e-4 .. 7e-4 off on problems like these."""
+was 2e-4 .. 7e-4 off on problems like these.  Round 3: the QP ends with an exact active-set solve, and the bar is 1e-9 on every
+input of every stage (no allowance for degenerate bounds any more)."""
 import os
 import sys
 
@@ -61,7 +62,9 @@ def test_random_qps_against_independent_answers(oracle, recipe, golden_traj, har
             r = oracle.rti_step(op, x0, yref, p, xo, uo, pi, lam)
             assert r["status"] == 0 and info["qp_kkt"] < 1e-9, (t, k, r, info)
             e = np.abs(uo - u).max()
-            assert e < 2e-6, (t, k, N, Ts, e, info)
+            # round 3: the active-set polish ends on the minimiser itself -- every instance, every stage (measured: 4e-12 on the
+            # standard draws, 2e-11 on the hard ones; the interior-point rule alone was 9e-8 / 1.1e-6 and needed a 2e-6 bar)
+            assert e < 1e-9, (t, k, N, Ts, e, info)
             worst, n_active = max(worst, e), n_active + info["nact"]
             xo, uo = x.copy(), u.copy()    # both continue from the independent iterate
     assert n_active > (400 if hard else 300)   # the draws do contain active bounds (interior-point solves)
