@@ -93,8 +93,14 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 #define IPM_FTB 0.9999  /* fraction to the boundary of a (nearly) full step */
 #define IPM_FTBLO 0.9   /* ... of a blocked step: alpha = a ((1 - a) FTBLO + a FTB), a = min(1, step to the boundary); see the oracle */
 #define IPM_MU0F 0.1    /* mu0 = IPM_MU0F * stationarity residual of the clamped point */
-#define IPM_STALL_MU 1e-10   /* floor detection: mu below this fraction of the gradient scale ... */
-#define IPM_STALL_RATIO 0.3  /* ... and not cut to less than this fraction of its previous value (see the oracle) */
+// active-set tries around the interior-point loop: constants and schedule of the oracle (bluerov2_oracle.c "ACTIVE-SET POLISH")
+#define POL_BIG 1e30      /* Hessian entry that pins an input */
+#define POL_FIRST 5       /* tries before the first interior-point iteration (at most) */
+#define POL_LOOP 3        /* ... per round after an interior-point iteration (at most) */
+#define POL_NCHG 8        /* a round ends when a try repairs more than this many inputs, or more than the try before it */
+#define POL_MU_GATE 0.5   /* after a failed round the next one waits until the interior-point loop has cut mu by this factor */
+#define POL_TOL_G 1e-9    /* wrong-signed multiplier of a pinned input: tolerated up to POL_TOL_G * R + POL_TOL_GREL * |g|max */
+#define POL_TOL_GREL 1e-13
 
 // everything one wave needs to know about its instance
 struct Inst {
@@ -969,6 +975,12 @@ __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, 
     W.valid |= mask;
 }
 
+// windowed kernel: every sweep re-derives the lane index behind an opaque move, so that its per-lane addresses are computed where the
+// sweep starts and are not live across the other sweeps of the solve (the register file is full)
+__device__ __forceinline__ void opaque_lane(Inst& I) {
+    asm volatile("v_mov_b32 %0, %0" : "+v"(I.lane));
+    I.rg = I.lane >> 4; I.cl = I.lane & 15;
+}
 // NaN among the window's candidate inputs / state steps (checked where they are produced, on the LDS copy)
 __device__ __forceinline__ bool win_nan_check(const Inst& I, const Win& W, bool first) {
     const lds_f64* vh = (const lds_f64*)(W.lds + win_off_vh(W.Lc));
@@ -996,6 +1008,7 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
     if constexpr (LDS != 3) {
         riccati_forward<LDS>(I, d0);
     } else {
+        opaque_lane(I);
         wave_fence();
         d4 xx = d0;
         bool bad = false, infeas = false;
@@ -1042,6 +1055,7 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
     if constexpr (LDS != 3) {
         rollout<LDS>(I, d0, varr);
     } else {
+        opaque_lane(I);
         wave_fence();
         d4 xx = d0;
         bool bad = false;
@@ -1062,6 +1076,7 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
     if constexpr (LDS != 3) {
         adjoint<COMMIT, LDS>(I, varr, garr, pi_out);
     } else {
+        opaque_lane(I);
         wave_fence();
         d4 atpi = {0, 0, 0, 0};
         for (int c = W->nc - 1; c >= 0; c--) {
@@ -1151,6 +1166,7 @@ __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
     if constexpr (LDS != 3) {
         return riccati_backward<FACTOR, LDS>(I);
     } else {
+        opaque_lane(I);
         wave_fence();
         BwdState S;
         for (int c = W->nc - 1; c >= 0; c--) {
@@ -1182,16 +1198,19 @@ struct IpmVec {
     double* g;
     __device__ __forceinline__ double get(int t, int j) const { return MODE ? r[t % T] : g[j]; }
     __device__ __forceinline__ void set(int t, int j, double v) { if (MODE) r[t % T] = v; else g[j] = v; }
+    // element indices are UNSIGNED: base pointer (uniform, SGPR pair) + zero-extended 32-bit offset is one addressing mode of
+    // global_load / global_store, so the 8 offsets of a lane serve every vector; with a signed index the compiler forms one 64-bit
+    // address per element and vector (160 VGPRs in the windowed kernel) and keeps them all live across the interior-point loop
     __device__ __forceinline__ void fetch(int lane, int nv) {
         if constexpr (MODE == 2) {
 #pragma unroll
-            for (int t = 0; t < T; t++) { const int j = lane + 64 * t; r[t] = g[j < nv ? j : 0]; }
+            for (int t = 0; t < T; t++) { const unsigned j = (unsigned)lane + 64u * t; r[t] = g[j < (unsigned)nv ? j : 0u]; }
         }
     }
     __device__ __forceinline__ void flush(int lane, int nv) const {
         if constexpr (MODE == 2) {
 #pragma unroll
-            for (int t = 0; t < T; t++) { const int j = lane + 64 * t; if (j < nv) g[j] = r[t]; }
+            for (int t = 0; t < T; t++) { const unsigned j = (unsigned)lane + 64u * t; if (j < (unsigned)nv) g[j] = r[t]; }
         }
     }
 };
@@ -1247,6 +1266,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     double* GAM = I.ipm + (size_t)IPM_GAM * nv;
     double* RT = I.ipm + (size_t)IPM_RT * nv;
     double* DVA = I.ipm + (size_t)IPM_DVA * nv;
+    double* ACT = I.ipm + (size_t)IPM_ACT * nv;
     // where adjoint<> leaves the input gradient g: HBM array, or (fused path) the dead feed-forward array in LDS
     const double* GRAD = EL ? (const double*)I.kff : (const double*)DVA;
     // element accessors: LDS-typed on the fused path (a generic pointer into LDS compiles to flat loads / stores)
@@ -1274,7 +1294,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     }
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
-    bool early = false;
+    bool early = false, polished = false, use_vhat = false;
     bool ok = pre_ok;
     if constexpr (LDS != 3) ok = riccati_backward<true, LDS, false, true>(I);
     d4 d0;
@@ -1324,7 +1344,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         if (allfeas && P.early_exit) {
             early = true;  // the accepted inputs stay where the forward sweep left them (I.vhat)
         } else {
-            // interior start: clamp into the box, multipliers from mu0 = stationarity residual of the clamped point.
+            // Active-set tries and interior-point iterations (the oracle's schedule, bluerov2_oracle.c "ACTIVE-SET POLISH"): a round of
+            // equality-constrained solves with the guessed active inputs pinned at their bounds -- first from the inputs the
+            // Newton point violates, later from the interior-point iterate's classification --, each checked for the two
+            // conditions that make it THE minimiser (free inputs inside the box, multipliers of pinned inputs of the right sign)
+            // and repaired the primal-dual active-set way if not; interior-point iterations in between as the globally
+            // convergent fallback.  iters counts Newton systems (tries + iterations).
             // Fused path: the interior-point vectors (two elements per lane, nv <= 92) live in registers -- at one wave per
             // SIMD every element loop over HBM-resident vectors costs an exposed L2 round trip; only Gamma and the right-hand
             // side, which the backward sweep reads by stage, go through memory.
@@ -1335,91 +1360,205 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             constexpr int kIpmT = EL ? 2 : 8;    // elements per lane; streaming / windowed path: nv <= 512
             using Vec = IpmVec<EL ? 1 : (CACHE ? 2 : 0), kIpmT>;
             Vec vV{{}, V}, vTL{{}, TL}, vTU{{}, TU}, vLL{{}, LL}, vLU{{}, LU}, vDVA{{}, DVA},
-                vDLL{{}, GAM}, vDLU{{}, RT};   // dual steps: registers, or (streaming) parked in GAM / RT, both rebuilt every iteration
-#define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const int j = lane + 64 * t; j < nv)
+                vDLL{{}, GAM}, vDLU{{}, RT},   // dual steps: registers, or (streaming) parked in GAM / RT, both rebuilt every iteration
+                vACT{{}, ACT};                 // active-set guess: -1 / +1 pinned at the lower / upper bound, 0 free
+#define IPM_FOR(t, j) _Pragma("unroll") for (int t = 0; t < kIpmT; t++) if (const unsigned j = (unsigned)lane + 64u * t; j < (unsigned)nv)
             // MODE 2: the group's other operands (inputs, references, Newton point ...), requested with the fetches
 #define IPM_PRE(arr, expr)                                                                     \
             double arr[CACHE ? kIpmT : 1];                                                         \
             if constexpr (CACHE) {                                                                 \
                 _Pragma("unroll") for (int t = 0; t < kIpmT; t++) {                                \
-                    const int j = (lane + 64 * t < nv) ? lane + 64 * t : 0;                        \
+                    const unsigned j = ((unsigned)lane + 64u * t < (unsigned)nv) ? (unsigned)lane + 64u * t : 0u; \
                     arr[t] = (expr);                                                               \
                 }                                                                                  \
             }
+            // windowed kernel: the guess is stored element by element where it is produced (its register copy would be 16 more VGPRs
+            // across loops that have none to spare); the loads of a group are all ahead of its first store anyway
+            auto set_act = [&](int t, int j, double v) __attribute__((always_inline)) { if constexpr (CACHE) ACT[j] = v; else vACT.set(t, j, v); };
+            // Every element group works on its own opaque copy of the lane index.  Element addresses are then formed where they are
+            // used (base pointer in SGPRs + 32-bit offset: one addressing mode); computed from the kernel's lane index they are loop
+            // invariants, and the compiler hoists one 64-bit address per element and vector out of the loop -- 160 VGPRs live across
+            // every sweep of the windowed kernel, which then spills into scratch
+#define GROUP_LANE int lane_g_ = I.lane; asm volatile("v_mov_b32 %0, %0" : "+v"(lane_g_)); const int lane = lane_g_
             const int mI = lane & 3;   // input index of every element of this lane (j = lane + 64 t)
             // bounds and weight of that input: loaded once and made opaque, so that the compiler cannot sink the (re-)loads into
             // the guarded element blocks below, where every one of them would be waited for under the exec mask
             double lbI = cst[32 + mI], ubI = cst[36 + mI], wuI = cst[12 + mI];
             asm volatile("" : "+v"(lbI), "+v"(ubI), "+v"(wuI));
             const double rdI = P.Ts * wuI;   // the input's own Hessian entry
-            {
+            {   // first guess: the inputs of the Newton point that violate their bounds
+                GROUP_LANE;
                 IPM_PRE(up, I.u[j]);
                 IPM_PRE(vh, I.vhat[j]);
                 IPM_FOR(t, j) {
                     const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
-                    const double lb = lbI - uj, ub = ubI - uj;
-                    const double wdt = ub - lb;
-                    double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
-                    const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
-                    vj = (vj < lo) ? lo : vj;
-                    vj = (vj > hi) ? hi : vj;
-                    vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
-                    if constexpr (EL) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
+                    const double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
+                    set_act(t, j, vj < lbI - uj ? -1.0 : (vj > ubI - uj ? 1.0 : 0.0));
                 }
-                vV.flush(lane, nv); vTL.flush(lane, nv); vTU.flush(lane, nv);
-            }
-            sw_rollout<LDS>(I, W, d0, V);
-            sw_adjoint<false, LDS>(I, W, V, DVA, nullptr);
-            double mu0, gscale;
-            {
-                vTL.fetch(lane, nv); vTU.fetch(lane, nv);
-                IPM_PRE(gr, GRAD[j]);
-                double g0 = 0.0;
-                IPM_FOR(t, j) g0 = fmax(g0, fabs(CACHE ? gr[CACHE ? t : 0] : rd_grad(j)));
-                g0 = wave_max(g0);
-                mu0 = fmax(IPM_MU0F * g0, 1e-4);
-                gscale = fmax(g0, 1.0);   // the tolerances are relative to the QP's gradient scale
-                double r0 = 0.0;
-                IPM_FOR(t, j) {
-                    const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
-                    vLL.set(t, j, ll); vLU.set(t, j, lu);
-                    r0 = fmax(r0, fabs((CACHE ? gr[CACHE ? t : 0] : rd_grad(j)) - ll + lu));
-                }
-                rho = wave_max(r0);
-                vLL.flush(lane, nv); vLU.flush(lane, nv);
             }
             status = BROV_STATUS_MAXITER;
             const double inv2nv = 1.0 / (2.0 * nv);
-            double mu_prev = 1e300;
+            int round_k = 0, round_cap = POL_FIRST, nchg_prev = nv + 1;
+            double mu_gate = 1e300;
+            bool ipm_on = false, converged = false;
             IPM_T(0);
-            for (iters = 1; iters <= P.qp_iter_max; iters++) {
-                double s = 0.0;
-                double gam_r[2] = {0.0, 0.0};
-                {   // group A: Gamma and the predictor's right-hand side
-                    vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
-                    IPM_PRE(up, I.u[j]);
-                    IPM_PRE(yr, I.yref[(size_t)(j >> 2) * 16 + 12 + (j & 3)]);
-                    IPM_FOR(t, j) {
-                        const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
-                        s += ll * tl + lu * tu;
-                        const double gm = ll / tl + lu / tu;
-                        GAM[j] = gm;
-                        if constexpr (EL) gam_r[t & 1] = gm;
-                        const double rr = EL ? (double)I.lds_r[j]
-                                             : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
-                                                                           : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
-                        RT[j] = rr - gm * vV.get(t, j);
+            iters = 0;
+            double gam_r[2] = {0.0, 0.0};
+            while (iters < P.qp_iter_max) {
+                // One Newton system per trip: an active-set try (the guessed active inputs pinned) while a round is on, else an
+                // interior-point iteration.  Both factorise and solve through the same pair of sweeps.
+                const bool try_mode = round_k < round_cap;
+                // nothing lane-dependent may be hoisted out of this loop: the sweeps' per-lane addresses, computed once ahead of the
+                // loop, would all be live across all of its sweeps (the register file is full: the kernels then spill into scratch)
+                asm volatile("v_mov_b32 %0, %0" : "+v"(I.lane));
+                I.rg = I.lane >> 4; I.cl = I.lane & 15;
+                if (!try_mode && !ipm_on) {
+                    // interior start at the last active-set point: clamp into the box, multipliers from mu0 = stationarity
+                    // residual of the clamped point
+                    ipm_on = true;
+                    {
+                        GROUP_LANE;
+                        IPM_PRE(up, I.u[j]);
+                        IPM_PRE(vh, I.vhat[j]);
+                        IPM_FOR(t, j) {
+                            const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
+                            const double lb = lbI - uj, ub = ubI - uj;
+                            const double wdt = ub - lb;
+                            double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
+                            const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
+                            vj = (vj < lo) ? lo : vj;
+                            vj = (vj > hi) ? hi : vj;
+                            vV.set(t, j, vj); vTL.set(t, j, vj - lb); vTU.set(t, j, ub - vj);
+                            if constexpr (EL) wr_vhat(j, vj);  // roll-out / adjoint read their inputs from the LDS copy
+                        }
+                        vV.flush(lane, nv); vTL.flush(lane, nv); vTU.flush(lane, nv);
                     }
+                    sw_rollout<LDS>(I, W, d0, V);
+                    sw_adjoint<false, LDS>(I, W, V, DVA, nullptr);
+                    {
+                        GROUP_LANE;
+                        vTL.fetch(lane, nv); vTU.fetch(lane, nv);
+                        IPM_PRE(gr, GRAD[j]);
+                        double g0 = 0.0;
+                        IPM_FOR(t, j) g0 = fmax(g0, fabs(CACHE ? gr[CACHE ? t : 0] : rd_grad(j)));
+                        g0 = wave_max(g0);
+                        const double mu0 = fmax(IPM_MU0F * g0, 1e-4);
+                        double r0 = 0.0;
+                        IPM_FOR(t, j) {
+                            const double ll = mu0 / vTL.get(t, j), lu = mu0 / vTU.get(t, j);
+                            vLL.set(t, j, ll); vLU.set(t, j, lu);
+                            r0 = fmax(r0, fabs((CACHE ? gr[CACHE ? t : 0] : rd_grad(j)) - ll + lu));
+                        }
+                        rho = wave_max(r0);
+                        vLL.flush(lane, nv); vLU.flush(lane, nv);
+                    }
+                    IPM_T(0);
                 }
-                mu = wave_sum(s) * inv2nv;
+                iters++;
+                double s = 0.0;
+                if (try_mode) {   // pin: Gamma = POL_BIG and a right-hand side that lands the input on its bound
+                    round_k++;
+                    {
+                        GROUP_LANE;
+                        vACT.fetch(lane, nv);
+                        IPM_PRE(up, I.u[j]);
+                        IPM_PRE(yr, I.yref[(size_t)(j >> 2) * 16 + 12 + (j & 3)]);
+                        IPM_FOR(t, j) {
+                            const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
+                            const double rr = EL ? (double)I.lds_r[j]
+                                                 : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                                                               : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
+                            const double ac = vACT.get(t, j);
+                            const double gm = ac != 0.0 ? POL_BIG : 0.0;
+                            GAM[j] = gm;
+                            RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj);
+                        }
+                    }
+                } else {   // group A of an interior-point iteration: Gamma and the predictor's right-hand side
+                    {   // group A: Gamma and the predictor's right-hand side
+                        GROUP_LANE;
+                        vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
+                        IPM_PRE(up, I.u[j]);
+                        IPM_PRE(yr, I.yref[(size_t)(j >> 2) * 16 + 12 + (j & 3)]);
+                        IPM_FOR(t, j) {
+                            const double ll = vLL.get(t, j), lu = vLU.get(t, j), tl = vTL.get(t, j), tu = vTU.get(t, j);
+                            s += ll * tl + lu * tu;
+                            const double gm = ll / tl + lu / tu;
+                            GAM[j] = gm;
+                            if constexpr (EL) gam_r[t & 1] = gm;
+                            const double rr = EL ? (double)I.lds_r[j]
+                                                 : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                                                               : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
+                            RT[j] = rr - gm * vV.get(t, j);
+                        }
+                    }
+                    mu = wave_sum(s) * inv2nv;
+                }
                 IPM_T(1);
                 ok = sw_backward<true, LDS>(I, W);
                 IPM_T(2);
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
                 sw_forward<LDS>(I, W, d0);
                 IPM_T(3);
+                if (try_mode) {
+                    bool bad = false;
+                    {   // pinned inputs exactly onto their bounds; free inputs that leave the box are marked (+-2: to be pinned)
+                        GROUP_LANE;
+                        vACT.fetch(lane, nv);
+                        IPM_PRE(up, I.u[j]);
+                        IPM_PRE(vh, I.vhat[j]);
+                        IPM_FOR(t, j) {
+                            const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
+                            const double lb = lbI - uj, ub = ubI - uj;
+                            double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
+                            double ac = vACT.get(t, j);
+                            if (!(vj == vj)) bad = true;
+                            if (ac != 0.0) vj = ac < 0.0 ? lb : ub;
+                            else ac = vj < lb ? -2.0 : (vj > ub ? 2.0 : 0.0);
+                            set_act(t, j, ac);
+                            if constexpr (EL) wr_vhat(j, vj); else I.vhat[j] = vj;
+                        }
+                            }
+                    if constexpr (LDS == 3) bad = bad || W->nan;
+                    if (__ballot(bad) != 0ull) { status = BROV_STATUS_NAN; break; }
+                    // multipliers of this point: the state steps of the forward sweep are its roll-out (the snap of a pinned input
+                    // is a rounding error), so the adjoint recursion alone gives g = R v + r + B'pi
+                    sw_adjoint<false, LDS>(I, W, I.vhat, DVA, nullptr);
+                    IPM_T(4);
+                    int nchg;
+                    {
+                        GROUP_LANE;
+                        vACT.fetch(lane, nv);
+                        IPM_PRE(gr, GRAD[j]);
+                        double gmx = 0.0;
+                        IPM_FOR(t, j) gmx = fmax(gmx, fabs(CACHE ? gr[CACHE ? t : 0] : rd_grad(j)));
+                        gmx = wave_max(gmx);
+                        const double tolg = POL_TOL_G * rdI + POL_TOL_GREL * gmx;
+                        double cnt = 0.0;
+                        IPM_FOR(t, j) {
+                            const double g = CACHE ? gr[CACHE ? t : 0] : rd_grad(j);
+                            double ac = vACT.get(t, j);
+                            if (ac == 2.0 || ac == -2.0) { ac *= 0.5; cnt += 1.0; }                       // newly pinned
+                            else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) { ac = 0.0; cnt += 1.0; }   // released
+                            set_act(t, j, ac);
+                        }
+                                nchg = (int)wave_sum(cnt);
+                    }
+                    IPM_T(1);
+                    if (nchg == 0) { polished = true; status = BROV_STATUS_SUCCESS; break; }
+                    // the round goes on while the repairs are few and do not grow (a guess that is converging)
+                    if (nchg > POL_NCHG || nchg > nchg_prev) round_cap = 0;
+                    nchg_prev = nchg;
+                    if (round_k >= round_cap) {   // failed round: the next one waits until the interior-point loop has halved mu
+                        if (ipm_on) mu_gate = mu;
+                        if (converged) break;
+                    }
+                    continue;
+                }
+                // ---- the rest of the interior-point iteration (Mehrotra predictor-corrector)
                 double smu;
                 {   // group B: predictor step length, centering, corrector right-hand side
+                    GROUP_LANE;
                     vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
                     IPM_PRE(vh, I.vhat[j]);
                     IPM_PRE(up, I.u[j]);
@@ -1466,7 +1605,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 IPM_T(5);
                 bool bad = false;
                 double s2 = 0.0, alpha, unres = 0.0;
-                {   // group C: step length of the combined direction, update
+                {   // group C: step length of the combined direction, update, classification of the bounds
+                    GROUP_LANE;
                     vLL.fetch(lane, nv); vLU.fetch(lane, nv); vTL.fetch(lane, nv); vTU.fetch(lane, nv); vV.fetch(lane, nv);
                     vDVA.fetch(lane, nv);
                     IPM_PRE(vh, I.vhat[j]);
@@ -1508,34 +1648,56 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         vV.set(t, j, vj); vTL.set(t, j, tl); vTU.set(t, j, tu); vLL.set(t, j, ll); vLU.set(t, j, lu);
                         if (!(vj == vj)) bad = true;
                         s2 += ll * tl + lu * tu;
-                        // how far this element's bounds are from resolved: min(distance to the bound, multiplier / input weight)
-                        unres = fmax(unres, fmax(fmin(tl, ll / rdI), fmin(tu, lu / rdI)));
+                        // how far this element's bounds are from resolved: min(distance to the bound, multiplier / input weight);
+                        // the same two quantities classify the bound for the next active-set round (active <=> the multiplier
+                        // could move the input further than it is away from the bound)
+                        const double al = ll / rdI, au = lu / rdI;
+                        unres = fmax(unres, fmax(fmin(tl, al), fmin(tu, au)));
+                        set_act(t, j, al > tl ? -1.0 : (au > tu ? 1.0 : 0.0));
                     }
                     vV.flush(lane, nv); vTL.flush(lane, nv); vTU.flush(lane, nv); vLL.flush(lane, nv); vLU.flush(lane, nv);
-                }
+                    }
                 if (__ballot(bad) != 0ull) { status = BROV_STATUS_NAN; break; }
                 rho *= (1.0 - alpha);
                 mu = wave_sum(s2) * inv2nv;
                 IPM_T(1);
-                // termination (same rule as the oracle, bluerov2_oracle.c): every bound resolved to tol_mu -- the input within that
+                // the loop's own rule (same as the oracle, bluerov2_oracle.c): every bound resolved to tol_mu -- the input within that
                 // distance of it, or its multiplier too small to move the input that far -- and the tracked stationarity residual
-                // below tol_stat; escape when mu has reached the floor of what FP64 resolves for this QP (tiny and no longer falling)
+                // below tol_stat.  Then one more active-set round for the exact answer; if that fails too the iterate is the answer.
                 unres = wave_max(unres);
-                const bool stalled = mu <= IPM_STALL_MU * gscale && mu > IPM_STALL_RATIO * mu_prev;
-                mu_prev = mu;
-                if ((unres <= P.tol_mu || stalled) && rho <= P.tol_stat) { status = BROV_STATUS_SUCCESS; break; }
+                if (unres <= P.tol_mu && rho <= P.tol_stat) converged = true;
+                if (converged || mu <= POL_MU_GATE * mu_gate) { round_k = 0; round_cap = POL_LOOP; nchg_prev = nv + 1; }
             }
+            if (converged && status == BROV_STATUS_MAXITER) status = BROV_STATUS_SUCCESS;
 #ifdef BROV_DBG_IPM
             if (P.dbg && lane == 0) {
                 ipm_t[6] = iters;
                 for (int k = 0; k < 7; k++) P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + k] = ipm_t[k];
             }
 #endif
-            // the final inputs go where the finalisation expects them: V (streaming path, already there) / the LDS copy
-            if constexpr (EL) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
+            // the final inputs go where the finalisation expects them.  Polished: the LDS copy / I.vhat holds them (with their state
+            // steps and, on the fused path, their multipliers).  Otherwise the interior-point iterate: V (streaming / windowed path) /
+            // the LDS copy; or, when the limit was reached before the first interior-point iteration, the last active-set point
+            // clamped into the box.
+            use_vhat = polished || !ipm_on;
+            if (!polished) {
+                if (ipm_on) {
+                    if constexpr (EL) { IPM_FOR(t, j) wr_vhat(j, vV.get(t, j)); }
+                } else if (status == BROV_STATUS_MAXITER) {
+                    GROUP_LANE;
+                    IPM_PRE(up, I.u[j]);
+                    IPM_PRE(vh, I.vhat[j]);
+                    IPM_FOR(t, j) {
+                        const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
+                        double vj = CACHE ? vh[CACHE ? t : 0] : rd_vhat(j);
+                        vj = fmin(fmax(vj, lbI - uj), ubI - uj);
+                        if constexpr (EL) wr_vhat(j, vj); else I.vhat[j] = vj;
+                    }
+                }
+            }
 #undef IPM_FOR
 #undef IPM_PRE
-            if (iters > P.qp_iter_max) iters = P.qp_iter_max;
+#undef GROUP_LANE
         }
     }
 
@@ -1543,14 +1705,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     // Element loops issue all their loads before the first use (UX/UU elements per lane per chunk): at one wave per SIMD
     // every dependent global round trip is otherwise fully exposed (~2 us each).
     constexpr int UX = EL ? 5 : 4, UU = EL ? 2 : 4;
-    const double* vfin = (early || EL) ? I.vhat : V;   // fused path: the interior-point loop leaves its inputs in the LDS copy
+    const double* vfin = (early || EL || use_vhat) ? I.vhat : V;   // fused path: the interior-point loop leaves its inputs in the LDS copy
     const int nxe = (N + 1) * 12;
     double cost = 0.0;
     bool wrote_u0 = false;
     double u0v = 0.0;   // lanes 0..3: first input of the result record
     if (status == BROV_STATUS_SUCCESS || status == BROV_STATUS_MAXITER) {
-        if (!early) {  // early exit: dxb already holds the states of the accepted Newton point
-            sw_rollout<LDS>(I, W, d0, V);
+        if (!early && !polished) {  // early exit / accepted active-set point: dxb already holds its state steps
+            sw_rollout<LDS>(I, W, d0, vfin);
         }
         DBG_STAMP(4);
         // fused path: the iterate and the reference of the commit loops below are requested before the adjoint sweep, which
@@ -1585,7 +1747,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if constexpr (LDS == 1) wupre[t] = cst[12 + (jj & 3)];
             }
         }
-        sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
+        // fused kernels, accepted active-set point: the try's own adjoint sweep has left multipliers and input gradient in LDS
+        if (!(EL && polished)) sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
         DBG_STAMP(5);
         bool nanv = false;
         // fused kernels: the lane's elements of the accepted inputs and state steps (all of them: nv <= 128, nxe <= 320) are read

@@ -464,7 +464,6 @@ static double rollout_adjoint(int N, const double* A, const double* B, const dou
 #define POL_LOOP 3        /* ... per round after an interior-point iteration (at most) */
 #define POL_NCHG 8        /* a round ends when a try repairs more than this many inputs, or more than the try before it */
 #define POL_MU_GATE 0.5   /* after a failed round the next one waits until the interior-point loop has cut mu by this factor */
-#define POL_TOL_FEAS 1e-9 /* a free input may leave the box by this much (it is clamped) */
 #define POL_TOL_G 1e-9    /* wrong-signed multiplier of a pinned input: tolerated up to POL_TOL_G * R (+ POL_TOL_GREL * |g|max) */
 #define POL_TOL_GREL 1e-13
 
@@ -478,7 +477,7 @@ size_t orc_ws_doubles(int N) {
 
 /* one equality-constrained solve with the inputs act[j] != 0 pinned at their bounds (-1 lower, +1 upper).  Returns 1 when the
  * result is the QP's minimiser (-> vp, with xs / pis / g of that point), 0 when the guess was wrong (act_new = repaired guess,
- * vp = the point clamped into the box), -4 / -1 on a factorisation failure / NaN. */
+ * vp = the equality-constrained solution, which may leave the box), -4 / -1 on a factorisation failure / NaN. */
 static int polish_try(qp_ws* w, const double* A, const double* B, const double* b, const double* Qd, const double* q,
                       const double* Rd, const double* r, const double* d0, const double* lb, const double* ub, const double* act,
                       double* gam, double* rt, double* vp, double* xs, double* pis, double* g, double* act_new, const double* lamz) {
@@ -492,13 +491,13 @@ static int polish_try(qp_ws* w, const double* A, const double* B, const double* 
     int ok = 1;
     for (int j = 0; j < nv; j++) {
         act_new[j] = act[j];
-        double vj = w->vs[j];
+        const double vj = w->vs[j];
         if (!(vj == vj)) return -1;
-        if (act[j] != 0.0) { vp[j] = act[j] < 0.0 ? lb[j] : ub[j]; continue; }
-        if (vj < lb[j]) { if (lb[j] - vj > POL_TOL_FEAS) { ok = 0; act_new[j] = -1.0; } vj = lb[j]; }
-        if (vj > ub[j]) { if (vj - ub[j] > POL_TOL_FEAS) { ok = 0; act_new[j] = 1.0; } vj = ub[j]; }
-        vp[j] = vj;
+        vp[j] = act[j] != 0.0 ? (act[j] < 0.0 ? lb[j] : ub[j]) : vj;   /* pinned inputs exactly onto their bounds */
+        if (act[j] == 0.0 && vj < lb[j]) { ok = 0; act_new[j] = -1.0; }   /* a free input that leaves the box is pinned next time */
+        if (act[j] == 0.0 && vj > ub[j]) { ok = 0; act_new[j] = 1.0; }
     }
+    /* multipliers of this point (the primal-dual active-set method evaluates them at the equality-constrained solution itself) */
     (void)rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, vp, lamz, xs, pis, g);
     double gmax = 0.0;
     for (int j = 0; j < nv; j++) if (fabs(g[j]) > gmax) gmax = fabs(g[j]);
@@ -576,7 +575,7 @@ int orc_qp_solve_ws(const orc_opts* o, const double* A, const double* B, const d
             if (nchg > POL_NCHG || nchg > nchg_prev) round_cap = 0;
             nchg_prev = nchg;
             if (round_k >= round_cap) {   /* the round has failed: the next one waits for the interior-point loop to halve mu */
-                mu_gate = mu;
+                if (ipm_on) mu_gate = mu;
                 if (converged) break;
             }
             continue;
@@ -694,7 +693,8 @@ int orc_qp_solve_ws(const orc_opts* o, const double* A, const double* B, const d
      * KKT error shows up as complementarity, reported in stats[2]) */
     if (status == 4 || status == 1) goto done;
     if (converged && status == 2) status = 0;
-    if (status == 2 && !ipm_on) memcpy(v, vp, nv * sizeof(double));   /* limit reached before the first interior-point iteration */
+    if (status == 2 && !ipm_on)   /* limit reached before the first interior-point iteration: the last point, clamped into the box */
+        for (int j = 0; j < nv; j++) v[j] = vp[j] < lb[j] ? lb[j] : (vp[j] > ub[j] ? ub[j] : vp[j]);
     (void)rollout_adjoint(N, A, B, b, Qd, q, Rd, r, d0, v, lamz, dx, pi, gam);
     rho = 0.0;
     for (int i = 0; i < N; i++)

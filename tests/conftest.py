@@ -70,26 +70,22 @@ def status_agreement(r_status, o_status, o_kkt, max_ambiguous=4):
     mism = r_status != o_status
     assert np.all((o_kkt[mism] > 1e6) | ~np.isfinite(o_kkt[mism])), (np.nonzero(mism)[0], r_status[mism], o_status[mism], o_kkt[mism])
     assert mism.sum() <= max_ambiguous, (np.nonzero(mism)[0], r_status[mism], o_status[mism])
+    if mism.sum():
+        print(f"[status_agreement] {int(mism.sum())} status-ambiguous instance(s) (entering KKT > 1e6): gpu {r_status[mism]} oracle {o_status[mism]}")
     return ~mism
 
 
-def values_agree(ok, kkt, what, max_diverged=4, err=None, degenerate_tol=1e-4, max_degenerate=2):
+def values_agree(ok, kkt, what, max_diverged=4, err=None):
     """Value parity rule shared by the batch tests: `ok` is the per-instance verdict of a KKT-scaled comparison
-    (|gpu - oracle| <= 1e-7 max(1, KKT)).  Every instance whose step is numerically meaningful (entering KKT <= 1e6) must pass.
-    A diverged instance (KKT > 1e6, see status_agreement) may miss even the scaled tolerance -- its QP is conditioned beyond what
-    FP64 resolves, and both sides may well report success with different garbage -- but there may be at most `max_diverged` of
-    them per tick."""
+    (|gpu - oracle| <= 1e-7 max(1, KKT)).  Every instance whose step is numerically meaningful (entering KKT <= 1e6) must pass --
+    round 3: without the allowance for degenerate bounds round 2 needed (two instances per tick at 1e-4): both sides now end
+    their QPs with an exact active-set solve.  A diverged instance (KKT > 1e6, see status_agreement) may miss even the scaled
+    tolerance -- its QP is conditioned beyond what FP64 resolves, and both sides may well report success with different garbage --
+    but there may be at most `max_diverged` of them per tick; their number is printed so that a creeping regression shows."""
     ok, kkt = np.asarray(ok), np.asarray(kkt)
     bad = ~ok
-    if err is not None:
-        # Degenerate bounds.  Where a bound is active with a vanishing multiplier (strict complementarity fails) an interior-point
-        # method converges like sqrt(mu), and mu has a floor in FP64: the minimiser is then resolved to ~1e-5 at best, by ANY
-        # implementation.  Measured against the independent BVLS answer (scripts/dev/fuzz_truth.py, seed 1 / instance 88: N = 80,
-        # 92 active bounds): kernel 1.9e-6, oracle 3.0e-5 away, both stopped by the stall rule at mu ~ 5e-15.  At most
-        # `max_degenerate` instances per tick may miss the scaled tolerance while agreeing to `degenerate_tol` (the north star
-        # asks 1e-5 on u0; this is over all stages).
-        soft = bad & (np.asarray(err) <= degenerate_tol) & ~(kkt > 1e6)
-        assert soft.sum() <= max_degenerate, (what, "degenerate", np.nonzero(soft)[0][:8], np.asarray(err)[soft][:8])
-        bad = bad & ~soft
-    assert not np.any(bad & ~(kkt > 1e6)), (what, np.nonzero(bad & ~(kkt > 1e6))[0][:8], kkt[bad][:8])
+    assert not np.any(bad & ~(kkt > 1e6)), (what, np.nonzero(bad & ~(kkt > 1e6))[0][:8], kkt[bad][:8],
+                                            None if err is None else np.asarray(err)[bad][:8])
     assert bad.sum() <= max_diverged, (what, np.nonzero(bad)[0][:8], kkt[bad][:8])
+    if bad.sum():
+        print(f"[values_agree] {what}: {int(bad.sum())} diverged instance(s) (KKT > 1e6) outside the scaled tolerance")

@@ -55,7 +55,7 @@ def test_random_problems_against_independent_answers(ba, recipe, golden_traj, se
     if seed % 3 == 0:
         us[:, :, 1] = 5.0
     s.set_iterate(x=xs, u=us, pi=np.zeros((nb, N, 12)), lam=np.zeros((nb, N, 8)))
-    n_active, loose = 0, 0
+    n_active = 0
     for k in range(2):
         yref = circ[2 * k:2 * k + N + 1].copy()
         s.set_yref(yref); s.solve()
@@ -64,13 +64,13 @@ def test_random_problems_against_independent_answers(ba, recipe, golden_traj, se
         for b in range(nb):
             xb, ub, info = G.rti_step_independent(ref, N, Ts, x0[b], yref, p[b], xs[b], us[b], Wd=W, lbu=lbu, ubu=ubu, Wed=We)
             assert info["qp_kkt"] < 1e-9
-            e = np.abs(gu[b] - ub).max()
-            assert e < 1e-4, (seed, k, b, e, info)          # north star: 1e-5 on u0; this is over all stages, degenerate bounds included
-            loose += int(e >= 2e-6)
+            e, e0 = np.abs(gu[b] - ub).max(), np.abs(gu[b, 0] - ub[0]).max()
+            # round 3: every QP ends with an exact active-set solve -- every instance, every stage, no allowance for degenerate
+            # bounds (the north star asks 1e-5 on u0; round 2 needed 1e-4 for one instance in twelve)
+            assert e < 1e-8 and e0 < 1e-9, (seed, k, b, e, e0, info)
             n_active += info["nact"]
             xs[b], us[b] = xb, ub
         # both continue from the independent iterate (multipliers: the kernel's own)
         s.set_iterate(x=xs, u=us, pi=gpi, lam=glam)
-    assert loose <= 1, (seed, loose)      # at most one (degenerate) instance of the 12 solves misses 2e-6
     assert n_active > 0
     s.close()

@@ -162,17 +162,21 @@ def test_iterate_outside_bounds_is_pulled_back(ba, oracle, golden_traj, path):
 def test_iteration_cap_reports_maxiter_and_still_steps(ba, oracle, golden_traj):
     N, B = 20, 6
     x0, circ = _inputs(golden_traj, B, seed=4, big=4.0)
-    s = ba.BatchSolver(B, ba.SolverOptions(N, qp_iter_max=2))
+    # one Newton system: a single active-set try, which the far-off instances' QPs do not finish with (round 3 counts tries and
+    # interior-point iterations alike; with 2 every one of these QPs is solved)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, qp_iter_max=1))
     s.set_x0(x0); s.set_params(ba.P_NOMINAL)
-    op = oracle.opts(N, qp_iter_max=2)
+    op = oracle.opts(N, qp_iter_max=1)
     it = oracle.init_iterate(op, B)
     for k in range(2):
         s.set_yref(circ[k:k + N + 1]); s.solve()
         _, ro = _oracle_step(oracle, op, x0, circ[k:k + N + 1], ba.P_NOMINAL, it)
     r = s.results()
     assert np.array_equal(r["status"], ro["status"]) and (r["status"] == 2).any()
-    assert np.all(r["qp_iter"][r["status"] == 2] == 2)
-    assert np.abs(s.get_iterate()[1] - it[1]).max() < 1e-5  # same truncated IPM iterate
+    assert np.all(r["qp_iter"][r["status"] == 2] == 1)
+    gu = s.get_iterate()[1]
+    assert np.abs(gu - it[1]).max() < 1e-7  # same truncated point: the last active-set point, clamped into the box
+    assert gu.max() <= 50.0 and gu.min() >= -50.0
 
 
 def test_runtime_option_change_and_reset(ba, oracle, golden_traj):
