@@ -121,36 +121,110 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(batch, reps=5, ticks=4, warmup=3):
-    """the C oracle on the config-2 workload, OpenMP over instances, all host threads: median over `reps` repetitions of `ticks`
-    consecutive RTI ticks"""
-    from oracle.oracle_ffi import Oracle, build
-    build()
-    orc = Oracle()
-    op = orc.opts(HORIZON, TS)
-    x0, circ = synthetic_inputs(batch, seed=1)
-    from bluerov2_amd import P_NOMINAL
-    p = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (batch, HORIZON + 1, NP)))
-    x, u, pi, lam = orc.init_iterate(op, batch)
-    nthreads = orc.num_threads()
-    rates, k = [], 0
+def physical_cores():
+    """(physical id, core id) pairs of /proc/cpuinfo; falls back to the logical count"""
+    cores, phys, core = set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    return max(1, min(len(cores), avail)) if cores else avail
 
-    def tick():
-        nonlocal k
-        yref = np.ascontiguousarray(np.broadcast_to(circ[k:k + HORIZON + 1], (batch, HORIZON + 1, NY)))
-        t0 = time.perf_counter()
-        orc.rti_step_batch(op, x0, yref, p, x, u, pi, lam, nthreads=0)
-        k += 1
-        return time.perf_counter() - t0
-    for _ in range(warmup):
-        tick()
-    for _ in range(reps):
-        rates.append(batch * ticks / sum(tick() for _ in range(ticks)))
-    return dict(value=float(np.median(rates)), unit="solves/s", cores=nthreads, kind="port", cpu=cpu_model(),
-                min=float(min(rates)), max=float(max(rates)), repetitions=reps,
-                sample=f"median of {reps} repetitions of {ticks} RTI ticks x {batch} instances of the same workload (after "
-                       f"{warmup} warm-up ticks), oracle/bluerov2_oracle.c -O3, OpenMP over instances, {nthreads} threads; acados "
-                       "itself was not run (not vendored/installed) and no published acados timing exists for this OCP")
+
+def cpu_quota_cores():
+    """CPU bandwidth limit of this container's cgroup in cores (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(batch, reps=5, ticks=4, warmup=3):
+    """The C oracle on the config-2 workload, OpenMP over instances.  Runs in child processes, one per thread count: thread
+    placement (OMP_PROC_BIND=close, OMP_PLACES=cores) must be in the environment before the OpenMP runtime starts, and this
+    process has long loaded one (torch).  Thread counts tried: one per physical core, and -- when the container's cgroup limits
+    CPU bandwidth below that (threads beyond the quota only get throttled) -- the quota; the best is reported, with the others."""
+    phys, quota = physical_cores(), cpu_quota_cores()
+    cands = [phys]
+    if quota is not None and quota < phys:
+        cands += sorted({max(1, int(quota)), max(1, int(2 * quota))} - {phys})
+    runs = []
+    for threads in cands:
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+        if quota is not None and quota < phys:   # pinning 8 threads onto cores 0..7 of a shared host helps nobody
+            env.pop("OMP_PROC_BIND"); env.pop("OMP_PLACES")
+        cmd = [sys.executable, os.path.abspath(__file__), "--_cpu_worker", f"{batch},{reps},{ticks},{warmup},{threads}"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        if out.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed: " + out.stderr[-2000:])
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    best = max(runs, key=lambda r: r["value"])
+    best["host"] = dict(physical_cores=phys, logical_cpus=os.cpu_count(), cgroup_cpu_quota_cores=quota,
+                        tried={str(r["cores"]): r["value"] for r in runs},
+                        # NOT a measurement: what the whole host would deliver at this run's per-thread rate and parallel efficiency
+                        projection_all_physical_cores=phys * best["single_thread_batched"] * min(1.0, best["parallel_efficiency"]))
+    if quota is not None and quota < phys:
+        best["sample"] += (f"; NOTE this container's cgroup caps CPU bandwidth at {quota:g} cores of the host's {phys}: the figure is what "
+                           "that quota delivers, not what the whole host could")
+    return best
+
+
+def cpu_baseline_worker(spec):
+    """child of cpu_baseline(): numpy + the oracle only.  Times (a) the same code path on ONE thread over a 256-instance sample,
+    then (b) the batch on all threads, median of `reps` repetitions of `ticks` RTI ticks, and reports the parallel efficiency
+    (b) / (T x (a))."""
+    batch, reps, ticks, warmup, threads = (int(v) for v in spec.split(","))
+    from oracle.oracle_ffi import Oracle, build, build_native
+    build()
+    native = build_native()     # -march=native for THIS host; the portable build if no compiler is here
+    orc = Oracle(native)
+    op = orc.opts(HORIZON, TS)
+    P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
+
+    def rate(nb, nthreads, reps_, ticks_, warm_):
+        x0, circ = synthetic_inputs(nb, seed=1)
+        p = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (nb, HORIZON + 1, NP)))
+        x, u, pi, lam = orc.init_iterate(op, nb)
+        yrefs = [np.ascontiguousarray(np.broadcast_to(circ[k:k + HORIZON + 1], (nb, HORIZON + 1, NY))) for k in range(warm_ + reps_ * ticks_)]
+        k, rates = 0, []
+        for _ in range(warm_):
+            orc.rti_step_batch(op, x0, yrefs[k], p, x, u, pi, lam, nthreads=nthreads); k += 1
+        for _ in range(reps_):
+            t0 = time.perf_counter()
+            for _ in range(ticks_):
+                orc.rti_step_batch(op, x0, yrefs[k], p, x, u, pi, lam, nthreads=nthreads); k += 1
+            rates.append(nb * ticks_ / (time.perf_counter() - t0))
+        return rates
+    one = float(np.median(rate(256, 1, 3, 2, 1)))   # before the thread team exists: idle team members spin for a while after a region
+    rates = rate(batch, threads, reps, ticks, warmup)
+    val = float(np.median(rates))
+    print(json.dumps(dict(
+        value=val, unit="solves/s", cores=threads, kind="port", cpu=cpu_model(), min=float(min(rates)), max=float(max(rates)),
+        repetitions=reps, single_thread_batched=one, threads_x_single=threads * one, parallel_efficiency=val / (threads * one),
+        build="-O3 -march=native (built on this host)" if native else "-O3 -march=x86-64-v3 (portable build; no compiler on this host)",
+        sample=f"median of {reps} repetitions of {ticks} RTI ticks x {batch} instances of the same workload (after {warmup} warm-up "
+               f"ticks), oracle/bluerov2_oracle.c, OpenMP over instances (static schedule, one preallocated workspace per thread), "
+               f"{threads} threads; single_thread_batched = the same code on one thread over 256 instances; acados itself was not "
+               "run (not vendored/installed) and no published acados timing exists for this OCP")))
 
 
 def cpu_single_thread(ticks=1000):
@@ -193,7 +267,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json configs[config-1]")
-    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0 = the config's own)")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (0 = the config's own); with --scaling strong: the TOTAL")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank solves the config's per-GPU batch (total grows with --gpus); strong: the config's TOTAL "
+                         "(config 2: 4096, 3: 16384, 4: 65536, 5: 32768) is split over the ranks")
     ap.add_argument("--horizon", type=int, default=0, help="N for configs 2/3 (0 = 20); config 5: run this horizon only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the forced-IPM / mixed-batch legs of the default run")
@@ -201,6 +278,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-gather", action="store_true", help="run the result all-gather even with one rank")
     ap.add_argument("--path", type=int, default=0, help="0 auto (LDS-resident kernels), 1 streaming, 2 fused")
     ap.add_argument("--dry-run", action="store_true", help="no GPU, no solver: launcher + gloo collectives on synthetic records")
+    ap.add_argument("--_cpu_worker", default="", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -235,12 +313,30 @@ def relaunch(args, argv):
     return 0
 
 
+STRONG_TOTAL = {2: BATCH_PER_GPU, 3: 16384, 4: CAND_TOTAL, 5: 32768}   # BASELINE.json configs[1..4] as totals
+
+
+def shard_of(args, rank, world, per_gpu):
+    """(lo, hi, total): the global instance range of this rank.  weak: per_gpu instances on every rank; strong: the config's total
+    (or --batch) split contiguously, the first total % world ranks one instance larger (bluerov2_amd.distributed.shard_bounds)."""
+    from bluerov2_amd.distributed import shard_bounds
+    if args.scaling == "strong":
+        total = args.batch or STRONG_TOTAL[args.config]
+        lo, hi = shard_bounds(total, rank, world)
+        return lo, hi, total
+    B = args.batch or per_gpu
+    return rank * B, (rank + 1) * B, world * B
+
+
 def workload(args, rank, world):
-    """what one rank solves: dict(name, B, horizons=[(N, Ts)], make(N, Ts, early_exit) -> (solver, tick(k, stream), shared_yref))"""
+    """what one rank solves: dict(name, B, total, horizons=[(N, Ts)], make(N, Ts, early_exit) -> (solver, tick(k, stream), shared_yref)).
+    The synthetic inputs are generated for the GLOBAL batch from the config's seed and sliced, so that a sharded run solves
+    exactly the instances the single-GPU run of the same total solves."""
     import torch
     import bluerov2_amd as ba
     cfg = args.config
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    strong = args.scaling == "strong"
 
     def opts(N, Ts, early):
         return ba.SolverOptions(N, Ts, qp_early_exit=early, kernel_path=args.path)
@@ -252,20 +348,33 @@ def workload(args, rank, world):
             s.set_yref_from_trajectory(k, 16, stream=stream)
         return tick
 
+    def global_x0(seed, total, lo, hi, noise=True):
+        """weak scaling keeps round 2's per-rank seeds (seed + 1000 rank: rank 0 of any world = the single-GPU workload); strong
+        scaling draws the whole batch once and slices it"""
+        if strong:
+            x0, circ = synthetic_inputs(total, seed=seed, noise=noise)
+            return x0[lo:hi], circ
+        return synthetic_inputs(hi - lo, seed=seed + 1000 * rank, noise=noise)
+
     if cfg == 2 or cfg == 3:
         N = args.horizon or HORIZON
         Ts = TS if N == HORIZON else 1.0 / N
-        B = args.batch or (BATCH_PER_GPU if cfg == 2 else 16384)
+        lo, hi, total = shard_of(args, rank, world, BATCH_PER_GPU if cfg == 2 else 16384)
+        B = hi - lo
 
         def make(N, Ts, early, sat=0.0):
             s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
-            x0, circ = synthetic_inputs(B, seed=(1 if cfg == 2 else 2) + 1000 * rank, noise=(cfg == 2))
+            x0, circ = global_x0(1 if cfg == 2 else 2, total, lo, hi, noise=(cfg == 2))
             if sat:
                 x0 = saturate(x0, sat, seed=77)
             p = np.tile(ba.P_NOMINAL, (B, 1))
             if cfg == 3:   # Monte-Carlo current disturbance, converted like the node does (bluerov2_dob.cpp:334-337)
-                rng = np.random.default_rng(2 + 1000 * rank)
-                d = np.concatenate([rng.uniform(-10, 10, (B, 3)), rng.uniform(-3, 3, (B, 1))], axis=1)
+                if strong:
+                    rng = np.random.default_rng(2)
+                    d = np.concatenate([rng.uniform(-10, 10, (total, 3)), rng.uniform(-3, 3, (total, 1))], axis=1)[lo:hi]
+                else:
+                    rng = np.random.default_rng(2 + 1000 * rank)
+                    d = np.concatenate([rng.uniform(-10, 10, (B, 3)), rng.uniform(-3, 3, (B, 1))], axis=1)
                 p[:, 0:2] = d[:, 0:2] / 0.032546960744430276
                 p[:, 2:4] = d[:, 2:4] / 0.026546960744430276
             s.set_x0(x0)
@@ -275,13 +384,14 @@ def workload(args, rank, world):
                 "window advancing one row per step, per-instance x0 noise (seed 1), nominal parameters" % (B, N, Ts)) if cfg == 2 else (
                 "BASELINE.json configs[2]: batch=%d DOB-MPC Monte-Carlo current-disturbance draws per GPU (p[0..3] per instance, "
                 "seed 2), N=%d, Ts=%g s, shared circle window" % (B, N, Ts))
-        return dict(name=name, B=B, horizons=[(N, Ts)], make=make)
+        return dict(name=name, B=B, lo=lo, total=total, horizons=[(N, Ts)], make=make)
     if cfg == 4:
-        if world > CAND_SHARDS:
-            raise SystemExit("config 4 has 8 shards of 8192 candidates")
-        B = args.batch or CAND_TOTAL // CAND_SHARDS
         amp, frq, ph = candidate_params()
-        sl = slice(rank * B, (rank + 1) * B)
+        lo, hi, total = shard_of(args, rank, world, CAND_TOTAL // CAND_SHARDS)
+        if total > CAND_TOTAL:
+            raise SystemExit("config 4 has 65536 candidates (8 shards of 8192)")
+        B = hi - lo
+        sl = slice(lo, hi)
 
         def make(N, Ts, early, sat=0.0):
             s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
@@ -293,40 +403,47 @@ def workload(args, rank, world):
             def tick(k, stream):
                 s.set_yref_candidates_tick(TS * k, TS, stream=stream)   # one kernel per tick, parameters resident
             return s, tick, False
-        return dict(name="BASELINE.json configs[3]: 65536 lemniscate-trajectory candidates (amp~U(1,3), omega~U(.25,.75), "
-                         "phase~U(0,2pi), seed 3) sharded %d per GPU, N=20, x0 = lemniscate row 0; every step: candidate windows "
-                         "rebuilt on the device, RTI step, all-gather of the result records, global arg-min of cost" % B,
-                    B=B, horizons=[(HORIZON, TS)], make=make, always_gather=True)
+        return dict(name="BASELINE.json configs[3]: %d of the 65536 lemniscate-trajectory candidates (amp~U(1,3), omega~U(.25,.75), "
+                         "phase~U(0,2pi), seed 3), %d on this rank, N=20, x0 = lemniscate row 0; every step: candidate windows "
+                         "rebuilt on the device, RTI step, all-gather of the result records, global arg-min of cost" % (total, B),
+                    B=B, lo=lo, total=total, horizons=[(HORIZON, TS)], make=make, always_gather=True)
     # cfg 5
-    B = args.batch or BATCH_PER_GPU
+    lo, hi, total = shard_of(args, rank, world, BATCH_PER_GPU)
+    B = hi - lo
     Ns = [args.horizon] if args.horizon else [10, 20, 40, 80]
 
     def make(N, Ts, early, sat=0.0):
         s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
-        x0, circ = synthetic_inputs(B, seed=4 + 1000 * rank)
+        x0, circ = global_x0(4, total, lo, hi)
         s.set_x0(x0)
         s.set_params(ba.P_NOMINAL)
         return s, circle_ticks(s, circ), True
-    return dict(name="BASELINE.json configs[4]: horizon sweep N in %s at batch=%d per GPU (32768 over 8 GPUs), Ts = 1/N, x0 as "
-                     "config 2 (seed 4), shared circle window (one row per node)" % (Ns, B),
-                B=B, horizons=[(N, 1.0 / N) for N in Ns], make=make)
+    return dict(name="BASELINE.json configs[4]: horizon sweep N in %s, %d instances in total (%d on this rank; 32768 over 8 GPUs), "
+                     "Ts = 1/N, x0 as config 2 (seed 4), shared circle window (one row per node)" % (Ns, total, B),
+                B=B, lo=lo, total=total, horizons=[(N, 1.0 / N) for N in Ns], make=make)
 
 
 def dry_run(args, rank, world):
-    """no GPU: the launcher, the rendezvous, the record all-gather and the arg-min on synthetic records under gloo"""
+    """no GPU: the launcher, the rendezvous, the shard arithmetic of --scaling, the (padded) record all-gather and the arg-min on
+    synthetic records under gloo"""
     import torch
     import torch.distributed as dist
     from bluerov2_amd import distributed as D
     from bluerov2_amd.solver import RESULT_DTYPE
-    B = args.batch or 64
+    if args.scaling == "weak" and not args.batch:
+        args.batch = 64
+    lo, hi, total = shard_of(args, rank, world, 64)
+    counts = [shard_of(args, r, world, 64)[1] - shard_of(args, r, world, 64)[0] for r in range(world)]
+    B, Bmax = hi - lo, max(counts)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     rec = np.zeros(B, dtype=RESULT_DTYPE)
-    g = np.arange(rank * B, (rank + 1) * B)
-    rec["cost"] = 100.0 + ((g * 7919 + 266) % 1013)          # global minimum at a known index
+    g = np.arange(lo, hi)
+    rec["cost"] = 100.0 + ((g * 7919 + 266) % 1013) + g * 1e-9   # global minimum at a known, unique index
     rec["status"][g % 17 == 3] = 4                     # some failed instances: must be skipped by the arg-min
     rec["u0"][:, 0] = g
-    local = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy())
+    local = torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8)    # padding records: status -1, cost NaN -> never selected
+    local[: B * D.RECORD_BYTES] = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy())
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
         allb = D.gather_records(local)
@@ -338,14 +455,18 @@ def dry_run(args, rank, world):
     else:
         seen = [ranks]
     idx, best = D.select_best(allb)
-    gall = np.arange(world * B)
-    cost = np.where(gall % 17 == 3, np.inf, 100.0 + ((gall * 7919 + 266) % 1013))
+    gidx = D.padded_to_global(idx, counts)
+    gall = np.arange(total)
+    cost = np.where(gall % 17 == 3, np.inf, 100.0 + ((gall * 7919 + 266) % 1013) + gall * 1e-9)
+    valid = int(sum(counts))
     out = {"metric": "NMPC RTI solves/s", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / (args.warmup + args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": dt / (args.warmup + args.steps) * 1e3, "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f64", "data": "dry-run: synthetic records, NO solver, gloo on CPU", "dry_run": True,
-           "config": {"workload": "launcher / collective plumbing only"}, "ranks_seen": sorted(int(t.item()) for t in seen),
-           "select_best": {"index": idx, "expected_index": int(np.argmin(cost)), "cost": float(best["cost"]),
-                           "records_gathered": int(allb.numel() // D.RECORD_BYTES)}}
+           "config": {"workload": "launcher / collective plumbing only", "config": args.config, "total_instances": total,
+                      "instances_per_rank": counts},
+           "ranks_seen": sorted(int(t.item()) for t in seen),
+           "select_best": {"index": gidx, "expected_index": int(np.argmin(cost)), "cost": float(best["cost"]),
+                           "records_gathered": valid, "record_slots_gathered": int(allb.numel() // D.RECORD_BYTES)}}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -357,6 +478,8 @@ def dry_run(args, rank, world):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args._cpu_worker:
+        return cpu_baseline_worker(args._cpu_worker)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(args, argv))
     rank = int(os.environ.get("RANK", "0"))
@@ -388,6 +511,9 @@ def main(argv=None):
     wl = workload(args, rank, world)
     gather = gather or (wl.get("always_gather", False) and dist.is_initialized())
     B, K, W = wl["B"], args.steps, args.warmup
+    total = wl["total"]
+    counts = [shard_of(args, r, world, B)[1] - shard_of(args, r, world, B)[0] for r in range(world)] if args.scaling == "strong" else [B] * world
+    Bmax = max(counts)      # shards of unequal size are gathered in slots of the largest; padding records can never be selected
     dev = f"cuda:{local_rank}"
 
     side = torch.cuda.Stream(device=dev) if gather else None
@@ -399,9 +525,10 @@ def main(argv=None):
         main = torch.cuda.current_stream()
         stream = main.cuda_stream
         res_view = D.records_tensor_from_solver(s) if gather else None
-        stage = [torch.empty_like(res_view) for _ in range(2)] if gather else None
-        gathered = [torch.empty(world * D.RECORD_BYTES * B, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
+        stage = [torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
+        gathered = [torch.empty(world * D.RECORD_BYTES * Bmax, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
         done = [None, None]
+        gev = []   # (before gather, after gather, after select) events on the side stream, one triple per timed step
         if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
             with torch.cuda.stream(side):
                 dist.all_gather_into_tensor(gathered[0], stage[0])
@@ -418,16 +545,21 @@ def main(argv=None):
                 j = k & 1
                 if done[j] is not None:
                     main.wait_event(done[j])          # the gather that last read this staging buffer has finished
-                stage[j].copy_(res_view, non_blocking=True)
+                stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record(main)
                 side.wait_event(ready)
                 with torch.cuda.stream(side):
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
                     dist.all_gather_into_tensor(gathered[j], stage[j])
+                    e1.record(side)
                     if select:
                         best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
-                    done[j] = torch.cuda.Event()
-                    done[j].record(side)
+                    e2.record(side)
+                    if k >= warmup:
+                        gev.append((e0, e1, e2))
+                    done[j] = e2
         for k in range(warmup):
             step(k)
         s.enable_timing(timing)
@@ -446,11 +578,17 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        info = dict(per_rank_ms=[dt / max(steps, 1) * 1e3])
+        if gev:   # side-stream event pairs: the collective itself and the device-side arg-min, per step
+            info["gather_ms"] = float(np.mean([a.elapsed_time(b) for a, b, _ in gev]))
+            info["select_ms"] = float(np.mean([b.elapsed_time(c) for _, b, c in gev])) if select else None
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best)
+            every = torch.empty(world, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(every, tt)
+            info["per_rank_ms"] = [float(v) / max(steps, 1) * 1e3 for v in every.cpu()]
+            dt = float(every.max().item())
+        return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best, info)
 
     early = 0 if args.force_ipm else 1
     select = bool(wl.get("always_gather", False))
@@ -458,19 +596,19 @@ def main(argv=None):
     for (N, Ts) in wl["horizons"]:
         s, tick, shared = wl["make"](N, Ts, early)
         # pass 1: the timed region that defines `value` (no per-kernel events inside)
-        dt, _, _ = run(s, tick, K, W, False, select)
+        dt, _, (_, _, info) = run(s, tick, K, W, False, select)
         n_bad = int((s.results()["status"] != 0).sum())
         # pass 2: same steps again with HIP events around each kernel for the roofline numbers
-        _, ksec, (gathered, best) = run(s, tick, K, W, True, select)
+        _, ksec, (gathered, best, _) = run(s, tick, K, W, True, select)
         res2 = s.results()
-        legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
+        legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, info=info, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
                          shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
         last = (s, gathered, best)
         if (N, Ts) != wl["horizons"][-1]:
             s.close()
     s, gathered, best = last
     total_dt = sum(l["dt"] for l in legs)
-    value = B * world * K * len(legs) / total_dt
+    value = total * K * len(legs) / total_dt
 
     ranks_seen = [0]
     if dist.is_initialized():
@@ -511,7 +649,9 @@ def main(argv=None):
             else f"NMPC RTI solves/s (12 states / 4 inputs), config {args.config}",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": total_dt / (K * len(legs)) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "total_instances": total, "instances_per_rank": counts,
+            "per_rank_ms": lg["info"]["per_rank_ms"], "gather_ms": lg["info"].get("gather_ms"), "select_ms": lg["info"].get("select_ms"),
             "config": {"workload": wl["name"] + ", default options " +
                        ("with qp_early_exit=0 (forced interior point)" if args.force_ipm else
                         "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
@@ -533,21 +673,25 @@ def main(argv=None):
                              "formula": "8*[12 + (0 if one window is shared by the batch else 16(N+1)) + 16(N+1) + 2*(12(N+1)+4N)] + 104"},
         }
         if len(legs) > 1:
-            out["sweep"] = {f"N{l['N']}": dict(solves_per_s=B * world * K / l["dt"], ms_per_step=l["dt"] / K * 1e3,
+            out["sweep"] = {f"N{l['N']}": dict(solves_per_s=total * K / l["dt"], ms_per_step=l["dt"] / K * 1e3,
+                                               per_rank_ms=l["info"]["per_rank_ms"], gather_ms=l["info"].get("gather_ms"),
                                                kernel_path={1: "streaming", 2: "fused", 3: "windowed"}.get(l["path"], "?"),
                                                status_nonzero=l["n_bad"], mean_qp_iter=float(l["qp_iter"].mean()))
                             for l in legs}
     if gather:
-        allrec = D.gather_records(D.records_tensor_from_solver(s))  # every rank takes part in the collective
+        fin = torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev)
+        fin[: B * D.RECORD_BYTES].copy_(D.records_tensor_from_solver(s))
+        allrec = D.gather_records(fin)  # every rank takes part in the collective
         if rank == 0:
             idx, brec = D.select_best(allrec)
+            idx = D.padded_to_global(idx, counts)
             out["select_best"] = {"index": idx, "cost": None if brec is None else float(brec["cost"]),
                                   "u0": None if brec is None else [float(v) for v in brec["u0"]],
                                   "thrust": None if brec is None else [float(v) for v in brec["thrust"]],
-                                  "records_gathered": int(allrec.numel() // D.RECORD_BYTES),
+                                  "records_gathered": int(sum(counts)), "record_slots_gathered": int(allrec.numel() // D.RECORD_BYTES),
                                   "selected_every_step_on_device": select}
             if select and best is not None:
-                out["select_best"]["last_step_index_on_device"] = int(best[0].item())
+                out["select_best"]["last_step_index_on_device"] = D.padded_to_global(int(best[0].item()), counts)
     s.close()
 
     extra = rank == 0 and world == 1 and args.config == 2 and not args.force_ipm and not args.no_extra

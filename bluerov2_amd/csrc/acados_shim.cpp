@@ -67,6 +67,14 @@ int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N
     brov_shim_state* s = new brov_shim_state();
     s->N = N;
     brov_default_opts(&s->opts, N, Ts);
+    // a failed step: acados' SQP_RTI returns before update_variables and leaves everything as it is -- so does the drop-in by
+    // default (BROV_ON_FAILURE_KEEP).  BROV_ON_FAILURE=restart in the environment opts in to the batched API's default, a cold
+    // start of the failed iterate at the measured state ("Failed steps").
+    {
+        const char* of = std::getenv("BROV_ON_FAILURE");
+        s->opts.on_failure = (of && (!std::strcmp(of, "restart") || !std::strcmp(of, "RESTART") || !std::strcmp(of, "1")))
+                                 ? BROV_ON_FAILURE_RESTART : BROV_ON_FAILURE_KEEP;
+    }
     // which GPU: the reference has no such notion; BROV_DEVICE selects one on a multi-GPU host (default 0)
     const char* dev_env = std::getenv("BROV_DEVICE");
     const int device = dev_env ? std::atoi(dev_env) : 0;
@@ -350,7 +358,16 @@ void ocp_nlp_out_get(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_out* out, int stage
     if (stage < 0 || stage > s->N) return;
     pull_iterate(s);
     if (!std::strcmp(field, "x")) std::memcpy(v, &s->x[(size_t)stage * 12], 12 * sizeof(double));
-    else if (!std::strcmp(field, "u")) { if (stage < s->N) std::memcpy(v, &s->u[(size_t)stage * 4], 4 * sizeof(double)); }
+    else if (!std::strcmp(field, "u")) {
+        if (stage >= s->N) return;
+        // The node publishes thrusts from this getter whatever the status was (bluerov2_dob.cpp:375-395).  After a failed step
+        // (status 1 / 3 / 4) acados has not touched the iterate, so stage 0 still holds the last input it computed; here the iterate
+        // of a failed instance may have diverged (KEEP) or been cold-started (RESTART: u = 0), and the input to apply is the one
+        // the result record holds: the last successfully computed one, clamped into the box, NaN -> 0.
+        const bool failed = s->last_status == ACADOS_NAN_DETECTED || s->last_status == ACADOS_MINSTEP || s->last_status == ACADOS_QP_FAILURE;
+        if (stage == 0 && failed) std::memcpy(v, s->last.u0, 4 * sizeof(double));
+        else std::memcpy(v, &s->u[(size_t)stage * 4], 4 * sizeof(double));
+    }
     else if (!std::strcmp(field, "pi")) { if (stage < s->N) std::memcpy(v, &s->pi[(size_t)stage * 12], 12 * sizeof(double)); }
     else if (!std::strcmp(field, "lam")) { if (stage < s->N) std::memcpy(v, &s->lam[(size_t)stage * 8], 8 * sizeof(double)); }
 }

@@ -46,7 +46,10 @@ __device__ __forceinline__ ModelPar make_par(const double* __restrict__ p) {
 }
 
 // generalised forces of the 6 thrusters for the 4 wrench commands (bluerov2.py:95-121), constant over an RK step
-struct Wrench { double k0, k1, k2, k5; };
+// k3 / k4: roll / pitch moments.  The propulsion matrix gives the thrusters none (K rows 3, 4 are zero, bluerov2.py:95-100); they carry
+// the roll / pitch DISTURBANCE moments of the 6-disturbance model variant (the symbols bluerov2.py:37-38 keeps commented out,
+// entering dp, dq the way the other four disturbances enter their rows, :123-128) and are 0 in the shipped np = 16 model.
+struct Wrench { double k0, k1, k2, k5, k3, k4; };
 
 __device__ __forceinline__ Wrench make_wrench(const double* __restrict__ u) {
     const double ir = 1.0 / kRotor;
@@ -58,6 +61,7 @@ __device__ __forceinline__ Wrench make_wrench(const double* __restrict__ u) {
     w.k1 = 0.707 * t0 - 0.707 * t1 + 0.707 * t2 - 0.707 * t3;
     w.k2 = t4 + t4;
     w.k5 = 0.167 * t0 - 0.167 * t1 - 0.175 * t2 + 0.175 * t3;
+    w.k3 = 0.0; w.k4 = 0.0;
     return w;
 }
 
@@ -118,8 +122,8 @@ __device__ __forceinline__ void model_f(const double (&x)[NX], const Wrench& w, 
     f[6] = (w.k0 - kBouy * sp.sth + m.dx + m.lx * sp.vu + m.qx * fabs(sp.vu) * sp.vu) * m.imx;
     f[7] = (w.k1 + kBouy * r21 + m.dy + m.ly * sp.vv + m.qy * fabs(sp.vv) * sp.vv) * m.imy;
     f[8] = (w.k2 + kBouy * r22 + m.dz + m.lz * sp.vw + m.qz * fabs(sp.vw) * sp.vw) * m.imz;
-    f[9] = ((kIy - kIz) * sp.wq * sp.wr - kMzg * r21) * (1.0 / kIx);
-    f[10] = ((kIz - kIx) * sp.wp * sp.wr - kMzg * sp.sth) * (1.0 / kIy);
+    f[9] = (w.k3 + (kIy - kIz) * sp.wq * sp.wr - kMzg * r21) * (1.0 / kIx);
+    f[10] = (w.k4 + (kIz - kIx) * sp.wp * sp.wr - kMzg * sp.sth) * (1.0 / kIy);
     f[11] = (w.k5 - (kIy - kIx) * sp.wp * sp.wq + m.dn + m.ln * sp.wr + m.qn * fabs(sp.wr) * sp.wr) * m.imn;
 }
 

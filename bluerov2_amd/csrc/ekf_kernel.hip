@@ -802,13 +802,16 @@ __global__ void ekf_inputs_from_solver_kernel(int B, double dt, double inv_rc, c
 }
 
 // p[0..3] of every stage of instance b := estimate of instance b (bluerov2_dob.cpp:332-337)
-__global__ void ekf_apply_kernel(int B, int stages, const double* __restrict__ mp, double* __restrict__ par) {
+// 6-disturbance variant (rp != nullptr): the roll / pitch estimates esti_x(15), esti_x(16) too, scaled like the z / yaw channels
+__global__ void ekf_apply_kernel(int B, int stages, const double* __restrict__ mp, double* __restrict__ par, const double* __restrict__ xest,
+                                 double inv_rc, double* __restrict__ rp) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= B * stages) return;
     const int b = k / stages;
     double* p = par + (size_t)k * 16;
 #pragma unroll
     for (int j = 0; j < 4; j++) p[j] = mp[(size_t)b * 4 + j];
+    if (rp) { rp[(size_t)k * 2] = xest[(size_t)b * 18 + 15] * inv_rc; rp[(size_t)k * 2 + 1] = xest[(size_t)b * 18 + 16] * inv_rc; }
 }
 
 }  // namespace brov
@@ -1070,7 +1073,7 @@ extern "C" int brov_ekf_apply_to_solver(brov_ekf* e, brov_solver* s, void* strea
     const int stages = o.N + 1;
     const long long n = (long long)e->B * stages;
     hipLaunchKernelGGL(ekf_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->B, stages,
-                       (const double*)e->mp, brov_params_device(s));
+                       (const double*)e->mp, brov_params_device(s), (const double*)e->x, e->c.inv_rc, brov_rp_disturbance_device(s));
     EKFCHK(hipGetLastError());
     e->last_stream = (hipStream_t)stream;
     return BROV_OK;

@@ -47,6 +47,9 @@ struct brov_solver {
     int traj_rows = 0;
     double* scratch3 = nullptr;  // [3][B] candidate parameters
     double* pplant = nullptr;    // [B][16] true plant parameters
+    double* par_rp = nullptr;    // 6-disturbance variant: roll / pitch disturbance moments [B][N+1][2] (allocated by brov_enable_dist6)
+    double* prp_plant = nullptr; // ... of the plant [B][2] (brov_plant_set_rp_disturbance_host); else the controller's stage 0
+    bool dist6 = false, prp_plant_set = false;
     bool pplant_set = false;     // explicit plant parameters given (brov_plant_set_params_host)
     bool pplant_stale = true;    // controller parameters changed since the plant's copy of them was taken
     bool cand_set = false;       // candidate shape parameters resident in scratch3
@@ -308,6 +311,103 @@ extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, co
     if (stage == 0) s->pplant_stale = true;
     return BROV_OK;
 }
+// ---- 6-disturbance model variant ----------------------------------------------------------------
+__global__ void bcast_rp_kernel(const double* __restrict__ d2, double* __restrict__ rp, int B, int N1) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * N1 * 2) return;
+    rp[t] = d2[(t / ((size_t)N1 * 2)) * 2 + (t & 1)];
+}
+__global__ void split_p18_kernel(const double* __restrict__ p18, double* __restrict__ par, double* __restrict__ rp, size_t rows, int N1, int per_stage) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (instance, stage)
+    if (t >= rows) return;
+    const double* src = p18 + (per_stage ? t : t / N1) * 18;
+    double* p = par + t * 16;
+    p[0] = src[0]; p[1] = src[1]; p[2] = src[2]; p[3] = src[5];
+#pragma unroll
+    for (int j = 0; j < 12; j++) p[4 + j] = src[6 + j];
+    rp[t * 2] = src[3]; rp[t * 2 + 1] = src[4];
+}
+extern "C" int brov_enable_dist6(brov_solver* s, int on) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (on && !s->par_rp) {
+        const size_t n = (size_t)s->B * (s->N + 1) * 2;
+        int rc = dalloc(s, &s->par_rp, n);
+        if (rc == BROV_OK) rc = dalloc(s, &s->prp_plant, (size_t)s->B * 2);
+        if (rc != BROV_OK) return rc;
+        HIPCHK(hipMemset(s->par_rp, 0, n * sizeof(double)));
+        HIPCHK(hipMemset(s->prp_plant, 0, (size_t)s->B * 2 * sizeof(double)));
+    }
+    s->dist6 = on != 0;
+    return BROV_OK;
+}
+extern "C" int brov_dist6_enabled(const brov_solver* s) { return s ? (s->dist6 ? 1 : 0) : BROV_ERR_ARG; }
+static int need_dist6(brov_solver* s, const char* who) {
+    if (!s) return BROV_ERR_ARG;
+    if (!s->dist6) { g_err = std::string(who) + ": the 6-disturbance model variant is off (brov_enable_dist6)"; return BROV_ERR_ARG; }
+    return BROV_OK;
+}
+static int set_rp(brov_solver* s, const double* d, int per_stage, bool host, void* st) {
+    if (int rc = need_dist6(s, "brov_set_rp_disturbance")) return rc;
+    if (!d) return BROV_ERR_ARG;
+    const size_t N1 = s->N + 1;
+    if (per_stage) return copy_in(s, s->par_rp, d, (size_t)s->B * N1 * 2, host, st);
+    HIPCHK(hipSetDevice(s->device));
+    const double* src = d;
+    double* tmp = nullptr;
+    if (host) {
+        HIPCHK(hipStreamSynchronize(s->last_stream));
+        HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 2 * sizeof(double)));
+        hipError_t e = hipMemcpy(tmp, d, (size_t)s->B * 2 * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(tmp); g_err = hipGetErrorString(e); return BROV_ERR_HIP; }
+        src = tmp;
+    }
+    const size_t tot = (size_t)s->B * N1 * 2;
+    hipLaunchKernelGGL(bcast_rp_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)st, src, s->par_rp, s->B, (int)N1);
+    if (host) { hipStreamSynchronize((hipStream_t)st); hipFree(tmp); }
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
+extern "C" int brov_set_rp_disturbance_host(brov_solver* s, const double* d, int per_stage) { return set_rp(s, d, per_stage, true, nullptr); }
+extern "C" int brov_set_rp_disturbance_device(brov_solver* s, const double* d, int per_stage, void* st) { return set_rp(s, d, per_stage, false, st); }
+extern "C" double* brov_rp_disturbance_device(brov_solver* s) { return (s && s->dist6) ? s->par_rp : nullptr; }
+extern "C" int brov_get_rp_disturbance_host(brov_solver* s, double* d) {
+    if (int rc = need_dist6(s, "brov_get_rp_disturbance_host")) return rc;
+    if (!d) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(d, s->par_rp, (size_t)s->B * (s->N + 1) * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+extern "C" int brov_set_params18_host(brov_solver* s, const double* p18, int per_stage) {
+    if (int rc = need_dist6(s, "brov_set_params18_host")) return rc;
+    if (!p18) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    const size_t N1 = s->N + 1, rows = (size_t)s->B * N1, nsrc = (per_stage ? rows : (size_t)s->B) * 18;
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, nsrc * sizeof(double)));
+    hipError_t e = hipMemcpy(tmp, p18, nsrc * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(split_p18_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, nullptr, tmp, s->par, s->par_rp, rows, (int)N1, per_stage);
+        e = hipDeviceSynchronize();
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) { g_err = hipGetErrorString(e); return BROV_ERR_HIP; }
+    s->pplant_stale = true;
+    return BROV_OK;
+}
+extern "C" int brov_plant_set_rp_disturbance_host(brov_solver* s, const double* d) {
+    if (int rc = need_dist6(s, "brov_plant_set_rp_disturbance_host")) return rc;
+    if (!d) { s->prp_plant_set = false; return BROV_OK; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(hipMemcpy(s->prp_plant, d, (size_t)s->B * 2 * sizeof(double), hipMemcpyHostToDevice));
+    s->prp_plant_set = true;
+    return BROV_OK;
+}
+
 extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, const double* y, int ny) {
     if (!s || !y || inst < 0 || inst >= s->B || stage < 0 || stage > s->N || ny < 1 || ny > 16) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
@@ -427,6 +527,9 @@ extern "C" int brov_plant_set_params_host(brov_solver* s, const double* p) {
 }
 // Without explicit plant parameters the plant is the controller's own model: stage-0 parameters, re-read whenever the
 // controller's parameters may have changed (setters, brov_params_device() hand-outs, the EKF's write-back).
+// roll / pitch disturbance moments the plant integrates (6-disturbance variant): its own, else the controller's stage 0, else none
+static const double* plant_rp(const brov_solver* s) { return s->prp_plant_set ? s->prp_plant : (s->dist6 && !s->pplant_set ? s->par_rp : nullptr); }
+static int plant_rp_stride(const brov_solver* s) { return s->prp_plant_set ? 2 : (s->N + 1) * 2; }
 static int ensure_plant_params(brov_solver* s, hipStream_t st) {
     if (!s->pplant_set && s->pplant_stale) {
         hipLaunchKernelGGL(copy_stage0_par_kernel, dim3((s->B * 16 + 255) / 256), dim3(256), 0, st, s->par, s->pplant, s->B, s->N + 1);
@@ -438,7 +541,7 @@ extern "C" int brov_plant_step(brov_solver* s, double dt, int substeps, void* st
     if (!s || !(dt > 0.0) || substeps < 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     ensure_plant_params(s, (hipStream_t)stream);
-    launch_plant(s->x0, s->res, s->pplant, s->B, dt, substeps, nullptr, nullptr, (hipStream_t)stream);
+    launch_plant(s->x0, s->res, s->pplant, plant_rp(s), plant_rp_stride(s), s->B, dt, substeps, nullptr, nullptr, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return BROV_OK;
 }
@@ -480,7 +583,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
         s->yref_shared = true;
         rc = brov_solve_phase(s, st, 0);
         if (dst) hipLaunchKernelGGL(gather_status_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, s->res, dst + (size_t)k * B, (int)B);
-        launch_plant(s->x0, s->res, s->pplant, s->B, dt, substeps, dx ? dx + (size_t)(k + 1) * B * 12 : nullptr,
+        launch_plant(s->x0, s->res, s->pplant, plant_rp(s), plant_rp_stride(s), s->B, dt, substeps, dx ? dx + (size_t)(k + 1) * B * 12 : nullptr,
                      du ? du + (size_t)k * B * 4 : nullptr, st);
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -497,6 +600,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
 extern "C" int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));   // a solve on a non-blocking stream may still be writing the iterate
     const size_t B = s->B, N = s->N;
     if (x) HIPCHK(hipMemcpy(s->x, x, B * (N + 1) * 12 * sizeof(double), hipMemcpyHostToDevice));
     if (u) HIPCHK(hipMemcpy(s->u, u, B * N * 4 * sizeof(double), hipMemcpyHostToDevice));
@@ -518,11 +622,14 @@ extern "C" int brov_get_iterate_host(brov_solver* s, double* x, double* u, doubl
 extern "C" int brov_reset(brov_solver* s) {  // acados_solver_bluerov2.c:797-830: everything to zero
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
     const size_t B = s->B, N = s->N;
     HIPCHK(hipMemset(s->x, 0, B * (N + 1) * 12 * sizeof(double)));
     HIPCHK(hipMemset(s->u, 0, B * N * 4 * sizeof(double)));
     HIPCHK(hipMemset(s->pi, 0, B * N * 12 * sizeof(double)));
     HIPCHK(hipMemset(s->lam, 0, B * N * 8 * sizeof(double)));
+    // the records too: their u0 / thrust is what a failed step holds, and a reset must not hand the previous run's input on
+    HIPCHK(hipMemset(s->res, 0, B * sizeof(brov_result)));
     return BROV_OK;
 }
 
@@ -540,6 +647,7 @@ static DevParams make_params(const brov_solver* s) {
     P.yref = s->yref_shared ? shared_window(s) : s->yref;
     P.yref_stride = s->yref_shared ? 0 : (int64_t)(s->N + 1) * 16;
     P.par = s->par;
+    P.par_rp = s->dist6 ? s->par_rp : nullptr;
     P.x = s->x; P.u = s->u; P.pi = s->pi; P.lam = s->lam;
     P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
@@ -582,6 +690,12 @@ extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phas
 extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
     if (!s || !o || o->N != s->N) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
     if (const char* why = opts_problem(o)) { g_err = std::string("brov_set_opts: ") + why; return BROV_ERR_ARG; }
+    if (o->kernel_path == BROV_PATH_FUSED && !fused_supported(o->N) && !s->ws) {
+        // the windowed kernel's workspace is allocated at create, from the path and batch asked for then
+        g_err = "brov_set_opts: BROV_PATH_FUSED at this horizon needs the windowed kernel's workspace, which this solver was created without "
+                "(created with BROV_PATH_STREAMING, or BROV_PATH_AUTO at a batch of <= 8): create it with BROV_PATH_FUSED";
+        return BROV_ERR_ARG;
+    }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->last_stream));
     s->opts = *o;

@@ -28,6 +28,7 @@ struct DevParams {
     const double* yref;
     int64_t yref_stride;  // doubles between instances (0 when one window is shared)
     const double* par;    // always [B][N+1][16]
+    const double* par_rp; // 6-disturbance model variant: roll / pitch disturbance moments [B][N+1][2]; nullptr = the shipped model
     // iterate
     double* x;
     double* u;
@@ -68,8 +69,8 @@ int windowed_stage_count(int N);          // stages per window
 int windowed_blocks(int N, int B);        // persistent blocks that will be launched on the current device
 size_t windowed_ws_doubles(int N);        // per-block workspace
 void launch_window(const double* traj, int rows, const int* lines, int line0, int B, int N, int ncols, double* out, hipStream_t st);
-void launch_plant(double* x0, const brov_result* res, const double* pplant, int B, double dt, int substeps, double* xlog, double* ulog,
-                  hipStream_t st);
+void launch_plant(double* x0, const brov_result* res, const double* pplant, const double* prp, int rp_stride, int B, double dt, int substeps,
+                  double* xlog, double* ulog, hipStream_t st);   // prp: roll / pitch disturbance moments, instance b at prp + b * rp_stride (or nullptr)
 void launch_candidates(int kind, const double* p0, const double* p1, const double* phase, double t0, double dt, int B, int N,
                        double* out, hipStream_t st);
 

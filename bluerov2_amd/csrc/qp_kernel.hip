@@ -2012,6 +2012,12 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     const int i = active ? g : n - 1;   // index inside the chunk
     const int ig = i0 + i;              // global interval
     const double* __restrict__ ui = P.u + ((size_t)b * N + ig) * NU;
+    // 6-disturbance model variant: this interval's roll / pitch disturbance moments.  One-wave kernels request them ahead of the
+    // staging below (nothing else would cover the round trip); the two-wave kernel has no registers to carry them that far
+    double rp0 = 0.0, rp1 = 0.0;
+    if constexpr (TWO) {
+        if (P.par_rp) { const double* rp = P.par_rp + ((size_t)b * (N + 1) + ig) * 2; rp0 = rp[0]; rp1 = rp[1]; }
+    }
     // the chunk's iterate, parameters, reference and multipliers are contiguous: fetch them with 13 wave-wide 16-byte
     // requests into the (still unused) [A B] area instead of ~90 requests that each touch 20 cache lines, then let every
     // lane pick its interval's operands out of LDS
@@ -2039,11 +2045,11 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     const double* yr = syr + i * NY;
     const double* pil = spi + (i + po) * NX;
     const double* pim1 = spi + (ig > 0 ? i + po - 1 : 0) * NX;
-    double uu[NU], x0r[NX], x1r[NX], yrr[NY], pir[NX], pm1[3];
+    double uu[NU], x0r[NX], yrr[NY], pir[NX], pm1[3];
 #pragma unroll
     for (int j = 0; j < NU; j++) uu[j] = su[i * NU + j];
 #pragma unroll
-    for (int j = 0; j < NX; j++) { x0r[j] = xi[j]; x1r[j] = xi[NX + j]; pir[j] = pil[j]; }
+    for (int j = 0; j < NX; j++) { x0r[j] = xi[j]; pir[j] = pil[j]; }
 #pragma unroll
     for (int j = 0; j < NY; j++) yrr[j] = yr[j];
 #pragma unroll
@@ -2055,7 +2061,11 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
 #pragma unroll
     for (int j = 0; j < NX; j++) yrn[j] = yr[NY + j];   // row i+1 of the staged reference: valid for every interval, used by the last one
     const ModelPar m = make_par(pp);
-    const Wrench w = make_wrench(uu);
+    Wrench w = make_wrench(uu);
+    if constexpr (!TWO) {
+        if (P.par_rp) { const double* rp = P.par_rp + ((size_t)b * (N + 1) + ig) * 2; rp0 = rp[0]; rp1 = rp[1]; }
+    }
+    w.k3 = rp0; w.k4 = rp1;
     // cost gradients of this stage (and of the terminal node from the last interval), kept in LDS for all sweeps, and the
     // stationarity rows of the position columns (exactly e_c).  The L lanes of a group write identical values.
     KktAcc ka;
@@ -2070,7 +2080,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     if (last) {
 #pragma unroll
         for (int k = 0; k < NX; k++) {
-            const double qn = cst[16 + k] * (x1r[k] - yrn[k]);
+            const double qn = cst[16 + k] * (xi[NX + k] - yrn[k]);
             q_s[n * NX + k] = qn;
             if (k < 3) ka.upd(qn - pir[k]);
         }
@@ -2091,7 +2101,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     // b_i and the dynamics gap
 #pragma unroll
     for (int k = 0; k < NX; k++) {
-        const double bk = xn[k] - x1r[k];
+        const double bk = xn[k] - xi[NX + k];   // x_{i+1}: read from the staging copy here, not carried through the integration in registers
         bv_s[i * NX + k] = bk;
         ka.upd(bk);
     }
@@ -2509,7 +2519,9 @@ int windowed_blocks(int N, int B) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rti_window_kernel, 64, windowed_lds_bytes(N)) != hipSuccess || per_cu < 1)
         per_cu = 4;
-    const long long fit = (long long)cus * per_cu;
+    long long fit = (long long)cus * per_cu;
+    // development knob (tests/test_gpu_windowed.py): fewer persistent blocks, so that small batches take several instances per block
+    if (const char* e = getenv("BROV_DEV_WIN_BLOCKS")) { const long long v = atoll(e); if (v >= 1 && v < fit) fit = v; }
     return (int)(B < fit ? B : fit);
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {

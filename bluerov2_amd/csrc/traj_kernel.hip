@@ -81,8 +81,9 @@ void launch_candidates(int kind, const double* p0, const double* p1, const doubl
 #include "bluerov2_model.hpp"
 namespace brov {
 
-__global__ __launch_bounds__(128) void plant_kernel(double* __restrict__ x0, const brov_result* __restrict__ res, const double* __restrict__ pplant, int B,
-                             double dt, int substeps, double* __restrict__ xlog, double* __restrict__ ulog) {
+__global__ __launch_bounds__(128) void plant_kernel(double* __restrict__ x0, const brov_result* __restrict__ res, const double* __restrict__ pplant,
+                             const double* __restrict__ prp, int rp_stride, int B, double dt, int substeps, double* __restrict__ xlog,
+                             double* __restrict__ ulog) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double x[NX], u[NU], k[NX], xs[NX], acc[NX];
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(128) void plant_kernel(double* __restrict__ x0, con
 #pragma unroll
     for (int j = 0; j < NU; j++) u[j] = res[b].u0[j];
     const ModelPar m = make_par(pplant + (size_t)b * NP);
-    const Wrench w = make_wrench(u);
+    Wrench w = make_wrench(u);
+    if (prp) { w.k3 = prp[(size_t)b * rp_stride]; w.k4 = prp[(size_t)b * rp_stride + 1]; }   // 6-disturbance variant
     const double h = dt / substeps;
     StagePoint sp;
     for (int s = 0; s < substeps; s++) {
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(128) void plant_kernel(double* __restrict__ x0, con
     }
 }
 
-void launch_plant(double* x0, const brov_result* res, const double* pplant, int B, double dt, int substeps, double* xlog, double* ulog,
-                  hipStream_t st) {
-    hipLaunchKernelGGL(plant_kernel, dim3((B + 127) / 128), dim3(128), 0, st, x0, res, pplant, B, dt, substeps, xlog, ulog);
+void launch_plant(double* x0, const brov_result* res, const double* pplant, const double* prp, int rp_stride, int B, double dt, int substeps,
+                  double* xlog, double* ulog, hipStream_t st) {
+    hipLaunchKernelGGL(plant_kernel, dim3((B + 127) / 128), dim3(128), 0, st, x0, res, pplant, prp, rp_stride, B, dt, substeps, xlog, ulog);
 }
 
 }  // namespace brov

@@ -51,6 +51,15 @@ def gather_records_uneven(local_bytes, counts, group=None):
     return torch.cat([allb[r * nmax: r * nmax + counts[r] * RECORD_BYTES] for r in range(world)])
 
 
+def padded_to_global(idx, counts):
+    """index into an all-gather of shards padded to max(counts) slots -> index into the concatenated (unpadded) batch"""
+    if idx < 0:
+        return idx
+    nmax = max(counts)
+    r, i = divmod(int(idx), nmax)
+    return int(sum(counts[:r]) + i)
+
+
 def records_to_numpy(rec_bytes):
     return np.frombuffer(rec_bytes.detach().cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
 

@@ -98,6 +98,8 @@ def _load():
         "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double],
         "brov_set_candidate_params_host": [vp, C.c_int, dp, dp, dp], "brov_set_yref_candidates": [vp, C.c_double, C.c_double, vp],
         "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
+        "brov_enable_dist6": [vp, C.c_int], "brov_dist6_enabled": [vp], "brov_set_rp_disturbance_host": [vp, dp, C.c_int],
+        "brov_set_params18_host": [vp, dp, C.c_int], "brov_plant_set_rp_disturbance_host": [vp, dp], "brov_get_rp_disturbance_host": [vp, dp],
     }.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -261,6 +263,37 @@ class BatchSolver:
         return y
 
     # ---- closed loop on the device ---------------------------------------------------------------
+    # ---- 6-disturbance model variant: roll / pitch disturbance moments next to p[16] ---------------------
+    def enable_dist6(self, on=True):
+        self._chk(self._L.brov_enable_dist6(self._h, int(bool(on))), "enable_dist6")
+
+    def set_rp_disturbance(self, d):
+        """d: [2] / [B, 2] (constant over the horizon) or [B, N+1, 2] (per stage): d_phi, d_theta"""
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        if d.shape == (2,):
+            d = np.ascontiguousarray(np.broadcast_to(d, (self.B, 2)))
+        if d.shape == (self.B, 2):
+            self._chk(self._L.brov_set_rp_disturbance_host(self._h, _dp(d), 0), "set_rp_disturbance")
+        else:
+            self._chk(self._L.brov_set_rp_disturbance_host(self._h, _dp(_arr(d, (self.B, self.N + 1, 2))), 1), "set_rp_disturbance")
+
+    def get_rp_disturbance(self):
+        d = np.empty((self.B, self.N + 1, 2))
+        self._chk(self._L.brov_get_rp_disturbance_host(self._h, _dp(d)), "get_rp_disturbance")
+        return d
+
+    def set_params18(self, p18):
+        """the parameter vector of the uncommented 6-disturbance model: [dx dy dz d_phi d_theta d_psi | 12 hydrodynamic], [B, 18] or
+        [B, N+1, 18]"""
+        p18 = np.ascontiguousarray(p18, dtype=np.float64)
+        if p18.shape == (self.B, 18):
+            self._chk(self._L.brov_set_params18_host(self._h, _dp(p18), 0), "set_params18")
+        else:
+            self._chk(self._L.brov_set_params18_host(self._h, _dp(_arr(p18, (self.B, self.N + 1, 18))), 1), "set_params18")
+
+    def set_plant_rp_disturbance(self, d):
+        self._chk(self._L.brov_plant_set_rp_disturbance_host(self._h, None if d is None else _dp(_arr(d, (self.B, 2)))), "set_plant_rp_disturbance")
+
     def set_plant_params(self, p):
         self._chk(self._L.brov_plant_set_params_host(self._h, _dp(_arr(p, (self.B, NP)))), "set_plant_params")
 

@@ -199,6 +199,24 @@ double* brov_u_device(brov_solver* s);
 int brov_get_linearisation_host(brov_solver* s, double* AB /*[B][N][12][16]*/, double* b /*[B][N][12]*/);
 int brov_debug_dump_linearisation(brov_solver* s, int enable);
 
+/* ---- 6-disturbance model variant (BASELINE configs[2] "6 disturbance states") ------------------
+ * The reference's EKF estimates six disturbances (bluerov2_dob.h:200-205), its OCP model takes four: the roll / pitch symbols are
+ * there but commented out (bluerov2_dobmpc/scripts/bluerov2.py:37-38), so the shipped solver has np = 16.  This switch (default
+ * OFF = the shipped model) adds the two terms the way the other four enter their rows (bluerov2.py:123-128):
+ *     dp += d_phi / Ix,   dq += d_theta / Iy            (additive: df/dx and df/du are untouched)
+ * with d_phi, d_theta per instance and stage, next to p[16].  brov_set_params18_host takes the parameter vector the uncommented
+ * model would have, [dx dy dz d_phi d_theta d_psi | added mass 4 | linear damping 4 | quadratic damping 4]; with the variant on,
+ * brov_ekf_apply_to_solver fills all six disturbances from the estimate, and brov_plant_step integrates the controller's stage-0
+ * values unless brov_plant_set_rp_disturbance_host gave the plant its own. */
+int brov_enable_dist6(brov_solver* s, int on);
+int brov_dist6_enabled(const brov_solver* s);
+int brov_set_rp_disturbance_host(brov_solver* s, const double* d /*[B][2] or [B][N+1][2]*/, int per_stage);
+int brov_set_rp_disturbance_device(brov_solver* s, const double* d, int per_stage, void* stream);
+int brov_set_params18_host(brov_solver* s, const double* p18 /*[B][18] or [B][N+1][18]*/, int per_stage);
+double* brov_rp_disturbance_device(brov_solver* s);   /* [B][N+1][2]; NULL while the variant is off */
+int brov_get_rp_disturbance_host(brov_solver* s, double* d /*[B][N+1][2]*/);
+int brov_plant_set_rp_disturbance_host(brov_solver* s, const double* d /*[B][2]; NULL: back to the controller's stage 0*/);
+
 /* argmin of cost over instances with status SUCCESS (config 4 "best-trajectory select"); writes the winning index
  * and its record; runs on the GPU, result copied to HOST */
 int brov_select_best_host(brov_solver* s, int* best_index, brov_result* best);

@@ -54,11 +54,21 @@ def _c(a, shape=None):
     return a
 
 
+def build_native():
+    """-march=native build for the host this runs on (bench.py's cpu_baseline); returns its path, or None if it cannot be built"""
+    so = os.path.join(HERE, "_build", "libbluerov2_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return so if os.path.exists(so) else None
+
+
 class Oracle:
-    def __init__(self):
-        if not os.path.exists(ORACLE_SO):
+    def __init__(self, so_path=None):
+        if so_path is None and not os.path.exists(ORACLE_SO):
             build()
-        self.lib = L = C.CDLL(ORACLE_SO)
+        self.lib = L = C.CDLL(so_path or ORACLE_SO)
         L.orc_default_opts.argtypes = [C.POINTER(OrcOpts), C.c_int, C.c_double]
         L.orc_f.argtypes = [_dp] * 4
         L.orc_jac.argtypes = [_dp] * 5
@@ -70,6 +80,10 @@ class Oracle:
         L.orc_rti_step.restype = C.c_int
         L.orc_rti_step_batch.argtypes = [C.POINTER(OrcOpts), C.c_int] + [_dp] * 7 + [C.c_void_p, C.c_int]
         L.orc_rti_step_batch.restype = C.c_int
+        L.orc_rti_step_batch6.argtypes = [C.POINTER(OrcOpts), C.c_int] + [_dp] * 8 + [C.c_void_p, C.c_int]
+        L.orc_rti_step_batch6.restype = C.c_int
+        L.orc_rk4_6.argtypes = [_dp, _dp, _dp, _dp, C.c_double, _dp]
+        L.orc_f6.argtypes = [_dp] * 5
         L.orc_init_iterate.argtypes = [C.POINTER(OrcOpts)] + [_dp] * 4
         L.orc_thrust_alloc.argtypes = [_dp, _dp]
         L.orc_num_threads.restype = C.c_int
@@ -103,12 +117,6 @@ class Oracle:
         xn, A, B = np.empty(NX), np.empty((NX, NX)), np.empty((NX, NU))
         self.lib.orc_rk4_sens(_p(x), _p(u), _p(p), float(h), _p(xn), _p(A), _p(B))
         return xn, A, B
-
-    def rk4(self, x, u, p, h):
-        x, u, p = _c(x, (NX,)), _c(u, (NU,)), _c(p, (NP,))
-        xn = np.empty(NX)
-        self.lib.orc_rk4(_p(x), _p(u), _p(p), float(h), _p(xn))
-        return xn
 
     def init_iterate(self, o, nb=None):
         N = o.N
@@ -153,16 +161,34 @@ class Oracle:
             out.update(A=A, B=B, b=b)
         return out
 
-    def rti_step_batch(self, o, x0, yref, p, x, u, pi, lam, nthreads=0, res_prev=None):
-        """res_prev: the previous tick's records (their u0 is what a failed step holds); default zeros"""
+    def rk4(self, x, u, p, h, drp=None):
+        x, u, p = _c(x, (NX,)), _c(u, (NU,)), _c(p, (NP,))
+        xn = np.empty(NX)
+        if drp is None:
+            self.lib.orc_rk4(_p(x), _p(u), _p(p), float(h), _p(xn))
+        else:
+            self.lib.orc_rk4_6(_p(x), _p(u), _p(p), _p(_c(drp, (2,))), float(h), _p(xn))
+        return xn
+
+    def f6(self, x, u, p, drp):
+        x, u, p, drp = _c(x, (NX,)), _c(u, (NU,)), _c(p, (NP,)), _c(drp, (2,))
+        out = np.empty(NX)
+        self.lib.orc_f6(_p(x), _p(u), _p(p), _p(drp), _p(out))
+        return out
+
+    def rti_step_batch(self, o, x0, yref, p, x, u, pi, lam, nthreads=0, res_prev=None, drp=None):
+        """res_prev: the previous tick's records (their u0 is what a failed step holds); default zeros.  drp: roll / pitch
+        disturbance moments [nb, N+1, 2] of the 6-disturbance model variant (None = the shipped model)"""
         N = o.N
         nb = x0.shape[0]
+        if drp is not None:
+            drp = _c(drp, (nb, N + 1, 2))
         x0, yref, p = _c(x0, (nb, NX)), _c(yref, (nb, N + 1, NY)), _c(p, (nb, N + 1, NP))
         for a, s in ((x, (nb, N + 1, NX)), (u, (nb, N, NU)), (pi, (nb, N, NX)), (lam, (nb, N, 8))):
             assert a.dtype == np.float64 and a.flags.c_contiguous and a.shape == s, (a.shape, s)
         res = np.zeros(nb, dtype=RESULT_DTYPE) if res_prev is None else np.array(res_prev, dtype=RESULT_DTYPE, copy=True)
-        worst = self.lib.orc_rti_step_batch(C.byref(o), nb, _p(x0), _p(yref), _p(p), _p(x), _p(u), _p(pi), _p(lam),
-                                            res.ctypes.data, int(nthreads))
+        worst = self.lib.orc_rti_step_batch6(C.byref(o), nb, _p(x0), _p(yref), _p(p), None if drp is None else _p(drp), _p(x), _p(u),
+                                             _p(pi), _p(lam), res.ctypes.data, int(nthreads))
         return worst, res
 
     def thrust_alloc(self, u0):

@@ -1,7 +1,8 @@
 /* tests/shim_caller.c -- a C caller written against the acados-shaped drop-in headers (include/acados_shim) that makes the
  * same sequence of calls as the reference's control tick (BLUEROV2_DOB::solve, bluerov2_dobmpc/src/bluerov2_dob.cpp:306-388):
  * lbx/ubx <- x0, update_params for stages 0..N, yref for stages 0..N, solve, status / inf_norm_res / time_tot / u0.
- * Inputs come from a binary file written by the test (x0[12], p[16], nticks, yref[nticks][N+1][16]); results go to stdout. */
+ * Inputs come from a binary file written by the test (x0[12], p[16], nticks, yref[nticks][N+1][16]); results go to stdout.
+ * A second argument "F" appends a failed step (NaN measurement) and a recovery tick. */
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -49,6 +50,24 @@ int main(int argc, char** argv) {
                cpu_time, u0[0], u0[1], u0[2], u0[3], x1[0], x1[1], x1[2]);
     }
     fclose(f);
+    if (argc >= 3 && argv[2][0] == 'F') {
+        /* a failed step: a sensor glitch (NaN in the measured state) -> status 1.  The node publishes thrusts from the "u" getter
+         * whatever the status (bluerov2_dob.cpp:375-395): it must see the last successfully computed input, as with acados. */
+        double bad[BLUEROV2_NX], u0[BLUEROV2_NU];
+        for (int j = 0; j < BLUEROV2_NX; j++) bad[j] = x0[j];
+        bad[3] = 0.0 / 0.0;
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", bad);
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", bad);
+        int st = bluerov2_acados_solve(mpc_capsule);
+        ocp_nlp_out_get(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_out, 0, "u", (void*)u0);
+        printf("FAILED status %d u0 %.17g %.17g %.17g %.17g\n", st, u0[0], u0[1], u0[2], u0[3]);
+        /* ... and the next tick with a sane measurement solves again */
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", x0);
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", x0);
+        st = bluerov2_acados_solve(mpc_capsule);
+        ocp_nlp_out_get(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_out, 0, "u", (void*)u0);
+        printf("RECOVERED status %d u0 %.17g %.17g %.17g %.17g\n", st, u0[0], u0[1], u0[2], u0[3]);
+    }
     bluerov2_acados_print_stats(mpc_capsule);
     /* misuse that must not kill the process */
     int rc = bluerov2_acados_custom_update(mpc_capsule, NULL, 0);

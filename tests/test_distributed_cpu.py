@@ -125,6 +125,23 @@ def test_bench_spawns_its_own_ranks_from_a_plain_shell():
     assert sb["records_gathered"] == 128 and sb["index"] == sb["expected_index"] and sb["index"] >= 64   # winner lives on rank 1
 
 
+@pytest.mark.parametrize("world,cfg,total,per_rank", [(8, 4, 65536, [8192] * 8), (4, 5, 32768, [8192] * 4), (3, 5, 32768, [10923, 10923, 10922])])
+def test_strong_scaling_shards_the_configs_total(world, cfg, total, per_rank):
+    """--scaling strong: BASELINE configs[3] = 65 536 candidates and configs[4] = 32 768 instances are TOTALS split over the ranks
+    (round 2's bench gave every rank the per-GPU batch whatever the world size).  Launcher dry-runs at the world sizes the driver
+    uses, plus an uneven split: every rank seen, every record gathered (shards padded to the largest with never-selectable
+    slots), the arg-min lands on the expected global index."""
+    pr, out = _run_bench(["--gpus", str(world), "--config", str(cfg), "--scaling", "strong", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    assert len(out) == 1
+    o = out[0]
+    assert o["n_gpus"] == world and o["ranks_seen"] == list(range(world)) and o["scaling"] == "strong"
+    assert o["config"]["total_instances"] == total and o["config"]["instances_per_rank"] == per_rank
+    sb = o["select_best"]
+    assert sb["records_gathered"] == total and sb["record_slots_gathered"] == world * max(per_rank)
+    assert sb["index"] == sb["expected_index"]
+
+
 def test_bench_under_the_drivers_torchrun_command_line():
     """the round contract's launch form: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
     port = _free_port()

@@ -159,24 +159,28 @@ def test_iterate_outside_bounds_is_pulled_back(ba, oracle, golden_traj, path):
     assert np.abs(r["kkt"] - ro["kkt"]).max() < 1e-6 * (1 + ro["kkt"].max())  # feasibility violation enters the KKT norm (20, 15)
 
 
-def test_iteration_cap_reports_maxiter_and_still_steps(ba, oracle, golden_traj):
-    N, B = 20, 6
-    x0, circ = _inputs(golden_traj, B, seed=4, big=4.0)
-    # one Newton system: a single active-set try, which the far-off instances' QPs do not finish with (round 3 counts tries and
-    # interior-point iterations alike; with 2 every one of these QPs is solved)
-    s = ba.BatchSolver(B, ba.SolverOptions(N, qp_iter_max=1))
+@pytest.mark.parametrize("N,big,cap", [(20, 4.0, 1), (40, 6.0, 7)])
+def test_iteration_cap_reports_maxiter_and_still_steps(ba, oracle, golden_traj, N, big, cap):
+    """qp_iter_max counts Newton systems (active-set tries + interior-point iterations).  cap = 1: a single try, which these QPs
+    (inputs limited to +-8, states metres off) do not finish with -- the step is the last active-set point clamped into the box;
+    cap = 7: the limit falls into the interior-point loop (5 tries, 2 iterations) -- the step is the interior-point iterate."""
+    B = 8
+    x0, circ = _inputs(golden_traj, B, seed=4, big=big)
+    kw = dict(qp_iter_max=cap, lbu=[-8.0] * 4, ubu=[8.0] * 4)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, **kw))
     s.set_x0(x0); s.set_params(ba.P_NOMINAL)
-    op = oracle.opts(N, qp_iter_max=1)
+    op = oracle.opts(N, **kw)
     it = oracle.init_iterate(op, B)
     for k in range(2):
         s.set_yref(circ[k:k + N + 1]); s.solve()
         _, ro = _oracle_step(oracle, op, x0, circ[k:k + N + 1], ba.P_NOMINAL, it)
-    r = s.results()
-    assert np.array_equal(r["status"], ro["status"]) and (r["status"] == 2).any()
-    assert np.all(r["qp_iter"][r["status"] == 2] == 1)
-    gu = s.get_iterate()[1]
-    assert np.abs(gu - it[1]).max() < 1e-7  # same truncated point: the last active-set point, clamped into the box
-    assert gu.max() <= 50.0 and gu.min() >= -50.0
+        r = s.results()
+        assert np.array_equal(r["status"], ro["status"]) and (r["status"] == 2).any(), (k, r["status"], ro["status"])
+        assert np.array_equal(r["qp_iter"], ro["qp_iter"]) and np.all(r["qp_iter"][r["status"] == 2] == cap)
+        gu = s.get_iterate()[1]
+        assert np.abs(gu - it[1]).max() < 1e-6  # same truncated point
+        assert gu.max() <= 8.0 and gu.min() >= -8.0
+        s.set_iterate(x=it[0], u=it[1], pi=it[2], lam=it[3])
 
 
 def test_runtime_option_change_and_reset(ba, oracle, golden_traj):

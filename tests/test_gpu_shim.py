@@ -43,6 +43,33 @@ def test_control_tick_call_sequence_matches_known_answers(tmp_path, golden_rti, 
     assert "custom_update 1" in r.stdout and "free 0" in r.stdout
 
 
+@pytest.mark.parametrize("policy", ["keep", "restart"])
+def test_failed_step_leaves_the_last_good_input_in_the_getter(tmp_path, golden_rti, policy):
+    """acados leaves nlp_out untouched when a step fails, and the node publishes thrusts from ocp_nlp_out_get(.., 0, "u") whatever
+    the status was (bluerov2_dob.cpp:375-395): after a failed step the getter must hold the last successfully computed input --
+    under the drop-in's default (keep the iterate, as acados does) and under BROV_ON_FAILURE=restart (cold start at the measurement)."""
+    g, name = golden_rti, "circle_N80"
+    exe = tmp_path / "shim_caller"
+    subprocess.check_call(["gcc", "-O2", f"-I{INC}", "-o", str(exe), os.path.join(ROOT, "tests", "shim_caller.c"),
+                           f"-L{LIBDIR}", "-lacados_ocp_solver_bluerov2", f"-Wl,-rpath,{LIBDIR}"])
+    nt = 2
+    blob = np.concatenate([g[f"{name}/x0_meas"], g[f"{name}/p"][0], [float(nt)]] + [g[f"{name}/yref{k}"].ravel() for k in range(nt)])
+    inp = tmp_path / "in.bin"
+    inp.write_bytes(blob.astype(np.float64).tobytes())
+    env = dict(os.environ)
+    env.pop("BROV_ON_FAILURE", None)
+    if policy == "restart":
+        env["BROV_ON_FAILURE"] = "restart"
+    r = subprocess.run([str(exe), str(inp), "F"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    last_good = np.array([float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("TICK")][-1].split()[9:13]])
+    failed = [ln for ln in r.stdout.splitlines() if ln.startswith("FAILED")][0].split()
+    assert int(failed[2]) == 1                                                      # ACADOS_NAN_DETECTED
+    assert np.array_equal(np.array([float(v) for v in failed[4:8]]), last_good)     # the held input, bit for bit
+    rec = [ln for ln in r.stdout.splitlines() if ln.startswith("RECOVERED")][0].split()
+    assert int(rec[2]) == 0 and np.all(np.isfinite([float(v) for v in rec[4:8]]))
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "main_bluerov2_shim")),
                     reason="reference example not prebuilt (oracle/_ref/main_bluerov2_shim)")
 def test_reference_generated_example_runs_on_the_shim(golden_rti):

@@ -89,3 +89,17 @@ def test_against_compiled_reference_on_fresh_points(oracle):
         xn, A, B = oracle.rk4_sens(x, u, p, 0.05)
         xr, Ar, Br = ref.rk4_sens(x, u, p, 0.05)
         assert max(_rel(xn, xr), _rel(A, Ar), _rel(B, Br)) < RTOL
+
+
+def test_six_disturbance_variant_is_the_shipped_model_plus_two_additive_terms(oracle):
+    """SURVEY.md 8 f-4: d_phi, d_theta enter dp, dq the way the other four disturbances enter their rows (bluerov2.py:123-128;
+    the two symbols are commented out at :37-38): f6 = f + [0.., d_phi / Ix, d_theta / Iy, 0], so A and B are untouched."""
+    rng = np.random.default_rng(5)
+    P = np.array([3.0, -2.0, 1.0, 0.5, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
+    for _ in range(16):
+        x = rng.normal(size=12) * 0.3; u = rng.uniform(-20, 20, 4); d = rng.uniform(-2, 2, 2)
+        f0, f6 = oracle.f(x, u, P), oracle.f6(x, u, P, d)
+        exp = f0.copy(); exp[9] += d[0] / 0.3; exp[10] += d[1] / 0.63
+        assert np.abs(f6 - exp).max() < 1e-13
+        assert np.array_equal(oracle.f6(x, u, P, np.zeros(2)), f0)
+        assert not np.allclose(oracle.rk4(x, u, P, 0.05, drp=d), oracle.rk4(x, u, P, 0.05))
