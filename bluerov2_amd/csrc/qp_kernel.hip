@@ -891,7 +891,9 @@ __device__ void adjoint(const Inst& I, const double* varr, double* garr, double*
 // window, a verbatim copy of the slice, so that parking and fetching are single contiguous transfers.  WM_LIN = the prefix
 // [A B] | b | q | r (184 L + 12 doubles; what the backward, roll-out and adjoint sweeps read), WM_GAIN = K^T | kff (the rest;
 // what the forward sweep reads in addition), WM_DX = the state steps (flat array of the whole horizon in HBM).
-enum : unsigned { WM_LIN = 1, WM_GAIN = 2, WM_DX = 4 };
+// (round 3) the prefix is tracked and fetched in three parts, so that a sweep moves only the arrays it reads: the forward sweep
+// [A B] | b and K^T | kff (not q | r), the roll-out [A B] | b, the adjoint sweeps [A B] and q | r (not b)
+enum : unsigned { WM_AB = 1, WM_BV = 2, WM_QR = 4, WM_LIN = 7, WM_GAIN = 8, WM_DX = 16 };
 struct Win {
     int nc, Lc;         // number of windows, stages per window (the last one may be shorter)
     int cur;            // resident window
@@ -965,9 +967,21 @@ __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, 
     const int i0 = I.i0, n = I.N, lane = I.lane, L = W.Lc;
     const double* img = W.img + (size_t)c * win_img_doubles(L);
     __syncthreads();   // single wave: every lane is done with the slice's previous content, earlier stores are issued
-    if ((need & (WM_LIN | WM_GAIN)) == (WM_LIN | WM_GAIN)) win_fetch(img, W.lds, win_img_doubles(L), lane);
-    else if (need & WM_LIN) win_fetch(img, W.lds, win_lin_doubles(L), lane);
-    else if (need & WM_GAIN) win_fetch(img + win_off_kt(L), W.lds + win_off_kt(L), 52 * L, lane);
+    {   // the parts of the image in its order, neighbouring needed parts merged into one contiguous run
+        const int beg[5] = {0, win_off_bv(L), win_off_q(L), win_off_kt(L), win_img_doubles(L)};
+        const unsigned bit[4] = {WM_AB, WM_BV, WM_QR, WM_GAIN};
+        int run0 = -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool want = (need & bit[k]) != 0;
+            if (want && run0 < 0) run0 = beg[k];
+            if (run0 >= 0 && (!want || k == 3)) {
+                const int end = want ? beg[k + 1] : beg[k];
+                win_fetch(img + run0, W.lds + run0, end - run0, lane);
+                run0 = -1;
+            }
+        }
+    }
     if (need & WM_DX) win_fetch(I.dxb + i0 * NX, W.lds + win_off_dx(L), (n + 1) * NX, lane);
     if (vh_src) win_fetch(vh_src + i0 * 4, W.lds + win_off_vh(L), n * 4, lane);
     __builtin_amdgcn_s_waitcnt(0);
@@ -1026,7 +1040,7 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
         double uw[2] = {0.0, 0.0}, un[2] = {0.0, 0.0};
         if (cst) load_u(0, uw);
         for (int c = 0; c < W->nc; c++) {
-            win_need(I, *W, c, WM_LIN | WM_GAIN, nullptr);
+            win_need(I, *W, c, WM_AB | WM_BV | WM_GAIN, nullptr);
             if (cst && c + 1 < W->nc) load_u(c + 1, un);
             fwd_chunk<3>(I, xx);
             __syncthreads();
@@ -1060,7 +1074,7 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
         d4 xx = d0;
         bool bad = false;
         for (int c = 0; c < W->nc; c++) {
-            win_need(I, *W, c, WM_LIN, varr);
+            win_need(I, *W, c, WM_AB | WM_BV, varr);
             roll_chunk<3>(I, xx, varr);
             __syncthreads();
             win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
@@ -1080,7 +1094,7 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
         wave_fence();
         d4 atpi = {0, 0, 0, 0};
         for (int c = W->nc - 1; c >= 0; c--) {
-            win_need(I, *W, c, WM_LIN | WM_DX, varr);
+            win_need(I, *W, c, WM_AB | WM_QR | WM_DX, varr);
             adj_chunk<COMMIT, 3>(I, atpi, varr, garr, pi_out);
             W->valid &= ~WM_GAIN;   // multipliers / input gradient were staged in the K^T / feed-forward areas
             __syncthreads();
@@ -1127,7 +1141,7 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
             yr[t] = I.yref[(size_t)(i0 + i) * 16 + cc];
             wx[t] = (i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc];
         }
-        win_need(I, W, c, WM_LIN | WM_DX, vfin);
+        win_need(I, W, c, WM_AB | WM_QR | WM_DX, vfin);
         adj_chunk<true, 3>(I, atpi, vfin, nullptr, nullptr);
         W.valid &= ~WM_GAIN;   // multipliers / input gradient are staged in the K^T / feed-forward areas
         __syncthreads();
@@ -2474,7 +2488,9 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
             bwd_chunk<true, 3, false, true>(I, S);
             __syncthreads();
             const unsigned long long t2 = P.dbg ? __builtin_readcyclecounter() : 0;
-            win_flush(W.img + (size_t)c * win_img_doubles(Lc), smem, win_img_doubles(Lc), lane);   // park the window: one contiguous image
+            // park the window: one contiguous image.  Window 0 keeps its K^T | kff in LDS only: the forward sweep starts on the resident
+            // copy, and every later factor sweep parks its own gains
+            win_flush(W.img + (size_t)c * win_img_doubles(Lc), smem, c == 0 ? win_off_kt(Lc) : win_img_doubles(Lc), lane);
             if (P.dbg) { const unsigned long long t3 = __builtin_readcyclecounter(); t_lin += t1 - t0; t_bwd += t2 - t1; t_fl += t3 - t2; }
         }
         if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + 7] = (t_lin & 0xFFFFF) | ((t_bwd & 0xFFFFF) << 20) | ((t_fl & 0xFFFFF) << 40);
