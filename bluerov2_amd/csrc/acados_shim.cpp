@@ -187,12 +187,11 @@ int bluerov2_acados_update_params_sparse(bluerov2_solver_capsule* c, int stage, 
     return 0;
 }
 
-static int push_inputs(brov_shim_state* s) {
+// options and a caller-written iterate (rare) go through their blocking setters; x0 / reference / parameters -- what the node
+// rewrites every tick -- ride with the solve itself (brov_tick_host: one pinned staging buffer, asynchronous copies, one wait)
+static int push_rare_inputs(brov_shim_state* s) {
     int rc = BROV_OK;
     if (s->dirty_opts) { rc = brov_set_opts(s->solver, &s->opts); s->dirty_opts = false; if (rc) return rc; }
-    if (s->dirty_x0) { rc = brov_set_x0_host(s->solver, s->x0.data()); s->dirty_x0 = false; if (rc) return rc; }
-    if (s->dirty_yref) { rc = brov_set_yref_host(s->solver, s->yref.data(), 0); s->dirty_yref = false; if (rc) return rc; }
-    if (s->dirty_par) { rc = brov_set_params_host(s->solver, s->par.data(), 1); s->dirty_par = false; if (rc) return rc; }
     if (s->dirty_iter) {
         rc = brov_set_iterate_host(s->solver, s->x.data(), s->u.data(), s->pi.data(), s->lam.data());
         s->dirty_iter = false;
@@ -205,10 +204,13 @@ int ocp_nlp_solve(ocp_nlp_solver* solver, ocp_nlp_in*, ocp_nlp_out* out) {  // w
     brov_shim_state* s = solver ? solver->shim : nullptr;
     if (!s) return ACADOS_QP_FAILURE;
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = push_inputs(s);
-    if (rc == BROV_OK) rc = brov_solve_phase(s->solver, nullptr, s->rti_phase);
+    int rc = push_rare_inputs(s);
     brov_result r{};
-    if (rc == BROV_OK) rc = brov_get_results_host(s->solver, &r);
+    if (rc == BROV_OK) {
+        rc = brov_tick_host(s->solver, s->dirty_x0 ? s->x0.data() : nullptr, s->dirty_yref ? s->yref.data() : nullptr,
+                            s->dirty_par ? s->par.data() : nullptr, s->rti_phase, &r);
+        if (rc == BROV_OK) s->dirty_x0 = s->dirty_yref = s->dirty_par = false;
+    }
     if (rc != BROV_OK) {
         std::fprintf(stderr, "bluerov2_acados_solve: MI355X solver error %d: %s\n", rc, brov_last_error());
         return ACADOS_QP_FAILURE;
@@ -356,6 +358,9 @@ void ocp_nlp_out_get(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_out* out, int stage
     double* v = (double*)value;
     if (!std::strcmp(field, "kkt_norm_inf")) { *v = out->inf_norm_res; return; }
     if (stage < 0 || stage > s->N) return;
+    // the node's per-tick read (bluerov2_dob.cpp:388: "u" of stage 0) is answered from the result record of the last solve: after a
+    // successful step its u0 IS the new first input, after a failed one the held input (below) -- no copy of the iterate off the device
+    if (stage == 0 && !std::strcmp(field, "u") && !s->iter_host_valid && s->rti_phase != 1) { std::memcpy(v, s->last.u0, 4 * sizeof(double)); return; }
     pull_iterate(s);
     if (!std::strcmp(field, "x")) std::memcpy(v, &s->x[(size_t)stage * 12], 12 * sizeof(double));
     else if (!std::strcmp(field, "u")) {

@@ -68,6 +68,9 @@ struct brov_solver {
     int win_blocks = 0;
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
+    hipStream_t tick_stream = nullptr;   // brov_tick_host: the solver's own stream and pinned staging buffer
+    double* pin = nullptr;
+    size_t pin_doubles = 0;
 };
 
 extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
@@ -230,6 +233,8 @@ extern "C" void brov_destroy(brov_solver* s) {
     for (void* p : s->allocs) hipFree(p);
     if (s->traj) hipFree(s->traj);
     if (s->dbg) hipFree(s->dbg);
+    if (s->pin) hipHostFree(s->pin);
+    if (s->tick_stream) hipStreamDestroy(s->tick_stream);
     for (int k = 0; k < 3; k++)
         if (s->ev[k]) hipEventDestroy(s->ev[k]);
     delete s;
@@ -687,6 +692,46 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     return BROV_OK;
 }
 extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phase(s, stream, 0); }
+
+// One control tick with the fewest host round trips (what the acados-shaped drop-in calls per bluerov2_acados_solve): the inputs that
+// changed go through ONE pinned staging buffer and asynchronous copies on the solver's own stream, the step is enqueued behind them,
+// the result records come back the same way, and the host waits once.  The separate setters + brov_solve + brov_get_results_host
+// cost five blocking pageable copies and three synchronisations per tick -- 0.2 .. 0.4 ms at batch 1, more than the kernels.
+extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
+                              brov_result* res) {
+    if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const size_t B = s->B, N1 = s->N + 1;
+    const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8;
+    if (!s->tick_stream) HIPCHK(hipStreamCreateWithFlags(&s->tick_stream, hipStreamNonBlocking));
+    if (s->pin_doubles < n_x0 + n_y + n_p + n_r) {
+        if (s->pin) hipHostFree(s->pin);
+        s->pin = nullptr; s->pin_doubles = 0;
+        HIPCHK(hipHostMalloc((void**)&s->pin, (n_x0 + n_y + n_p + n_r) * sizeof(double), hipHostMallocDefault));
+        s->pin_doubles = n_x0 + n_y + n_p + n_r;
+    }
+    hipStream_t st = s->tick_stream;
+    if (s->last_stream != st) HIPCHK(hipStreamSynchronize(s->last_stream));   // an earlier solve on the caller's stream
+    double* px = s->pin; double* py = px + n_x0; double* pp = py + n_y; double* pr = pp + n_p;
+    if (x0) { std::memcpy(px, x0, n_x0 * sizeof(double)); HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, st)); }
+    if (yref_shared) {
+        std::memcpy(py, yref_shared, n_y * sizeof(double));
+        HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, st));
+        s->yref_view = nullptr;
+        s->yref_shared = true;
+    }
+    if (par_stage) {
+        std::memcpy(pp, par_stage, n_p * sizeof(double));
+        HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, st));
+        s->pplant_stale = true;
+    }
+    if (int rc = brov_solve_phase(s, st, rti_phase)) return rc;
+    HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (res) std::memcpy(res, pr, B * sizeof(brov_result));
+    return BROV_OK;
+}
+
 extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
     if (!s || !o || o->N != s->N) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
     if (const char* why = opts_problem(o)) { g_err = std::string("brov_set_opts: ") + why; return BROV_ERR_ARG; }

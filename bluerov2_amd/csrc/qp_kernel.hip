@@ -213,14 +213,43 @@ __device__ __forceinline__ double fast_rcp(double d) {
 
 // acc += a * (src of lane K of this lane's 16-lane row): v_fmac_f64_dpp with row_newbcast, the one DPP control gfx950 has for
 // 64-bit operands.  The broadcast costs nothing beyond the FMA (5.3 cycles against 4.9, scripts/dev/dpp_fmac_rate.hip) -- a
-// v_readlane pair into SGPRs costs 8 plus the SGPR hazard.  FIRST = the source register was written by the previous VALU
-// instruction: a DPP read needs two wait states behind a VALU write, and the compiler does not see into inline assembly.
-template <int K, bool FIRST = false>
-__device__ __forceinline__ void fmac_bc(double& acc, double src, double a) {
-    if constexpr (FIRST)
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
-    else
-        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(a), "n"(K));
+// v_readlane pair into SGPRs costs 8 plus the SGPR hazard.  A DPP read needs two wait states behind a VALU write of the register
+// it reads, and the compiler's hazard recogniser does not see into inline assembly: round 2 issued one asm statement per product
+// with an s_nop in front of the first one only, which left any VALU write the compiler might place between two of them (a copy,
+// an AGPR reload of a spilled source) unguarded.  A whole chain is now ONE asm block behind one s_nop: nothing can be scheduled
+// into it, and the source register is not written inside it.
+//   fmac_bc12: d[c & 3] += m[c] * src@lane c, c = 0..11 (four independent chains of three: a dependent FP64 DPP operation issues
+//              ~13 cycles behind its producer, an independent one after ~5)
+//   fmac_bc4 : da += k0 * src@lane 12 + k1 * src@lane 13,  db += k2 * src@lane 14 + k3 * src@lane 15   (issue order 12, 14, 13, 15)
+__device__ __forceinline__ void fmac_bc12(double& d0, double& d1, double& d2, double& d3, double src, double m0, double m1, double m2,
+                                          double m3, double m4, double m5, double m6, double m7, double m8, double m9, double m10,
+                                          double m11) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7), "v"(m8), "v"(m9), "v"(m10), "v"(m11));
+}
+__device__ __forceinline__ void fmac_bc4(double& da, double& db, double src, double k0, double k1, double k2, double k3) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, %3 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %2, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %4 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %2, %6 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(da), "+v"(db)
+        : "v"(src), "v"(k0), "v"(k1), "v"(k2), "v"(k3));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -373,12 +402,10 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
         const int i = N - 1 - kk;
         const double l = in.pb + pcur;                        // lanes 12..15: a finite don't-care value, never broadcast
         double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-        fmac_bc<0, true>(d0, l, in.m[0]); fmac_bc<1>(d1, l, in.m[1]); fmac_bc<2>(d2, l, in.m[2]); fmac_bc<3>(d3, l, in.m[3]);
-        fmac_bc<4>(d0, l, in.m[4]); fmac_bc<5>(d1, l, in.m[5]); fmac_bc<6>(d2, l, in.m[6]); fmac_bc<7>(d3, l, in.m[7]);
-        fmac_bc<8>(d0, l, in.m[8]); fmac_bc<9>(d1, l, in.m[9]); fmac_bc<10>(d2, l, in.m[10]); fmac_bc<11>(d3, l, in.m[11]);
+        fmac_bc12(d0, d1, d2, d3, l, in.m[0], in.m[1], in.m[2], in.m[3], in.m[4], in.m[5], in.m[6], in.m[7], in.m[8], in.m[9], in.m[10], in.m[11]);
         const double g = (ecol ? l : (d0 + d1) + (d2 + d3)) + (rowx ? in.q : in.rt);   // columns 0..2 of [A B] are e_k
         double t0 = 0.0, t1 = 0.0;                            // column k of (gain | M) against g_u = lanes 12..15 of g
-        fmac_bc<12, true>(t0, g, in.ks[0]); fmac_bc<13>(t1, g, in.ks[1]); fmac_bc<14>(t0, g, in.ks[2]); fmac_bc<15>(t1, g, in.ks[3]);
+        fmac_bc4(t0, t1, g, in.ks[0], in.ks[1], in.ks[2], in.ks[3]);
         const double t = t0 + t1;
         lds_f64* kp = rowx ? I.lds_tr + 16 : I.lds_kff + i * 4 + ku;   // rows 12..15: M g_u -> kff = -M g_u; the others park
         *kp = -t;
@@ -664,13 +691,10 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
             // (measured: 65 cycles per stage for the B v chain), an independent one after ~5.  Four chains of three for the 12-term
             // products, a two-level sum, two chains of two for B v: 8 operations deep (three chains of four + serial B v: 10).
             double d0 = in.cv, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-            fmac_bc<0, true>(d0, xcur, m0); fmac_bc<1>(d1, xcur, m1); fmac_bc<2>(d2, xcur, m2); fmac_bc<3>(d3, xcur, in.m[3]);
-            fmac_bc<4>(d0, xcur, in.m[4]); fmac_bc<5>(d1, xcur, in.m[5]); fmac_bc<6>(d2, xcur, in.m[6]); fmac_bc<7>(d3, xcur, in.m[7]);
-            fmac_bc<8>(d0, xcur, in.m[8]); fmac_bc<9>(d1, xcur, in.m[9]); fmac_bc<10>(d2, xcur, in.m[10]); fmac_bc<11>(d3, xcur, in.m[11]);
+            fmac_bc12(d0, d1, d2, d3, xcur, m0, m1, m2, in.m[3], in.m[4], in.m[5], in.m[6], in.m[7], in.m[8], in.m[9], in.m[10], in.m[11]);
             const double dot = (d0 + d1) + (d2 + d3);   // rows 12..15: v_m = K x + kff; rows 0..11: A x + b
             double xa = dot, xb = 0.0;                  // + B v, the inputs v_m out of lanes 12..15 of the same register
-            fmac_bc<12, true>(xa, dot, in.b4[0]); fmac_bc<14>(xb, dot, in.b4[2]);
-            fmac_bc<13>(xa, dot, in.b4[1]); fmac_bc<15>(xb, dot, in.b4[3]);
+            fmac_bc4(xa, xb, dot, in.b4[0], in.b4[1], in.b4[2], in.b4[3]);
             const double xn = xa + xb;
             out0[i * ostr] = rowx ? xn : dot;
             xcur = xn;
@@ -900,6 +924,9 @@ struct Win {
     unsigned valid;     // parts of the resident window that are valid in LDS
     double* lds;        // slice base (generic pointer)
     double* img;        // parked images of this block: nc x img_doubles(Lc)
+#ifdef BROV_DBG_WIN
+    unsigned long long t_fetch = 0, n_fetch = 0;   // development build: cycles spent waiting for window fetches, their number
+#endif
     bool nan, feas;     // set by the forward / roll-out wrappers: a NaN among the inputs / state steps they produced; all inputs of
                         // the last forward sweep inside their bounds (wave-uniform)
 };
@@ -967,6 +994,9 @@ __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, 
     const int i0 = I.i0, n = I.N, lane = I.lane, L = W.Lc;
     const double* img = W.img + (size_t)c * win_img_doubles(L);
     __syncthreads();   // single wave: every lane is done with the slice's previous content, earlier stores are issued
+#ifdef BROV_DBG_WIN
+    const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
     {   // the parts of the image in its order, neighbouring needed parts merged into one contiguous run
         const int beg[5] = {0, win_off_bv(L), win_off_q(L), win_off_kt(L), win_img_doubles(L)};
         const unsigned bit[4] = {WM_AB, WM_BV, WM_QR, WM_GAIN};
@@ -986,6 +1016,9 @@ __device__ __forceinline__ void win_need(Inst& I, Win& W, int c, unsigned mask, 
     if (vh_src) win_fetch(vh_src + i0 * 4, W.lds + win_off_vh(L), n * 4, lane);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+#ifdef BROV_DBG_WIN
+    if (need & (WM_LIN | WM_GAIN)) { W.t_fetch += __builtin_readcyclecounter() - tf0; W.n_fetch++; }
+#endif
     W.valid |= mask;
 }
 
@@ -1040,7 +1073,9 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
         double uw[2] = {0.0, 0.0}, un[2] = {0.0, 0.0};
         if (cst) load_u(0, uw);
         for (int c = 0; c < W->nc; c++) {
-            win_need(I, *W, c, WM_AB | WM_BV | WM_GAIN, nullptr);
+            // (the last window also takes q | r along: the adjoint sweep that follows starts on it, and a separate fetch of those 332
+            // doubles would cost a whole round trip)
+            win_need(I, *W, c, c == W->nc - 1 ? (WM_LIN | WM_GAIN) : (WM_AB | WM_BV | WM_GAIN), nullptr);
             if (cst && c + 1 < W->nc) load_u(c + 1, un);
             fwd_chunk<3>(I, xx);
             __syncthreads();
@@ -2499,8 +2534,14 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
         W.cur = -1;
         win_select(I, W, 0);
         W.valid = WM_LIN | WM_GAIN;   // window 0 is resident, complete
+#ifdef BROV_DBG_WIN
+        W.t_fetch = 0; W.n_fetch = 0;
+#endif
 #if !defined(BROV_WIN_EXP) || BROV_WIN_EXP != 1
         qp_body<3>(P, I, b, part, nanp, &W, S.ok);
+#endif
+#ifdef BROV_DBG_WIN
+        if (P.dbg && lane == 0) { P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 3] = W.t_fetch; P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 4] = W.n_fetch; }
 #endif
         __syncthreads();
     }
