@@ -19,6 +19,9 @@ struct brov_shim_state {
     brov_opts opts{};
     int N = 0;
     std::vector<double> x0, yref, par, x, u, pi, lam;
+    std::vector<double> ts;        // per-stage time steps (create_with_discretization / update_time_steps); uniform ones collapse to opts.Ts
+    double W0[16] = {0};           // stage-0 weight ("W" of stage 0)
+    bool has_W0 = false, dirty_grid = false;
     bool dirty_x0 = true, dirty_yref = true, dirty_par = true, dirty_iter = false, dirty_opts = false;
     bool iter_host_valid = true;  // host mirror of the iterate is current
     int rti_phase = 0;
@@ -58,14 +61,12 @@ int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N
     double Ts = 0.0125;  // :389
     if (new_time_steps) {
         Ts = new_time_steps[0];
-        for (int i = 1; i < N; i++)
-            if (std::fabs(new_time_steps[i] - Ts) > 1e-12 * std::fabs(Ts)) {
-                std::fprintf(stderr, "bluerov2 (MI355X shim): non-uniform time steps are not supported\n");
-                return 1;
-            }
+        for (int i = 0; i < N; i++)
+            if (!(new_time_steps[i] > 0.0)) { std::fprintf(stderr, "bluerov2 (MI355X shim): time steps must be positive\n"); return 1; }
     }
     brov_shim_state* s = new brov_shim_state();
     s->N = N;
+    if (new_time_steps) { s->ts.assign(new_time_steps, new_time_steps + N); s->dirty_grid = true; }   // :375-387 -> update_time_steps
     brov_default_opts(&s->opts, N, Ts);
     // a failed step: acados' SQP_RTI returns before update_variables and leaves everything as it is -- so does the drop-in by
     // default (BROV_ON_FAILURE_KEEP).  BROV_ON_FAILURE=restart in the environment opts in to the batched API's default, a cold
@@ -128,13 +129,11 @@ int bluerov2_acados_update_time_steps(bluerov2_solver_capsule* c, int N, double*
                      N, s->N);
         return 1;
     }
-    for (int i = 1; i < N; i++)
-        if (std::fabs(ts[i] - ts[0]) > 1e-12 * std::fabs(ts[0])) {
-            std::fprintf(stderr, "bluerov2 (MI355X shim): non-uniform time steps are not supported\n");
-            return 1;
-        }
-    s->opts.Ts = ts[0];
-    s->dirty_opts = true;
+    for (int i = 0; i < N; i++)
+        if (!(ts[i] > 0.0)) { std::fprintf(stderr, "bluerov2 (MI355X shim): time steps must be positive\n"); return 1; }
+    // :122-127: "Ts" and the cost "scaling" of every stage := new_time_steps[i] (a uniform vector is the uniform grid again)
+    s->ts.assign(ts, ts + N);
+    s->dirty_grid = true;
     return 0;
 }
 
@@ -192,6 +191,13 @@ int bluerov2_acados_update_params_sparse(bluerov2_solver_capsule* c, int stage, 
 static int push_rare_inputs(brov_shim_state* s) {
     int rc = BROV_OK;
     if (s->dirty_opts) { rc = brov_set_opts(s->solver, &s->opts); s->dirty_opts = false; if (rc) return rc; }
+    if (s->dirty_grid) {
+        rc = brov_set_time_steps(s->solver, s->ts.empty() ? nullptr : s->ts.data());
+        if (rc == BROV_OK) rc = brov_set_stage0_weight(s->solver, s->has_W0 ? s->W0 : nullptr);
+        if (rc == BROV_OK) rc = brov_get_opts(s->solver, &s->opts);   // a uniform vector has become opts.Ts
+        s->dirty_grid = false;
+        if (rc) return rc;
+    }
     if (s->dirty_iter) {
         rc = brov_set_iterate_host(s->solver, s->x.data(), s->u.data(), s->pi.data(), s->lam.data());
         s->dirty_iter = false;
@@ -300,6 +306,14 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
         s->dirty_yref = true;
         return 0;
     }
+    if (!std::strcmp(field, "W") && stage == 0 && s->N > 1) {
+        // the generated solver keeps a separate stage-0 weight W_0 (:422-441).  Stage 0 gets its own here too; it collapses back
+        // into the shared stage weight when the two are equal (brov_set_stage0_weight)
+        for (int j = 0; j < 16; j++) s->W0[j] = v[j + 16 * j];
+        s->has_W0 = true;
+        s->dirty_grid = true;
+        return 0;
+    }
     if (!std::strcmp(field, "W")) {  // column-major ny x ny, diagonal (:422-481)
         const int ny = stage == s->N ? 12 : 16;
         double* dst = stage == s->N ? s->opts.We : s->opts.W;
@@ -308,9 +322,9 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
         bool differs = false;
         for (int j = 0; j < ny; j++) differs = differs || dst[j] != v[j + ny * j];
         static bool warned = false;
-        if (differs && stage > 0 && stage < s->N && !warned) {
+        if (differs && stage > 1 && stage < s->N && !warned) {
             std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): \"W\" of stage %d differs from the shared stage weight; this "
-                                 "solver keeps ONE stage weight, it now applies to stages 0..N-1\n", stage);
+                                 "solver keeps ONE weight for stages 1..N-1 (and W_0 for stage 0), it now applies to all of them\n", stage);
             warned = true;
         }
         for (int j = 0; j < ny; j++) dst[j] = v[j + ny * j];
@@ -321,9 +335,10 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
         // :393 sets the stage cost scaling to the time step, and this solver has ONE number for both (brov_opts::Ts is the ERK4
         // step and the cost scaling).  Re-stating the current value is accepted; a scaling that differs from the integrator's step
         // is refused instead of silently changing the discretisation (use ocp_nlp_in_set "Ts" / update_time_steps for that).
-        if (stage < s->N && std::fabs(v[0] - s->opts.Ts) > 1e-12 * std::fabs(s->opts.Ts)) {
-            std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): cost scaling %g differs from the time step %g; the two are one "
-                                 "parameter here -- refused\n", v[0], s->opts.Ts);
+        const double tsi = (stage < s->N && !s->ts.empty()) ? s->ts[stage] : s->opts.Ts;
+        if (stage < s->N && std::fabs(v[0] - tsi) > 1e-12 * std::fabs(tsi)) {
+            std::fprintf(stderr, "ocp_nlp_cost_model_set (MI355X shim): cost scaling %g of stage %d differs from its time step %g; the two "
+                                 "are one parameter here (bluerov2_acados_update_time_steps sets both) -- refused\n", v[0], stage, tsi);
             return 1;
         }
         return 0;
@@ -332,10 +347,16 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
     return 1;
 }
 
-int ocp_nlp_in_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int, const char* field, void* value) {
+int ocp_nlp_in_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int stage, const char* field, void* value) {
     brov_shim_state* s = in ? in->shim : nullptr;
     if (!s || !field || !value) return 1;
-    if (!std::strcmp(field, "Ts")) { s->opts.Ts = *(const double*)value; s->dirty_opts = true; return 0; }
+    if (!std::strcmp(field, "Ts")) {   // one stage's time step (step and cost scaling together, as update_time_steps sets them)
+        if (stage < 0 || stage >= s->N || !(*(const double*)value > 0.0)) return 1;
+        if (s->ts.empty()) s->ts.assign((size_t)s->N, s->opts.Ts);
+        s->ts[stage] = *(const double*)value;
+        s->dirty_grid = true;
+        return 0;
+    }
     return 1;
 }
 

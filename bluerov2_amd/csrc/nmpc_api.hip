@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,6 +69,12 @@ struct brov_solver {
     int win_blocks = 0;
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
+    // general grid (streaming kernels): per-stage time steps and / or a separate stage-0 weight
+    std::vector<double> ts_host;     // N time steps, empty = uniform
+    double W0_host[16] = {0};
+    bool has_W0 = false;
+    double* tsv = nullptr;           // device [N]
+    double* wst = nullptr;           // device [N+1][16] scaled weights per stage
     hipStream_t tick_stream = nullptr;   // brov_tick_host: the solver's own stream and pinned staging buffer
     double* pin = nullptr;
     size_t pin_doubles = 0;
@@ -124,6 +131,26 @@ static int dalloc(brov_solver* s, T** p, size_t n) {
     return BROV_OK;
 }
 
+static bool general_grid(const brov_solver* s) { return !s->ts_host.empty() || s->has_W0; }
+// per-stage time steps and scaled weights of the general grid: wst[i] = ts_i * (i == 0 ? W_0 : W) for i < N, wst[N] = [We | 0]
+static int upload_grid(brov_solver* s) {
+    if (!general_grid(s)) return BROV_OK;
+    const int N = s->N;
+    if (!s->tsv) {
+        if (int rc = dalloc(s, &s->tsv, (size_t)N)) return rc;
+        if (int rc = dalloc(s, &s->wst, (size_t)(N + 1) * 16)) return rc;
+    }
+    std::vector<double> ts(N), w((size_t)(N + 1) * 16, 0.0);
+    for (int i = 0; i < N; i++) {
+        ts[i] = s->ts_host.empty() ? s->opts.Ts : s->ts_host[i];
+        const double* Wi = (i == 0 && s->has_W0) ? s->W0_host : s->opts.W;
+        for (int j = 0; j < 16; j++) w[(size_t)i * 16 + j] = ts[i] * Wi[j];
+    }
+    for (int j = 0; j < 12; j++) w[(size_t)N * 16 + j] = s->opts.We[j];
+    HIPCHK(hipMemcpy(s->tsv, ts.data(), ts.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->wst, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+    return BROV_OK;
+}
 static int upload_cst(brov_solver* s) {
     double c[40];
     std::memset(c, 0, sizeof c);
@@ -131,7 +158,7 @@ static int upload_cst(brov_solver* s) {
     for (int j = 0; j < 12; j++) c[16 + j] = s->opts.We[j];
     for (int j = 0; j < 4; j++) { c[32 + j] = s->opts.lbu[j]; c[36 + j] = s->opts.ubu[j]; }
     HIPCHK(hipMemcpy(s->cst, c, sizeof c, hipMemcpyHostToDevice));
-    return BROV_OK;
+    return upload_grid(s);
 }
 
 extern "C" int brov_init_iterate_default(brov_solver* s) {
@@ -316,6 +343,39 @@ extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, co
     if (stage == 0) s->pplant_stale = true;
     return BROV_OK;
 }
+// ---- boundary corners of the reference API: non-uniform grids and a separate stage-0 weight ------------------------------------
+extern "C" int brov_set_time_steps(brov_solver* s, const double* ts) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (!ts) s->ts_host.clear();
+    else {
+        for (int i = 0; i < s->N; i++)
+            if (!(ts[i] > 0.0) || !(ts[i] < 1e6)) { g_err = "brov_set_time_steps: every time step must be positive and finite"; return BROV_ERR_ARG; }
+        bool uniform = true;
+        for (int i = 0; i < s->N; i++) uniform = uniform && std::fabs(ts[i] - ts[0]) <= 1e-12 * std::fabs(ts[0]);
+        if (uniform) { s->ts_host.clear(); s->opts.Ts = ts[0]; }     // a uniform vector is the uniform grid: every kernel path stays open
+        else s->ts_host.assign(ts, ts + s->N);
+    }
+    return upload_cst(s);
+}
+extern "C" int brov_set_stage0_weight(brov_solver* s, const double* W0) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    s->has_W0 = false;
+    if (W0) {
+        bool same = true;
+        for (int j = 0; j < 16; j++) {
+            if (!(W0[j] >= 0.0) || !(W0[j] < 1e300) || (j >= 12 && !(W0[j] > 0.0))) { g_err = "brov_set_stage0_weight: weights must be finite, >= 0 (inputs > 0)"; return BROV_ERR_ARG; }
+            same = same && W0[j] == s->opts.W[j];
+        }
+        if (!same) { std::memcpy(s->W0_host, W0, 16 * sizeof(double)); s->has_W0 = true; }
+    }
+    return upload_cst(s);
+}
+extern "C" int brov_general_grid(const brov_solver* s) { return s ? (general_grid(s) ? 1 : 0) : BROV_ERR_ARG; }
+
 // ---- 6-disturbance model variant ----------------------------------------------------------------
 __global__ void bcast_rp_kernel(const double* __restrict__ d2, double* __restrict__ rp, int B, int N1) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,6 +713,8 @@ static DevParams make_params(const brov_solver* s) {
     P.yref_stride = s->yref_shared ? 0 : (int64_t)(s->N + 1) * 16;
     P.par = s->par;
     P.par_rp = s->dist6 ? s->par_rp : nullptr;
+    P.tsv = general_grid(s) ? s->tsv : nullptr;
+    P.wst = general_grid(s) ? s->wst : nullptr;
     P.x = s->x; P.u = s->u; P.pi = s->pi; P.lam = s->lam;
     P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
@@ -671,7 +733,12 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     const int path = s->opts.kernel_path;
     // LDS-resident kernels (one launch): whole horizon for N <= 23, windowed above.  rti_phase 1 / 2 (preparation and feedback as
     // separate calls) need the linearisation in HBM between the calls: streaming kernels.
-    const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING;
+    // a general grid (per-stage time steps / separate stage-0 weight) is implemented by the streaming kernels only
+    if (general_grid(s) && path == BROV_PATH_FUSED) {
+        g_err = "brov_solve: per-stage time steps / a stage-0 weight need the streaming kernels (BROV_PATH_AUTO or BROV_PATH_STREAMING)";
+        return BROV_ERR_ARG;
+    }
+    const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING && !general_grid(s);
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
     const bool windowed = lds_path && !fused && s->ws != nullptr;
     if (s->timing) hipEventRecord(s->ev[0], st);

@@ -48,6 +48,11 @@ struct DevParams {
     double* ipm;    // [B][IPM_NARR][N*4]
     double* dxb;    // [B][N+1][12] QP primal step of the states
     const double* cst;  // [W16 | We12 pad4 | lbu4 | ubu4]
+    // general grid (streaming kernels only; both nullptr = uniform step Ts and one stage weight): tsv [N] time steps = ERK4 step and
+    // cost scaling per stage (acados_solver_bluerov2.c:111-131), wst [N+1][16] = the scaled weights per stage, ts_i * (i == 0 ? W_0 : W),
+    // row N = [We | 0] (separate stage-0 weight: :422-441)
+    const double* tsv;
+    const double* wst;
     brov_result* res;
     // windowed kernel (N >= 24): per-block parking image + scratch, instance hand-out counter, stages per window
     double* ws;

@@ -126,6 +126,7 @@ struct Inst {
     lds_f64 *lds_kff, *lds_vhat, *lds_dxb, *lds_zero;  // fused path: same arrays as kff/vhat/dxb, typed as LDS so that the sweeps
                                             // issue ds_* instead of flat_*
     double Ts;
+    const double* wst;   // streaming kernel, general grid: scaled weights per stage [N+1][16] (else nullptr)
     double Wr[4];   // W[row] for the lane's 4 rows (rows 12..15 = input weights)
     double Wer[3];  // We[row]
     double Wq, Weq, Wuq;  // adjoint sweep (lane = (column c, row group)): W[c], We[c] for c = min(lane >> 2, 11); W[12 + (lane >> 2 & 3)]
@@ -324,7 +325,7 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
     }
     if constexpr (STEP0) {  // Gamma = 0, rhs = r_i: no IPM arrays involved
         if constexpr (LDS) s.rtv = I.lds_r[i * 4 + I.rg];
-        else s.rtv = I.Ts * I.Wr[3] * (I.u[i * 4 + I.rg] - I.yref[(size_t)i * 16 + 12 + I.rg]);
+        else s.rtv = I.u[i * 4 + I.rg] - I.yref[(size_t)i * 16 + 12 + I.rg];   // streaming kernel: weighted in the stage body
         s.gm = 0.0;
     } else {
         s.rtv = rt[ig * 4 + I.rg];
@@ -444,7 +445,20 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
         d4 qr;
 #pragma unroll
         for (int r = 0; r < 3; r++) qr[r] = LDS ? in.xv[r] : I.Ts * I.Wr[r] * (in.xv[r] - in.yv[r]);
-        qr[3] = in.rtv;
+        qr[3] = (!LDS && STEP0) ? I.Ts * I.Wr[3] * in.rtv : in.rtv;
+        d4 dg = diagm;   // stage cost diagonal: loop-invariant ...
+        if constexpr (!LDS) {
+            // ... except on the streaming kernel's general grid (per-stage time steps / a separate stage-0 weight): the stage's scaled
+            // weights come from DevParams::wst, loaded here -- a wave-uniform branch, taken only by solvers that use the feature
+            if (I.wst) {
+                const double* ws = I.wst + (size_t)i * 16 + rg;
+                const double w0 = ws[0], w1 = ws[4], w2 = ws[8], w3 = ws[12];
+                qr[0] = w0 * (in.xv[0] - in.yv[0]); qr[1] = w1 * (in.xv[1] - in.yv[1]); qr[2] = w2 * (in.xv[2] - in.yv[2]);
+                if (STEP0) qr[3] = w3 * in.rtv;
+                dg[0] = (rg == cl) ? w0 : 0.0; dg[1] = (rg + 4 == cl) ? w1 : 0.0; dg[2] = (rg + 8 == cl) ? w2 : 0.0;
+                dg[3] = (12 + rg == cl) ? w3 : 0.0;
+            }
+        }
         if (FACTOR) {
             // One wave's FP64 MFMAs and VALU work do not overlap (scripts/dev/mfma_valu_overlap.hip): a stage costs 64 cycles
             // per MFMA whatever it computes, so the gradient recursion gets no MFMAs of its own -- it rides in column 0 of the
@@ -486,8 +500,8 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
             const double t0 = tr[rg], t1 = tr[rg + 4], t2 = tr[rg + 8], t3 = tr[rg + 12];
             // + diag(Ts*Wx, Ts*Wu + Gamma_i)
 #pragma unroll
-            for (int r = 0; r < 3; r++) H[r] += diagm[r];
-            H[3] += STEP0 ? diagm[3] : diagm[3] + (12 + rg == cl ? in.gm : 0.0);
+            for (int r = 0; r < 3; r++) H[r] += dg[r];
+            H[3] += STEP0 ? dg[3] : dg[3] + (12 + rg == cl ? in.gm : 0.0);
             // ---- 4x4 pivot block Huu = H[12..15][12..15]: lane 16m+12+n holds Huu[m][n] in H[3]
             const double a00 = readlane_f64(H[3], 12), a10 = readlane_f64(H[3], 28), a11 = readlane_f64(H[3], 29);
             const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
@@ -523,7 +537,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
                 msel = (a == 0) ? r0 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
                 mt = (cl < 4) ? msel : 0.0;
             }
-            H[0] = blend(mk_col0, lane == 0 ? P[0] + diagm[0] : t0, H[0]);   // H[0][0] = (P e_0)[0] + Ts W_0
+            H[0] = blend(mk_col0, lane == 0 ? P[0] + dg[0] : t0, H[0]);   // H[0][0] = (P e_0)[0] + Ts W_0
             H[1] = blend(mk_col0, t1, H[1]);
             H[2] = blend(mk_col0, t2, H[2]);
             H[3] = blend(mk_col0, t3, H[3]);
@@ -878,15 +892,23 @@ __device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double*
     const d4 z4 = {0, 0, 0, 0};
     auto stage = [&](int i, const AdjIn& in) __attribute__((always_inline)) {
         d4 pi;
+        // scaled weights: of node i + 1 for the states (terminal: We), of stage i for the inputs; per stage on the general grid
+        double wq[3], wr;
+        if (I.wst) {
+            const double* ws = I.wst + (size_t)(i + 1) * 16 + rg;
+            wq[0] = ws[0]; wq[1] = ws[4]; wq[2] = ws[8];
+            wr = I.wst[(size_t)i * 16 + 12 + rg];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const double qd = (I.i0 + i + 1 == I.NT) ? I.Wer[r] : I.Ts * I.Wr[r];
-            pi[r] = qd * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
+            for (int r = 0; r < 3; r++) wq[r] = (I.i0 + i + 1 == I.NT) ? I.Wer[r] : I.Ts * I.Wr[r];
+            wr = I.Ts * I.Wr[3];
         }
+#pragma unroll
+        for (int r = 0; r < 3; r++) pi[r] = wq[r] * (in.dx[r] + in.xn[r] - in.yn[r]) + atpi[r];
         pi[3] = 0.0;
         if (COMMIT) store_vec12(pi_out + (size_t)i * 12, pi, rg, cl);
         d4 G = tn<3>(in.ba, pi, z4);
-        const double rd = I.Ts * I.Wr[3];
+        const double rd = wr;
         if (cl == 0) garr[i * 4 + rg] = rd * in.v + rd * (in.u - in.ur) + G[3];
         atpi = G;
     };
@@ -1435,6 +1457,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             double lbI = cst[32 + mI], ubI = cst[36 + mI], wuI = cst[12 + mI];
             asm volatile("" : "+v"(lbI), "+v"(ubI), "+v"(wuI));
             const double rdI = P.Ts * wuI;   // the input's own Hessian entry
+            // ... per stage on the streaming kernel's general grid (time steps / stage-0 weight differ from stage to stage)
+            auto rd_el = [&](unsigned j) __attribute__((always_inline)) -> double {
+                if constexpr (LDS == 0) return I.wst ? I.wst[(size_t)(j >> 2) * 16 + 12 + mI] : rdI;
+                else return rdI;
+            };
             {   // first guess: the inputs of the Newton point that violate their bounds
                 GROUP_LANE;
                 IPM_PRE(up, I.u[j]);
@@ -1515,7 +1542,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         IPM_FOR(t, j) {
                             const double uj = EL ? ureg[t & 1] : (CACHE ? up[CACHE ? t : 0] : I.u[j]);
                             const double rr = EL ? (double)I.lds_r[j]
-                                                 : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                                 : rd_el(j) * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
                                                                                : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
                             const double ac = vACT.get(t, j);
                             const double gm = ac != 0.0 ? POL_BIG : 0.0;
@@ -1536,7 +1563,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                             GAM[j] = gm;
                             if constexpr (EL) gam_r[t & 1] = gm;
                             const double rr = EL ? (double)I.lds_r[j]
-                                                 : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                                 : rd_el(j) * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
                                                                                : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
                             RT[j] = rr - gm * vV.get(t, j);
                         }
@@ -1582,11 +1609,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         double gmx = 0.0;
                         IPM_FOR(t, j) gmx = fmax(gmx, fabs(CACHE ? gr[CACHE ? t : 0] : rd_grad(j)));
                         gmx = wave_max(gmx);
-                        const double tolg = POL_TOL_G * rdI + POL_TOL_GREL * gmx;
                         double cnt = 0.0;
                         IPM_FOR(t, j) {
                             const double g = CACHE ? gr[CACHE ? t : 0] : rd_grad(j);
                             double ac = vACT.get(t, j);
+                            const double tolg = POL_TOL_G * rd_el(j) + POL_TOL_GREL * gmx;
                             if (ac == 2.0 || ac == -2.0) { ac *= 0.5; cnt += 1.0; }                       // newly pinned
                             else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) { ac = 0.0; cnt += 1.0; }   // released
                             set_act(t, j, ac);
@@ -1640,7 +1667,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
                         const double cl_ = dll * dv, cu_ = -dlu * dv;
                         const double rr = EL ? (double)I.lds_r[j]
-                                             : P.Ts * wuI * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
+                                             : rd_el(j) * (CACHE ? up[CACHE ? t : 0] - yr[CACHE ? t : 0]
                                                                            : I.u[j] - I.yref[(size_t)(j >> 2) * 16 + 12 + mI]);
                         const double gm = EL ? gam_r[t & 1] : (CACHE ? gmp[CACHE ? t : 0] : GAM[j]);
                         RT[j] = rr - gm * vV.get(t, j) - (smu - cl_) / tl + (smu - cu_) / tu;
@@ -1700,7 +1727,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         // how far this element's bounds are from resolved: min(distance to the bound, multiplier / input weight);
                         // the same two quantities classify the bound for the next active-set round (active <=> the multiplier
                         // could move the input further than it is away from the bound)
-                        const double al = ll / rdI, au = lu / rdI;
+                        const double rde = rd_el(j), al = ll / rde, au = lu / rde;
                         unres = fmax(unres, fmax(fmin(tl, al), fmin(tu, au)));
                         set_act(t, j, al > tl ? -1.0 : (au > tu ? 1.0 : 0.0));
                     }
@@ -1850,7 +1877,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         if (j < 4) { P.res[b].u0[j] = un; u0v = un; }
                         const double e = un - ur[t];
                         const double wgt = (LDS == 1 && j0 == lane) ? wupre[LDS == 1 ? t : 0] : cst[12 + m];
-                        cost += 0.5 * P.Ts * wgt * e * e;
+                        const double sw = (LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + 12 + m] : P.Ts * wgt;
+                        cost += 0.5 * sw * e * e;
                     }
                 }
             }
@@ -1886,7 +1914,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         x_it[j] = xn;
                         const double e = xn - yr[t];
                         const double wgt = (LDS == 1 && j0 == lane) ? wxpre[LDS == 1 ? t : 0] : cst[(i == N) ? 16 + c : c];
-                        cost += 0.5 * ((i == N) ? wgt : P.Ts * wgt) * e * e;
+                        const double sw = (LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + c] : ((i == N) ? wgt : P.Ts * wgt);
+                        cost += 0.5 * sw * e * e;
                     }
                 }
             }
@@ -1903,13 +1932,13 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         for (int j = lane; j < nv; j += 64) {
             const int i = j >> 2, m = j & 3;
             const double e = u_it[j] - I.yref[(size_t)i * 16 + 12 + m];
-            cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+            cost += 0.5 * ((LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + 12 + m] : P.Ts * cst[12 + m]) * e * e;
             if (restart) { u_it[j] = 0.0; lam_it[i * 8 + m] = 0.0; lam_it[i * 8 + 4 + m] = 0.0; }
         }
         for (int j = lane; j < nxe; j += 64) {
             const int i = j / 12, c = j - i * 12;
             const double e = x_it[j] - I.yref[(size_t)i * 16 + c];
-            cost += 0.5 * ((i == N) ? cst[16 + c] : P.Ts * cst[c]) * e * e;
+            cost += 0.5 * ((LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + c] : ((i == N) ? cst[16 + c] : P.Ts * cst[c])) * e * e;
             if (restart) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
         }
     }
@@ -1979,6 +2008,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     I.ipm = P.ipm + (size_t)b * IPM_NARR * nv;
     I.dxb = P.dxb + (size_t)b * (N + 1) * 12;
     I.Ts = P.Ts;
+    I.wst = P.wst;
     I.lds_ba = nullptr;
     I.lds_bv = nullptr;
     I.lds_kt = nullptr;
@@ -2047,7 +2077,7 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 // ([A B] compact [n][12][13]), so the scattered 8-byte writes that rule this mapping out against HBM cost nothing.
 //   ba_s [n][12][13], bv_s [n][12], q_s [n+1][12] (row n: terminal gradient if the chunk ends the horizon), r_s [n][4];
 //   rec_s: scratch for the stage records, n*68 doubles.  part / nanp: this lane's share of the KKT max / NaN flag.
-template <bool TWO = true>
+template <bool TWO = true, bool GRID = false>
 __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
                                           double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
 #ifdef BROV_DBG_LIN
@@ -2061,6 +2091,8 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     const int i = active ? g : n - 1;   // index inside the chunk
     const int ig = i0 + i;              // global interval
     const double* __restrict__ ui = P.u + ((size_t)b * N + ig) * NU;
+    // step of this interval and scaled weights of its stage: one number / one weight vector, except on the streaming path's general grid
+    const double hstep = GRID ? P.tsv[ig] : P.Ts;
     // 6-disturbance model variant: this interval's roll / pitch disturbance moments.  One-wave kernels request them ahead of the
     // staging below (nothing else would cover the round trip); the two-wave kernel has no registers to carry them that far
     double rp0 = 0.0, rp1 = 0.0;
@@ -2120,12 +2152,12 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     KktAcc ka;
 #pragma unroll
     for (int k = 0; k < NX; k++) {
-        const double qk = P.Ts * cst[k] * (x0r[k] - yrr[k]);
+        const double qk = (GRID ? P.wst[(size_t)ig * 16 + k] : P.Ts * cst[k]) * (x0r[k] - yrr[k]);
         q_s[i * NX + k] = qk;
         if (k < 3) ka.upd(ig >= 1 ? qk + pir[k] - pm1[k] : 0.0);
     }
 #pragma unroll
-    for (int k = 0; k < NU; k++) r_s[i * NU + k] = P.Ts * cst[NX + k] * (uu[k] - yrr[NX + k]);
+    for (int k = 0; k < NU; k++) r_s[i * NU + k] = (GRID ? P.wst[(size_t)ig * 16 + NX + k] : P.Ts * cst[NX + k]) * (uu[k] - yrr[NX + k]);
     if (last) {
 #pragma unroll
         for (int k = 0; k < NX; k++) {
@@ -2138,7 +2170,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
     LIN_T(1);
     StagePoint sp[4];
     double xn[NX];
-    rk4_state(x0r, w, m, P.Ts, sp, xn);
+    rk4_state(x0r, w, m, hstep, sp, xn);
     const unsigned long long tC = (stamp && P.dbg) ? __builtin_readcyclecounter() : 0;
     LIN_T(2);
     double* tb = ba_s + i * kBaStage;
@@ -2177,7 +2209,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             double acc0[NX], acc1[NX];
             const KktOperands koa = load_kkt_operands(P, cst, b, ig, i, n, ca, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
             const KktOperands kob = load_kkt_operands(P, cst, b, ig, i, n, cb, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-            sens_column_rec2(rec, m, P.Ts, ca, cb, acc0, acc1);
+            sens_column_rec2(rec, m, hstep, ca, cb, acc0, acc1);
             finish(ca, koa, acc0);
             finish(cb, kob, acc1);
         }
@@ -2190,7 +2222,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             const int ca = qa < 3 ? 3 + qa : 6 + qa;
             double acc0[NX];
             const KktOperands koa = load_kkt_operands(P, cst, b, ig, i, n, ca, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-            sens_column_rec(rec, m, P.Ts, ca, acc0);
+            sens_column_rec(rec, m, hstep, ca, acc0);
             finish(ca, koa, acc0);
         }
     }
@@ -2216,7 +2248,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
         const int jc = 1 + 2 * q, c = NX + jc;
         double acc[NX];
         const KktOperands ko = load_kkt_operands(P, cst, b, ig, i, n, c, ui, (const lds_f64*)q_s, (const lds_f64*)r_s);
-        sens_column_rec_u(rec, m, P.Ts, jc, acc);
+        sens_column_rec_u(rec, m, hstep, jc, acc);
         finish(c, ko, acc);
     }
     LIN_T(5);
@@ -2230,7 +2262,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
             const int j = input ? (q == 3 ? 0 : 2) : q;       // velocity row 6 + j
             constexpr double ir = 1.0 / kRotor;
             const double kbv = !input ? 0.0 : (j == 0 ? (-4.0 * 0.707) * ir * m.imx : -2.0 * ir * m.imz);   // model_bcol rows 6 / 8
-            sens_column_cheap(rec, P.Ts, j, input, kbv, cv[t]);
+            sens_column_cheap(rec, hstep, j, input, kbv, cv[t]);
         }
     }
     LIN_T(6);
@@ -2292,7 +2324,8 @@ __device__ __forceinline__ void copy_out_linearisation(const DevParams& P, int b
 constexpr int kLinChunkMax = 21;
 __host__ __device__ inline int lin_chunks(int N) { return (N + kLinChunkMax - 1) / kLinChunkMax; }
 __host__ __device__ inline int lin_chunk_len(int N) { const int nc = lin_chunks(N); return (N + nc - 1) / nc; }
-__global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
+template <bool GRID>
+__device__ __forceinline__ void lin_wave_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double lsm[];
     const int N = P.N, lane = threadIdx.x;
     const int nc = lin_chunks(N), C = lin_chunk_len(N);
@@ -2307,7 +2340,7 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
     double* part_s = r_s + (size_t)C * NU;           // [64]
     double part = 0.0;
     bool nanp = false;
-    lin_phase(P, b, i0, n, lane, ba_s, bv_s, rec_s, q_s, r_s, part, nanp, false);
+    lin_phase<true, GRID>(P, b, i0, n, lane, ba_s, bv_s, rec_s, q_s, r_s, part, nanp, false);
     part_s[lane] = nanp ? __builtin_nan("") : part;
     __syncthreads();
     const size_t g0 = (size_t)b * N + i0;
@@ -2326,6 +2359,10 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) {
         }
     }
 }
+
+__global__ __launch_bounds__(64, 1) void lin_wave_kernel(DevParams P) { lin_wave_body<false>(P); }
+// the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
+__global__ __launch_bounds__(64, 1) void lin_wave_kernel_grid(DevParams P) { lin_wave_body<true>(P); }
 
 // fused path: ONE wavefront owns one OCP instance from linearisation to the updated iterate.  The wave first integrates
 // all N intervals at once (64/N lanes per interval, lin_device.hpp) and leaves [A_i B_i] and b_i in its LDS slice
@@ -2550,9 +2587,12 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
     const size_t lds = ((size_t)C * (kBaStage + NX + kRecInterval + NU) + (size_t)(C + 1) * NX + 64) * sizeof(double);
-    if (first_launch_on_device(0))
+    if (first_launch_on_device(0)) {
         (void)hipFuncSetAttribute((const void*)lin_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    hipLaunchKernelGGL(lin_wave_kernel, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
+        (void)hipFuncSetAttribute((const void*)lin_wave_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    }
+    if (P.tsv) hipLaunchKernelGGL(lin_wave_kernel_grid, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
+    else hipLaunchKernelGGL(lin_wave_kernel, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
 }
 
 void launch_qp(const DevParams& P, hipStream_t st) {

@@ -98,6 +98,7 @@ def _load():
         "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double],
         "brov_set_candidate_params_host": [vp, C.c_int, dp, dp, dp], "brov_set_yref_candidates": [vp, C.c_double, C.c_double, vp],
         "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
+        "brov_set_time_steps": [vp, dp], "brov_set_stage0_weight": [vp, dp], "brov_general_grid": [vp],
         "brov_enable_dist6": [vp, C.c_int], "brov_dist6_enabled": [vp], "brov_set_rp_disturbance_host": [vp, dp, C.c_int],
         "brov_set_params18_host": [vp, dp, C.c_int], "brov_plant_set_rp_disturbance_host": [vp, dp], "brov_get_rp_disturbance_host": [vp, dp],
     }.items():
@@ -263,6 +264,13 @@ class BatchSolver:
         return y
 
     # ---- closed loop on the device ---------------------------------------------------------------
+    # ---- non-uniform grid / separate stage-0 weight (acados_solver_bluerov2.h:141,146; .c:422-441): streaming kernels ------------
+    def set_time_steps(self, ts):
+        self._chk(self._L.brov_set_time_steps(self._h, None if ts is None else _dp(_arr(ts, (self.N,)))), "set_time_steps")
+
+    def set_stage0_weight(self, W0):
+        self._chk(self._L.brov_set_stage0_weight(self._h, None if W0 is None else _dp(_arr(W0, (NY,)))), "set_stage0_weight")
+
     # ---- 6-disturbance model variant: roll / pitch disturbance moments next to p[16] ---------------------
     def enable_dist6(self, on=True):
         self._chk(self._L.brov_enable_dist6(self._h, int(bool(on))), "enable_dist6")

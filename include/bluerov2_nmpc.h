@@ -206,6 +206,17 @@ double* brov_u_device(brov_solver* s);
 int brov_get_linearisation_host(brov_solver* s, double* AB /*[B][N][12][16]*/, double* b /*[B][N][12]*/);
 int brov_debug_dump_linearisation(brov_solver* s, int enable);
 
+/* ---- boundary corners of the reference API -----------------------------------------------------------------------------------
+ * Non-uniform grids: bluerov2_acados_create_with_discretization(capsule, N, new_time_steps) / bluerov2_acados_update_time_steps
+ * (c_generated_code/acados_solver_bluerov2.h:141,146; .c:111-131) set the ERK4 step AND the cost scaling of stage i to
+ * new_time_steps[i].  brov_set_time_steps does the same for the whole batch (ts[N]; NULL or a uniform vector = the uniform grid
+ * with brov_opts::Ts).  Separate stage-0 weight: the generated solver carries W_0 next to W (.c:422-441, same numbers as
+ * shipped); brov_set_stage0_weight(W0[16]) gives stage 0 its own (NULL or W itself = one stage weight).
+ * Either feature is implemented by the streaming kernels: BROV_PATH_AUTO selects them, BROV_PATH_FUSED is refused (BROV_ERR_ARG). */
+int brov_set_time_steps(brov_solver* s, const double* ts /*[N] or NULL*/);
+int brov_set_stage0_weight(brov_solver* s, const double* W0 /*[16] or NULL*/);
+int brov_general_grid(const brov_solver* s);   /* 1 while either feature is in force */
+
 /* ---- 6-disturbance model variant (BASELINE configs[2] "6 disturbance states") ------------------
  * The reference's EKF estimates six disturbances (bluerov2_dob.h:200-205), its OCP model takes four: the roll / pitch symbols are
  * there but commented out (bluerov2_dobmpc/scripts/bluerov2.py:37-38), so the shipped solver has np = 16.  This switch (default

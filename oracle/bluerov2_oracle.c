@@ -34,6 +34,8 @@ void orc_default_opts(orc_opts* o, int N, double Ts) {
     o->qp_tol_mu = 1e-7;
     o->qp_tol_stat = 1e-9;
     o->qp_early_exit = 1;
+    o->ts_vec = NULL;
+    o->W0 = NULL;
     o->on_failure = 1;
 }
 
@@ -750,19 +752,21 @@ int orc_rti_step_ws(const orc_opts* o, const double* x0, const double* yref, con
     /* preparation: ERK4 + sensitivities on every interval */
     for (int i = 0; i < N; i++) {
         double xn[NX];
-        orc_rk4_sens6(x + (size_t)i * NX, u + (size_t)i * NU, p + (size_t)i * NP, drp ? drp + (size_t)i * 2 : NULL, o->Ts, xn,
-                      A + (size_t)i * 144, B + (size_t)i * 48);
+        orc_rk4_sens6(x + (size_t)i * NX, u + (size_t)i * NU, p + (size_t)i * NP, drp ? drp + (size_t)i * 2 : NULL,
+                      o->ts_vec ? o->ts_vec[i] : o->Ts, xn, A + (size_t)i * 144, B + (size_t)i * 48);
         for (int j = 0; j < NX; j++) b[i * NX + j] = xn[j] - x[(i + 1) * NX + j];
     }
     /* Gauss-Newton LS cost: y = [x;u], J = I, Hess = s W, grad = s W (y - yref) */
     for (int i = 0; i < N; i++) {
+        const double sc = o->ts_vec ? o->ts_vec[i] : o->Ts;            /* cost scaling = the stage's time step (:393, :126-127) */
+        const double* Wi = (i == 0 && o->W0) ? o->W0 : o->W;           /* separate stage-0 weight (:422-441) */
         for (int j = 0; j < NX; j++) {
-            Qd[i * NX + j] = o->Ts * o->W[j];
-            q[i * NX + j] = o->Ts * o->W[j] * (x[i * NX + j] - yref[i * NY + j]);
+            Qd[i * NX + j] = sc * Wi[j];
+            q[i * NX + j] = sc * Wi[j] * (x[i * NX + j] - yref[i * NY + j]);
         }
         for (int j = 0; j < NU; j++) {
-            Rd[i * NU + j] = o->Ts * o->W[NX + j];
-            r[i * NU + j] = o->Ts * o->W[NX + j] * (u[i * NU + j] - yref[i * NY + NX + j]);
+            Rd[i * NU + j] = sc * Wi[NX + j];
+            r[i * NU + j] = sc * Wi[NX + j] * (u[i * NU + j] - yref[i * NY + NX + j]);
             lb[i * NU + j] = o->lbu[j] - u[i * NU + j];
             ub[i * NU + j] = o->ubu[j] - u[i * NU + j];
         }
@@ -814,8 +818,10 @@ int orc_rti_step_ws(const orc_opts* o, const double* x0, const double* yref, con
     }
     double cost = 0.0;
     for (int i = 0; i < N; i++) {
-        for (int j = 0; j < NX; j++) { double e = x[i * NX + j] - yref[i * NY + j]; cost += 0.5 * o->Ts * o->W[j] * e * e; }
-        for (int j = 0; j < NU; j++) { double e = u[i * NU + j] - yref[i * NY + NX + j]; cost += 0.5 * o->Ts * o->W[NX + j] * e * e; }
+        const double sc = o->ts_vec ? o->ts_vec[i] : o->Ts;
+        const double* Wi = (i == 0 && o->W0) ? o->W0 : o->W;
+        for (int j = 0; j < NX; j++) { double e = x[i * NX + j] - yref[i * NY + j]; cost += 0.5 * sc * Wi[j] * e * e; }
+        for (int j = 0; j < NU; j++) { double e = u[i * NU + j] - yref[i * NY + NX + j]; cost += 0.5 * sc * Wi[NX + j] * e * e; }
     }
     for (int j = 0; j < NX; j++) { double e = x[N * NX + j] - yref[N * NY + j]; cost += 0.5 * o->We[j] * e * e; }
     const int failed = !(status == 0 || status == 2);

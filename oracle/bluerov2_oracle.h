@@ -48,6 +48,10 @@ typedef struct orc_opts {
     double qp_tol_mu;     /* bound resolution: input within this distance of a bound, or its multiplier / input weight below it (1e-7) */
     double qp_tol_stat;   /* stationarity target of the QP (tracked residual, absolute) */
     int    qp_early_exit; /* 1: return the equality-constrained minimiser when it is feasible (exact) */
+    const double* ts_vec; /* NULL: uniform grid, step Ts.  Else N time steps (bluerov2_acados_create_with_discretization / _update_time_steps,
+                           * acados_solver_bluerov2.c:111-131,375-387): ERK4 step AND cost scaling of stage i = ts_vec[i] */
+    const double* W0;     /* NULL: stage 0 weighs like the other stages.  Else the 16 diagonal entries of W_0 (the generated solver keeps a
+                           * separate stage-0 weight, acados_solver_bluerov2.c:422-441, set to the same numbers) */
     int    on_failure;    /* failed step (status 1/3/4): 0 keep the iterate (acados: SQP_RTI returns before update_variables),
                            * 1 cold restart at the measured state if it is finite (x_i = x0, u = 0, multipliers 0).  Either way the record's u0
                            * holds the last successfully computed input, clamped to the bounds, NaN -> 0. */

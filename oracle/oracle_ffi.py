@@ -21,7 +21,8 @@ _dp = C.POINTER(C.c_double)
 class OrcOpts(C.Structure):
     _fields_ = [("N", C.c_int), ("Ts", C.c_double), ("W", C.c_double * NY), ("We", C.c_double * NX),
                 ("lbu", C.c_double * NU), ("ubu", C.c_double * NU), ("qp_iter_max", C.c_int),
-                ("qp_tol_mu", C.c_double), ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int), ("on_failure", C.c_int)]
+                ("qp_tol_mu", C.c_double), ("qp_tol_stat", C.c_double), ("qp_early_exit", C.c_int), ("ts_vec", _dp), ("W0", _dp),
+                ("on_failure", C.c_int)]
 
 
 class OrcResult(C.Structure):
@@ -91,7 +92,15 @@ class Oracle:
     def opts(self, N=20, Ts=None, **kw):
         o = OrcOpts()
         self.lib.orc_default_opts(C.byref(o), N, 1.0 / N if Ts is None else Ts)
+        o._keep = {}   # numpy arrays the pointer fields refer to
         for k, v in kw.items():
+            if k in ("ts_vec", "W0"):
+                if v is not None:
+                    a = np.ascontiguousarray(v, dtype=np.float64)
+                    assert a.shape == ((N,) if k == "ts_vec" else (NY,))
+                    o._keep[k] = a
+                    setattr(o, k, a.ctypes.data_as(_dp))
+                continue
             if k in ("W", "We", "lbu", "ubu"):
                 arr = getattr(o, k)
                 for i, x in enumerate(v):

@@ -2,7 +2,7 @@
  * same sequence of calls as the reference's control tick (BLUEROV2_DOB::solve, bluerov2_dobmpc/src/bluerov2_dob.cpp:306-388):
  * lbx/ubx <- x0, update_params for stages 0..N, yref for stages 0..N, solve, status / inf_norm_res / time_tot / u0.
  * Inputs come from a binary file written by the test (x0[12], p[16], nticks, yref[nticks][N+1][16]); results go to stdout.
- * A second argument "F" appends a failed step (NaN measurement) and a recovery tick. */
+ * A second argument "F" appends a failed step (NaN measurement) and a recovery tick; "G" creates the solver on a non-uniform grid. */
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -28,7 +28,17 @@ int main(int argc, char** argv) {
     static double acados_param[BLUEROV2_N + 1][BLUEROV2_NP];
 
     bluerov2_solver_capsule* mpc_capsule = bluerov2_acados_create_capsule();
-    int create_status = bluerov2_acados_create(mpc_capsule);
+    int create_status;
+    if (argc >= 3 && argv[2][0] == 'G') {
+        /* non-uniform grid through the reference's own entry point (acados_solver_bluerov2.h:141): a geometric grid, 0.008 s growing
+         * by 1 % per interval (the test builds the same numbers) */
+        static double new_time_steps[BLUEROV2_N];
+        double t = 0.008;
+        for (int i = 0; i < BLUEROV2_N; i++) { new_time_steps[i] = t; t *= 1.01; }
+        create_status = bluerov2_acados_create_with_discretization(mpc_capsule, BLUEROV2_N, new_time_steps);
+    } else {
+        create_status = bluerov2_acados_create(mpc_capsule);
+    }
     if (create_status != 0) { printf("acados_create() returned status %d. Exiting.\n", create_status); return 1; }
 
     for (int tick = 0; tick < nticks; tick++) {

@@ -1,0 +1,129 @@
+"""Boundary corners of the reference API on the GPU (SURVEY.md section 8 row b): non-uniform grids -- per-stage time steps as
+bluerov2_acados_create_with_discretization / bluerov2_acados_update_time_steps set them (c_generated_code/acados_solver_bluerov2.h:
+141,146; .c:111-131: ERK4 step AND cost scaling of stage i) -- and a separate stage-0 weight W_0 (.c:422-441).  Implemented by the
+streaming kernels; against the oracle on the same grid and against the independent recipe (reference CasADi model -> numpy
+condensing -> scipy BVLS)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import status_agreement, values_agree
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import bluerov2_amd
+    return bluerov2_amd
+
+
+def _inputs(golden_traj, B, seed):
+    rng = np.random.default_rng(seed)
+    circ = golden_traj["circle"]
+    x0 = np.zeros((B, 12)); x0[:, :6] = circ[0, :6]
+    x0 += rng.normal(size=(B, 12)) * np.array([0.05] * 3 + [0.02] * 3 + [0.05] * 3 + [0.02] * 3)
+    x0[: B // 3, :3] += rng.uniform(-3, 3, size=(B // 3, 3))
+    return x0, circ
+
+
+@pytest.mark.parametrize("N,grow,with_w0", [(20, 1.08, True), (40, 1.04, False), (80, 1.01, True), (7, 1.3, True)])
+def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_traj, N, grow, with_w0):
+    B = 48
+    x0, circ = _inputs(golden_traj, B, seed=N)
+    ts = (0.5 / N) * grow ** np.arange(N)
+    rng = np.random.default_rng(N + 1)
+    W0 = np.array(ba.SolverOptions(N).W) * rng.uniform(0.5, 2.0, 16) if with_w0 else None
+    kw = dict(lbu=[-25.0] * 4, ubu=[25.0] * 4)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, float(ts[0]), **kw))     # BROV_PATH_AUTO
+    s.set_time_steps(ts)
+    if with_w0:
+        s.set_stage0_weight(W0)
+    s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+    op = oracle.opts(N, float(ts[0]), ts_vec=ts, W0=W0, **kw)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16)))
+    prev, n_qp = None, 0
+    for k in range(3):
+        yref = circ[k:k + N + 1]
+        s.set_yref(yref); s.solve()
+        assert s.last_kernel_path() == 1          # the streaming kernels implement the general grid
+        res = s.results(); gx, gu, gpi, glam = s.get_iterate()
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        kk = ro["kkt"]
+        cmp = status_agreement(res["status"], ro["status"], kk)
+        for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi)):
+            err = np.abs(a.reshape(B, -1) - b.reshape(B, -1)).max(axis=1)
+            values_agree((err <= (1e-6 if name == "pi" else 1e-7) * np.maximum(1.0, kk))[cmp], kk[cmp], (N, k, name), err=err[cmp])
+        values_agree((np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))[cmp], kk[cmp], (N, k, "cost"))
+        assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
+        n_qp += int((res["qp_iter"] > 0).sum())
+        x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
+        prev = res.copy()
+    assert n_qp > 0
+    s.close()
+
+
+def test_against_the_independent_recipe(ba, golden_traj):
+    import oracle.oracle_ffi as F
+    if not os.path.exists(F.REF_SO):
+        pytest.skip("oracle/_ref is not in this snapshot")
+    import make_golden as G
+    ref = F.CasadiRef()
+    N, B = 20, 4
+    x0, circ = _inputs(golden_traj, B, seed=3)
+    x0[:, :3] += np.array([[2.0, -1.5, 0.5]])
+    ts = 0.02 * 1.08 ** np.arange(N)
+    W0 = G.W * np.random.default_rng(0).uniform(0.5, 2.0, 16)
+    lbu, ubu = np.full(4, -15.0), np.full(4, 15.0)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, float(ts[0]), lbu=list(lbu), ubu=list(ubu)))
+    s.set_time_steps(ts); s.set_stage0_weight(W0)
+    s.set_x0(x0); s.set_params(G.P_NOMINAL)
+    xs = np.tile([0, 0, -20.0] + [0] * 9, (B, N + 1, 1)).astype(float); us = np.zeros((B, N, 4))
+    p = np.tile(G.P_NOMINAL, (N + 1, 1))
+    nact = 0
+    for k in range(2):
+        yref = circ[k:k + N + 1].copy()
+        s.set_yref(yref); s.solve()
+        gx, gu, gpi, glam = s.get_iterate()
+        assert np.all(s.results()["status"] == 0)
+        for b in range(B):
+            xb, ub, info = G.rti_step_independent(ref, N, ts, x0[b], yref, p, xs[b], us[b], lbu=lbu, ubu=ubu, W0d=W0)
+            assert info["qp_kkt"] < 1e-9 and np.abs(gu[b] - ub).max() < 1e-8, (k, b, np.abs(gu[b] - ub).max(), info)
+            nact += info["nact"]
+            xs[b], us[b] = xb, ub
+        s.set_iterate(x=xs, u=us, pi=gpi, lam=glam)
+    assert nact > 0
+    s.close()
+
+
+def test_feature_gating(ba, golden_traj):
+    N, B = 20, 8
+    x0, circ = _inputs(golden_traj, B, seed=1)
+    # a uniform vector of steps / W_0 == W is the plain problem: LDS-resident kernel again, bit-identical to never having set them
+    outs = []
+    for mode in ("plain", "uniform_vector"):
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05))
+        if mode == "uniform_vector":
+            s.set_time_steps(np.full(N, 0.05)); s.set_stage0_weight(np.array(ba.SolverOptions(N).W))
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1]); s.solve()
+        assert s.last_kernel_path() == 2
+        outs.append(s.get_iterate()[1].copy()); s.close()
+    assert np.array_equal(outs[0], outs[1])
+    # BROV_PATH_FUSED cannot honour a general grid: refused, not silently ignored
+    s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05, kernel_path=ba.PATH_FUSED))
+    s.set_time_steps(0.04 * 1.05 ** np.arange(N))
+    s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1])
+    with pytest.raises(RuntimeError):
+        s.solve()
+    s.set_time_steps(None); s.solve()          # back to the uniform grid
+    assert s.last_kernel_path() == 2
+    with pytest.raises(RuntimeError):
+        s.set_time_steps(np.array([0.05] * (N - 1) + [-0.01]))
+    s.close()

@@ -43,6 +43,40 @@ def test_control_tick_call_sequence_matches_known_answers(tmp_path, golden_rti, 
     assert "custom_update 1" in r.stdout and "free 0" in r.stdout
 
 
+def test_non_uniform_grid_through_create_with_discretization(tmp_path, golden_rti, oracle):
+    """bluerov2_acados_create_with_discretization(capsule, N, new_time_steps) (acados_solver_bluerov2.h:141; .c:111-131 sets the ERK4
+    step and the cost scaling of stage i to new_time_steps[i]): the reference's own entry point for a non-uniform grid, refused by
+    round 2's shim.  A geometric grid; every tick against the oracle stepping on the same grid."""
+    g, name = golden_rti, "circle_N80"
+    exe = tmp_path / "shim_caller"
+    subprocess.check_call(["gcc", "-O2", f"-I{INC}", "-o", str(exe), os.path.join(ROOT, "tests", "shim_caller.c"),
+                           f"-L{LIBDIR}", "-lacados_ocp_solver_bluerov2", f"-Wl,-rpath,{LIBDIR}"])
+    nt = 3
+    blob = np.concatenate([g[f"{name}/x0_meas"], g[f"{name}/p"][0], [float(nt)]] + [g[f"{name}/yref{k}"].ravel() for k in range(nt)])
+    inp = tmp_path / "in.bin"
+    inp.write_bytes(blob.astype(np.float64).tobytes())
+    r = subprocess.run([str(exe), str(inp), "G"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ticks = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("TICK")]
+    assert len(ticks) == nt
+    ts, t = np.zeros(80), 0.008
+    for i in range(80):
+        ts[i] = t; t *= 1.01
+    op = oracle.opts(80, 0.0125, ts_vec=ts)
+    x, u = g[f"{name}/x_init"].copy(), g[f"{name}/u_init"].copy()
+    pi, lam = np.zeros((80, 12)), np.zeros((80, 8))
+    for k, tk in enumerate(ticks):
+        ro = oracle.rti_step(op, g[f"{name}/x0_meas"], g[f"{name}/yref{k}"], g[f"{name}/p"], x, u, pi, lam)
+        assert int(tk[3]) == 0 and ro["status"] == 0
+        assert np.abs(np.array([float(v) for v in tk[9:13]]) - u[0]).max() < 1e-7
+        assert np.abs(np.array([float(v) for v in tk[14:17]]) - x[1, :3]).max() < 1e-7
+        assert abs(float(tk[5]) - ro["kkt"]) < 1e-6 * (1 + abs(ro["kkt"]))
+    # and the uniform grid gives something else (the grid is in force)
+    r0 = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, timeout=120)
+    u_uni = np.array([float(v) for v in [ln for ln in r0.stdout.splitlines() if ln.startswith("TICK")][0].split()[9:13]])
+    assert np.abs(u_uni - np.array([float(v) for v in ticks[0][9:13]])).max() > 1e-3
+
+
 @pytest.mark.parametrize("policy", ["keep", "restart"])
 def test_failed_step_leaves_the_last_good_input_in_the_getter(tmp_path, golden_rti, policy):
     """acados leaves nlp_out untouched when a step fails, and the node publishes thrusts from ocp_nlp_out_get(.., 0, "u") whatever

@@ -137,3 +137,37 @@ def test_thrust_allocation(oracle):
     c = 0.026546960744430276
     t = oracle.thrust_alloc(u0)
     assert np.allclose(t, [(-1 - 2 + 0.5) / c, (-1 + 2 - 0.5) / c, (1 - 2 - 0.5) / c, (1 + 2 + 0.5) / c, -3 / c, -3 / c])
+
+
+def test_non_uniform_grid_and_stage0_weight_against_the_independent_recipe(oracle, golden_traj):
+    """per-stage time steps (acados_solver_bluerov2.c:111-131: ERK4 step and cost scaling of stage i) and a separate stage-0 weight
+    (:422-441): the oracle against reference CasADi model -> numpy condensing -> scipy BVLS on a geometric grid, tight boxes"""
+    import os
+    import sys
+    import oracle.oracle_ffi as F
+    if not os.path.exists(F.REF_SO):
+        pytest.skip("oracle/_ref is not here")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import make_golden as G
+    ref = F.CasadiRef()
+    circ = golden_traj["circle"]
+    rng = np.random.default_rng(0)
+    for N, grow in ((20, 1.08), (40, 1.03)):
+        ts = (0.6 / N) * grow ** np.arange(N)
+        W0 = G.W * rng.uniform(0.5, 2.0, 16)
+        x0 = np.zeros(12); x0[:6] = circ[0, :6]; x0[:3] += [2.0, -1.5, 0.5]
+        p = np.tile(G.P_NOMINAL, (N + 1, 1))
+        x = np.tile([0, 0, -20.0] + [0] * 9, (N + 1, 1)).astype(float); u = np.zeros((N, 4))
+        lbu, ubu = np.full(4, -12.0), np.full(4, 12.0)
+        op = oracle.opts(N, float(ts[0]), ts_vec=ts, W0=W0, lbu=list(lbu), ubu=list(ubu))
+        xo, uo, pi, lam = x.copy(), u.copy(), np.zeros((N, 12)), np.zeros((N, 8))
+        nact = 0
+        for k in range(3):
+            yref = circ[k:k + N + 1].copy()
+            x, u, info = G.rti_step_independent(ref, N, ts, x0, yref, p, x, u, lbu=lbu, ubu=ubu, W0d=W0)
+            r = oracle.rti_step(op, x0, yref, p, xo, uo, pi, lam)
+            assert r["status"] == 0 and info["qp_kkt"] < 1e-9
+            assert np.abs(uo - u).max() < 1e-9 and np.abs(xo - x).max() < 1e-9, (N, k, np.abs(uo - u).max())
+            nact += info["nact"]
+            xo, uo = x.copy(), u.copy()
+        assert nact > 0
