@@ -362,11 +362,13 @@ def workload(args, rank, world):
         lo, hi, total = shard_of(args, rank, world, BATCH_PER_GPU if cfg == 2 else 16384)
         B = hi - lo
 
-        def make(N, Ts, early, sat=0.0):
+        def make(N, Ts, early, sat=0.0, shuffle=False):
             s = ba.BatchSolver(B, opts(N, Ts, early), device=local_rank)
             x0, circ = global_x0(1 if cfg == 2 else 2, total, lo, hi, noise=(cfg == 2))
             if sat:
                 x0 = saturate(x0, sat, seed=77)
+            if shuffle:
+                x0 = x0[np.random.default_rng(5).permutation(x0.shape[0])]
             p = np.tile(ba.P_NOMINAL, (B, 1))
             if cfg == 3:   # Monte-Carlo current disturbance, converted like the node does (bluerov2_dob.cpp:334-337)
                 if strong:
@@ -633,7 +635,7 @@ def main(argv=None):
         achieved = dom_fl / dom_t / 1e12
         alg_bytes = algorithmic_bytes(N, lg["shared"])
         traffic, traffic_src = None, None
-        for pj in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+        for pj in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
                 ent = pm.get("runs", {}).get(f"cfg{args.config}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
@@ -710,10 +712,22 @@ def main(argv=None):
         r3 = s3.results()
         out["mixed_batch_25pct_saturated"] = dict(value=B * K / dt3, unit="solves/s", ms_per_step=dt3 / K * 1e3,
                                                   ipm_instance_fraction=float((r3["qp_iter"] > 0).mean()),
-                                                  mean_qp_iter=float(r3["qp_iter"].mean()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
+                                                  mean_qp_iter=float(r3["qp_iter"].mean()), max_qp_iter_last_tick=int(r3["qp_iter"].max()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
                                                   note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
                                                        "the launch ends with its slowest interior-point instance")
         s3.close()
+        # the same instances in a random order (the leg above has the saturated quarter FIRST, an artefact of the generator: the slow
+        # instances then start in the first round anyway).  The kernels reorder the work themselves -- instances whose QP had active
+        # bounds in the previous tick are handed out first (qp_kernel.hip, sched_map)
+        s4, tick4, _ = wl["make"](N, Ts, 1, sat=0.25, shuffle=True)
+        dt4, _, _ = run(s4, tick4, K, W, False, False)
+        r4 = s4.results()
+        out["mixed_batch_25pct_saturated_shuffled"] = dict(value=B * K / dt4, unit="solves/s", ms_per_step=dt4 / K * 1e3,
+                                                           ipm_instance_fraction=float((r4["qp_iter"] > 0).mean()),
+                                                           max_qp_iter_last_tick=int(r4["qp_iter"].max()),
+                                                           status_histogram=np.bincount(r4["status"], minlength=5).tolist(),
+                                                           note="the mixed batch with its instances in random order")
+        s4.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(BATCH_PER_GPU)
         if extra:

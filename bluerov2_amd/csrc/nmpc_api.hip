@@ -75,6 +75,9 @@ struct brov_solver {
     bool has_W0 = false;
     double* tsv = nullptr;           // device [N]
     double* wst = nullptr;           // device [N+1][16] scaled weights per stage
+    int32_t* sched = nullptr;        // work ordering: 3 rotating buffers of 64 class counters | lists | pos[B] (qp_kernel.hip, sched_map)
+    unsigned sched_tick = 0;
+    bool sched_on = true;
     hipStream_t tick_stream = nullptr;   // brov_tick_host: the solver's own stream and pinned staging buffer
     double* pin = nullptr;
     size_t pin_doubles = 0;
@@ -224,6 +227,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(lines, Bz);
     AL(pplant, Bz * 16);
     AL(counter, 4);
+    AL(sched, 3 * (size_t)sched_buffer_ints_host(B));
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
     s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
     // BROV_PATH_AUTO at long horizons: the windowed kernel solves an instance on ONE wavefront, the streaming pair spreads its
@@ -241,6 +245,9 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     hipMemset(s->yref_sh, 0, (N + 1) * 16 * sizeof(double));
     hipMemset(s->par, 0, Bz * (N + 1) * 16 * sizeof(double));
     hipMemset(s->res, 0, Bz * sizeof(brov_result));
+    hipMemset(s->sched, 0, 3 * (size_t)sched_buffer_ints_host(B) * sizeof(int32_t));
+    // development knob: BROV_SCHED=0 hands the instances out in index order (A/B of the work ordering)
+    s->sched_on = !(getenv("BROV_SCHED") && atoi(getenv("BROV_SCHED")) == 0);
     {
         std::vector<double> h0(Bz * 12, 0.0);
         for (size_t k = 0; k < Bz; k++) h0[k * 12 + 2] = -20.0;
@@ -714,6 +721,9 @@ static DevParams make_params(const brov_solver* s) {
     P.par = s->par;
     P.par_rp = s->dist6 ? s->par_rp : nullptr;
     P.tsv = general_grid(s) ? s->tsv : nullptr;
+    P.sched = s->sched_on ? s->sched : nullptr;
+    P.sched_stride = sched_buffer_ints_host(s->B);
+    P.sched_r = (int)(s->sched_tick % 3); P.sched_w = (int)((s->sched_tick + 1) % 3); P.sched_z = (int)((s->sched_tick + 2) % 3);
     P.wst = general_grid(s) ? s->wst : nullptr;
     P.x = s->x; P.u = s->u; P.pi = s->pi; P.lam = s->lam;
     P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
@@ -752,6 +762,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
         if (rti_phase != 1) launch_qp(P, st);
     }
     if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
+    if (rti_phase != 1) s->sched_tick++;   // a QP kernel ran: it wrote the next ordering
     s->last_fused = fused;
     s->last_windowed = windowed;
     s->last_stream = st;

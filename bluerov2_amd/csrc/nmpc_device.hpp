@@ -59,11 +59,16 @@ struct DevParams {
     int64_t ws_stride;   // doubles per block
     int32_t* counter;
     int32_t win_L, win_blocks;
+    // work ordering (qp_kernel.hip, sched_map): three rotating buffers of [64 class counters | class lists | pos[B]] int32 -- the
+    // instances whose QP had active bounds in the previous solve are handed out first in this one; nullptr = instances in index order
+    int32_t* sched;
+    int32_t sched_stride, sched_r, sched_w, sched_z;   // buffer read / written / zeroed by this launch
     unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_ACT, IPM_NARR };
 
+int sched_buffer_ints_host(int B);   // int32 per work-ordering buffer (three of them)
 void launch_linearise(const DevParams& P, hipStream_t st);
 void launch_qp(const DevParams& P, hipStream_t st);
 void launch_fused(const DevParams& P, hipStream_t st);  // linearise + QP in one kernel, stage blocks in LDS

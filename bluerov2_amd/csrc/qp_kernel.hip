@@ -89,7 +89,7 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 // Start and step rule of the interior-point loop (the oracle uses the same three numbers; oracle/bluerov2_oracle.c says how they
 // were chosen): a start close to the box (0.3 % of its width inside) with a small complementarity target needs 2 iterations
 // where no bound is active and 4-5 where inputs saturate, instead of 4 and 7 with the textbook 0.1 / 0.995 / mu0 = g0.
-#define IPM_TAU0 0.003  /* interior push of the start point (fraction of the box width) */
+#define IPM_TAU0 0.05   /* interior push of the start point (fraction of the box width; see the oracle) */
 #define IPM_FTB 0.9999  /* fraction to the boundary of a (nearly) full step */
 #define IPM_FTBLO 0.9   /* ... of a blocked step: alpha = a ((1 - a) FTBLO + a FTB), a = min(1, step to the boundary); see the oracle */
 #define IPM_MU0F 0.1    /* mu0 = IPM_MU0F * stationarity residual of the clamped point */
@@ -98,7 +98,8 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 #define POL_FIRST 5       /* tries before the first interior-point iteration (at most) */
 #define POL_LOOP 3        /* ... per round after an interior-point iteration (at most) */
 #define POL_NCHG 8        /* a round ends when a try repairs more than this many inputs, or more than the try before it */
-#define POL_MU_GATE 0.5   /* after a failed round the next one waits until the interior-point loop has cut mu by this factor */
+#define POL_MU_GATE 0.5   /* after a failed round the next one waits until the interior-point loop has cut mu by this factor ... */
+#define POL_ALPHA_GATE 0.9 /* ... and has just taken a (nearly) full step */
 #define POL_TOL_G 1e-9    /* wrong-signed multiplier of a pinned input: tolerated up to POL_TOL_G * R + POL_TOL_GREL * |g|max */
 #define POL_TOL_GREL 1e-13
 
@@ -1286,6 +1287,64 @@ struct IpmVec {
     }
 };
 
+// ---- work ordering: expensive instances first ----------------------------------------------------------------------------------
+// A launch ends with its slowest instance, and which instances are slow is known in advance with good odds: an instance whose QP had
+// active bounds in the previous control tick (it ran active-set tries / interior-point iterations: 2 .. 6 times the cycles of an
+// early exit) almost always has them again in this one.  Every solve therefore records the instances that entered the QP loop
+// (atomic append to a list L of length n, and pos[b] = position in L or -1), and the next solve hands THOSE out first:
+//     (per class of instances, see below)
+//     ticket t <  n            -> instance L[t]
+//     ticket t >= n, pos[t] < 0 -> instance t
+//     ticket t >= n, pos[t] >= 0 (t is in L): the prefix instance its list position names, following pos while that instance is
+//                                 itself in L -- the chain ends on a prefix instance outside L, and two chains never meet (pos is
+//                                 injective on L), so the map is a bijection of [0, B)
+// Tickets are block indices (fused / streaming kernels: the hardware dispatches blocks in index order) or the atomic counter's
+// values (windowed kernel).  Only the ORDER of the work changes: every instance is still solved by one wave on its own data, the
+// results are bit-identical with and without (tests/test_gpu_edge.py).  Three buffers rotate: read (written by the previous
+// solve), written, and zeroed for the next solve.  Measured: mixed batch 17.4 -> see DESIGN.md section 7.
+// Contention: all resident waves reach the end of an equally long solve within microseconds of each other, and atomics on ONE
+// address serialise (~4 ns each: 4 us per round of 1024 waves when every instance runs the loop, 7 % of that leg).  The instances
+// are therefore split into 64 classes (index mod 64), each with its own counter (on its own 128-byte line), list and bijection;
+// ticket t is served by class t mod 64, position t / 64.
+constexpr int kSchedClasses = 64, kSchedCntStride = 32;
+__host__ __device__ inline int sched_class_len(int B) { return (B + kSchedClasses - 1) / kSchedClasses; }
+__host__ __device__ inline int sched_buffer_ints(int B) { return kSchedClasses * kSchedCntStride + kSchedClasses * sched_class_len(B) + B; }
+__device__ __forceinline__ int sched_map(const DevParams& P, int t) {
+    if (!P.sched) return t;
+    const int32_t* __restrict__ Rd = P.sched + (size_t)P.sched_r * P.sched_stride;
+    const int k = t & (kSchedClasses - 1), i = t >> 6, Bc = sched_class_len(P.B);
+    const int n = Rd[k * kSchedCntStride];
+    // nothing to gain when most instances of the class are listed (every ticket would pay a dependent look-up for an order that does
+    // not matter)
+    if (n <= 0 || 2 * n > Bc) return t;
+    const int32_t* __restrict__ L = Rd + kSchedClasses * kSchedCntStride + k * Bc;
+    const int32_t* __restrict__ pos = Rd + kSchedClasses * kSchedCntStride + kSchedClasses * Bc;
+    if (i < n) return L[i];
+    int x = pos[t];
+    if (x < 0) return t;
+    for (int guard = 0; guard < n; guard++) {
+        const int y = pos[x * kSchedClasses + k];
+        if (y < 0) break;
+        x = y;
+    }
+    return x * kSchedClasses + k;
+}
+// lane 0 of the wave that solves instance b.  sched_ticket: where the instance enters the QP loop -- the atomic's round trip is then
+// covered by the work that follows.  sched_note: at the end of the wave.
+__device__ __forceinline__ int sched_ticket(const DevParams& P, int b) {
+    return P.sched ? atomicAdd(P.sched + (size_t)P.sched_w * P.sched_stride + (b & (kSchedClasses - 1)) * kSchedCntStride, 1) : -1;
+}
+__device__ __forceinline__ void sched_note(const DevParams& P, int b, int p) {
+    if (!P.sched) return;
+    int32_t* Wr = P.sched + (size_t)P.sched_w * P.sched_stride;
+    const int Bc = sched_class_len(P.B);
+    if (p >= 0 && p < Bc) Wr[kSchedClasses * kSchedCntStride + (b & (kSchedClasses - 1)) * Bc + p] = b;
+    Wr[kSchedClasses * kSchedCntStride + kSchedClasses * Bc + b] = p;
+}
+__device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) {   // one wave of the launch
+    if (P.sched && lane < kSchedClasses) P.sched[(size_t)P.sched_z * P.sched_stride + lane * kSchedCntStride] = 0;
+}
+
 // everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
 // lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
@@ -1366,6 +1425,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false, polished = false, use_vhat = false;
+    int sched_p = -1;   // lane 0: this instance's place in the next solve's list of expensive instances (work ordering)
     bool ok = pre_ok;
     if constexpr (LDS != 3) ok = riccati_backward<true, LDS, false, true>(I);
     d4 d0;
@@ -1473,6 +1533,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
             status = BROV_STATUS_MAXITER;
+            if (lane == 0) sched_p = sched_ticket(P, b);   // this instance runs the QP loop: first in line in the next solve
             const double inv2nv = 1.0 / (2.0 * nv);
             int round_k = 0, round_cap = POL_FIRST, nchg_prev = nv + 1;
             double mu_gate = 1e300;
@@ -1623,7 +1684,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     IPM_T(1);
                     if (nchg == 0) { polished = true; status = BROV_STATUS_SUCCESS; break; }
                     // the round goes on while the repairs are few and do not grow (a guess that is converging)
-                    if (nchg > POL_NCHG || nchg > nchg_prev) round_cap = 0;
+                    // (the first round is the patient one: see the oracle)
+                    if (nchg > POL_NCHG || (nchg > nchg_prev && ipm_on)) round_cap = 0;
                     nchg_prev = nchg;
                     if (round_k >= round_cap) {   // failed round: the next one waits until the interior-point loop has halved mu
                         if (ipm_on) mu_gate = mu;
@@ -1742,7 +1804,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 // below tol_stat.  Then one more active-set round for the exact answer; if that fails too the iterate is the answer.
                 unres = wave_max(unres);
                 if (unres <= P.tol_mu && rho <= P.tol_stat) converged = true;
-                if (converged || mu <= POL_MU_GATE * mu_gate) { round_k = 0; round_cap = POL_LOOP; nchg_prev = nv + 1; }
+                if (converged || (mu <= POL_MU_GATE * mu_gate && alpha >= POL_ALPHA_GATE)) { round_k = 0; round_cap = POL_LOOP; nchg_prev = nv + 1; }
             }
             if (converged && status == BROV_STATUS_MAXITER) status = BROV_STATUS_SUCCESS;
 #ifdef BROV_DBG_IPM
@@ -1949,6 +2011,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         r->kkt = kkt;
         r->status = status;
         r->qp_iter = early ? 0 : iters;
+        sched_note(P, b, sched_p);
     }
     // first input of the record.  Failed step: the last successfully computed input is held (clamped into the box, NaN -> 0),
     // so that the plant / thrust consumers never see a diverged iterate's input.
@@ -2035,9 +2098,11 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
 // streaming path: linearisation tiles come from HBM (written by lin_wave_kernel); any horizon
 __global__ __launch_bounds__(256, BROV_QP_WAVES) void qp_kernel(DevParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> SGPR addressing
-    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (b >= P.B) return;
+    const int t = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (t >= P.B) return;
+    const int b = __builtin_amdgcn_readfirstlane(sched_map(P, t));
     const int lane = threadIdx.x & 63;
+    if (t == 0) sched_zero_next(P, lane);
     __shared__ double tr_s[4 * 17];   // per-wave transposition scratch of the backward sweep
     Inst I;
     setup_inst(P, I, b, lane);
@@ -2373,9 +2438,10 @@ constexpr int kFusedMaxN = 23;
 template <int W>
 __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x;
+    const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
     const int lane = threadIdx.x;
     const int N = P.N;
+    if (blockIdx.x == 0) sched_zero_next(P, lane);
     DBG_STAMP(0);
     // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
     double* ba_s = smem;                          // [N][12][13]
@@ -2477,6 +2543,7 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
     double* dx_s = smem + win_off_dx(Lc);     // [Lc+1][12]
     double* const_s = smem + win_off_const(Lc);
     if (lane0 == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
+    if (blockIdx.x == 0) sched_zero_next(P, lane0);
     double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
     Win W;
     W.nc = nc; W.Lc = Lc; W.cur = -1; W.valid = 0;
@@ -2497,6 +2564,7 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
         if (lane == 0) b = atomicAdd(P.counter, 1);
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= P.B) break;
+        b = __builtin_amdgcn_readfirstlane(sched_map(P, b));   // expensive instances first
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
         // lin_phase (which needs the whole architectural register file)
         const LaneCst lc = load_lane_cst(P.cst, lane);
@@ -2602,6 +2670,7 @@ void launch_qp(const DevParams& P, hipStream_t st) {
 }
 
 bool fused_supported(int N) { return N <= kFusedMaxN; }
+int sched_buffer_ints_host(int B) { return (sched_buffer_ints(B) + 31) & ~31; }
 
 int windowed_stage_count(int N) { return win_len(N); }
 size_t windowed_ws_doubles(int N) { return win_ws_doubles(N); }

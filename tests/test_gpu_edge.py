@@ -255,3 +255,41 @@ def test_unusable_options_are_rejected_with_a_reason(ba, kw, what):
     s.set_x0(np.zeros((2, 12))); s.solve()          # the solver is still usable with its old options
     assert np.all(s.results()["status"] == 0)
     s.close()
+
+
+@pytest.mark.parametrize("N,B,path", [(20, 1500, 2), (10, 700, 2), (40, 1300, 2), (20, 600, 1)])
+def test_work_ordering_changes_nothing_but_the_order(ba, golden_traj, N, B, path):
+    """The kernels hand the instances whose QP had active bounds in the previous solve out first (qp_kernel.hip, sched_map) -- a
+    bijection of the instance indices rebuilt by every solve.  Same results, bit for bit, as the index order (BROV_SCHED=0), over
+    ticks in which the set of such instances changes; every instance solved exactly once (its record carries this tick's KKT)."""
+    import os
+    rng = np.random.default_rng(N)
+    circ = golden_traj["circle"]
+    x0 = np.zeros((B, 12)); x0[:, :6] = circ[0, :6]
+    x0 += rng.normal(size=(B, 12)) * 0.03
+    far = rng.random(B) < 0.3
+    x0[far, :3] += rng.uniform(-3.5, 3.5, size=(int(far.sum()), 3))
+    outs = []
+    for sched in ("1", "0"):
+        os.environ["BROV_SCHED"] = sched
+        try:
+            s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / max(N, 20), kernel_path=path))
+        finally:
+            os.environ.pop("BROV_SCHED", None)
+        s.set_params(ba.P_NOMINAL)
+        rec = []
+        for k in range(5):
+            xk = x0.copy()
+            if k >= 2:
+                xk[:, :3] = x0[::-1, :3]     # another set of far-off instances from tick 2 on
+            s.set_x0(xk); s.set_yref(circ[k:k + N + 1]); s.solve()
+            r = s.results()
+            rec.append((r["u0"].copy(), r["cost"].copy(), r["kkt"].copy(), r["status"].copy(), r["qp_iter"].copy(), s.get_iterate()[1].copy()))
+        outs.append(rec)
+        s.close()
+    n_qp = 0
+    for a, b in zip(*outs):
+        for fa, fb in zip(a, b):
+            assert np.array_equal(fa, fb)
+        n_qp += int((a[4] > 0).sum())
+    assert n_qp > B // 4
