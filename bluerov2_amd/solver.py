@@ -98,6 +98,7 @@ def _load():
         "brov_set_yref_candidates_host": [vp, C.c_int, dp, dp, dp, C.c_double, C.c_double],
         "brov_set_candidate_params_host": [vp, C.c_int, dp, dp, dp], "brov_set_yref_candidates": [vp, C.c_double, C.c_double, vp],
         "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
+        "brov_tick_host": [vp, dp, dp, dp, C.c_int, vp],
         "brov_set_time_steps": [vp, dp], "brov_set_stage0_weight": [vp, dp], "brov_general_grid": [vp],
         "brov_enable_dist6": [vp, C.c_int], "brov_dist6_enabled": [vp], "brov_set_rp_disturbance_host": [vp, dp, C.c_int],
         "brov_set_params18_host": [vp, dp, C.c_int], "brov_plant_set_rp_disturbance_host": [vp, dp], "brov_get_rp_disturbance_host": [vp, dp],
@@ -264,6 +265,17 @@ class BatchSolver:
         return y
 
     # ---- closed loop on the device ---------------------------------------------------------------
+    def tick(self, x0=None, yref=None, params=None, rti_phase=0):
+        """one control tick with ONE host wait (brov_tick_host): the inputs that changed (None = unchanged; x0 [B,12], ONE reference
+        window shared by the batch [N+1,16], per-stage parameters [B,N+1,16]) + the step + the result records"""
+        res = np.zeros(self.B, dtype=RESULT_DTYPE)
+        a = None if x0 is None else _arr(x0, (self.B, NX))
+        b = None if yref is None else _arr(yref, (self.N + 1, NY))
+        c = None if params is None else _arr(params, (self.B, self.N + 1, NP))
+        self._chk(self._L.brov_tick_host(self._h, None if a is None else _dp(a), None if b is None else _dp(b),
+                                         None if c is None else _dp(c), int(rti_phase), C.c_void_p(res.ctypes.data)), "tick")
+        return res
+
     # ---- non-uniform grid / separate stage-0 weight (acados_solver_bluerov2.h:141,146; .c:422-441): streaming kernels ------------
     def set_time_steps(self, ts):
         self._chk(self._L.brov_set_time_steps(self._h, None if ts is None else _dp(_arr(ts, (self.N,)))), "set_time_steps")

@@ -293,3 +293,26 @@ def test_work_ordering_changes_nothing_but_the_order(ba, golden_traj, N, B, path
             assert np.array_equal(fa, fb)
         n_qp += int((a[4] > 0).sum())
     assert n_qp > B // 4
+
+
+def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj):
+    """brov_tick_host (what the acados-shaped drop-in makes of one bluerov2_acados_solve): pinned staging, asynchronous copies, one
+    wait -- the same records and the same iterate, bit for bit, as the separate setters + brov_solve + brov_get_results_host; inputs
+    passed as None keep their values"""
+    N, B = 20, 12
+    x0, circ = _inputs(golden_traj, B, seed=21, big=2.5)
+    p = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16))).copy()
+    p[:, :, 0] = np.linspace(-50, 50, B)[:, None]
+    a = ba.BatchSolver(B, ba.SolverOptions(N)); b = ba.BatchSolver(B, ba.SolverOptions(N))
+    for k in range(4):
+        a.set_x0(x0); a.set_yref(circ[k:k + N + 1])
+        if k == 0:
+            a.set_params(p)
+        a.solve(); ra = a.results()
+        rb = b.tick(x0=x0 if k != 2 else None, yref=circ[k:k + N + 1], params=p if k == 0 else None)   # tick 2: x0 unchanged -> not passed
+        for f in ("u0", "cost", "kkt", "status", "qp_iter", "thrust"):
+            assert np.array_equal(ra[f], rb[f]), (k, f)
+        for ia, ib in zip(a.get_iterate(), b.get_iterate()):
+            assert np.array_equal(ia, ib)
+    assert (ra["qp_iter"] > 0).any()
+    a.close(); b.close()
