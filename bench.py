@@ -12,15 +12,17 @@ hydrodynamic parameters; the reference window advances one row per step and is s
     python bench.py --gpus 8 --config 4      65 536 lemniscate candidates, 8192 per GPU, all-gather + global arg-min every step
     python bench.py --gpus 8 --config 5      horizon sweep N in {10,20,40,80}, 4096 per GPU (Ts = 1/N)
     python bench.py --config 3               16 384 DOB-MPC disturbance draws on one GPU
+    python bench.py --gpus 8 --config 4 --scaling strong    the config's TOTAL (65 536 candidates) split over the ranks
     python bench.py --gpus 2 --dry-run       launcher / rendezvous / gather / select plumbing on CPU (gloo), no solver
 
 Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL), each rank owns its own instances
-(weak scaling), no communication during the solve, ONE all-gather of the 104-byte result records per step (u0, cost, KKT,
+(--scaling weak, the default: the per-GPU batch on every rank; --scaling strong: the config's total split over the ranks), no
+communication during the solve, ONE all-gather of the 104-byte result records per step (u0, cost, KKT,
 status, thrusts), arg-min of cost on the gathered records for the candidate workload.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel; bound = FP64 MFMA),
 `roofline_hbm`, `cpu_baseline` (the C oracle timed on the host cores -- never the thing measured as `value`) and, for the
-default single-GPU run, `forced_ipm`, `mixed_batch_25pct_saturated` and `cpu_baseline_single_thread`.
+default single-GPU run, `forced_ipm`, `mixed_batch_25pct_saturated[_shuffled]` and `cpu_baseline_single_thread`.
 """
 import argparse
 import json

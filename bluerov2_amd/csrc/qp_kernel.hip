@@ -1,5 +1,6 @@
-// qp_kernel.hip -- RTI feedback phase on gfx950: box-constrained OCP-QP by a Riccati-based primal-dual interior point
-// method + full-step SQP update, ONE WAVEFRONT PER OCP INSTANCE.
+// qp_kernel.hip -- RTI feedback phase on gfx950: box-constrained OCP-QP by Riccati-based active-set rounds around a primal-dual
+// interior-point loop (round 3; the schedule is the oracle's, bluerov2_oracle.c "ACTIVE-SET POLISH") + full-step SQP update,
+// ONE WAVEFRONT PER OCP INSTANCE.
 //
 // Replaces what the reference hands to HPIPM through acados (FULL_CONDENSING_HPIPM, qp_iter_max 50;
 // /root/reference/bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.c:146,664-669) and the
@@ -22,8 +23,9 @@
 //
 // File map: tile primitives, per-stage operand access -> sweeps (bwd_* / fwd_* / roll_* / adj_*, each split into an
 // initialisation and a "stages of the resident window" part) -> window manager of the windowed kernel (Win, win_*, sw_*) ->
-// qp_body (QP solve, multiplier recovery, full step; shared by all kernels) -> lin_phase (wave-wide linearisation) -> kernels
-// (qp_kernel + lin_wave_kernel streaming pair, rti_fused_kernel / _w2, rti_window_kernel) and their launchers.
+// work ordering (sched_*) -> qp_body (QP solve, multiplier recovery, full step; shared by all kernels) -> lin_phase (wave-wide
+// linearisation) -> kernels (qp_kernel + lin_wave_kernel[_grid] streaming pair, rti_fused_kernel / _w2, rti_window_kernel) and
+// their launchers.
 #include "lin_device.hpp"
 #include "nmpc_device.hpp"
 
