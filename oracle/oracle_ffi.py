@@ -248,15 +248,21 @@ class CasadiRef:
         _, A, B = self.vde_forw(x, np.eye(NX), np.zeros((NX, NU)), u, p)
         return A, B
 
-    def rk4_sens(self, x, u, p, h):
-        """textbook ERK4 driving the reference's expl_vde_forw (acados sim_erk with 4 stages, 1 step)."""
+    def rk4_sens(self, x, u, p, h, drp=None):
+        """textbook ERK4 driving the reference's expl_vde_forw (acados sim_erk with 4 stages, 1 step).
+        drp = (d_phi, d_theta): the 6-disturbance variant -- the reference's own xdot plus the two additive terms d_phi / Ix on dp and
+        d_theta / Iy on dq (constants of the step: the variational equation, i.e. A and B, is the reference's unchanged)"""
         ca, cb = [0.0, 0.5, 0.5, 1.0], [1 / 6, 1 / 3, 1 / 3, 1 / 6]
         x = np.asarray(x, dtype=np.float64)
         Sx0, Su0 = np.eye(NX), np.zeros((NX, NU))
         k, KSx, KSu = np.zeros(NX), np.zeros((NX, NX)), np.zeros((NX, NU))
         xa, Sxa, Sua = x.copy(), Sx0.copy(), Su0.copy()
+        off = np.zeros(NX)
+        if drp is not None:
+            off[9], off[10] = drp[0] / 0.3, drp[1] / 0.63     # Ix, Iy: bluerov2.py:78-79
         for s in range(4):
             k, KSx, KSu = self.vde_forw(x + h * ca[s] * k, Sx0 + h * ca[s] * KSx, Su0 + h * ca[s] * KSu, u, p)
+            k = k + off
             xa, Sxa, Sua = xa + h * cb[s] * k, Sxa + h * cb[s] * KSx, Sua + h * cb[s] * KSu
         return xa, Sxa, Sua
 

@@ -70,10 +70,10 @@ def model_vectors(ref, n=128, n_rk=64, seed=0):
     return dict(x=X, u=U, p=P, f=F, A=A, B=B, h=hs, xn=XN, Ad=AD, Bd=BD)
 
 
-def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU, Wed=None, W0d=None):
+def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU, Wed=None, W0d=None, drp=None):
     """one SQP-RTI step: linearise with the reference model, condense, solve the box QP by BVLS, full step.
     Ts: one step or N of them (non-uniform grid: ERK4 step and cost scaling of stage i, acados_solver_bluerov2.c:111-131);
-    W0d: separate stage-0 weight (:422-441)"""
+    W0d: separate stage-0 weight (:422-441); drp[N+1][2]: roll / pitch disturbance moments of the 6-disturbance variant"""
     Wed = Wd[:NX] if Wed is None else Wed
     Tsv = np.broadcast_to(np.asarray(Ts, dtype=float), (N,))
     Wst = np.tile(Wd, (N, 1))
@@ -81,7 +81,7 @@ def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU, 
         Wst[0] = W0d
     A, B, b = np.zeros((N, NX, NX)), np.zeros((N, NX, NU)), np.zeros((N, NX))
     for i in range(N):
-        xn, A[i], B[i] = ref.rk4_sens(x[i], u[i], p[i], float(Tsv[i]))
+        xn, A[i], B[i] = ref.rk4_sens(x[i], u[i], p[i], float(Tsv[i]), drp=None if drp is None else drp[i])
         b[i] = xn - x[i + 1]
     Qd = np.concatenate([Tsv[:, None] * Wst[:, :NX], Wed[None, :]])
     q = Qd * (x - yref[:, :NX])

@@ -171,3 +171,41 @@ def test_non_uniform_grid_and_stage0_weight_against_the_independent_recipe(oracl
             nact += info["nact"]
             xo, uo = x.copy(), u.copy()
         assert nact > 0
+
+
+def test_six_disturbance_variant_against_the_independent_recipe(oracle, golden_traj):
+    """the variant's RTI step (oracle) against the recipe built on the REFERENCE's model -- its own expl_vde_forw
+    plus the two additive terms on dp, dq --, numpy condensing and scipy BVLS; per-stage disturbance draws, active bounds"""
+    import os
+    import sys
+    import oracle.oracle_ffi as F
+    if not os.path.exists(F.REF_SO):
+        pytest.skip("oracle/_ref is not here")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import make_golden as G
+    ref = F.CasadiRef()
+    circ = golden_traj["circle"]
+    rng = np.random.default_rng(4)
+    N = 20
+    x0 = np.zeros(12); x0[:6] = circ[0, :6]; x0[:3] += [2.5, -2.0, 1.0]
+    p = np.tile(G.P_NOMINAL, (N + 1, 1)); p[:, :4] = rng.uniform(-150, 150, (N + 1, 4))
+    drp = rng.uniform(-1.5, 1.5, (N + 1, 2))
+    x = np.tile([0, 0, -20.0] + [0] * 9, (N + 1, 1)).astype(float); u = np.zeros((N, 4))
+    lbu, ubu = np.full(4, -10.0), np.full(4, 10.0)     # a tight box: active bounds on every tick
+    op = oracle.opts(N, 0.05, lbu=list(lbu), ubu=list(ubu))
+    xo, uo = x.copy()[None], u.copy()[None]
+    pi, lam = np.zeros((1, N, 12)), np.zeros((1, N, 8))
+    nact = 0
+    for k in range(3):
+        yref = circ[k:k + N + 1].copy()
+        x, u, info = G.rti_step_independent(ref, N, 0.05, x0, yref, p, x, u, drp=drp, lbu=lbu, ubu=ubu)
+        _, r = oracle.rti_step_batch(op, x0[None], yref[None], p[None], xo, uo, pi, lam, drp=drp[None])
+        assert r["status"][0] == 0 and info["qp_kkt"] < 1e-9
+        assert np.abs(uo[0] - u).max() < 1e-9 and np.abs(xo[0] - x).max() < 1e-9, (k, np.abs(uo[0] - u).max())
+        nact += info["nact"]
+        xo[0], uo[0] = x, u
+    assert nact > 0
+    # and the two terms matter: the shipped model lands elsewhere
+    x2, u2, _ = G.rti_step_independent(ref, N, 0.05, x0, circ[:N + 1].copy(), p, np.tile([0, 0, -20.0] + [0] * 9, (N + 1, 1)).astype(float), np.zeros((N, 4)))
+    x3, u3, _ = G.rti_step_independent(ref, N, 0.05, x0, circ[:N + 1].copy(), p, np.tile([0, 0, -20.0] + [0] * 9, (N + 1, 1)).astype(float), np.zeros((N, 4)), drp=drp)
+    assert np.abs(x2 - x3).max() > 1e-3
