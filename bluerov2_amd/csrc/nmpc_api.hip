@@ -15,7 +15,7 @@
 
 using namespace brov;
 
-#define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N >= 24: up to this many instances run on the streaming kernels */
+#define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N > 81: up to this many instances run on the streaming kernels */
 
 static thread_local std::string g_err;
 extern "C" const char* brov_last_error(void) { return g_err.c_str(); }
@@ -66,7 +66,7 @@ struct brov_solver {
     bool last_fused = false, last_windowed = false;
     double* ws = nullptr;        // windowed kernel: per-block parking images
     int32_t* counter = nullptr;
-    int win_blocks = 0;
+    int win_blocks = 0, win_L = 0;
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
     // general grid (streaming kernels): per-stage time steps and / or a separate stage-0 weight
@@ -230,13 +230,16 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(sched, 3 * (size_t)sched_buffer_ints_host(B));
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
     s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
-    // BROV_PATH_AUTO at long horizons: the windowed kernel solves an instance on ONE wavefront, the streaming pair spreads its
-    // linearisation over several -- for a handful of instances (the ROS node's batch of one: 164 vs 187 us at N = 80) the
-    // streaming pair has the shorter latency, from a few dozen instances on the windowed kernel wins (profiles/r2_batch_sweep.json)
-    const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed;
+    // BROV_PATH_AUTO at long horizons and a handful of instances (the ROS node's batch of one): when the whole horizon fits one
+    // window (N <= 81: resident mode, no parking and no window fetches) the windowed kernel has the shorter latency (N = 80, B = 1:
+    // 150 vs 172 us); beyond that the streaming pair, which spreads the linearisation over several wavefronts, is as fast and
+    // needs no workspace (profiles/r3_small_batch_latency.txt)
+    const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed &&
+                     windowed_stage_count(opts->N, B) != opts->N;
     if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few) {
-        s->win_blocks = windowed_blocks(opts->N, B);
-        AL(ws, (size_t)s->win_blocks * windowed_ws_doubles(opts->N));
+        s->win_L = windowed_stage_count(opts->N, B);
+        s->win_blocks = windowed_blocks(opts->N, B, s->win_L);
+        AL(ws, (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L));
     }
 #undef AL
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
@@ -729,8 +732,8 @@ static DevParams make_params(const brov_solver* s) {
     P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
-    P.ws = s->ws; P.ws_stride = (int64_t)windowed_ws_doubles(s->N); P.counter = s->counter;
-    P.win_L = windowed_stage_count(s->N); P.win_blocks = s->win_blocks;
+    P.ws = s->ws; P.ws_stride = s->win_L ? (int64_t)windowed_ws_doubles(s->N, s->win_L) : 0; P.counter = s->counter;
+    P.win_L = s->win_L; P.win_blocks = s->win_blocks;
     P.dbg = s->dbg;
     return P;
 }
@@ -838,6 +841,7 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
 extern "C" int brov_last_kernel_path(const brov_solver* s) {
     return s ? (s->last_fused ? BROV_PATH_FUSED : (s->last_windowed ? BROV_PATH_WINDOWED : BROV_PATH_STREAMING)) : BROV_ERR_ARG;
 }
+extern "C" int brov_window_stages(const brov_solver* s) { return s ? (s->ws ? s->win_L : 0) : BROV_ERR_ARG; }
 extern "C" int brov_debug_dump_linearisation(brov_solver* s, int enable) {
     if (!s) return BROV_ERR_ARG;
     s->dump_lin = enable != 0;

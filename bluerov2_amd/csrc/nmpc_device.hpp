@@ -75,9 +75,9 @@ void launch_fused(const DevParams& P, hipStream_t st);  // linearise + QP in one
 bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
 // windowed LDS-resident kernel for longer horizons: persistent blocks (one wavefront each) that take instances from a counter
 void launch_windowed(const DevParams& P, hipStream_t st);
-int windowed_stage_count(int N);          // stages per window
-int windowed_blocks(int N, int B);        // persistent blocks that will be launched on the current device
-size_t windowed_ws_doubles(int N);        // per-block workspace
+int windowed_stage_count(int N, int B);   // stages per window (= N for batches of at most one instance per CU: resident mode)
+int windowed_blocks(int N, int B, int L); // persistent blocks that will be launched on the current device
+size_t windowed_ws_doubles(int N, int L); // per-block workspace
 void launch_window(const double* traj, int rows, const int* lines, int line0, int B, int N, int ncols, double* out, hipStream_t st);
 void launch_plant(double* x0, const brov_result* res, const double* pplant, const double* prp, int rp_stride, int B, double dt, int substeps,
                   double* xlog, double* ulog, hipStream_t st);   // prp: roll / pitch disturbance moments, instance b at prp + b * rp_stride (or nullptr)

@@ -1054,6 +1054,7 @@ __device__ __forceinline__ void opaque_lane(Inst& I) {
     I.rg = I.lane >> 4; I.cl = I.lane & 15;
 }
 // NaN among the window's candidate inputs / state steps (checked where they are produced, on the LDS copy)
+template <bool RES>
 __device__ __forceinline__ bool win_nan_check(const Inst& I, const Win& W, bool first) {
     const lds_f64* vh = (const lds_f64*)(W.lds + win_off_vh(W.Lc));
     const lds_f64* dx = (const lds_f64*)(W.lds + win_off_dx(W.Lc));
@@ -1073,11 +1074,15 @@ __device__ __forceinline__ bool win_nan_check(const Inst& I, const Win& W, bool 
     bool bad = false;
 #pragma unroll
     for (int t = 0; t < 6; t++) bad = bad | !(v[t] == v[t]);
+    if constexpr (RES) {   // resident mode: windows longer than 20 stages
+        for (int j = I.lane + 128; j < I.N * 4; j += 64) { const double e = vh[j]; bad = bad | !(e == e); }
+        for (int j = I.lane + 256 + (first ? 0 : NX); j < (I.N + 1) * NX; j += 64) { const double e = dx[j]; bad = bad | !(e == e); }
+    }
     return bad;
 }
 template <int LDS>
 __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const double* cst = nullptr) {
-    if constexpr (LDS != 3) {
+    if constexpr (LDS < 3) {
         riccati_forward<LDS>(I, d0);
     } else {
         opaque_lane(I);
@@ -1107,7 +1112,7 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
             win_flush_small(I.vhat + I.i0 * 4, W->lds + win_off_vh(W->Lc), I.N * 4, I.lane);
             win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
-            bad = bad | win_nan_check(I, *W, c == 0);
+            bad = bad | win_nan_check<LDS == 4>(I, *W, c == 0);
             if (cst) {
                 const lds_f64* vh = (const lds_f64*)(W->lds + win_off_vh(W->Lc));
 #pragma unroll
@@ -1115,6 +1120,12 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
                     const int j = I.lane + 64 * t;
                     const double vj = vh[j < I.N * 4 ? j : 0], lb = lbm - uw[t], ub = ubm - uw[t];   // read unconditionally (clamped)
                     infeas = infeas | ((j < I.N * 4) & !(vj >= lb && vj <= ub));
+                }
+                if constexpr (LDS == 4) {   // resident mode: windows longer than 20 stages
+                    for (int j = I.lane + 128; j < I.N * 4; j += 64) {
+                        const double vj = vh[j], uj = I.u[I.i0 * 4 + j];
+                        infeas = infeas | !(vj >= lbm - uj && vj <= ubm - uj);
+                    }
                 }
                 uw[0] = un[0]; uw[1] = un[1];
             }
@@ -1126,7 +1137,7 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
 }
 template <int LDS>
 __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const double* varr) {
-    if constexpr (LDS != 3) {
+    if constexpr (LDS < 3) {
         rollout<LDS>(I, d0, varr);
     } else {
         opaque_lane(I);
@@ -1139,7 +1150,7 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
             __syncthreads();
             win_flush_small(I.dxb + I.i0 * NX, W->lds + win_off_dx(W->Lc), (I.N + 1) * NX, I.lane);
             W->valid |= WM_DX;
-            bad = bad | win_nan_check(I, *W, c == 0);
+            bad = bad | win_nan_check<LDS == 4>(I, *W, c == 0);
         }
         W->nan = __ballot(bad) != 0ull;
         wave_fence();
@@ -1147,7 +1158,7 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
 }
 template <bool COMMIT, int LDS>
 __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, double* garr, double* pi_out) {
-    if constexpr (LDS != 3) {
+    if constexpr (LDS < 3) {
         adjoint<COMMIT, LDS>(I, varr, garr, pi_out);
     } else {
         opaque_lane(I);
@@ -1168,6 +1179,7 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
 // steps, inputs, input gradient and multipliers are all in LDS; the iterate rows and the reference of the window are requested
 // before the window is fetched and swept, so the step costs no exposed HBM round trip.  cost: this lane's share of the NLS
 // objective at the updated iterate; u0v: lanes 0..3 the new first input.
+template <bool RES>
 __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, Win& W, int b, const double* vfin, bool early,
                                                    double& cost, double& u0v) {
     const int lane = I.lane, NT = I.NT, L = W.Lc;
@@ -1231,13 +1243,32 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
                 cost += 0.5 * wx[t] * e * e;
             }
         }
+        if constexpr (RES) {   // resident mode: windows longer than 20 stages, the elements beyond the preloaded 128 / 256
+            for (int j = lane + 128; j < nu; j += 64) {
+                const int i = j >> 2, m = j & 3;
+                const double gg = early ? 0.0 : (double)gl[j];
+                lam_it[(size_t)(i0 + i) * 8 + m] = gg > 0 ? gg : 0.0;
+                lam_it[(size_t)(i0 + i) * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
+                const double un = u_it[i0 * 4 + j] + vh[j];
+                u_it[i0 * 4 + j] = un;
+                const double e = un - I.yref[(size_t)(i0 + i) * 16 + 12 + m];
+                cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+            }
+            for (int j = lane + 256; j < nxr; j += 64) {
+                const int i = j / 12, cc = j - i * 12;
+                const double xn = x_it[i0 * 12 + j] + dx[j];
+                x_it[i0 * 12 + j] = xn;
+                const double e = xn - I.yref[(size_t)(i0 + i) * 16 + cc];
+                cost += 0.5 * ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc]) * e * e;
+            }
+        }
     }
     wave_fence();
 }
 
 template <bool FACTOR, int LDS>
 __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
-    if constexpr (LDS != 3) {
+    if constexpr (LDS < 3) {
         return riccati_backward<FACTOR, LDS>(I);
     } else {
         opaque_lane(I);
@@ -1251,8 +1282,10 @@ __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
             // park what the sweep produced: K^T | kff (contiguous), or kff alone after a solve-only sweep.  The resident K^T stays
             // valid in both cases (a solve-only sweep does not touch it) unless an adjoint sweep has overwritten the area since.
             double* img = W->img + (size_t)c * win_img_doubles(W->Lc);
-            if (FACTOR) win_flush(img + win_off_kt(W->Lc), W->lds + win_off_kt(W->Lc), 52 * W->Lc, I.lane);
-            else win_flush(img + win_off_kff(W->Lc), W->lds + win_off_kff(W->Lc), 4 * W->Lc, I.lane);
+            if constexpr (LDS != 4) {   // (resident mode: the single window keeps what the sweep produced where it is)
+                if (FACTOR) win_flush(img + win_off_kt(W->Lc), W->lds + win_off_kt(W->Lc), 52 * W->Lc, I.lane);
+                else win_flush(img + win_off_kff(W->Lc), W->lds + win_off_kff(W->Lc), 4 * W->Lc, I.lane);
+            }
             if (FACTOR) W->valid |= WM_GAIN;
         }
         wave_fence();
@@ -1429,7 +1462,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     bool early = false, polished = false, use_vhat = false;
     int sched_p = -1;   // lane 0: this instance's place in the next solve's list of expensive instances (work ordering)
     bool ok = pre_ok;
-    if constexpr (LDS != 3) ok = riccati_backward<true, LDS, false, true>(I);
+    if constexpr (LDS < 3) ok = riccati_backward<true, LDS, false, true>(I);
     d4 d0;
     double kkt = 0.0;
     {
@@ -1455,7 +1488,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         sw_forward<LDS>(I, W, d0, cst);
         DBG_STAMP(3);
         bool feas = true;
-        if constexpr (LDS == 3) {
+        if constexpr (LDS >= 3) {
             feas = W->feas;   // checked window by window inside the sweep wrapper
         } else if constexpr (EL) {  // nv <= 92: two elements per lane, u already in registers
 #pragma unroll
@@ -1489,7 +1522,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
 #ifdef BROV_DBG_IPM
             unsigned long long ipm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipm_last = __builtin_readcyclecounter();
 #endif
-            constexpr bool CACHE = (LDS == 3);   // windowed kernel: register copies per loop group (IpmVec MODE 2)
+            constexpr bool CACHE = (LDS >= 3);   // windowed kernel: register copies per loop group (IpmVec MODE 2)
             constexpr int kIpmT = EL ? 2 : 8;    // elements per lane; streaming / windowed path: nv <= 512
             using Vec = IpmVec<EL ? 1 : (CACHE ? 2 : 0), kIpmT>;
             Vec vV{{}, V}, vTL{{}, TL}, vTU{{}, TU}, vLL{{}, LL}, vLU{{}, LU}, vDVA{{}, DVA},
@@ -1658,7 +1691,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                             if constexpr (EL) wr_vhat(j, vj); else I.vhat[j] = vj;
                         }
                             }
-                    if constexpr (LDS == 3) bad = bad || W->nan;
+                    if constexpr (LDS >= 3) bad = bad || W->nan;
                     if (__ballot(bad) != 0ull) { status = BROV_STATUS_NAN; break; }
                     // multipliers of this point: the state steps of the forward sweep are its roll-out (the snap of a pinned input
                     // is a rounding error), so the adjoint recursion alone gives g = R v + r + B'pi
@@ -1857,11 +1890,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         DBG_STAMP(4);
         // fused path: the iterate and the reference of the commit loops below are requested before the adjoint sweep, which
         // hides their round trip (the single resident wave has nothing else to switch to)
-        if constexpr (LDS == 3) {
+        if constexpr (LDS >= 3) {
             if (W->nan) {
                 status = BROV_STATUS_NAN;
             } else {
-                win_adjoint_commit(P, I, *W, b, vfin, early, cost, u0v);
+                win_adjoint_commit<LDS == 4>(P, I, *W, b, vfin, early, cost, u0v);
                 wrote_u0 = true;
             }
             DBG_STAMP(5);
@@ -1984,7 +2017,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
         }
-        }   // LDS != 3
+        }   // LDS < 3
     }
     if (status != BROV_STATUS_SUCCESS && status != BROV_STATUS_MAXITER) {
         // failed step: report the cost of the entering iterate; the iterate is left as it is (acados: SQP_RTI returns before
@@ -2524,14 +2557,19 @@ static bool first_launch_on_device(int which) {
 // takes instances from an atomic counter -- the parked working set is (blocks x horizon), not (batch x horizon), and stays
 // hot in L2 / Infinity Cache.
 constexpr int kWinMaxStages = 20;
+constexpr int kLinMaxIntervals = 23;   // lin_phase: 64 / n >= 2 lanes per interval
 __host__ __device__ inline int win_chunks(int N) { return (N + kWinMaxStages - 1) / kWinMaxStages; }
 __host__ __device__ inline int win_len(int N) { const int nc = win_chunks(N); return (N + nc - 1) / nc; }
-__host__ __device__ inline size_t win_ws_doubles(int N) {
-    return (size_t)win_chunks(N) * win_img_doubles(win_len(N))            // parked window images
+__host__ __device__ inline size_t win_ws_doubles(int N, int L) {
+    return (size_t)((N + L - 1) / L) * win_img_doubles(L)                  // parked window images
            + (size_t)N * 4 + (size_t)(N + 1) * NX                          // vhat, dx (flat over the horizon)
            + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N;        // Ks Mt Pb | interior-point vectors
 }
-__global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
+// RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
+// one instance per CU.  Nothing is parked and no window is fetched.  A separate instantiation (rti_window_kernel_res), so that the
+// large-batch kernel carries none of its code.
+template <bool RES>
+__device__ __forceinline__ void rti_window_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x;
     const int N = P.N, Lc = P.win_L, nc = (N + Lc - 1) / Lc;
@@ -2618,7 +2656,20 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
                 wq = P.cst[lane];
             }
             __syncthreads();
-            lin_phase<true>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+            if (!RES || n <= kLinMaxIntervals) {
+                lin_phase<true>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+            } else {
+                // resident mode (one window = the whole horizon in a 160 KB slice, small batches): the wave-wide linearisation takes
+                // at most 23 intervals at a time -- sub-chunks, each into its own part of the slice (row n_j of a sub-chunk's q is
+                // row 0 of the next one's: contiguous)
+                const int nsub = (n + kWinMaxStages - 1) / kWinMaxStages, lsub = (n + nsub - 1) / nsub;
+                for (int j0 = 0; j0 < n; j0 += lsub) {
+                    const int nj = n - j0 < lsub ? n - j0 : lsub;
+                    lin_phase<true>(P, b, i0 + j0, nj, lane, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s, q_s + (size_t)j0 * NX,
+                                    r_s + (size_t)j0 * NU, part, nanp, false);
+                    __syncthreads();
+                }
+            }
             if (c < nc - 1 && lane < NX) q_s[n * NX + lane] = P.Ts * wq * (xq - yq);
             __syncthreads();
             if (P.dump_lin) copy_out_linearisation(P, b, i0, n, lane, ba_s, bv_s);
@@ -2632,7 +2683,8 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
             const unsigned long long t2 = P.dbg ? __builtin_readcyclecounter() : 0;
             // park the window: one contiguous image.  Window 0 keeps its K^T | kff in LDS only: the forward sweep starts on the resident
             // copy, and every later factor sweep parks its own gains
-            win_flush(W.img + (size_t)c * win_img_doubles(Lc), smem, c == 0 ? win_off_kt(Lc) : win_img_doubles(Lc), lane);
+            // (a single window is never fetched back: nothing to park)
+            if (!RES) win_flush(W.img + (size_t)c * win_img_doubles(Lc), smem, c == 0 ? win_off_kt(Lc) : win_img_doubles(Lc), lane);
             if (P.dbg) { const unsigned long long t3 = __builtin_readcyclecounter(); t_lin += t1 - t0; t_bwd += t2 - t1; t_fl += t3 - t2; }
         }
         if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + 7] = (t_lin & 0xFFFFF) | ((t_bwd & 0xFFFFF) << 20) | ((t_fl & 0xFFFFF) << 40);
@@ -2645,7 +2697,7 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
         W.t_fetch = 0; W.n_fetch = 0;
 #endif
 #if !defined(BROV_WIN_EXP) || BROV_WIN_EXP != 1
-        qp_body<3>(P, I, b, part, nanp, &W, S.ok);
+        qp_body<(RES ? 4 : 3)>(P, I, b, part, nanp, &W, S.ok);
 #endif
 #ifdef BROV_DBG_WIN
         if (P.dbg && lane == 0) { P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 3] = W.t_fetch; P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 4] = W.n_fetch; }
@@ -2653,6 +2705,8 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) {
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_window_body<false>(P); }
+__global__ __launch_bounds__(64, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
@@ -2674,19 +2728,32 @@ void launch_qp(const DevParams& P, hipStream_t st) {
 bool fused_supported(int N) { return N <= kFusedMaxN; }
 int sched_buffer_ints_host(int B) { return (sched_buffer_ints(B) + 31) & ~31; }
 
-int windowed_stage_count(int N) { return win_len(N); }
-size_t windowed_ws_doubles(int N) { return win_ws_doubles(N); }
-static size_t windowed_lds_bytes(int N) {
-    return ((size_t)win_off_const(win_len(N)) + 2 + 17) * sizeof(double);
+static size_t windowed_lds_bytes(int L) { return ((size_t)win_off_const(L) + 2 + 17) * sizeof(double); }
+// stages per window.  Large batches: windows of <= 20 stages, four blocks per CU.  Batches of at most one instance per CU (the ROS
+// node's batch of one, small Monte-Carlo sets): RESIDENT mode -- one window = the whole horizon in a slice of up to 160 KB, one
+// block per CU: no parking, no window fetches (N <= 80 fits)
+int windowed_stage_count(int N, int B) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool no_resident = getenv("BROV_DEV_NO_RESIDENT") && atoi(getenv("BROV_DEV_NO_RESIDENT")) != 0;   // development knob (tests)
+    if (!no_resident && N > kWinMaxStages && B <= cus && windowed_lds_bytes(N) <= 160 * 1024) return N;
+    return win_len(N);
 }
-int windowed_blocks(int N, int B) {
-    if (first_launch_on_device(2))
+size_t windowed_ws_doubles(int N, int L) { return win_ws_doubles(N, L); }
+static bool windowed_resident(int L) { return L > kWinMaxStages; }
+int windowed_blocks(int N, int B, int L) {
+    if (first_launch_on_device(2)) {
         (void)hipFuncSetAttribute((const void*)rti_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     int dev = 0, cus = 256, per_cu = 4;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rti_window_kernel, 64, windowed_lds_bytes(N)) != hipSuccess || per_cu < 1)
-        per_cu = 4;
+    (void)N;
+    const void* fn = windowed_resident(L) ? (const void*)rti_window_kernel_res : (const void*)rti_window_kernel;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, windowed_lds_bytes(L)) != hipSuccess || per_cu < 1)
+        per_cu = windowed_resident(L) ? 1 : 4;
     long long fit = (long long)cus * per_cu;
     // development knob (tests/test_gpu_windowed.py): fewer persistent blocks, so that small batches take several instances per block
     if (const char* e = getenv("BROV_DEV_WIN_BLOCKS")) { const long long v = atoll(e); if (v >= 1 && v < fit) fit = v; }
@@ -2694,7 +2761,8 @@ int windowed_blocks(int N, int B) {
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
     (void)hipMemsetAsync(P.counter, 0, sizeof(int32_t), st);
-    hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.N), st, P);
+    if (windowed_resident(P.win_L)) hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+    else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }
 
 

@@ -86,7 +86,7 @@ def _load():
         "brov_set_yref_stage_host": [vp, C.c_int, C.c_int, dp, C.c_int],
         "brov_set_iterate_host": [vp, dp, dp, dp, dp], "brov_get_iterate_host": [vp, dp, dp, dp, dp],
         "brov_set_opts": [vp, vp], "brov_get_opts": [vp, vp],
-        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_last_kernel_path": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
+        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_last_kernel_path": [vp], "brov_window_stages": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
         "brov_get_results_host": [vp, vp], "brov_get_u0_host": [vp, dp],
         "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
         "brov_get_thrusts_host": [vp, dp], "brov_last_solve_seconds": [vp, dp, dp], "brov_enable_timing": [vp, C.c_int],
@@ -407,6 +407,10 @@ class BatchSolver:
 
     def last_kernel_path(self):
         return int(self._L.brov_last_kernel_path(self._h))
+
+    def window_stages(self):
+        """stages per LDS window of the windowed kernel (0: none; == N: resident mode, the whole horizon in one window)"""
+        return int(self._L.brov_window_stages(self._h))
 
     def last_solve_seconds(self):
         tot, k2 = C.c_double(0), (C.c_double * 2)()

@@ -66,7 +66,7 @@ typedef struct brov_opts {
     double  qp_tol_stat;    /* interior point, stationarity target (1e-9, tracked residual, absolute) */
     int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
     int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above -- except for batches of
-                             * <= 8 instances at N >= 24, where the streaming pair has the shorter latency), _STREAMING, _FUSED */
+                             * <= 8 instances at N > 81, which run on the streaming pair), _STREAMING, _FUSED */
     int32_t on_failure;     /* what happens to an instance whose step fails (status NAN / MINSTEP / QP_FAILURE):
                              *   BROV_ON_FAILURE_KEEP    iterate left untouched -- what acados' SQP_RTI does (it returns before
                              *                           update_variables); a diverged iterate then fails again every tick
@@ -247,6 +247,9 @@ int brov_last_solve_seconds(brov_solver* s, double* total, double* kernels2);
 int brov_enable_timing(brov_solver* s, int on);
 /* which kernels the last brov_solve launched: BROV_PATH_FUSED, BROV_PATH_WINDOWED or BROV_PATH_STREAMING */
 int brov_last_kernel_path(const brov_solver* s);
+/* stages per LDS window of the windowed kernel this solver was created for (0: no windowed workspace).  Equal to N: resident mode,
+ * the whole horizon in one window (batches of at most one instance per CU at N <= 81); otherwise <= 20 */
+int brov_window_stages(const brov_solver* s);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Batched EKF disturbance observer: B independent copies of the reference's 18-state filter

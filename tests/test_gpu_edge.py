@@ -75,13 +75,14 @@ def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
 
 
 def test_auto_path_selection(ba, golden_traj):
-    """BROV_PATH_AUTO: fused for N <= 23; at longer horizons the windowed kernel, except for a handful of instances (<= 8, e.g.
-    the ROS node's batch of one), where the streaming pair has the shorter latency"""
-    for N, B, want in ((20, 1, ba.PATH_FUSED), (23, 300, ba.PATH_FUSED), (24, 8, ba.PATH_STREAMING), (80, 1, ba.PATH_STREAMING),
-                       (24, 9, ba.PATH_WINDOWED), (80, 64, ba.PATH_WINDOWED)):
+    """BROV_PATH_AUTO: fused for N <= 23; at longer horizons the windowed kernel (for small batches with the whole horizon in one
+    window, N <= 81), except for a handful of instances (<= 8) at N > 81, where the streaming pair is as fast and needs no workspace"""
+    for N, B, want in ((20, 1, ba.PATH_FUSED), (23, 300, ba.PATH_FUSED), (24, 8, ba.PATH_WINDOWED), (80, 1, ba.PATH_WINDOWED),
+                       (82, 8, ba.PATH_STREAMING), (128, 1, ba.PATH_STREAMING), (82, 9, ba.PATH_WINDOWED), (80, 64, ba.PATH_WINDOWED)):
         x0, circ = _inputs(golden_traj, B, seed=N)
         s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
-        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1]); s.solve()
+        win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])[:N + 1]   # the golden head is short: pad like the reference
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(win); s.solve()
         assert s.last_kernel_path() == want, (N, B)
         assert not s.results()["status"].any()
         s.close()

@@ -37,15 +37,24 @@ def _scaled_ok(a, b, kkt, tol=1e-7):
     return err <= tol * np.maximum(1.0, kkt), err
 
 
-def _run_against_oracle(ba, oracle, N, B, ticks=3, blocks=None):
+def _run_against_oracle(ba, oracle, N, B, ticks=3, blocks=None, resident=True):
+    """resident: batches of at most one instance per CU keep the whole horizon in one 160 KB window (N <= 81); False forces the
+    20-stage windows of the large-batch mode onto the small batch"""
     x0, circ = _cfg5_inputs(B)
     if blocks:
         os.environ["BROV_DEV_WIN_BLOCKS"] = str(blocks)
+    if not resident:
+        os.environ["BROV_DEV_NO_RESIDENT"] = "1"
     try:
         s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, kernel_path=ba.PATH_FUSED))
     finally:
         os.environ.pop("BROV_DEV_WIN_BLOCKS", None)
+        os.environ.pop("BROV_DEV_NO_RESIDENT", None)
     s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+    if resident and B <= 256 and 20 < N <= 81:
+        assert s.window_stages() == N          # rti_window_kernel_res: one window
+    else:
+        assert 0 < s.window_stages() <= 20     # rti_window_kernel: windows parked in HBM
     op = oracle.opts(N, 1.0 / N)
     x, u, pi, lam = oracle.init_iterate(op, B)
     pf = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16)))
@@ -97,5 +106,14 @@ def test_ragged_last_round(ba, oracle):
 
 @pytest.mark.parametrize("N,B,blocks", [(24, 64, 24), (57, 96, 32), (80, 64, 21), (128, 48, 16)])
 def test_several_instances_per_block_at_small_batches(ba, oracle, N, B, blocks):
-    s, *_ = _run_against_oracle(ba, oracle, N, B, ticks=2, blocks=blocks)
+    s, *_ = _run_against_oracle(ba, oracle, N, B, ticks=2, blocks=blocks, resident=False)
+    s.close()
+
+
+@pytest.mark.parametrize("N,B,blocks", [(24, 40, None), (40, 200, None), (57, 96, 32), (80, 64, 21), (80, 256, None), (81, 16, None)])
+def test_resident_mode_small_batches(ba, oracle, N, B, blocks):
+    """Batches of at most one instance per CU (the ROS node's batch of one, small Monte-Carlo sets): the whole horizon in ONE window of
+    up to 160 KB, one block per CU -- no parking, no window fetches; the linearisation in sub-chunks of <= 23 intervals.  Against the
+    oracle like every other mode, also with several instances per block."""
+    s, *_ = _run_against_oracle(ba, oracle, N, B, ticks=3, blocks=blocks)
     s.close()
