@@ -232,7 +232,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
     // BROV_PATH_AUTO at long horizons and a handful of instances (the ROS node's batch of one): when the whole horizon fits one
     // window (N <= 81: resident mode, no parking and no window fetches) the windowed kernel has the shorter latency (N = 80, B = 1:
-    // 150 vs 172 us); beyond that the streaming pair, which spreads the linearisation over several wavefronts, is as fast and
+    // 128 vs 172 us); beyond that the streaming pair, which spreads the linearisation over several wavefronts, is as fast and
     // needs no workspace (profiles/r3_small_batch_latency.txt)
     const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed &&
                      windowed_stage_count(opts->N, B) != opts->N;

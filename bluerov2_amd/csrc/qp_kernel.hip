@@ -2571,7 +2571,7 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 template <bool RES>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane0 = threadIdx.x;
+    const int lane0 = threadIdx.x & 63;       // (RES: four waves per block, see below)
     const int N = P.N, Lc = P.win_L, nc = (N + Lc - 1) / Lc;
     double* ba_s = smem;                      // [Lc][12][13]
     double* bv_s = smem + win_off_bv(Lc);     // [Lc][12]
@@ -2582,6 +2582,25 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     double* vh_s = smem + win_off_vh(Lc);     // [Lc][4]
     double* dx_s = smem + win_off_dx(Lc);     // [Lc+1][12]
     double* const_s = smem + win_off_const(Lc);
+    if constexpr (RES) {
+        // Resident mode serves batches of at most one instance per CU: three of the CU's four SIMDs would idle.  The block has FOUR
+        // waves; waves 1..3 linearise a quarter of the horizon each for the block's first instance (ticket = block index, known
+        // without communication), hand their KKT partials over through the (then dead) stage-record area and end.  The sweeps are
+        // serial recursions: wave 0 runs them alone, as it runs everything of any further instance of the block.
+        if (threadIdx.x >= 64) {
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const int b = __builtin_amdgcn_readfirstlane(sched_map(P, (int)blockIdx.x));
+            const int lsub = (N + 3) >> 2, j0 = wv * lsub, nj = N - j0 < lsub ? N - j0 : lsub;
+            double part = 0.0;
+            bool nanp = false;
+            __syncthreads();   // wave 0's barrier ahead of the linearisation
+            lin_phase<true>(P, b, j0, nj, lane0, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s + (size_t)j0 * kRecInterval,
+                            q_s + (size_t)j0 * NX, r_s + (size_t)j0 * NU, part, nanp, false);
+            ((lds_f64*)kt_s)[(size_t)j0 * kRecInterval + lane0] = nanp ? __builtin_nan("") : part;
+            __syncthreads();   // ... and the one behind it
+            return;
+        }
+    }
     if (lane0 == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
     if (blockIdx.x == 0) sched_zero_next(P, lane0);
     double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
@@ -2595,14 +2614,18 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     double* ws_Mt = ws_Ks + (size_t)N * 64;
     double* ws_Pb = ws_Mt + (size_t)N * 64;
     double* ws_ipm = ws_Pb + (size_t)N * NX;
-    for (;;) {
+    for (int trip = 0;; trip++) {
         // the lane index is re-derived behind an opaque move in every iteration: nothing lane-dependent is hoisted out of the
         // instance loop (such loop invariants otherwise sit in VGPRs across lin_phase and push the kernel into scratch)
         int lane;
         asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
         int b = 0;
-        if (lane == 0) b = atomicAdd(P.counter, 1);
-        b = __builtin_amdgcn_readfirstlane(b);
+        if (RES && trip == 0) {
+            b = (int)blockIdx.x;   // the helper waves work on this ticket
+        } else {
+            if (lane == 0) b = atomicAdd(P.counter, 1) + (RES ? (int)gridDim.x : 0);
+            b = __builtin_amdgcn_readfirstlane(b);
+        }
         if (b >= P.B) break;
         b = __builtin_amdgcn_readfirstlane(sched_map(P, b));   // expensive instances first
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
@@ -2656,7 +2679,17 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                 wq = P.cst[lane];
             }
             __syncthreads();
-            if (!RES || n <= kLinMaxIntervals) {
+            if (RES && trip == 0) {
+                // first instance of the block: this wave takes the first quarter of the horizon, waves 1..3 the others
+                const int lsub = (n + 3) >> 2;
+                lin_phase<true>(P, b, 0, lsub, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+                __syncthreads();
+                for (int wv = 1; wv < 4; wv++) {
+                    const double v = ((const lds_f64*)kt_s)[(size_t)wv * lsub * kRecInterval + lane];
+                    nanp = nanp | !(v == v);
+                    part = fmax(part, v);
+                }
+            } else if (!RES || n <= kLinMaxIntervals) {
                 lin_phase<true>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
             } else {
                 // resident mode (one window = the whole horizon in a 160 KB slice, small batches): the wave-wide linearisation takes
@@ -2706,7 +2739,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     }
 }
 __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_window_body<false>(P); }
-__global__ __launch_bounds__(64, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
+__global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
@@ -2752,7 +2785,7 @@ int windowed_blocks(int N, int B, int L) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     (void)N;
     const void* fn = windowed_resident(L) ? (const void*)rti_window_kernel_res : (const void*)rti_window_kernel;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, windowed_lds_bytes(L)) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, windowed_resident(L) ? 256 : 64, windowed_lds_bytes(L)) != hipSuccess || per_cu < 1)
         per_cu = windowed_resident(L) ? 1 : 4;
     long long fit = (long long)cus * per_cu;
     // development knob (tests/test_gpu_windowed.py): fewer persistent blocks, so that small batches take several instances per block
@@ -2761,7 +2794,7 @@ int windowed_blocks(int N, int B, int L) {
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
     (void)hipMemsetAsync(P.counter, 0, sizeof(int32_t), st);
-    if (windowed_resident(P.win_L)) hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+    if (windowed_resident(P.win_L)) hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }
 
