@@ -26,6 +26,7 @@ struct brov_shim_state {
     bool iter_host_valid = true;  // host mirror of the iterate is current
     int rti_phase = 0;
     double time_tot = 0.0, time_lin = 0.0, time_qp = 0.0;
+    bool times_valid = false, timing_on = false;
     brov_result last{};
     int last_status = 0;
 };
@@ -85,7 +86,11 @@ int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N
         delete s;
         return rc == BROV_ERR_NO_DEVICE ? ACADOS_QP_FAILURE : 1;  // non-zero: the callers exit(1) (bluerov2_dob.cpp:35-38)
     }
-    brov_enable_timing(s->solver, 1);
+    // kernel times (time_lin / time_qp_sol) come from HIP events around the kernels, which cost ~10 us of every tick: no reference
+    // caller asks for them (they read time_tot, host wall time), so the events are recorded only from the first request on -- or
+    // from the start with BROV_SHIM_TIMING=1
+    s->timing_on = std::getenv("BROV_SHIM_TIMING") && std::atoi(std::getenv("BROV_SHIM_TIMING")) != 0;
+    brov_enable_timing(s->solver, s->timing_on ? 1 : 0);
     const size_t n1 = (size_t)N + 1;
     s->x0.assign(12, 0.0);
     s->x0[2] = -20.0;  // :520-527 (lbx0 = ubx0 = [0,0,-20,0..])
@@ -223,8 +228,7 @@ int ocp_nlp_solve(ocp_nlp_solver* solver, ocp_nlp_in*, ocp_nlp_out* out) {  // w
     }
     s->iter_host_valid = false;
     s->last = r;
-    double k2[2] = {0, 0}, tot = 0;
-    if (brov_last_solve_seconds(s->solver, &tot, k2) == BROV_OK) { s->time_lin = k2[0]; s->time_qp = k2[1]; }
+    s->times_valid = false;   // kernel times are read from the events when (if) the caller asks for them: not a wait of every tick
     s->time_tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (s->rti_phase == 1) return ACADOS_SUCCESS;  // preparation only: nothing to report
     if (out) out->inf_norm_res = r.kkt;
@@ -402,8 +406,15 @@ void ocp_nlp_get(ocp_nlp_config*, ocp_nlp_solver* solver, const char* field, voi
     brov_shim_state* s = solver ? solver->shim : nullptr;
     if (!s || !field || !value) return;
     if (!std::strcmp(field, "time_tot")) *(double*)value = s->time_tot;          // bluerov2_dob.cpp:386
-    else if (!std::strcmp(field, "time_lin")) *(double*)value = s->time_lin;
-    else if (!std::strcmp(field, "time_qp_sol") || !std::strcmp(field, "time_qp")) *(double*)value = s->time_qp;
+    else if (!std::strcmp(field, "time_lin") || !std::strcmp(field, "time_qp_sol") || !std::strcmp(field, "time_qp")) {
+        if (!s->timing_on) { s->timing_on = true; brov_enable_timing(s->solver, 1); }   // measured from the next solve on (0 until then)
+        else if (!s->times_valid) {
+            double k2[2] = {0, 0}, tot = 0;
+            if (brov_last_solve_seconds(s->solver, &tot, k2) == BROV_OK) { s->time_lin = k2[0]; s->time_qp = k2[1]; }
+            s->times_valid = true;
+        }
+        *(double*)value = field[5] == 'l' ? s->time_lin : s->time_qp;
+    }
     else if (!std::strcmp(field, "sqp_iter")) *(int*)value = 1;                   // RTI: one iteration per call
     else if (!std::strcmp(field, "qp_iter")) *(int*)value = s->last.qp_iter;
     else if (!std::strcmp(field, "status")) *(int*)value = s->last_status;

@@ -9,12 +9,14 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "nmpc_device.hpp"
 
 using namespace brov;
 
+#define kTickMailboxMaxBatch 64          /* brov_tick_host: up to this many instances deliver their records through the host mailbox */
 #define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N > 81: up to this many instances run on the streaming kernels */
 
 static thread_local std::string g_err;
@@ -66,6 +68,7 @@ struct brov_solver {
     bool last_fused = false, last_windowed = false;
     double* ws = nullptr;        // windowed kernel: per-block parking images
     int32_t* counter = nullptr;
+    unsigned win_tick = 0;           // windowed launches so far: which of the two hand-out counters the next one uses
     int win_blocks = 0, win_L = 0;
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
@@ -81,6 +84,9 @@ struct brov_solver {
     hipStream_t tick_stream = nullptr;   // brov_tick_host: the solver's own stream and pinned staging buffer
     double* pin = nullptr;
     size_t pin_doubles = 0;
+    brov_result* mail = nullptr;     // host mailbox of the tick in flight (device-visible pinned memory), else nullptr
+    int32_t* mail_flag = nullptr;
+    int32_t mail_seq = 0;
 };
 
 extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
@@ -201,10 +207,11 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     const size_t N = opts->N, Bz = B;
     int rc = BROV_OK;
 #define AL(ptr, n) if (rc == BROV_OK) rc = dalloc(s, &s->ptr, (n))
-    AL(x0, Bz * 12);
+    // x0 | shared reference window | stage parameters in ONE allocation, in the order of brov_tick_host's staging buffer: a tick that
+    // rewrites all three (the ROS node does) uploads them with one copy
+    AL(x0, Bz * 12 + (size_t)(N + 1) * 16 + Bz * (N + 1) * 16);
+    if (rc == BROV_OK) { s->yref_sh = s->x0 + Bz * 12; s->par = s->yref_sh + (size_t)(N + 1) * 16; }
     AL(yref, Bz * (N + 1) * 16);
-    AL(yref_sh, (N + 1) * 16);
-    AL(par, Bz * (N + 1) * 16);
     AL(x, Bz * (N + 1) * 12);
     AL(u, Bz * N * 4);
     AL(pi, Bz * N * 12);
@@ -226,7 +233,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(scratch3, 3 * Bz);
     AL(lines, Bz);
     AL(pplant, Bz * 16);
-    AL(counter, 4);
+    AL(counter, 64);   // two hand-out counters of the windowed kernel, 128 bytes apart, used alternately
     AL(sched, 3 * (size_t)sched_buffer_ints_host(B));
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
     s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
@@ -249,6 +256,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     hipMemset(s->par, 0, Bz * (N + 1) * 16 * sizeof(double));
     hipMemset(s->res, 0, Bz * sizeof(brov_result));
     hipMemset(s->sched, 0, 3 * (size_t)sched_buffer_ints_host(B) * sizeof(int32_t));
+    hipMemset(s->counter, 0, 64 * sizeof(int32_t));
     // development knob: BROV_SCHED=0 hands the instances out in index order (A/B of the work ordering)
     s->sched_on = !(getenv("BROV_SCHED") && atoi(getenv("BROV_SCHED")) == 0);
     {
@@ -732,7 +740,9 @@ static DevParams make_params(const brov_solver* s) {
     P.BA = s->BA; P.bvec = s->bvec; P.kktp = s->kktp;
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
-    P.ws = s->ws; P.ws_stride = s->win_L ? (int64_t)windowed_ws_doubles(s->N, s->win_L) : 0; P.counter = s->counter;
+    P.mail = s->mail; P.mail_flag = s->mail_flag; P.mail_seq = s->mail_seq;
+    P.ws = s->ws; P.ws_stride = s->win_L ? (int64_t)windowed_ws_doubles(s->N, s->win_L) : 0; P.counter = s->counter + 32 * (s->win_tick & 1u);
+    P.counter_next = s->counter + 32 * ((s->win_tick + 1u) & 1u);
     P.win_L = s->win_L; P.win_blocks = s->win_blocks;
     P.dbg = s->dbg;
     return P;
@@ -758,7 +768,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     if (fused || windowed) {
         if (s->timing) hipEventRecord(s->ev[1], st);
         if (fused) launch_fused(P, st);
-        else launch_windowed(P, st);   // counter reset + persistent blocks
+        else { launch_windowed(P, st); s->win_tick++; }   // persistent blocks; the two hand-out counters alternate
     } else {
         if (rti_phase != 2) launch_linearise(P, st);
         if (s->timing) hipEventRecord(s->ev[1], st);
@@ -783,32 +793,65 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     const size_t B = s->B, N1 = s->N + 1;
-    const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8;
+    const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8, n_f = (B * sizeof(int32_t) + 7) / 8;
     if (!s->tick_stream) HIPCHK(hipStreamCreateWithFlags(&s->tick_stream, hipStreamNonBlocking));
-    if (s->pin_doubles < n_x0 + n_y + n_p + n_r) {
+    if (s->pin_doubles < n_x0 + n_y + n_p + n_r + n_f) {
         if (s->pin) hipHostFree(s->pin);
         s->pin = nullptr; s->pin_doubles = 0;
-        HIPCHK(hipHostMalloc((void**)&s->pin, (n_x0 + n_y + n_p + n_r) * sizeof(double), hipHostMallocDefault));
-        s->pin_doubles = n_x0 + n_y + n_p + n_r;
+        HIPCHK(hipHostMalloc((void**)&s->pin, (n_x0 + n_y + n_p + n_r + n_f) * sizeof(double), hipHostMallocDefault));
+        s->pin_doubles = n_x0 + n_y + n_p + n_r + n_f;
+        std::memset(s->pin, 0, s->pin_doubles * sizeof(double));
     }
     hipStream_t st = s->tick_stream;
     if (s->last_stream != st) HIPCHK(hipStreamSynchronize(s->last_stream));   // an earlier solve on the caller's stream
     double* px = s->pin; double* py = px + n_x0; double* pp = py + n_y; double* pr = pp + n_p;
-    if (x0) { std::memcpy(px, x0, n_x0 * sizeof(double)); HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, st)); }
+    volatile int32_t* pf = (volatile int32_t*)(pr + n_r);
+    if (x0) std::memcpy(px, x0, n_x0 * sizeof(double));
     if (yref_shared) {
         std::memcpy(py, yref_shared, n_y * sizeof(double));
-        HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, st));
         s->yref_view = nullptr;
         s->yref_shared = true;
     }
-    if (par_stage) {
-        std::memcpy(pp, par_stage, n_p * sizeof(double));
-        HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, st));
-        s->pplant_stale = true;
+    if (par_stage) { std::memcpy(pp, par_stage, n_p * sizeof(double)); s->pplant_stale = true; }
+    if (x0 && yref_shared && par_stage) {   // device side: one allocation in the same order (brov_create)
+        HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, st));
+    } else {
+        if (x0) HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, st));
+        if (yref_shared) HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, st));
+        if (par_stage) HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    if (int rc = brov_solve_phase(s, st, rti_phase)) return rc;
-    HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // Results.  Small batches (the ROS node's batch of one): the kernel writes every record into the pinned buffer itself and then the
+    // instance's sequence word; the host polls those words -- no copy command, no stream synchronisation on the way back.  The stream
+    // is queried now and then: a launch that ended without delivering (a device fault) falls back to the synchronous path's error.
+    const bool mailbox = rti_phase != 1 && B <= kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0);
+    if (mailbox) {
+        s->mail_seq = s->mail_seq == 0x7fffffff ? 1 : s->mail_seq + 1;
+        s->mail = (brov_result*)pr; s->mail_flag = (int32_t*)pf;
+    }
+    const int rc = brov_solve_phase(s, st, rti_phase);
+    const int32_t seq = s->mail_seq;
+    s->mail = nullptr; s->mail_flag = nullptr;
+    if (rc) return rc;
+    if (mailbox) {
+        size_t done = 0;
+        for (unsigned long spin = 1; done < B; spin++) {
+            while (done < B && pf[done] == seq) done++;
+            if (done < B && (spin & 0x3ff) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {   // the launch is over: everything it wrote is visible
+                    while (done < B && pf[done] == seq) done++;
+                    if (done < B) { g_err = "brov_tick_host: the solve ended without delivering its records"; return BROV_ERR_HIP; }
+                } else if (q != hipErrorNotReady) {
+                    g_err = std::string("brov_tick_host: ") + hipGetErrorString(q);
+                    return BROV_ERR_HIP;
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     if (res) std::memcpy(res, pr, B * sizeof(brov_result));
     return BROV_OK;
 }

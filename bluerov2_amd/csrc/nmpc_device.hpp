@@ -54,10 +54,16 @@ struct DevParams {
     const double* tsv;
     const double* wst;
     brov_result* res;
+    // host mailbox (brov_tick_host, small batches): the record additionally goes straight into pinned host memory, followed by the
+    // instance's sequence word -- the host polls that word instead of waiting for a copy and a stream synchronisation
+    brov_result* mail;
+    int32_t* mail_flag;
+    int32_t mail_seq;
     // windowed kernel (N >= 24): per-block parking image + scratch, instance hand-out counter, stages per window
     double* ws;
     int64_t ws_stride;   // doubles per block
-    int32_t* counter;
+    int32_t* counter;        // this launch's hand-out counter (zero on entry) ...
+    int32_t* counter_next;   // ... and the next launch's, which block 0 of this launch zeroes (no memset node between the launches)
     int32_t win_L, win_blocks;
     // work ordering (qp_kernel.hip, sched_map): three rotating buffers of [64 class counters | class lists | pos[B]] int32 -- the
     // instances whose QP had active bounds in the previous solve are handed out first in this one; nullptr = instances in index order

@@ -2063,6 +2063,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         const double s3 = (lane == 0 || lane == 3) ? a3 : -a3;
         const double th = ((lane < 4) ? (s0 + s1) + s3 : -a2) / kRotor;   // same operation order as the host helper
         if (lane < 6) P.res[b].thrust[lane] = th;
+        if (P.mail) {   // host mailbox: the same record into pinned host memory, then (behind a system-scope fence) the sequence word
+            brov_result* m = P.mail + b;
+            if (lane < 4) m->u0[lane] = u0v;
+            if (lane < 6) m->thrust[lane] = th;
+            if (lane == 0) { m->cost = cost; m->kkt = kkt; m->status = status; m->qp_iter = early ? 0 : iters; }
+            __threadfence_system();
+            if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     DBG_STAMP(6);
 }
@@ -2602,7 +2610,10 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         }
     }
     if (lane0 == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
-    if (blockIdx.x == 0) sched_zero_next(P, lane0);
+    if (blockIdx.x == 0) {
+        sched_zero_next(P, lane0);
+        if (lane0 == 0) *P.counter_next = 0;   // the next launch's hand-out counter (this launch uses the other one)
+    }
     double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
     Win W;
     W.nc = nc; W.Lc = Lc; W.cur = -1; W.valid = 0;
@@ -2793,7 +2804,6 @@ int windowed_blocks(int N, int B, int L) {
     return (int)(B < fit ? B : fit);
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
-    (void)hipMemsetAsync(P.counter, 0, sizeof(int32_t), st);
     if (windowed_resident(P.win_L)) hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }

@@ -183,8 +183,11 @@ int brov_synchronize(brov_solver* s, void* stream);
 /* One control tick with ONE host synchronisation: the inputs that changed since the last tick (NULL = unchanged; x0 [B][12], ONE
  * reference window shared by the batch [N+1][16], per-stage parameters [B][N+1][16]) are staged through a pinned buffer and copied
  * asynchronously on the solver's own stream, the step (rti_phase as brov_solve_phase) runs behind them, the result records come
- * back the same way.  This is what the acados-shaped drop-in makes of one bluerov2_acados_solve (bluerov2_dob.cpp:306-388: lbx /
- * ubx, (N+1) x update_params, (N+1) x yref, solve, u0 / status / kkt).  HOST pointers. */
+ * back the same way -- for up to 64 instances without a copy: the kernel writes each record into the pinned buffer itself, followed
+ * by a sequence word the host polls (BROV_TICK_MAILBOX=0 in the environment: copy + stream synchronisation, as for larger
+ * batches).  A tick that passes all three inputs uploads them with one copy.  This is what the acados-shaped drop-in makes of one
+ * bluerov2_acados_solve (bluerov2_dob.cpp:306-388: lbx / ubx, (N+1) x update_params, (N+1) x yref, solve, u0 / status / kkt).
+ * HOST pointers. */
 int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
                    brov_result* res /*[B] or NULL*/);
 /* replace weights / bounds / Ts / QP options of an existing solver (N must not change) */

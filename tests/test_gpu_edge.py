@@ -1,5 +1,7 @@
 """GPU edge cases through the C ABI: tiny / ragged batches and horizons, NaN inputs, iterates outside the bounds, iteration
 cap, run-time option changes, rti_phase split, iterate round trips -- each against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -296,24 +298,35 @@ def test_work_ordering_changes_nothing_but_the_order(ba, golden_traj, N, B, path
     assert n_qp > B // 4
 
 
-def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj):
-    """brov_tick_host (what the acados-shaped drop-in makes of one bluerov2_acados_solve): pinned staging, asynchronous copies, one
-    wait -- the same records and the same iterate, bit for bit, as the separate setters + brov_solve + brov_get_results_host; inputs
-    passed as None keep their values"""
-    N, B = 20, 12
+@pytest.mark.parametrize("N,B,mailbox", [(20, 12, True), (20, 12, False), (20, 70, True), (40, 3, True), (80, 1, True), (10, 1, True)])
+def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mailbox):
+    """brov_tick_host (what the acados-shaped drop-in makes of one bluerov2_acados_solve): pinned staging, ONE upload when all inputs
+    are rewritten, and -- for up to 64 instances -- the records written by the kernel straight into pinned host memory, each followed
+    by a sequence word the host polls (no copy back, no stream synchronisation; BROV_TICK_MAILBOX=0 and larger batches take the
+    copy + synchronise path).  The same records and the same iterate, bit for bit, as the separate setters + brov_solve +
+    brov_get_results_host on every kernel family; inputs passed as None keep their values"""
     x0, circ = _inputs(golden_traj, B, seed=21, big=2.5)
+    win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])
     p = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16))).copy()
     p[:, :, 0] = np.linspace(-50, 50, B)[:, None]
     a = ba.BatchSolver(B, ba.SolverOptions(N)); b = ba.BatchSolver(B, ba.SolverOptions(N))
-    for k in range(4):
-        a.set_x0(x0); a.set_yref(circ[k:k + N + 1])
-        if k == 0:
-            a.set_params(p)
-        a.solve(); ra = a.results()
-        rb = b.tick(x0=x0 if k != 2 else None, yref=circ[k:k + N + 1], params=p if k == 0 else None)   # tick 2: x0 unchanged -> not passed
-        for f in ("u0", "cost", "kkt", "status", "qp_iter", "thrust"):
-            assert np.array_equal(ra[f], rb[f]), (k, f)
-        for ia, ib in zip(a.get_iterate(), b.get_iterate()):
-            assert np.array_equal(ia, ib)
-    assert (ra["qp_iter"] > 0).any()
+    if not mailbox:
+        os.environ["BROV_TICK_MAILBOX"] = "0"
+    try:
+        for k in range(5):
+            a.set_x0(x0); a.set_yref(win[k:k + N + 1])
+            if k in (0, 3):
+                a.set_params(p)
+            a.solve(); ra = a.results()
+            # tick 2: x0 unchanged -> not passed; ticks 0 and 3 rewrite all three inputs (one upload)
+            rb = b.tick(x0=x0 if k != 2 else None, yref=win[k:k + N + 1], params=p if k in (0, 3) else None)
+            for f in ("u0", "cost", "kkt", "status", "qp_iter", "thrust"):
+                assert np.array_equal(ra[f], rb[f]), (k, f)
+            assert np.array_equal(b.results()["u0"], rb["u0"])   # the device-side records are the same ones
+            for ia, ib in zip(a.get_iterate(), b.get_iterate()):
+                assert np.array_equal(ia, ib)
+    finally:
+        os.environ.pop("BROV_TICK_MAILBOX", None)
+    if B >= 12:
+        assert (ra["qp_iter"] > 0).any()
     a.close(); b.close()
