@@ -22,7 +22,8 @@ status, thrusts), arg-min of cost on the gathered records for the candidate work
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel; bound = FP64 MFMA),
 `roofline_hbm`, `cpu_baseline` (the C oracle timed on the host cores -- never the thing measured as `value`) and, for the
-default single-GPU run, `forced_ipm`, `mixed_batch_25pct_saturated[_shuffled]` and `cpu_baseline_single_thread`.
+default single-GPU run, `forced_ipm`, `mixed_batch_25pct_saturated[_shuffled]`, `batch1_tick` (BASELINE configs[0] on the GPU: one instance, host
+buffers in, record out) and `cpu_baseline_single_thread`.
 """
 import argparse
 import json
@@ -83,6 +84,32 @@ def saturate(x0, frac, seed):
     x0[:n, :3] += rng.uniform(-4, 4, size=(n, 3))
     x0[:n, 5] += rng.uniform(-0.3, 0.3, size=n)
     return x0
+
+
+def batch1_tick(ba, ticks=300, warm=30):
+    """BASELINE configs[0] on the GPU: ONE instance, one control tick the way the ROS node makes it -- host buffers in (x0, the
+    reference window, the stage parameters), the step, the 104-byte record back on the host (brov_tick_host, what the acados-shaped
+    drop-in calls per bluerov2_acados_solve).  Wall time per tick, PCIe and launch included; N = 20 and the reference's shipped
+    N = 80, Ts = 0.0125."""
+    out = {}
+    for N, Ts in ((20, 0.05), (80, 0.0125)):
+        s = ba.BatchSolver(1, ba.SolverOptions(N, Ts))
+        x0, circ = synthetic_inputs(1, seed=5)
+        p = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (1, N + 1, NP)))
+        wall = []
+        for k in range(warm + ticks):
+            y = np.ascontiguousarray(circ[k % 16:k % 16 + N + 1])   # (x0 stays where it is: the reference window must not run away from it)
+            t0 = time.perf_counter()
+            r = s.tick(x0=x0, yref=y, params=p)
+            wall.append(time.perf_counter() - t0)
+            x0 = x0 + 0.0   # (a fresh buffer every tick, like the node's)
+        wall = np.sort(np.array(wall[warm:])) * 1e6
+        out[f"N{N}"] = dict(wall_us_median=float(np.median(wall)), wall_us_p99=float(wall[int(0.99 * len(wall))]), status=int(r["status"][0]),
+                            kernel_path=int(s.last_kernel_path()))
+        s.close()
+    out["note"] = ("one instance through brov_tick_host (python ctypes caller): host -> device upload, RTI step, record back; "
+                   "compare cpu_baseline_single_thread")
+    return out
 
 
 def candidate_params():
@@ -707,7 +734,7 @@ def main(argv=None):
         r2 = s2.results()
         out["forced_ipm"] = dict(value=B * K / dt2, unit="solves/s", ms_per_step=dt2 / K * 1e3, mean_qp_iter=float(r2["qp_iter"].mean()),
                                  status_nonzero=int((r2["status"] != 0).sum()),
-                                 note="same workload with qp_early_exit=0: every instance runs the Mehrotra interior-point loop")
+                                 note="same workload with qp_early_exit=0: every instance goes through the QP loop (active-set tries, interior-point fallback) although no bound is active")
         s2.close()
         s3, tick3, _ = wl["make"](N, Ts, 1, sat=0.25)
         dt3, _, _ = run(s3, tick3, K, W, False, False)
@@ -716,7 +743,7 @@ def main(argv=None):
                                                   ipm_instance_fraction=float((r3["qp_iter"] > 0).mean()),
                                                   mean_qp_iter=float(r3["qp_iter"].mean()), max_qp_iter_last_tick=int(r3["qp_iter"].max()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
                                                   note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
-                                                       "the launch ends with its slowest interior-point instance")
+                                                       "14 % of the batch runs the QP loop (active-set tries, interior-point fallback)")
         s3.close()
         # the same instances in a random order (the leg above has the saturated quarter FIRST, an artefact of the generator: the slow
         # instances then start in the first round anyway).  The kernels reorder the work themselves -- instances whose QP had active
@@ -730,6 +757,8 @@ def main(argv=None):
                                                            status_histogram=np.bincount(r4["status"], minlength=5).tolist(),
                                                            note="the mixed batch with its instances in random order")
         s4.close()
+    if extra:
+        out["batch1_tick"] = batch1_tick(ba)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(BATCH_PER_GPU)
         if extra:
