@@ -223,6 +223,14 @@ def test_rti_phase_split_equals_full_step(ba, golden_traj):
     split.set_x0(x0)
     assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0
     assert np.array_equal(full.results()["u0"], split.results()["u0"])
+    # the same split through the tick call (the drop-in's rti_phase option): phase 1 delivers no record, phase 2 the step's
+    tk = ba.BatchSolver(B, ba.SolverOptions(N, kernel_path=1))
+    tk.set_params(ba.P_NOMINAL); tk.set_yref(circ[:N + 1])
+    tk.tick(rti_phase=1)
+    r = tk.tick(x0=x0, rti_phase=2)
+    assert np.array_equal(full.results()["u0"], r["u0"]) and np.array_equal(full.results()["cost"], r["cost"])
+    for s in (full, split, tk):
+        s.close()
 
 
 def test_setters_reject_bad_shapes(ba):
