@@ -1,0 +1,23 @@
+"""dev tool: tests/test_gpu_parity.py::test_randomised_options_against_oracle over many more seeds than the suite runs
+   python scripts/dev/fuzz_sweep.py first last"""
+import sys, os, traceback, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import bluerov2_amd as ba
+from oracle.oracle_ffi import Oracle
+import test_gpu_parity as T
+orc = Oracle()
+traj = np.load(os.path.join(ROOT, "tests", "golden", "traj_head.npz"))
+first, last = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for seed in range(first, last):
+    try:
+        T.test_randomised_options_against_oracle(ba, orc, traj, seed)
+    except AssertionError as e:
+        bad += 1
+        print(f"seed {seed}: FAILED: {str(e)[:300]}")
+    except Exception as e:
+        bad += 1
+        print(f"seed {seed}: ERROR {type(e).__name__}: {str(e)[:300]}")
+print(f"seeds {first}..{last - 1}: {bad} failures")
