@@ -20,7 +20,8 @@ def main(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for sub, name in (("stats", "kernel_stats"), ("stats_cfg5", "cfg5_kernel_stats"), ("stats_ekf", "ekf_kernel_stats")):
+    for sub, name in (("stats", "kernel_stats"), ("stats_cfg5", "cfg5_kernel_stats"), ("stats_ekf", "ekf_kernel_stats"),
+                      ("stats_res", "resident_kernel_stats")):
         f = os.path.join(src, sub, "stats_kernel_stats.csv")
         if os.path.exists(f):
             shutil.copy(f, os.path.join(dst, f"{rnd}_{name}.csv"))

@@ -14,6 +14,8 @@ python $R/bench.py --config 5 --path 1 --no-cpu-baseline > $OUT/bench_cfg5_strea
 python $R/bench.py --batch 16384 --no-cpu-baseline --no-extra > $OUT/bench_b16384.json 2> $OUT/bench_b16384.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $R/bench.py --no-cpu-baseline --no-extra > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -o stats -- python $R/bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_stats.json 2> $OUT/bench_cfg5_stats.err
+# small batches at the shipped horizon: the resident windowed kernel (one window = the whole horizon, four waves per block)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_res -o stats -- python $R/bench.py --config 5 --horizon 80 --batch 64 --no-cpu-baseline > $OUT/bench_N80_B64_resident.json 2> $OUT/bench_N80_B64_resident.err
 # counters in their own runs, --kernel-trace only (no --stats / sys-trace together with --pmc on this pool)
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg2_N20
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80 --config 5 --horizon 80
@@ -23,6 +25,7 @@ $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_streaming --config 5 --horizon 80 --pat
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg2_N20_forced_ipm --force-ipm
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_forced_ipm --config 5 --horizon 80 --force-ipm
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg4_N20 --config 4
+$R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_B64_resident --config 5 --horizon 80 --batch 64
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch -o f -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o w -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
