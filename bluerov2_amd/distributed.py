@@ -77,6 +77,24 @@ def select_best_device(rec_bytes):
     return idx, masked[idx]
 
 
+def select_best_packed(local_bytes, index_offset, group=None):
+    """SURVEY.md 8e's alternative to gathering every record: arg-min over the LOCAL records, then one all-gather of a packed
+    (cost, global index) pair per rank (16 B) and an arg-min over those -- for callers that need only the winner.  Returns
+    (global index tensor, cost tensor, owner rank tensor) on the device of local_bytes; cost = +inf when no record anywhere
+    qualifies.  Ties go to the lowest global index, as in select_best_device on the gathered records."""
+    idx, cost = select_best_device(local_bytes)
+    pair = torch.stack([cost, (idx + int(index_offset)).to(torch.float64)])   # indices < 2^53: exact in a double
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return idx + int(index_offset), cost, torch.zeros((), dtype=torch.int64, device=pair.device)
+    allp = torch.empty(2 * world, dtype=torch.float64, device=pair.device)
+    dist.all_gather_into_tensor(allp, pair.contiguous(), group=group)
+    allp = allp.view(world, 2)
+    # lexicographic (cost, index): ranks hold disjoint, ascending index ranges, so the first minimal cost is the lowest index
+    owner = torch.argmin(allp[:, 0])
+    return allp[owner, 1].to(torch.int64), allp[owner, 0], owner
+
+
 def select_best(rec_bytes):
     """index and record of the successful instance with the smallest cost (ties -> lowest index); returns (index, numpy
     record) or (-1, None)"""

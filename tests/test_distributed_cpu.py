@@ -59,7 +59,8 @@ def _worker(rank, world, port, q):
     allb = D.gather_records_uneven(local, counts)
     idx, rec = D.select_best(allb)
     even = D.gather_records(local[: min(counts) * D.RECORD_BYTES])  # equal-size path (what bench.py uses)
-    q.put((rank, allb.numpy().tobytes(), idx, float(rec["cost"]), even.numel()))
+    pidx, pcost, powner = D.select_best_packed(local, lo)            # SURVEY 8e's 16-byte alternative: the winner only
+    q.put((rank, allb.numpy().tobytes(), idx, float(rec["cost"]), even.numel(), int(pidx), float(pcost), int(powner)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,10 +80,12 @@ def test_sharded_equals_single_process():
         p.join(60)
         assert p.exitcode == 0
     full = _solve_shard(0, total, N)
-    for rank, blob, idx, cost, even_n in outs:
+    for rank, blob, idx, cost, even_n, pidx, pcost, powner in outs:
         assert blob == full.tobytes()                      # sharded == unsharded, bitwise
         assert idx == int(np.argmin(full["cost"])) and cost == float(full["cost"].min())
         assert even_n == world * 18 * D.RECORD_BYTES
+        # local arg-min + all-gather of (cost, global index) pairs picks the same winner as the arg-min over all gathered records
+        assert pidx == idx and pcost == cost and powner == (0 if idx < 19 else 1)
     assert outs[0][1] == outs[1][1]
 
 
