@@ -21,6 +21,7 @@ kw = dict(W=list(W), We=list(We), lbu=list(lbu), ubu=list(ubu), on_failure=int(s
 path = ba.PATH_STREAMING if seed >= 9 and seed < 12 else ba.PATH_AUTO
 nb = 96
 x0, circ = T._batch_inputs(golden_traj, N, nb, seed=2000 + seed, sat_frac=0.3)
+print('N', N, 'Ts', Ts, 'test path', 'streaming' if seed >= 9 else 'auto')
 for pth in (ba.PATH_AUTO, ba.PATH_STREAMING):
     s = ba.BatchSolver(nb, ba.SolverOptions(N, Ts, kernel_path=pth, **kw))
     op = oracle.opts(N, Ts, **kw)
