@@ -34,7 +34,7 @@ for pth in (ba.PATH_AUTO, ba.PATH_STREAMING):
         s.set_params(p); s.set_yref(yref); s.solve()
         res = s.results()
         gx, gu, gpi, glam = s.get_iterate()
-        if k == 2 and pth == 0:
+        if k == int(os.environ.get('DUMP_TICK', '2')) and pth == 0:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_{seed}_{inst}.npz"), x=x[inst], u=u[inst], pi=pi[inst], lam=lam[inst], p=p[inst], yref=yref, x0=x0[inst],
                      gx=gx[inst], gu=gu[inst], gpi=gpi[inst], glam=glam[inst], N=N, Ts=Ts, W=W, We=We, lbu=lbu, ubu=ubu, on_failure=kw["on_failure"], early=kw["qp_early_exit"],
