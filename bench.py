@@ -23,7 +23,7 @@ status, thrusts), arg-min of cost on the gathered records for the candidate work
 Prints ONE JSON line on rank 0 (contract in the round prompt) including `roofline` (dominant kernel; bound = FP64 MFMA),
 `roofline_hbm`, `cpu_baseline` (the C oracle timed on the host cores -- never the thing measured as `value`) and, for the
 default single-GPU run, `forced_ipm`, `mixed_batch_25pct_saturated[_shuffled]`, `batch1_tick` (BASELINE configs[0] on the GPU: one instance, host
-buffers in, record out) and `cpu_baseline_single_thread`.
+buffers in, record out), `host_boundary` (the headline workload with inputs from and records to host buffers: PCIe-inclusive) and `cpu_baseline_single_thread`.
 """
 import argparse
 import json
@@ -110,6 +110,28 @@ def batch1_tick(ba, ticks=300, warm=30):
     out["note"] = ("one instance through brov_tick_host (python ctypes caller): host -> device upload, RTI step, record back; "
                    "compare cpu_baseline_single_thread")
     return out
+
+
+def host_boundary(ba, B, ticks=40, warm=8):
+    """the headline workload through the HOST side of the boundary (PCIe included): every tick uploads the B measured states
+    (B x 96 B) and the shared reference window, runs the step and brings the B result records (B x 104 B) back to the host --
+    brov_tick_host, one call per tick.  `value` of the bench line has its inputs resident in HBM; this is the rate a caller that
+    lives on the host sees."""
+    N, Ts = HORIZON, 1.0 / HORIZON
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    x0, circ = synthetic_inputs(B, seed=1)
+    s.set_params(ba.P_NOMINAL)
+    wall = []
+    for k in range(warm + ticks):
+        y = np.ascontiguousarray(circ[k:k + N + 1])
+        t0 = time.perf_counter()
+        r = s.tick(x0=x0, yref=y)
+        wall.append(time.perf_counter() - t0)
+    dt = float(np.median(wall[warm:]))
+    s.close()
+    return dict(value=B / dt, unit="solves/s", ms_per_step=dt * 1e3, status_nonzero=int((r["status"] != 0).sum()),
+                bytes_up_per_step=int(B * NX * 8 + (N + 1) * NY * 8), bytes_down_per_step=int(B * 104),
+                note="same workload, inputs from host buffers and records back to the host every step (PCIe-inclusive, python ctypes caller)")
 
 
 def candidate_params():
@@ -759,6 +781,7 @@ def main(argv=None):
         s4.close()
     if extra:
         out["batch1_tick"] = batch1_tick(ba)
+        out["host_boundary"] = host_boundary(ba, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(BATCH_PER_GPU)
         if extra:
