@@ -741,6 +741,7 @@ static DevParams make_params(const brov_solver* s) {
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
     P.mail = s->mail; P.mail_flag = s->mail_flag; P.mail_seq = s->mail_seq;
+    P.mail_early = !(getenv("BROV_DEV_NO_EARLY_RECORD") && atoi(getenv("BROV_DEV_NO_EARLY_RECORD")) != 0);   // development knob (A/B)
     P.ws = s->ws; P.ws_stride = s->win_L ? (int64_t)windowed_ws_doubles(s->N, s->win_L) : 0; P.counter = s->counter + 32 * (s->win_tick & 1u);
     P.counter_next = s->counter + 32 * ((s->win_tick + 1u) & 1u);
     P.win_L = s->win_L; P.win_blocks = s->win_blocks;

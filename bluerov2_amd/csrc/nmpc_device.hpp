@@ -59,6 +59,7 @@ struct DevParams {
     brov_result* mail;
     int32_t* mail_flag;
     int32_t mail_seq;
+    int32_t mail_early;      // resident windowed kernel: send the record ahead of the last adjoint sweep when the answer needs none of it
     // windowed kernel (N >= 24): per-block parking image + scratch, instance hand-out counter, stages per window
     double* ws;
     int64_t ws_stride;   // doubles per block

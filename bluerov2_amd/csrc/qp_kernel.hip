@@ -1179,9 +1179,9 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
 // steps, inputs, input gradient and multipliers are all in LDS; the iterate rows and the reference of the window are requested
 // before the window is fetched and swept, so the step costs no exposed HBM round trip.  cost: this lane's share of the NLS
 // objective at the updated iterate; u0v: lanes 0..3 the new first input.
-template <bool RES>
+template <bool RES, class Mid>
 __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, Win& W, int b, const double* vfin, bool early,
-                                                   double& cost, double& u0v) {
+                                                   double& cost, double& u0v, bool deliver_first, Mid&& mid) {
     const int lane = I.lane, NT = I.NT, L = W.Lc;
     const double* __restrict__ cst = P.cst;
     double* x_it = P.x + (size_t)b * (NT + 1) * 12;
@@ -1213,54 +1213,76 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
             yr[t] = I.yref[(size_t)(i0 + i) * 16 + cc];
             wx[t] = (i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc];
         }
-        win_need(I, W, c, WM_AB | WM_QR | WM_DX, vfin);
-        adj_chunk<true, 3>(I, atpi, vfin, nullptr, nullptr);
-        W.valid &= ~WM_GAIN;   // multipliers / input gradient are staged in the K^T / feed-forward areas
-        __syncthreads();
-        win_flush_small(pi_it + (size_t)i0 * NX, W.lds + win_off_kt(L), n * NX, lane);
+        auto adjoint_part = [&]() __attribute__((always_inline)) {
+            win_need(I, W, c, WM_AB | WM_QR | WM_DX, vfin);
+            adj_chunk<true, 3>(I, atpi, vfin, nullptr, nullptr);
+            W.valid &= ~WM_GAIN;   // multipliers / input gradient are staged in the K^T / feed-forward areas
+            __syncthreads();
+            win_flush_small(pi_it + (size_t)i0 * NX, W.lds + win_off_kt(L), n * NX, lane);
+        };
+        auto update_part = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int j = lane + 64 * t;
-            if (j < nu) {
-                const int i = j >> 2, m = j & 3;
-                const double gg = early ? 0.0 : (double)gl[j];
-                lam_it[(size_t)(i0 + i) * 8 + m] = gg > 0 ? gg : 0.0;
-                lam_it[(size_t)(i0 + i) * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
-                const double un = uo[t] + vh[j];
-                u_it[i0 * 4 + j] = un;
-                if (i0 == 0 && j < 4) { P.res[b].u0[j] = un; u0v = un; }
-                const double e = un - ur[t];
-                cost += 0.5 * P.Ts * wu[t] * e * e;
+            for (int t = 0; t < 2; t++) {
+                const int j = lane + 64 * t;
+                if (j < nu) {
+                    const int i = j >> 2, m = j & 3;
+                    const double gg = early ? 0.0 : (double)gl[j];
+                    lam_it[(size_t)(i0 + i) * 8 + m] = gg > 0 ? gg : 0.0;
+                    lam_it[(size_t)(i0 + i) * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
+                    const double un = uo[t] + vh[j];
+                    u_it[i0 * 4 + j] = un;
+                    if (i0 == 0 && j < 4) { P.res[b].u0[j] = un; u0v = un; }
+                    const double e = un - ur[t];
+                    cost += 0.5 * P.Ts * wu[t] * e * e;
+                }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = lane + 64 * t;
-            if (j < nxr) {
-                const double xn = xo[t] + dx[j];
-                x_it[i0 * 12 + j] = xn;
-                const double e = xn - yr[t];
-                cost += 0.5 * wx[t] * e * e;
+            for (int t = 0; t < 4; t++) {
+                const int j = lane + 64 * t;
+                if (j < nxr) {
+                    const double xn = xo[t] + dx[j];
+                    x_it[i0 * 12 + j] = xn;
+                    const double e = xn - yr[t];
+                    cost += 0.5 * wx[t] * e * e;
+                }
             }
-        }
-        if constexpr (RES) {   // resident mode: windows longer than 20 stages, the elements beyond the preloaded 128 / 256
-            for (int j = lane + 128; j < nu; j += 64) {
-                const int i = j >> 2, m = j & 3;
-                const double gg = early ? 0.0 : (double)gl[j];
-                lam_it[(size_t)(i0 + i) * 8 + m] = gg > 0 ? gg : 0.0;
-                lam_it[(size_t)(i0 + i) * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
-                const double un = u_it[i0 * 4 + j] + vh[j];
-                u_it[i0 * 4 + j] = un;
-                const double e = un - I.yref[(size_t)(i0 + i) * 16 + 12 + m];
-                cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+            if constexpr (RES) {   // resident mode: windows longer than 20 stages, the elements beyond the preloaded 128 / 256
+                for (int j = lane + 128; j < nu; j += 64) {
+                    const int i = j >> 2, m = j & 3;
+                    const double gg = early ? 0.0 : (double)gl[j];
+                    lam_it[(size_t)(i0 + i) * 8 + m] = gg > 0 ? gg : 0.0;
+                    lam_it[(size_t)(i0 + i) * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
+                    const double un = u_it[i0 * 4 + j] + vh[j];
+                    u_it[i0 * 4 + j] = un;
+                    const double e = un - I.yref[(size_t)(i0 + i) * 16 + 12 + m];
+                    cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+                }
+                for (int j = lane + 256; j < nxr; j += 64) {
+                    const int i = j / 12, cc = j - i * 12;
+                    const double xn = x_it[i0 * 12 + j] + dx[j];
+                    x_it[i0 * 12 + j] = xn;
+                    const double e = xn - I.yref[(size_t)(i0 + i) * 16 + cc];
+                    cost += 0.5 * ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc]) * e * e;
+                }
             }
-            for (int j = lane + 256; j < nxr; j += 64) {
-                const int i = j / 12, cc = j - i * 12;
-                const double xn = x_it[i0 * 12 + j] + dx[j];
-                x_it[i0 * 12 + j] = xn;
-                const double e = xn - I.yref[(size_t)(i0 + i) * 16 + cc];
-                cost += 0.5 * ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc]) * e * e;
+        };
+        if constexpr (RES) {
+            // Resident mode (one window).  An equality-constrained answer needs nothing of the adjoint sweep for its step (its bound
+            // multipliers are zero): with deliver_first the step and the record go out first -- mid() hands the record to the host
+            // mailbox -- and the multipliers pi of the iterate follow.  The two parts run in either order out of ONE copy each.
+            const bool update_first = early && deliver_first;
+#pragma clang loop unroll(disable)
+            for (int ph = 0; ph < 2; ph++) {
+                if ((ph == 0) == update_first) {
+                    update_part();
+                    if (update_first) mid(cost, u0v);
+                } else {
+                    adjoint_part();
+                }
             }
+        } else {
+            adjoint_part();
+            update_part();
         }
     }
     wave_fence();
@@ -1874,6 +1896,46 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         }
     }
 
+    // The result record (device copy and, for brov_tick_host at small batches, the host mailbox).  A lambda because the resident
+    // windowed kernel sends it BEFORE its last adjoint sweep when the answer is the equality-constrained one: nothing in the record
+    // depends on the multipliers that sweep computes for the iterate, and the host gets its input ~20 us earlier at N = 80.
+    bool emitted = false;
+    auto emit_record = [&](double cost_lane, double u0_lane, bool have_u0) __attribute__((always_inline)) {
+        const double cs = wave_sum(cost_lane);
+        if (lane == 0) {
+            brov_result* r = P.res + b;
+            r->cost = cs;
+            r->kkt = kkt;
+            r->status = status;
+            r->qp_iter = early ? 0 : iters;
+        }
+        // first input of the record.  Failed step: the last successfully computed input is held (clamped into the box, NaN -> 0),
+        // so that the plant / thrust consumers never see a diverged iterate's input.
+        double u0r = u0_lane;
+        if (!have_u0 && lane < 4) {
+            u0r = P.res[b].u0[lane];
+            u0r = (u0r == u0r) ? u0r : 0.0;
+            u0r = fmin(fmax(u0r, cst[32 + lane]), cst[36 + lane]);
+            P.res[b].u0[lane] = u0r;
+        }
+        // thrust allocation epilogue (bluerov2_dob.cpp:390-395), six lanes
+        const double a0 = readlane_f64(u0r, 0), a1 = readlane_f64(u0r, 1), a2 = readlane_f64(u0r, 2), a3 = readlane_f64(u0r, 3);
+        const double s0 = (lane == 0 || lane == 1) ? -a0 : a0;
+        const double s1 = (lane == 0 || lane == 2) ? a1 : -a1;
+        const double s3 = (lane == 0 || lane == 3) ? a3 : -a3;
+        const double th = ((lane < 4) ? (s0 + s1) + s3 : -a2) / kRotor;   // same operation order as the host helper
+        if (lane < 6) P.res[b].thrust[lane] = th;
+        if (P.mail) {   // host mailbox: the same record into pinned host memory, then (behind a system-scope fence) the sequence word
+            brov_result* m = P.mail + b;
+            if (lane < 4) m->u0[lane] = u0r;
+            if (lane < 6) m->thrust[lane] = th;
+            if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = status; m->qp_iter = early ? 0 : iters; }
+            __threadfence_system();
+            if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        emitted = true;
+    };
+
     // ---- finalise: consistent primal/dual for the final inputs, multiplier recovery, full step ---------------
     // Element loops issue all their loads before the first use (UX/UU elements per lane per chunk): at one wave per SIMD
     // every dependent global round trip is otherwise fully exposed (~2 us each).
@@ -1894,7 +1956,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             if (W->nan) {
                 status = BROV_STATUS_NAN;
             } else {
-                win_adjoint_commit<LDS == 4>(P, I, *W, b, vfin, early, cost, u0v);
+                win_adjoint_commit<LDS == 4>(P, I, *W, b, vfin, early, cost, u0v, P.mail != nullptr && P.mail_early != 0,
+                                             [&](double cost_lane, double u0_lane) __attribute__((always_inline)) { emit_record(cost_lane, u0_lane, true); });
                 wrote_u0 = true;
             }
             DBG_STAMP(5);
@@ -2039,39 +2102,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             if (restart) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
         }
     }
-    cost = wave_sum(cost);
-    if (lane == 0) {
-        brov_result* r = P.res + b;
-        r->cost = cost;
-        r->kkt = kkt;
-        r->status = status;
-        r->qp_iter = early ? 0 : iters;
-        sched_note(P, b, sched_p);
-    }
-    // first input of the record.  Failed step: the last successfully computed input is held (clamped into the box, NaN -> 0),
-    // so that the plant / thrust consumers never see a diverged iterate's input.
-    if (!wrote_u0 && lane < 4) {
-        u0v = P.res[b].u0[lane];
-        u0v = (u0v == u0v) ? u0v : 0.0;
-        u0v = fmin(fmax(u0v, cst[32 + lane]), cst[36 + lane]);
-        P.res[b].u0[lane] = u0v;
-    }
-    {   // thrust allocation epilogue (bluerov2_dob.cpp:390-395), six lanes
-        const double a0 = readlane_f64(u0v, 0), a1 = readlane_f64(u0v, 1), a2 = readlane_f64(u0v, 2), a3 = readlane_f64(u0v, 3);
-        const double s0 = (lane == 0 || lane == 1) ? -a0 : a0;
-        const double s1 = (lane == 0 || lane == 2) ? a1 : -a1;
-        const double s3 = (lane == 0 || lane == 3) ? a3 : -a3;
-        const double th = ((lane < 4) ? (s0 + s1) + s3 : -a2) / kRotor;   // same operation order as the host helper
-        if (lane < 6) P.res[b].thrust[lane] = th;
-        if (P.mail) {   // host mailbox: the same record into pinned host memory, then (behind a system-scope fence) the sequence word
-            brov_result* m = P.mail + b;
-            if (lane < 4) m->u0[lane] = u0v;
-            if (lane < 6) m->thrust[lane] = th;
-            if (lane == 0) { m->cost = cost; m->kkt = kkt; m->status = status; m->qp_iter = early ? 0 : iters; }
-            __threadfence_system();
-            if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (!emitted) emit_record(cost, u0v, wrote_u0);
+    if (lane == 0) sched_note(P, b, sched_p);
     DBG_STAMP(6);
 }
 

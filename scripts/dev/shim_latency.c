@@ -11,7 +11,8 @@
 
 static int cmp(const void* a, const void* b) { double d = *(const double*)a - *(const double*)b; return d < 0 ? -1 : d > 0; }
 
-int main(void) {
+int main(int argc, char** argv) {
+    const double gap_us = argc > 1 ? atof(argv[1]) : 0.0;   /* idle time between ticks (a control loop does not run back to back) */
     bluerov2_solver_capsule* c = bluerov2_acados_create_capsule();
     if (bluerov2_acados_create(c)) return 1;
     static double yref[BLUEROV2_N + 1][BLUEROV2_NY], par[BLUEROV2_N + 1][BLUEROV2_NP];
@@ -42,10 +43,15 @@ int main(void) {
         tot[k] = tt * 1e6;
         if (st != 0 && k > 5) { printf("tick %d status %d kkt %g\n", k, st, kkt); }
         x0[0] = yref[1][0]; x0[1] = yref[1][1]; x0[5] = yref[1][5];   /* a perfect plant: the state follows the reference */
+        if (gap_us > 0) {
+            struct timespec g0, g1;
+            clock_gettime(CLOCK_MONOTONIC, &g0);
+            do clock_gettime(CLOCK_MONOTONIC, &g1); while ((g1.tv_sec - g0.tv_sec) * 1e6 + (g1.tv_nsec - g0.tv_nsec) * 1e-3 < gap_us);
+        }
     }
     qsort(wall + 20, T - 20, sizeof(double), cmp);
     qsort(tot + 20, T - 20, sizeof(double), cmp);
-    printf("shim tick at N = %d, batch 1: wall median %.1f us, p99 %.1f us;  time_tot median %.1f us\n", BLUEROV2_N, wall[20 + (T - 20) / 2],
+    printf("shim tick at N = %d, batch 1, %.0f us idle between ticks: wall median %.1f us, p99 %.1f us;  time_tot median %.1f us\n", BLUEROV2_N, gap_us, wall[20 + (T - 20) / 2],
            wall[20 + (T - 20) * 99 / 100], tot[20 + (T - 20) / 2]);
     double tl = 0, tq = 0;
     ocp_nlp_get(c->nlp_config, c->nlp_solver, "time_lin", &tl);
