@@ -24,8 +24,8 @@
 // File map: tile primitives, per-stage operand access -> sweeps (bwd_* / fwd_* / roll_* / adj_*, each split into an
 // initialisation and a "stages of the resident window" part) -> window manager of the windowed kernel (Win, win_*, sw_*) ->
 // work ordering (sched_*) -> qp_body (QP solve, multiplier recovery, full step; shared by all kernels) -> lin_phase (wave-wide
-// linearisation) -> kernels (qp_kernel + lin_wave_kernel[_grid] streaming pair, rti_fused_kernel / _w2, rti_window_kernel) and
-// their launchers.
+// linearisation) -> kernels (qp_kernel + lin_wave_kernel[_grid] streaming pair, rti_fused_kernel / _w2, rti_window_kernel and its
+// resident-mode instantiation rti_window_kernel_res for small batches) and their launchers.
 #include "lin_device.hpp"
 #include "nmpc_device.hpp"
 
