@@ -2102,8 +2102,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             if (restart) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
         }
     }
-    if (lane == 0) sched_note(P, b, sched_p);
     if (!emitted) emit_record(cost, u0v, wrote_u0);
+    if (lane == 0) sched_note(P, b, sched_p);
     DBG_STAMP(6);
 }
 
