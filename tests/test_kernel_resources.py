@@ -7,6 +7,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -38,3 +40,48 @@ def test_solver_kernels_use_no_scratch_and_keep_their_occupancy():
         assert r["scratch"] == 0, (short, r)
         assert r["occ"] == occ, (short, r)
         assert r["VGPRs"] <= 256, (short, r)
+
+
+# ---- code-generation defect found in round 3 (scripts/check_exec_restore.py): copies of live registers ahead of a join block's
+# exec restore.  The Makefile runs the check on the library it links; here: the checker itself, and the library in the tree.
+_BAD = """
+_ZN4brov6kernelE:
+	s_and_saveexec_b64 s[4:5], s[6:7]
+	s_cbranch_execz .LBB5_323
+; %bb.320:
+	global_atomic_add v3, v3, v4, s[6:7] sc0
+.LBB5_323:
+	v_accvgpr_write_b32 a64, v162
+	v_writelane_b32 v255, s4, 3
+	v_accvgpr_write_b32 a65, v163
+	s_or_b64 exec, exec, s[4:5]
+	s_endpgm
+"""
+_GOOD = _BAD.replace("\tv_accvgpr_write_b32 a64, v162\n\tv_writelane_b32 v255, s4, 3\n\tv_accvgpr_write_b32 a65, v163\n\ts_or_b64 exec, exec, s[4:5]\n",
+                     "\tv_writelane_b32 v255, s4, 3\n\ts_or_b64 exec, exec, s[4:5]\n\tv_accvgpr_write_b32 a64, v162\n\tv_accvgpr_write_b32 a65, v163\n")
+
+
+def _checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_exec_restore", os.path.join(ROOT, "scripts", "check_exec_restore.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_exec_restore_checker_recognises_the_defect():
+    chk = _checker()
+    hits = chk.scan(_BAD.split("\n"))
+    assert len(hits) == 1 and hits[0][0] == "_ZN4brov6kernelE" and hits[0][3] == "s[4:5]"
+    assert [t for _, t in hits[0][4]] == ["v_accvgpr_write_b32 a64, v162", "v_accvgpr_write_b32 a65, v163"]   # v_writelane ignores exec
+    assert chk.scan(_GOOD.split("\n")) == []
+
+
+def test_shipped_library_has_no_vector_code_ahead_of_an_exec_restore():
+    lib = os.path.join(ROOT, "bluerov2_amd", "lib", "libbluerov2_nmpc.so")
+    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("library not built / no llvm-objdump")
+    chk = _checker()
+    lines = chk.listing(lib)
+    assert sum("s_cbranch_execz" in ln for ln in lines) > 500      # the disassembly is there and symbolised
+    assert chk.scan(lines) == []
