@@ -661,7 +661,7 @@ def main(argv=None):
         _, ksec, (gathered, best, _) = run(s, tick, K, W, True, select)
         res2 = s.results()
         legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, info=info, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
-                         shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
+                         lds=s.lds_kernel_info(), shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
         last = (s, gathered, best)
         if (N, Ts) != wl["horizons"][-1]:
             s.close()
@@ -735,6 +735,11 @@ def main(argv=None):
             out["sweep"] = {f"N{l['N']}": dict(solves_per_s=total * K / l["dt"], ms_per_step=l["dt"] / K * 1e3,
                                                per_rank_ms=l["info"]["per_rank_ms"], gather_ms=l["info"].get("gather_ms"),
                                                kernel_path={1: "streaming", 2: "fused", 3: "windowed"}.get(l["path"], "?"),
+                                               stage_solves_per_s=total * K / l["dt"] * l["N"],
+                                               # the LDS-occupancy crossover BASELINE configs[4] asks for: what one instance in flight
+                                               # takes of a CU's 160 KB, and how many the occupancy query lets a CU hold
+                                               kernel=l["lds"]["kind"], lds_bytes_per_instance=l["lds"]["lds_bytes_per_block"],
+                                               instances_in_flight_per_cu=l["lds"]["blocks_per_cu"],
                                                status_nonzero=l["n_bad"], mean_qp_iter=float(l["qp_iter"].mean()))
                             for l in legs}
     if gather:

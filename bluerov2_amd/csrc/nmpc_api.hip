@@ -885,6 +885,14 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
 extern "C" int brov_last_kernel_path(const brov_solver* s) {
     return s ? (s->last_fused ? BROV_PATH_FUSED : (s->last_windowed ? BROV_PATH_WINDOWED : BROV_PATH_STREAMING)) : BROV_ERR_ARG;
 }
+extern "C" int brov_lds_kernel_info(const brov_solver* s, int32_t info[4]) {
+    if (!s || !info) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const bool fused = fused_supported(s->N) && !s->force_windowed;
+    if (!fused && !s->ws) { info[0] = info[1] = info[2] = info[3] = 0; return BROV_OK; }   // streaming kernels: stage blocks in HBM
+    lds_kernel_info(s->N, s->win_L, !fused, info);
+    return BROV_OK;
+}
 extern "C" int brov_window_stages(const brov_solver* s) { return s ? (s->ws ? s->win_L : 0) : BROV_ERR_ARG; }
 extern "C" int brov_debug_dump_linearisation(brov_solver* s, int enable) {
     if (!s) return BROV_ERR_ARG;

@@ -86,7 +86,7 @@ def _load():
         "brov_set_yref_stage_host": [vp, C.c_int, C.c_int, dp, C.c_int],
         "brov_set_iterate_host": [vp, dp, dp, dp, dp], "brov_get_iterate_host": [vp, dp, dp, dp, dp],
         "brov_set_opts": [vp, vp], "brov_get_opts": [vp, vp],
-        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_last_kernel_path": [vp], "brov_window_stages": [vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
+        "brov_reset": [vp], "brov_init_iterate_default": [vp], "brov_last_kernel_path": [vp], "brov_window_stages": [vp], "brov_lds_kernel_info": [vp, vp], "brov_solve": [vp, vp], "brov_synchronize": [vp, vp],
         "brov_get_results_host": [vp, vp], "brov_get_u0_host": [vp, dp],
         "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
         "brov_get_thrusts_host": [vp, dp], "brov_last_solve_seconds": [vp, dp, dp], "brov_enable_timing": [vp, C.c_int],
@@ -411,6 +411,13 @@ class BatchSolver:
     def window_stages(self):
         """stages per LDS window of the windowed kernel (0: none; == N: resident mode, the whole horizon in one window)"""
         return int(self._L.brov_window_stages(self._h))
+
+    def lds_kernel_info(self):
+        """dict(lds_bytes_per_block, blocks_per_cu, threads_per_block, kind) of the LDS-resident kernel this solver launches"""
+        a = (C.c_int32 * 4)()
+        self._chk(self._L.brov_lds_kernel_info(self._h, a), "lds_kernel_info")
+        kind = {0: "streaming", 1: "fused", 2: "fused, two waves per SIMD", 3: "windowed", 4: "windowed, resident"}[int(a[3])]
+        return dict(lds_bytes_per_block=int(a[0]), blocks_per_cu=int(a[1]), threads_per_block=int(a[2]), kind=kind)
 
     def last_solve_seconds(self):
         tot, k2 = C.c_double(0), (C.c_double * 2)()

@@ -253,6 +253,10 @@ int brov_last_kernel_path(const brov_solver* s);
 /* stages per LDS window of the windowed kernel this solver was created for (0: no windowed workspace).  Equal to N: resident mode,
  * the whole horizon in one window (batches of at most one instance per CU at N <= 81); otherwise <= 20 */
 int brov_window_stages(const brov_solver* s);
+/* what the LDS-resident kernel this solver launches asks of a compute unit: info = {dynamic LDS bytes per block (= per instance in
+ * flight), blocks per CU granted by the occupancy query, threads per block, kind: 1 whole horizon / 2 whole horizon, two waves per
+ * SIMD / 3 windowed / 4 windowed, resident mode}; all 0 when the solver runs on the streaming kernels */
+int brov_lds_kernel_info(const brov_solver* s, int32_t info[4]);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Batched EKF disturbance observer: B independent copies of the reference's 18-state filter
