@@ -87,6 +87,20 @@ def test_auto_path_selection(ba, golden_traj):
         s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(win); s.solve()
         assert s.last_kernel_path() == want, (N, B)
         assert not s.results()["status"].any()
+        info = s.lds_kernel_info()
+        assert (info["kind"] == "streaming") == (want == ba.PATH_STREAMING)
+        s.close()
+    # the LDS-occupancy crossover the horizon sweep reports: four instances in flight per CU up to N = 20, three from N = 21,
+    # two waves per SIMD up to N = 13, one resident window for small batches at long horizons
+    for N, B, kind, per_cu in ((10, 64, "fused, two waves per SIMD", 7), (13, 64, "fused, two waves per SIMD", 6), (14, 64, "fused", 4), (20, 64, "fused", 4),
+                               (21, 64, "fused", 3), (23, 64, "fused", 3), (40, 4096, "windowed", 4), (80, 4096, "windowed", 4),
+                               (80, 64, "windowed, resident", 1)):
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
+        info = s.lds_kernel_info()
+        assert info["kind"] == kind and info["blocks_per_cu"] == per_cu, (N, B, info)
+        assert info["lds_bytes_per_block"] * per_cu <= 160 * 1024
+        if N in (20, 21, 23):   # LDS is what bounds these (N = 14: one 512-register wave per SIMD does)
+            assert info["lds_bytes_per_block"] * (per_cu + 1) > 160 * 1024
         s.close()
 
 
