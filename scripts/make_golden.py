@@ -119,6 +119,24 @@ def rti_step_independent(ref, N, Ts, x0, yref, p, x, u, Wd=W, lbu=LBU, ubu=UBU, 
     return x + dX, u + dU.reshape(N, NU), dict(nact=nact, qp_kkt=kkt, cond=np.linalg.cond(H))
 
 
+_WORKER_REF = None
+
+
+def independent_ticks(job):
+    """Worker entry of tests/test_gpu_bvls.py (process pool, no GPU in the workers): `ticks` RTI steps of ONE instance by the
+    independent recipe, each from the independent iterate of the step before.  job = dict(N, Ts, x0, yrefs[ticks], p, x, u, W, We,
+    lbu, ubu); returns [(x, u, info)] per tick."""
+    global _WORKER_REF
+    if _WORKER_REF is None:
+        _WORKER_REF = CasadiRef()
+    x, u, out = job["x"], job["u"], []
+    for yref in job["yrefs"]:
+        x, u, info = rti_step_independent(_WORKER_REF, job["N"], job["Ts"], job["x0"], yref, job["p"], x, u, Wd=job["W"], lbu=job["lbu"],
+                                          ubu=job["ubu"], Wed=job["We"])
+        out.append((x, u, info))
+    return out
+
+
 def scenario_list(circ, lem):
     """(name, N, Ts, nticks, x0(k), yref(k), p, init_x, init_u)"""
     sc = []

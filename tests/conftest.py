@@ -14,6 +14,41 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- record of what the parity rules excused --------------------------------------------------------------------------------
+# `pytest -q` swallows the prints of status_agreement / values_agree / u0_abs_ok, so every call also appends one line here and the
+# session writes the lot to gpurun_out/parity_excused.json (scripts/collect_profiles.py copies its summary into profiles/): a
+# count creeping from 0 to the allowance shows in a committed file, not only in a log nobody reads.
+_PARITY_LOG = []
+
+
+def _parity_note(rule, what, n_checked, n_excused, **detail):
+    _PARITY_LOG.append(dict(rule=rule, what=repr(what), checked=int(n_checked), excused=int(n_excused),
+                            **{k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in detail.items()}))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY_LOG:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    by_rule = {}
+    for e in _PARITY_LOG:
+        r = by_rule.setdefault(e["rule"], dict(calls=0, checked=0, excused=0, max_excused_per_call=0, calls_with_excused=0))
+        r["calls"] += 1; r["checked"] += e["checked"]; r["excused"] += e["excused"]
+        r["max_excused_per_call"] = max(r["max_excused_per_call"], e["excused"]); r["calls_with_excused"] += int(e["excused"] > 0)
+    u0 = [e for e in _PARITY_LOG if e["rule"] == "u0_abs"]
+    summary = dict(exitstatus=int(exitstatus), by_rule=by_rule,
+                   u0_abs_worst_held_error=max([e["worst_held"] for e in u0], default=None),
+                   u0_abs_kkt_histogram_of_held_instances=(np.sum([e["kkt_hist"] for e in u0], axis=0).tolist() if u0 else None),
+                   kkt_histogram_edges=KKT_EDGES,
+                   bvls_abs=[dict(what=e["what"], instances_x_ticks=e["checked"], kkt_hist=e["kkt_hist"], worst_u=e["worst_u"],
+                                  worst_u0=e["worst_u0"], active_bounds=e["active_bounds"]) for e in _PARITY_LOG if e["rule"] == "bvls_abs_1e-8"],
+                   entries_with_excused=[e for e in _PARITY_LOG if e["excused"] > 0][:200])
+    with open(os.path.join(out, "parity_excused.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.oracle_ffi import Oracle, build
@@ -72,6 +107,7 @@ def status_agreement(r_status, o_status, o_kkt, max_ambiguous=4):
     assert mism.sum() <= max_ambiguous, (np.nonzero(mism)[0], r_status[mism], o_status[mism])
     if mism.sum():
         print(f"[status_agreement] {int(mism.sum())} status-ambiguous instance(s) (entering KKT > 1e6): gpu {r_status[mism]} oracle {o_status[mism]}")
+    _parity_note("status", "status", len(mism), mism.sum(), kkt=o_kkt[mism], gpu=r_status[mism], oracle=o_status[mism])
     return ~mism
 
 
@@ -89,3 +125,32 @@ def values_agree(ok, kkt, what, max_diverged=4, err=None):
     assert bad.sum() <= max_diverged, (what, np.nonzero(bad)[0][:8], kkt[bad][:8])
     if bad.sum():
         print(f"[values_agree] {what}: {int(bad.sum())} diverged instance(s) (KKT > 1e6) outside the scaled tolerance")
+    _parity_note("values_scaled", what, len(ok), bad.sum(), kkt=kkt[bad])
+
+
+KKT_EDGES = [0.0, 1.0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6]
+U0_TOL = 1e-5          # BASELINE.json north_star: "matching acados u* within 1e-5"
+
+
+def u0_abs_ok(u0_gpu, u0_orc, st_gpu, st_orc, kkt, what, max_exceptions=2):
+    """The north star's own bar on the one output the node applies: |u0_gpu - u0_oracle|_inf <= 1e-5 ABSOLUTE, whatever the size of
+    the instance's QP data.  The KKT-scaled rule above (1e-7 max(1, KKT)) is tighter than this for well-posed instances and looser
+    for the saturated / far-off ones that run the QP loop (entering KKT 1e2 .. 1e5 -> 1e-5 .. 1e-2); this rule closes that gap.
+    Held: every instance both sides solved (status 0) whose entering KKT is finite and <= 1e6.  No exception at KKT <= 1e5; at most
+    `max_exceptions` per call between 1e5 and 1e6 (iterates on their way to divergence: the QP's own conditioning there costs more
+    than 11 digits), each printed and recorded.  Returns the per-instance errors."""
+    u0_gpu, u0_orc, kkt = np.asarray(u0_gpu), np.asarray(u0_orc), np.asarray(kkt)
+    st_gpu, st_orc = np.asarray(st_gpu), np.asarray(st_orc)
+    with np.errstate(invalid="ignore"):
+        err = np.abs(u0_gpu - u0_orc).reshape(len(kkt), -1).max(axis=1)
+        held = (st_gpu == 0) & (st_orc == 0) & np.isfinite(kkt) & (kkt <= 1e6)
+        viol = held & ~(err <= U0_TOL)
+    hard = viol & (kkt <= 1e5)
+    assert not hard.any(), (what, "u0 off by more than 1e-5 absolute", np.nonzero(hard)[0][:8], err[hard][:8], kkt[hard][:8])
+    assert viol.sum() <= max_exceptions, (what, np.nonzero(viol)[0][:8], err[viol][:8], kkt[viol][:8])
+    for i in np.nonzero(viol)[0]:
+        print(f"[u0_abs_ok] {what}: instance {i} |du0| = {err[i]:.2e} at entering KKT {kkt[i]:.2e} (excused: KKT > 1e5)")
+    hist = np.histogram(kkt[held], bins=KKT_EDGES)[0]
+    _parity_note("u0_abs", what, held.sum(), viol.sum(), worst_held=float(err[held].max()) if held.any() else 0.0,
+                 kkt_hist=hist, kkt=kkt[viol], err=err[viol])
+    return err

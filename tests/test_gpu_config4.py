@@ -11,7 +11,7 @@ cold-started at x0 and solves again on the next tick; with KEEP (acados behaviou
 import numpy as np
 import pytest
 
-from conftest import status_agreement, values_agree
+from conftest import status_agreement, u0_abs_ok, values_agree
 
 pytestmark = pytest.mark.gpu
 N, TS = 20, 0.05
@@ -74,6 +74,7 @@ def test_config4_shard_against_oracle_every_instance(ba, oracle, on_failure):
         for name, a, b in (("u0", r["u0"], ro["u0"]), ("u", gu, u), ("x", gx, x), ("thrust", r["thrust"] * ba.solver.ROTOR_CONSTANT, ro["thrust"] * ba.solver.ROTOR_CONSTANT)):
             ok, rel = scaled_close(a[cmp], b[cmp], kk[cmp])
             values_agree(ok, kk[cmp], (k, name))
+        u0_abs_ok(r["u0"], ro["u0"], r["status"], ro["status"], kk, ("config4", on_failure, k))   # absolute 1e-5 on the applied input
         ok, rel = scaled_close((r["cost"] / (1 + np.abs(ro["cost"])))[cmp, None], (ro["cost"] / (1 + np.abs(ro["cost"])))[cmp, None], kk[cmp])
         values_agree(ok, kk[cmp], (k, "cost"))
         well = okst & (kk < 1e3) & cmp

@@ -6,7 +6,7 @@ switch left off = the shipped np = 16 model, bit for bit."""
 import numpy as np
 import pytest
 
-from conftest import status_agreement, values_agree
+from conftest import status_agreement, u0_abs_ok, values_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,7 @@ def test_every_kernel_family_against_the_oracle(ba, oracle, golden_traj, N, path
         for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"])):
             err = np.abs(a.reshape(B, -1) - b.reshape(B, -1)).max(axis=1)
             values_agree((err <= 1e-7 * np.maximum(1.0, kk))[cmp], kk[cmp], (N, path, k, name), err=err[cmp])
+        u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("dist6", N, path, k))   # absolute 1e-5 on the applied input
         assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
         n_qp += int((res["qp_iter"] > 0).sum())
         if k == 0:   # the two terms do something: the same step WITHOUT them lands elsewhere (roll / pitch rates of node 1)

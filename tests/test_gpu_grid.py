@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import status_agreement, values_agree
+from conftest import status_agreement, u0_abs_ok, values_agree
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,6 +61,7 @@ def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_
         for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi)):
             err = np.abs(a.reshape(B, -1) - b.reshape(B, -1)).max(axis=1)
             values_agree((err <= (1e-6 if name == "pi" else 1e-7) * np.maximum(1.0, kk))[cmp], kk[cmp], (N, k, name), err=err[cmp])
+        u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("grid", N, k))
         values_agree((np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))[cmp], kk[cmp], (N, k, "cost"))
         assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
         n_qp += int((res["qp_iter"] > 0).sum())

@@ -7,7 +7,7 @@ cond ~1e5)."""
 import numpy as np
 import pytest
 
-from conftest import scenario_names, scenario_options, scenario_ticks, status_agreement, values_agree
+from conftest import scenario_names, scenario_options, scenario_ticks, status_agreement, u0_abs_ok, values_agree
 
 pytestmark = pytest.mark.gpu
 TOL_LIN = 1e-11
@@ -165,10 +165,14 @@ def test_batch_against_oracle_and_batch_invariance(ba, oracle, golden_traj, path
         kk = ro["kkt"]
         cmp = status_agreement(res["status"], ro["status"], kk)
         assert cmp.sum() >= nb - 4
-        assert (kk < 5e3).mean() > 0.95          # ... and for >95 % of them the scaled tolerance IS the absolute 1e-7
+        # the scaled tolerance is the absolute 1e-7 only where the entering KKT is <= 1 (the converged, unsaturated instances); for
+        # the saturated quarter of this batch (KKT 1e2 .. 1e4) it is 1e-5 .. 1e-3 -- which is why u0, the output the node applies,
+        # is ALSO held to the north star's absolute 1e-5 below, on every instance both sides solved
+        assert (kk < 5e3).mean() > 0.95
         for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"])):
             ok, err = _scaled_ok(a[cmp], b[cmp], kk[cmp])
             values_agree(ok, kk[cmp], (k, name))
+        u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("batch512", path, k))
         values_agree((np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))[cmp], kk[cmp], (k, "cost"))
         assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
         well = (kk < 5e3) & cmp
@@ -223,6 +227,7 @@ def test_model_parameter_variation_per_instance_and_stage(ba, oracle, golden_tra
         for name, a, b_ in (("u", gu, u), ("x", gx, x)):
             ok, err = _scaled_ok(a[cmp], b_[cmp], kk[cmp])
             assert ok.all(), (k, name, np.nonzero(cmp)[0][~ok], err[~ok], kk[cmp][~ok])
+        u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("f4", path, N, k))
         assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
         x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
         prev = res.copy()
@@ -380,6 +385,7 @@ def test_randomised_options_against_oracle(ba, oracle, golden_traj, seed):
         for name, a, b_ in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi), ("lam", glam, lam)):
             ok, err = _scaled_ok(a[cmp], b_[cmp], kk[cmp], tol=1e-6 if name in ("pi", "lam") else TOL_IT)
             values_agree(ok, kk[cmp], (seed, N, k, name), err=err if name in ("u", "x", "u0") else None)
+        u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("randomised", seed, N, k))
         fin = np.isfinite(kk)
         assert np.all(np.abs(res["kkt"][fin] - kk[fin]) <= 1e-6 * (1 + kk[fin]))
         okst = (res["status"] == 0) | (res["status"] == 2)
@@ -389,3 +395,60 @@ def test_randomised_options_against_oracle(ba, oracle, golden_traj, seed):
         prev = res.copy()
     assert n_ipm > 0
     s.close()
+
+
+def test_nominal_model_fuzz_at_the_headline_step(ba, oracle, golden_traj):
+    """The randomised-options sweeps of round 3 found single-instance disagreements with the oracle only at
+    Ts >= 0.039 s AND with the model parameters scattered +-30 % per stage (explicit RK4 at its stability edge in the roll channel
+    for some of the drawn damping values).  BASELINE's headline step is Ts = 0.05 s with the NOMINAL model
+    (bluerov2_dob.cpp:340-353): this sweep pins that no such disagreement exists there -- 512 option draws at exactly Ts = 0.05 s,
+    nominal added mass / damping, DOB-style disturbance draws, everything else brov_opts carries drawn as in the randomised test
+    (horizon 1..80 over all kernel families, weights, asymmetric boxes, failure policy, early exit, 30 % far-off states), 32
+    instances x 3 ticks each, every instance under the status rule, the KKT-scaled 1e-7 AND the absolute 1e-5 on u0.
+    ZERO disagreements are tolerated: any assertion of a draw fails the test."""
+    Ts, nb, bad, n_ipm_draws, checked = 0.05, 32, [], 0, 0
+    for seed in range(512):
+        rng = np.random.default_rng(70000 + seed)
+        N = int(rng.choice([1, 3, 7, 10, 13, 14, 19, 20, 20, 20, 23, 24, 31, 40, 57, 80]))
+        W = ba.SolverOptions(N).W * rng.uniform(0.3, 3.0, size=16)
+        We = ba.SolverOptions(N).We * rng.uniform(0.3, 3.0, size=12)
+        lbu, ubu = -rng.uniform(5.0, 60.0, size=4), rng.uniform(5.0, 60.0, size=4)
+        if seed % 3 == 0:
+            lbu[1], ubu[1] = 2.0, 30.0
+        kw = dict(W=list(W), We=list(We), lbu=list(lbu), ubu=list(ubu), on_failure=int(seed % 2), qp_early_exit=int(seed % 4 != 1))
+        path = ba.PATH_STREAMING if seed % 8 == 7 else ba.PATH_AUTO
+        x0, circ = _batch_inputs(golden_traj, N, nb, seed=80000 + seed, sat_frac=0.3)
+        p = np.tile(ba.P_NOMINAL, (nb, N + 1, 1))
+        p[..., :4] = rng.uniform(-300, 300, size=(nb, 1, 4))
+        p = np.ascontiguousarray(p)
+        s = ba.BatchSolver(nb, ba.SolverOptions(N, Ts, kernel_path=path, **kw))
+        op = oracle.opts(N, Ts, **kw)
+        x, u, pi, lam = oracle.init_iterate(op, nb)
+        s.set_x0(x0); s.set_params(p)
+        prev, n_ipm = None, 0
+        try:
+            for k in range(3):
+                yref = circ[2 * k:2 * k + N + 1]
+                s.set_yref(yref); s.solve()
+                res = s.results()
+                gx, gu, gpi, glam = s.get_iterate()
+                _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (nb, N + 1, 16))), p, x, u, pi, lam, res_prev=prev)
+                kk = ro["kkt"]
+                cmp = status_agreement(res["status"], ro["status"], kk, max_ambiguous=0)
+                for name, a, b_ in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi), ("lam", glam, lam)):
+                    ok, err = _scaled_ok(a[cmp], b_[cmp], kk[cmp], tol=1e-6 if name in ("pi", "lam") else TOL_IT)
+                    values_agree(ok, kk[cmp], ("nominal", seed, N, k, name), max_diverged=0, err=err)
+                u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("nominal", seed, N, k), max_exceptions=0)
+                n_ipm += int((res["qp_iter"] > 0).sum())
+                checked += nb
+                x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
+                prev = res.copy()
+        except AssertionError as e:
+            bad.append((seed, N, str(e)[:300]))
+        n_ipm_draws += int(n_ipm > 0)
+        s.close()
+    print(f"[nominal fuzz] 512 draws at Ts = 0.05 s, {checked} instance-ticks compared, {n_ipm_draws} draws ran the QP loop, {len(bad)} disagreements")
+    from conftest import _parity_note
+    _parity_note("nominal_fuzz_Ts0.05", "512 draws", checked, len(bad), draws_with_qp_loop=n_ipm_draws, disagreements=bad[:20])
+    assert not bad, bad[:5]
+    assert n_ipm_draws > 400

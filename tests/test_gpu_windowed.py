@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import status_agreement, values_agree
+from conftest import status_agreement, u0_abs_ok, values_agree
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,6 +70,7 @@ def _run_against_oracle(ba, oracle, N, B, ticks=3, blocks=None, resident=True):
         for name, a, b in (("u", gu, u), ("x", gx, x), ("u0", res["u0"], ro["u0"]), ("pi", gpi, pi)):
             ok, err = _scaled_ok(a[cmp], b[cmp], kk[cmp], tol=1e-6 if name == "pi" else 1e-7)
             values_agree(ok, kk[cmp], (N, B, k, name), err=err)
+        u0_abs_ok(res["u0"], ro["u0"], res["status"], ro["status"], kk, ("windowed", N, B, k))   # absolute 1e-5 on the applied input
         values_agree((np.abs(res["cost"] - ro["cost"]) <= 1e-7 * (1 + np.abs(ro["cost"])) * np.maximum(1.0, kk))[cmp], kk[cmp], (N, B, k, "cost"))
         assert np.all(np.abs(res["kkt"] - kk) <= 1e-6 * (1 + kk))
         well = (kk < 5e3) & cmp
