@@ -69,6 +69,10 @@ int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N
     s->N = N;
     if (new_time_steps) { s->ts.assign(new_time_steps, new_time_steps + N); s->dirty_grid = true; }   // :375-387 -> update_time_steps
     brov_default_opts(&s->opts, N, Ts);
+    // the generated solver carries W_0 next to W from the start (:422-441, same numbers as shipped): stage 0 keeps ITS weight when a
+    // caller later changes "W" of the stages 1..N-1 only
+    std::memcpy(s->W0, s->opts.W, sizeof s->W0);
+    s->has_W0 = true;
     // a failed step: acados' SQP_RTI returns before update_variables and leaves everything as it is -- so does the drop-in by
     // default (BROV_ON_FAILURE_KEEP).  BROV_ON_FAILURE=restart in the environment opts in to the batched API's default, a cold
     // start of the failed iterate at the measured state ("Failed steps").
@@ -155,8 +159,13 @@ int bluerov2_acados_reset(bluerov2_solver_capsule* c, int) {  // :797-830: itera
     std::fill(s->u.begin(), s->u.end(), 0.0);
     std::fill(s->pi.begin(), s->pi.end(), 0.0);
     std::fill(s->lam.begin(), s->lam.end(), 0.0);
+    // ... and the result record: its u0 is what the stage-0 "u" getter returns after a failed step (the held input), and a reset
+    // must not hand the previous run's input on
+    if (brov_reset(s->solver) != BROV_OK) return 1;
+    s->last = brov_result{};
+    s->last_status = 0;
     s->iter_host_valid = true;
-    s->dirty_iter = true;
+    s->dirty_iter = false;   // brov_reset has zeroed the device iterate too
     return 0;
 }
 
@@ -311,8 +320,8 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
         return 0;
     }
     if (!std::strcmp(field, "W") && stage == 0 && s->N > 1) {
-        // the generated solver keeps a separate stage-0 weight W_0 (:422-441).  Stage 0 gets its own here too; it collapses back
-        // into the shared stage weight when the two are equal (brov_set_stage0_weight)
+        // the generated solver keeps a separate stage-0 weight W_0 (:422-441).  Stage 0 has its own here too, from create on; the
+        // solver runs its single-weight kernels while the two are equal (brov_set_stage0_weight compares them on every push)
         for (int j = 0; j < 16; j++) s->W0[j] = v[j + 16 * j];
         s->has_W0 = true;
         s->dirty_grid = true;
@@ -333,6 +342,7 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in* in, int s
         }
         for (int j = 0; j < ny; j++) dst[j] = v[j + ny * j];
         s->dirty_opts = true;
+        if (stage < s->N) s->dirty_grid = true;   // W_0 is compared against the NEW shared weight when the options are pushed
         return 0;
     }
     if (!std::strcmp(field, "scaling")) {

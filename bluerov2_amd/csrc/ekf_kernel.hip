@@ -1059,6 +1059,7 @@ extern "C" int brov_ekf_update_from_solver(brov_ekf* e, brov_solver* s, void* st
     if (!e || !s || brov_batch(s) != e->B) { g_ekf_err = "brov_ekf_update_from_solver: batch sizes differ"; return BROV_ERR_ARG; }
     EKFCHK(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
+    if (brov_order_stream(s, stream) != BROV_OK) { g_ekf_err = "brov_ekf_update_from_solver: could not order behind the solver's last stream"; return BROV_ERR_HIP; }
     hipLaunchKernelGGL(ekf_inputs_from_solver_kernel, dim3((e->B + 255) / 256), dim3(256), 0, st, e->B, e->c.dt, 1.0 / kRotor,
                        (const double*)brov_x0_device(s), brov_results_device(s), e->vprev, e->thrust, e->y12, e->acc);
     EKFCHK(hipGetLastError());
@@ -1072,6 +1073,7 @@ extern "C" int brov_ekf_apply_to_solver(brov_ekf* e, brov_solver* s, void* strea
     if (brov_get_opts(s, &o) != BROV_OK) return BROV_ERR_ARG;
     const int stages = o.N + 1;
     const long long n = (long long)e->B * stages;
+    if (brov_order_stream(s, stream) != BROV_OK) { g_ekf_err = "brov_ekf_apply_to_solver: could not order behind the solver's last stream"; return BROV_ERR_HIP; }
     hipLaunchKernelGGL(ekf_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->B, stages,
                        (const double*)e->mp, brov_params_device(s), (const double*)e->x, e->c.inv_rc, brov_rp_disturbance_device(s));
     EKFCHK(hipGetLastError());

@@ -289,6 +289,21 @@ extern "C" int brov_batch(const brov_solver* s) { return s ? s->B : 0; }
 extern "C" int brov_horizon(const brov_solver* s) { return s ? s->N : 0; }
 extern "C" size_t brov_device_bytes(const brov_solver* s) { return s ? s->bytes : 0; }
 
+// Stream ordering.  Everything a solver enqueues runs on the stream its caller names, and brov_tick_host uses the solver's own
+// non-blocking stream and (mailbox path) returns while the tail of its kernel is still running.  A call that arrives on ANOTHER
+// stream than the one last used would overlap that work and race on the iterate / work-ordering buffers / hand-out counters: the
+// host waits for the earlier stream first.  Same stream (every loop in bench.py, the closed loop, tick after tick): a pointer
+// comparison, no cost.
+static int order_behind_last(brov_solver* s, hipStream_t st) {
+    if (s->last_stream != st) HIPCHK(hipStreamSynchronize(s->last_stream));
+    return BROV_OK;
+}
+extern "C" int brov_order_stream(brov_solver* s, void* stream) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    return order_behind_last(s, (hipStream_t)stream);
+}
+
 static int copy_in(brov_solver* s, double* dst, const double* src, size_t n, bool host, void* stream) {
     if (!s || !src) { g_err = "null argument"; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
@@ -298,6 +313,7 @@ static int copy_in(brov_solver* s, double* dst, const double* src, size_t n, boo
         HIPCHK(hipStreamSynchronize(s->last_stream));
         HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
     } else {
+        if (int rc = order_behind_last(s, (hipStream_t)stream)) return rc;
         HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return BROV_OK;
@@ -334,6 +350,7 @@ static int set_par(brov_solver* s, const double* p, int per_stage, bool host, vo
     HIPCHK(hipSetDevice(s->device));
     const double* src = p;
     double* tmp = nullptr;
+    if (!host) { if (int rc = order_behind_last(s, (hipStream_t)st)) return rc; }
     if (host) {
         HIPCHK(hipStreamSynchronize(s->last_stream));
         HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 16 * sizeof(double)));
@@ -439,6 +456,7 @@ static int set_rp(brov_solver* s, const double* d, int per_stage, bool host, voi
     HIPCHK(hipSetDevice(s->device));
     const double* src = d;
     double* tmp = nullptr;
+    if (!host) { if (int rc = order_behind_last(s, (hipStream_t)st)) return rc; }
     if (host) {
         HIPCHK(hipStreamSynchronize(s->last_stream));
         HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 2 * sizeof(double)));
@@ -523,6 +541,7 @@ extern "C" int brov_traj_rows(const brov_solver* s) { return s ? s->traj_rows : 
 extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void* stream) {
     if (!s || !s->traj || (ncols != 12 && ncols != 16)) { g_err = "brov_set_yref_from_traj: no trajectory or bad ncols"; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
+    if (int rc = order_behind_last(s, (hipStream_t)stream)) return rc;
     if (ncols == 16 && line >= 0 && line + s->N <= s->traj_rows - 1) {
         // the window is N+1 consecutive whole rows of the resident table: use them where they lie (no kernel, no copy)
         s->yref_view = s->traj + (size_t)line * 16;
@@ -560,6 +579,7 @@ extern "C" int brov_set_candidate_params_host(brov_solver* s, int kind, const do
 extern "C" int brov_set_yref_candidates(brov_solver* s, double t0, double dt, void* stream) {
     if (!s || !s->cand_set) { g_err = "brov_set_yref_candidates: no candidate parameters (brov_set_candidate_params_host)"; return BROV_ERR_ARG; }
     HIPCHK(hipSetDevice(s->device));
+    if (int rc = order_behind_last(s, (hipStream_t)stream)) return rc;
     launch_candidates(s->cand_kind, s->scratch3, s->scratch3 + s->B, s->scratch3 + 2 * (size_t)s->B, t0, dt, s->B, s->N, s->yref,
                       (hipStream_t)stream);
     s->yref_shared = false;
@@ -623,6 +643,7 @@ static int ensure_plant_params(brov_solver* s, hipStream_t st) {
 extern "C" int brov_plant_step(brov_solver* s, double dt, int substeps, void* stream) {
     if (!s || !(dt > 0.0) || substeps < 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
+    if (int rc = order_behind_last(s, (hipStream_t)stream)) return rc;
     ensure_plant_params(s, (hipStream_t)stream);
     launch_plant(s->x0, s->res, s->pplant, plant_rp(s), plant_rp_stride(s), s->B, dt, substeps, nullptr, nullptr, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
@@ -753,6 +774,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = order_behind_last(s, st)) return rc;   // e.g. a brov_tick_host whose kernel is still finishing on the solver's own stream
     const DevParams P = make_params(s);
     const int path = s->opts.kernel_path;
     // LDS-resident kernels (one launch): whole horizon for N <= 23, windowed above.  rti_phase 1 / 2 (preparation and feedback as
@@ -889,7 +911,8 @@ extern "C" int brov_lds_kernel_info(const brov_solver* s, int32_t info[4]) {
     if (!s || !info) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     const bool fused = fused_supported(s->N) && !s->force_windowed;
-    if (!fused && !s->ws) { info[0] = info[1] = info[2] = info[3] = 0; return BROV_OK; }   // streaming kernels: stage blocks in HBM
+    // streaming kernels (asked for, or forced by a general grid, or no windowed workspace): stage blocks in HBM, nothing to report
+    if (s->opts.kernel_path == BROV_PATH_STREAMING || general_grid(s) || (!fused && !s->ws)) { info[0] = info[1] = info[2] = info[3] = 0; return BROV_OK; }
     lds_kernel_info(s->N, s->win_L, !fused, info);
     return BROV_OK;
 }

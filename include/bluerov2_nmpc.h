@@ -180,6 +180,12 @@ int brov_solve(brov_solver* s, void* stream);
  * (linearise at the current iterate), 2 = feedback only (QP + step with the current x0; needs a prior phase 1) */
 int brov_solve_phase(brov_solver* s, void* stream, int rti_phase);
 int brov_synchronize(brov_solver* s, void* stream);
+/* Stream ordering.  One solver, one stream at a time: every call that enqueues work (brov_solve*, brov_plant_step, the *_device
+ * setters, the trajectory / candidate window builders, brov_ekf_*_solver) first waits -- on the host -- for the stream the solver
+ * used LAST when that is a different one (e.g. brov_tick_host's private stream, whose kernel may still be finishing when the tick
+ * returns its records).  Calls on the same stream cost nothing.  brov_order_stream does the same wait explicitly, for callers that
+ * work on the DEVICE pointers handed out below from a stream of their own. */
+int brov_order_stream(brov_solver* s, void* stream);
 /* One control tick with ONE host synchronisation: the inputs that changed since the last tick (NULL = unchanged; x0 [B][12], ONE
  * reference window shared by the batch [N+1][16], per-stage parameters [B][N+1][16]) are staged through a pinned buffer and copied
  * asynchronously on the solver's own stream, the step (rti_phase as brov_solve_phase) runs behind them, the result records come

@@ -77,11 +77,59 @@ def test_exec_restore_checker_recognises_the_defect():
     assert chk.scan(_GOOD.split("\n")) == []
 
 
+# round 4: the else-join shapes (the mask is transformed by s_xor between the saveexec and the branch, and the join block opens the
+# else arm with s_andn2_saveexec / s_or_saveexec instead of restoring), AGPR reads, and the per-function label numbering of the
+# disassembler (L43 exists once per kernel: a branch means the nearest one)
+_BAD_ELSE = """
+_ZN4brov6kernelE:
+	s_and_saveexec_b64 s[8:9], vcc
+	s_xor_b64 s[8:9], exec, s[8:9]
+	s_cbranch_execz L4
+	v_mov_b32 v1, v2
+L4:
+	v_accvgpr_read_b32 v3, a1
+	s_andn2_saveexec_b64 s[8:9], s[8:9]
+	v_mov_b32 v1, v2
+	s_or_b64 exec, exec, s[8:9]
+	s_endpgm
+_ZN4brov6otherE:
+	s_and_saveexec_b64 s[4:5], s[6:7]
+	s_cbranch_execz L4
+	v_mov_b32 v1, v2
+L4:
+	s_or_b64 exec, exec, s[4:5]
+	v_accvgpr_write_b32 a64, v162
+	s_endpgm
+"""
+
+
+def test_exec_restore_checker_knows_the_else_join_and_per_function_labels():
+    chk = _checker()
+    hits = chk.scan(_BAD_ELSE.split("\n"))
+    assert len(hits) == 1 and hits[0][0] == "_ZN4brov6kernelE" and [t for _, t in hits[0][4]] == ["v_accvgpr_read_b32 v3, a1"]
+    good = _BAD_ELSE.replace("\tv_accvgpr_read_b32 v3, a1\n\ts_andn2_saveexec_b64 s[8:9], s[8:9]\n", "\ts_andn2_saveexec_b64 s[8:9], s[8:9]\n\tv_accvgpr_read_b32 v3, a1\n")
+    assert chk.scan(good.split("\n")) == []
+
+
+def test_exec_restore_checker_refuses_to_pass_unchecked(tmp_path):
+    """a library without a code object of the architecture asked for, or no disassembler: exit status 2, not a silent pass"""
+    import subprocess, sys
+    lib = os.path.join(ROOT, "bluerov2_amd", "lib", "libbluerov2_nmpc.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    script = os.path.join(ROOT, "scripts", "check_exec_restore.py")
+    assert subprocess.run([sys.executable, script, "--arch", "gfx90a", lib], capture_output=True).returncode == 2
+    r = subprocess.run([sys.executable, script, "--objdump", str(tmp_path / "nope"), lib], capture_output=True,
+                       env={"PATH": str(tmp_path), "HIPCC": str(tmp_path / "hipcc"), "ROCM_PATH": str(tmp_path)})
+    assert r.returncode in (0, 2)   # 2 unless /opt/rocm provides the tool (the last resort the search still tries)
+
+
 def test_shipped_library_has_no_vector_code_ahead_of_an_exec_restore():
     lib = os.path.join(ROOT, "bluerov2_amd", "lib", "libbluerov2_nmpc.so")
-    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
-        pytest.skip("library not built / no llvm-objdump")
     chk = _checker()
+    chk.OBJDUMP = chk.find_objdump()
+    if not os.path.exists(lib) or not chk.OBJDUMP:
+        pytest.skip("library not built / no llvm-objdump")
     lines = chk.listing(lib)
     assert sum("s_cbranch_execz" in ln for ln in lines) > 500      # the disassembly is there and symbolised
     assert chk.scan(lines) == []
