@@ -1386,16 +1386,44 @@ __device__ __forceinline__ int sched_map(const DevParams& P, int t) {
     }
     return x * kSchedClasses + k;
 }
-// lane 0 of the wave that solves instance b.  sched_ticket: where the instance enters the QP loop -- the atomic's round trip is then
-// covered by the work that follows.  sched_note: at the end of the wave.
-__device__ __forceinline__ int sched_ticket(const DevParams& P, int b) {
-    return P.sched ? atomicAdd(P.sched + (size_t)P.sched_w * P.sched_stride + (b & (kSchedClasses - 1)) * kSchedCntStride, 1) : -1;
+// Ticket + note of an instance that ran the QP loop, at the END of its wave, by the whole wave (round 4).  Round 3 took the ticket
+// where the instance enters the QP loop, under `if (lane == 0)` -- a divergent region ahead of the loop, and the one place where
+// hipcc's register allocator once put copies of live registers ahead of the exec restore of the join block
+// (scripts/check_exec_restore.py).  The trigger is gone, not only fenced: the atomic is ONE inline-assembly block that narrows exec
+// to lane 0 and restores it itself, so the compiler sees straight-line code and builds no join block here; the block waits for the
+// returned value (an inline-asm result the compiler might copy before it has landed otherwise) -- one L2 round trip, ~1.5 us, per
+// instance that ran the QP loop (>= 60 us), where the wave has nothing left to overlap anyway.  Everything else is wave-uniform:
+// pointers in SGPRs, the two stores issued by all lanes with identical address and data.
+__device__ __forceinline__ const int32_t* uniform_ptr(const int32_t* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const int32_t*)(((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ void sched_note(const DevParams& P, int b, int p) {
+__device__ __forceinline__ int wave_atomic_inc(int32_t* addr_uniform) {
+    int ret = 0;
+    const int zero = 0, one = 1;
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %[r], %[off], %[one], %[base] sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "+v"(ret), [sv] "=&s"(saved)
+        : [off] "v"(zero), [one] "v"(one), [base] "s"(addr_uniform)
+        : "memory");
+    return __builtin_amdgcn_readfirstlane(ret);
+}
+// ran_loop: the instance entered the QP loop (wave-uniform); else only pos[b] = -1 is written
+__device__ __forceinline__ void sched_note(const DevParams& P, int b, bool ran_loop) {
     if (!P.sched) return;
-    int32_t* Wr = P.sched + (size_t)P.sched_w * P.sched_stride;
-    const int Bc = sched_class_len(P.B);
-    if (p >= 0 && p < Bc) Wr[kSchedClasses * kSchedCntStride + (b & (kSchedClasses - 1)) * Bc + p] = b;
+    int32_t* Wr = (int32_t*)uniform_ptr(P.sched + (size_t)P.sched_w * P.sched_stride);
+    const int Bc = sched_class_len(P.B), k = b & (kSchedClasses - 1);
+    int p = -1;
+    if (ran_loop) {
+        p = wave_atomic_inc(Wr + k * kSchedCntStride);
+        if (p < Bc) Wr[kSchedClasses * kSchedCntStride + k * Bc + p] = b;
+    }
     Wr[kSchedClasses * kSchedCntStride + kSchedClasses * Bc + b] = p;
 }
 __device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) {   // one wave of the launch
@@ -1482,7 +1510,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false, polished = false, use_vhat = false;
-    int sched_p = -1;   // lane 0: this instance's place in the next solve's list of expensive instances (work ordering)
+    bool ran_loop = false;   // this instance ran the QP loop: first in line in the next solve (work ordering, sched_note)
     bool ok = pre_ok;
     if constexpr (LDS < 3) ok = riccati_backward<true, LDS, false, true>(I);
     d4 d0;
@@ -1579,6 +1607,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if constexpr (LDS == 0) return I.wst ? I.wst[(size_t)(j >> 2) * 16 + 12 + mI] : rdI;
                 else return rdI;
             };
+            ran_loop = true;
             {   // first guess: the inputs of the Newton point that violate their bounds
                 GROUP_LANE;
                 IPM_PRE(up, I.u[j]);
@@ -1590,7 +1619,6 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
             status = BROV_STATUS_MAXITER;
-            if (lane == 0) sched_p = sched_ticket(P, b);   // this instance runs the QP loop: first in line in the next solve
             const double inv2nv = 1.0 / (2.0 * nv);
             int round_k = 0, round_cap = POL_FIRST, nchg_prev = nv + 1;
             double mu_gate = 1e300;
@@ -2103,7 +2131,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         }
     }
     if (!emitted) emit_record(cost, u0v, wrote_u0);
-    if (lane == 0) sched_note(P, b, sched_p);
+    sched_note(P, b, ran_loop);
     DBG_STAMP(6);
 }
 
