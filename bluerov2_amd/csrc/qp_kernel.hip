@@ -1386,14 +1386,16 @@ __device__ __forceinline__ int sched_map(const DevParams& P, int t) {
     }
     return x * kSchedClasses + k;
 }
-// Ticket + note of an instance that ran the QP loop, at the END of its wave, by the whole wave (round 4).  Round 3 took the ticket
-// where the instance enters the QP loop, under `if (lane == 0)` -- a divergent region ahead of the loop, and the one place where
-// hipcc's register allocator once put copies of live registers ahead of the exec restore of the join block
-// (scripts/check_exec_restore.py).  The trigger is gone, not only fenced: the atomic is ONE inline-assembly block that narrows exec
-// to lane 0 and restores it itself, so the compiler sees straight-line code and builds no join block here; the block waits for the
-// returned value (an inline-asm result the compiler might copy before it has landed otherwise) -- one L2 round trip, ~1.5 us, per
-// instance that ran the QP loop (>= 60 us), where the wave has nothing left to overlap anyway.  Everything else is wave-uniform:
-// pointers in SGPRs, the two stores issued by all lanes with identical address and data.
+// Ticket and note are WAVE-UNIFORM (round 4).  Round 3 took the ticket under `if (lane == 0)` -- a divergent region ahead of the QP
+// loop, next to the place where hipcc's register allocator once put AGPR copies of live registers ahead of the exec restore of a
+// join block (scripts/check_exec_restore.py).  Now the atomic is ONE inline-assembly block that narrows exec to lane 0 and restores
+// it itself: the compiler sees straight-line code and builds no join block here.  The block waits for the returned value (an
+// inline-asm result the compiler might otherwise copy before it has landed): one L2 round trip, ~1.5 us, per instance that runs
+// the QP loop (>= 60 us).  Pointers are forced into SGPRs, the two stores of sched_note are issued by all lanes with identical
+// address and data.  What round 4 learned about the defect itself: it is NOT tied to this region.  Taking the ticket at the end of
+// the wave instead (BROV_SCHED_TICKET_LATE) moves the allocator's copies to the join block of a guarded store of the first-guess
+// loop, 40 lines away -- any of the kernel's ~1000 divergent regions can host it when the allocation shifts, which is why the
+// link rule runs the checker on every build and tests/test_kernel_resources.py keeps that statement order as a live canary.
 __device__ __forceinline__ const int32_t* uniform_ptr(const int32_t* p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -1414,16 +1416,18 @@ __device__ __forceinline__ int wave_atomic_inc(int32_t* addr_uniform) {
         : "memory");
     return __builtin_amdgcn_readfirstlane(ret);
 }
-// ran_loop: the instance entered the QP loop (wave-uniform); else only pos[b] = -1 is written
-__device__ __forceinline__ void sched_note(const DevParams& P, int b, bool ran_loop) {
+// sched_ticket: where the instance enters the QP loop (wave-uniform result); sched_note: at the end of the wave, all lanes storing
+// identical data to identical addresses
+__device__ __forceinline__ int sched_ticket(const DevParams& P, int b) {
+    if (!P.sched) return -1;
+    int32_t* Wr = (int32_t*)uniform_ptr(P.sched + (size_t)P.sched_w * P.sched_stride);
+    return wave_atomic_inc(Wr + (b & (kSchedClasses - 1)) * kSchedCntStride);
+}
+__device__ __forceinline__ void sched_note(const DevParams& P, int b, int p) {
     if (!P.sched) return;
     int32_t* Wr = (int32_t*)uniform_ptr(P.sched + (size_t)P.sched_w * P.sched_stride);
     const int Bc = sched_class_len(P.B), k = b & (kSchedClasses - 1);
-    int p = -1;
-    if (ran_loop) {
-        p = wave_atomic_inc(Wr + k * kSchedCntStride);
-        if (p < Bc) Wr[kSchedClasses * kSchedCntStride + k * Bc + p] = b;
-    }
+    if (p >= 0 && p < Bc) Wr[kSchedClasses * kSchedCntStride + k * Bc + p] = b;
     Wr[kSchedClasses * kSchedCntStride + kSchedClasses * Bc + b] = p;
 }
 __device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) {   // one wave of the launch
@@ -1510,7 +1514,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     int status = 0, iters = 0;
     double mu = 0.0, rho = 0.0;
     bool early = false, polished = false, use_vhat = false;
-    bool ran_loop = false;   // this instance ran the QP loop: first in line in the next solve (work ordering, sched_note)
+    int sched_p = -1;   // this instance's place in the next solve's list of expensive instances (work ordering; wave-uniform)
     bool ok = pre_ok;
     if constexpr (LDS < 3) ok = riccati_backward<true, LDS, false, true>(I);
     d4 d0;
@@ -1607,7 +1611,6 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 if constexpr (LDS == 0) return I.wst ? I.wst[(size_t)(j >> 2) * 16 + 12 + mI] : rdI;
                 else return rdI;
             };
-            ran_loop = true;
             {   // first guess: the inputs of the Newton point that violate their bounds
                 GROUP_LANE;
                 IPM_PRE(up, I.u[j]);
@@ -1619,6 +1622,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
             status = BROV_STATUS_MAXITER;
+            // this instance runs the QP loop: first in line in the next solve.  (BROV_SCHED_TICKET_LATE: the ticket at the end of the wave
+            // instead -- the statement order that makes hipcc 7.2 build the exec-restore defect into rti_window_kernel, at a join block of
+            // the first-guess stores above; kept as the canary of tests/test_kernel_resources.py: the build gate must reject it.)
+#ifndef BROV_SCHED_TICKET_LATE
+            sched_p = sched_ticket(P, b);
+#else
+            sched_p = -2;
+#endif
             const double inv2nv = 1.0 / (2.0 * nv);
             int round_k = 0, round_cap = POL_FIRST, nchg_prev = nv + 1;
             double mu_gate = 1e300;
@@ -2131,7 +2142,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         }
     }
     if (!emitted) emit_record(cost, u0v, wrote_u0);
-    sched_note(P, b, ran_loop);
+#ifdef BROV_SCHED_TICKET_LATE
+    if (sched_p == -2) sched_p = sched_ticket(P, b);
+#endif
+    sched_note(P, b, sched_p);
     DBG_STAMP(6);
 }
 

@@ -133,3 +133,24 @@ def test_shipped_library_has_no_vector_code_ahead_of_an_exec_restore():
     lines = chk.listing(lib)
     assert sum("s_cbranch_execz" in ln for ln in lines) > 500      # the disassembly is there and symbolised
     assert chk.scan(lines) == []
+
+
+def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
+    """The canary (round 4): qp_kernel.hip compiled with -DBROV_SCHED_TICKET_LATE -- the work-ordering ticket taken at the end of the
+    wave instead of ahead of the QP loop, a harmless reordering -- makes hipcc (ROCm 7.2) place AGPR copies of live registers ahead
+    of an exec restore in rti_window_kernel.  The checker must find it in the compiler's own assembly (if a future compiler stops
+    producing it this test says so, and the canary can go), and must find nothing in the product order."""
+    chk = _checker()
+    src = os.path.join(ROOT, "bluerov2_amd", "csrc", "qp_kernel.hip")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = {}
+    for name, extra in (("product", []), ("late", ["-DBROV_SCHED_TICKET_LATE"])):
+        asm = tmp_path / f"qp_{name}.s"
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                        "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src, "-o", str(asm)] + extra,
+                       check=True, capture_output=True, timeout=900)
+        out[name] = chk.scan(open(asm).read().split("\n"))
+    assert out["product"] == []
+    assert len(out["late"]) >= 1 and all("rti_window" in h[0] for h in out["late"]), out["late"]
