@@ -318,6 +318,151 @@ def cpu_single_thread(ticks=1000):
     return out
 
 
+def pmc_traffic(tag, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary that has an entry `tag` (profiles/r*_pmc_summary.json,
+    written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes): (bytes or None, source or None)"""
+    for pj in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
+            t = pm.get("runs", {}).get(tag, {}).get("hbm_bytes_per_launch", {}).get(kernel)
+            if t is not None:
+                return t, f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run"
+        except Exception:
+            pass
+    return None, None
+
+
+def configs_block(ba, args, device):
+    """BASELINE.json configs[2], configs[3] (one of its 8 shards) and configs[4] (one of its 8 shards) on this GPU, with the same W / K
+    as the headline: what round 3 reported from builder-run side files, now inside the line the driver records.  ~6 s."""
+    import torch
+    K, W = args.steps, args.warmup
+    out = {}
+
+    def timed(step, K=K, W=W):
+        for k in range(W):
+            step(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(W, W + K):
+            step(k)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / K
+
+    def kernel_seconds(s, step):
+        s.enable_timing(True)
+        acc = np.zeros(2)
+        for k in range(W + K, W + K + 10):
+            step(k)
+            acc += s.last_solve_seconds()[1]
+        s.enable_timing(False)
+        return acc / 10
+
+    def solver_leg(s, step, N, shared):
+        s.init_iterate_default()
+        dt = timed(step)
+        r = s.results()
+        ks = kernel_seconds(s, step)
+        path = s.last_kernel_path()
+        fl = qp_flops(r["qp_iter"], N) + s.B * N * F_LIN
+        kt = ks[1] if path in KERNEL_NAMES else ks.sum()
+        return dict(solves_per_s=s.B / dt, ms_per_step=dt * 1e3, kernel_ms=kt * 1e3, kernel=KERNEL_NAMES.get(path, "lin_wave_kernel + qp_kernel"),
+                    status_nonzero=int((r["status"] != 0).sum()), mean_qp_iter=float(r["qp_iter"].mean()),
+                    ipm_instance_fraction=float((r["qp_iter"] > 0).mean()),
+                    roofline_frac=fl / kt / 1e12 / PEAK_FP64_MFMA_TFLOPS, achieved_tflops=fl / kt / 1e12,
+                    hbm_roofline_frac=s.B / dt * algorithmic_bytes(N, shared) / 1e9 / PEAK_HBM_GBS)
+
+    # ---- configs[2]: 16 384 DOB-MPC Monte-Carlo current-disturbance draws (SURVEY.md 8d config 3, seed 2), N = 20
+    B, N = 16384, HORIZON
+    rng = np.random.default_rng(2)
+    x0, circ = synthetic_inputs(B, seed=2, noise=False)
+    d = np.concatenate([rng.uniform(-10, 10, (B, 3)), rng.uniform(-3, 3, (B, 1))], axis=1)
+    p = np.tile(ba.P_NOMINAL, (B, 1))
+    p[:, 0:2] = d[:, 0:2] / 0.032546960744430276
+    p[:, 2:4] = d[:, 2:4] / 0.026546960744430276
+    s = ba.BatchSolver(B, ba.SolverOptions(N, TS), device=device)
+    s.set_x0(x0); s.set_params(p); s.set_trajectory(circ)
+    leg = solver_leg(s, lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()), N, True)
+    leg["workload"] = "BASELINE.json configs[2]: 16384 DOB-MPC Monte-Carlo current-disturbance draws (p[0..3] per instance, seed 2), N=20, Ts=0.05, shared circle window"
+    s.close()
+    # ... and closed on the device: plant with the TRUE disturbance per instance, the batched EKF observer (SURVEY.md 8 f-3)
+    # estimating it, the estimate written back into p[0..3] of every stage; tick = window -> RTI step -> plant step -> EKF -> apply
+    pt = np.tile(ba.P_NOMINAL, (B, 1)); pt[:, 0:4] = d
+    ep = ba.EkfParams.default(); ep.compensate_coef = 1.0; ep.rotor_constant = 1.0
+    for j in range(12, 24):
+        ep.K[j] = 0.0   # the device plant is the OCP model: no roll / pitch thrust, unit force scaling (include/bluerov2_nmpc.h)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, TS), device=device)
+    s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_plant_params(pt); s.set_trajectory(circ)
+    e = ba.BatchEkf(B, ep)
+
+    def cl_tick(k):
+        s.set_yref_from_trajectory(k, 16); s.solve(); s.plant_step(0.05, 1); e.update_from_solver(s); e.apply_to_solver(s)
+    dt = timed(cl_tick)
+    r = s.results(); _, mp, st = e.outputs()
+    leg["closed_loop_with_ekf"] = dict(ticks_per_s=B / dt, ms_per_tick=dt * 1e3, ekf_kernel_ms=e.last_update_seconds() * 1e3,
+                                       status_nonzero=int((r["status"] != 0).sum()), ekf_status_nonzero=int((st != 0).sum()),
+                                       median_abs_yaw_estimate_error=float(np.median(np.abs(mp[:, 3] - d[:, 3]))))
+    e.close(); s.close()
+    out["config3"] = leg
+
+    # ---- configs[3], one of its 8 shards: 8192 of the 65 536 lemniscate candidates, windows rebuilt on the device, then the RCCL
+    # all-gather + global arg-min THROUGH THE C ABI's group entry points (brov_group_*: one process, here one device)
+    B = CAND_TOTAL // CAND_SHARDS
+    amp, frq, ph = (a[:B] for a in candidate_params())
+    x0 = np.zeros((B, NX)); x0[:, 0] = 2.0; x0[:, 2] = -20.0
+    g = ba.SolverGroup([device], B, ba.SolverOptions(N, TS))
+    g.set_x0(x0); g.set_params(ba.P_NOMINAL); g.set_candidate_params("lemniscate", amp, frq, ph)
+    sh = g.shards[0]
+    sh.init_iterate_default()
+    g.enable_timing(False)
+    dt_solve = timed(lambda k: (g.set_yref_candidates_tick(TS * k, TS), g.solve()))
+    sh.init_iterate_default()
+    best = [None]
+
+    def c4_step(k):
+        g.set_yref_candidates_tick(TS * k, TS); g.solve(); g.gather(ba.GATHER_RECORDS); best[0] = g.select_best()
+    dt_all = timed(c4_step)
+    r = sh.results()
+    g.enable_timing(True)
+    acc = np.zeros(3)
+    for k in range(W + K, W + K + 10):
+        c4_step(k)
+        t = g.last_seconds(); acc += [t["solve"], t["gather"], t["select"]]
+    acc /= 10
+    sh.init_iterate_default()
+    g.enable_timing(False)
+    dt_packed = timed(lambda k: (g.set_yref_candidates_tick(TS * k, TS), g.solve(), g.gather(ba.GATHER_PACKED), g.select_best()))
+    out["config4_shard"] = dict(
+        workload="BASELINE.json configs[3], shard 0 of 8: 8192 of the 65536 lemniscate candidates (seed 3), N=20, x0 = lemniscate row 0; every step: "
+                 "candidate windows rebuilt on the device, RTI step, RCCL all-gather of the 104 B records and global arg-min through brov_group_* (one rank here)",
+        solves_per_s=B / dt_all, ms_per_step=dt_all * 1e3, solve_only_solves_per_s=B / dt_solve, solve_only_ms_per_step=dt_solve * 1e3,
+        packed_pair_gather_solves_per_s=B / dt_packed, per_rank_ms=[dt_all * 1e3], solve_ms=acc[0] * 1e3, gather_ms=acc[1] * 1e3, select_ms=acc[2] * 1e3,
+        ranks_seen=[0], rccl_version=ba.rccl_version(), status_nonzero=int((r["status"] != 0).sum()), ipm_instance_fraction=float((r["qp_iter"] > 0).mean()),
+        select_best=dict(index=int(best[0][0]), cost=None if best[0][1] is None else float(best[0][1]["cost"])),
+        note="solves_per_s includes one host wait per step (the selected record comes back to the host every step); solve_only = the same steps without gather / select")
+    g.close()
+
+    # ---- configs[4], one of its 8 shards: horizon sweep at 4096 instances, Ts = 1/N, with the LDS-occupancy crossover
+    sweep = {}
+    for N in (10, 20, 40, 80):
+        B = BATCH_PER_GPU
+        x0, circ = synthetic_inputs(B, seed=4)
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N), device=device)
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
+        leg = solver_leg(s, lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()), N, True)
+        lds = s.lds_kernel_info()
+        leg.update(kernel_kind=lds["kind"], lds_bytes_per_instance=lds["lds_bytes_per_block"], instances_in_flight_per_cu=lds["blocks_per_cu"],
+                   stage_solves_per_s=leg["solves_per_s"] * N, device_bytes=s.device_bytes)
+        leg["traffic"], leg["traffic_source"] = pmc_traffic(f"cfg5_N{N}", leg["kernel"])
+        if leg["traffic"] is not None:
+            leg["traffic_over_algorithmic"] = leg["traffic"] / (B * algorithmic_bytes(N, True))
+        sweep[f"N{N}"] = leg
+        s.close()
+    out["config5_shard_sweep"] = dict(workload="BASELINE.json configs[4], one of 8 shards: 4096 instances per horizon, N in {10,20,40,80}, Ts = 1/N, "
+                                               "x0 as config 2 (seed 4), shared circle window", legs=sweep)
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -559,7 +704,7 @@ def main(argv=None):
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
-    gather = world > 1 or args.force_gather
+    gather0 = world > 1 or args.force_gather
     if world > 1 or args.force_gather:
         # RCCL writes its debug/warn lines to stdout; keep them away from the one JSON line this script must print
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
@@ -567,232 +712,254 @@ def main(argv=None):
 
     import bluerov2_amd as ba
     from bluerov2_amd import distributed as D
-    wl = workload(args, rank, world)
-    gather = gather or (wl.get("always_gather", False) and dist.is_initialized())
-    B, K, W = wl["B"], args.steps, args.warmup
-    total = wl["total"]
-    counts = [shard_of(args, r, world, B)[1] - shard_of(args, r, world, B)[0] for r in range(world)] if args.scaling == "strong" else [B] * world
-    Bmax = max(counts)      # shards of unequal size are gathered in slots of the largest; padding records can never be selected
-    dev = f"cuda:{local_rank}"
+    def measure(args, extras_ok=True):
+        """one workload (args.config / args.scaling / ...) on this rank's GPU, all ranks together: (rank 0: the result line as a dict, else None)"""
+        wl = workload(args, rank, world)
+        gather = gather0 or (wl.get("always_gather", False) and dist.is_initialized())
+        B, K, W = wl["B"], args.steps, args.warmup
+        total = wl["total"]
+        counts = [shard_of(args, r, world, B)[1] - shard_of(args, r, world, B)[0] for r in range(world)] if args.scaling == "strong" else [B] * world
+        Bmax = max(counts)      # shards of unequal size are gathered in slots of the largest; padding records can never be selected
+        dev = f"cuda:{local_rank}"
 
-    side = torch.cuda.Stream(device=dev) if gather else None
+        side = torch.cuda.Stream(device=dev) if gather else None
 
-    def run(s, tick, steps, warmup, timing, select):
-        """`steps` timed RTI steps.  With more than one rank every step's result records are all-gathered -- on a side stream,
-        from a staging copy, so that the collective of step k (one small latency-bound ring all-gather over xGMI) overlaps the solve
-        of step k + 1; the timed region ends when the last gather has landed on every rank."""
-        main = torch.cuda.current_stream()
-        stream = main.cuda_stream
-        res_view = D.records_tensor_from_solver(s) if gather else None
-        stage = [torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
-        gathered = [torch.empty(world * D.RECORD_BYTES * Bmax, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
-        done = [None, None]
-        gev = []   # (before gather, after gather, after select) events on the side stream, one triple per timed step
-        if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered[0], stage[0])
-            torch.cuda.synchronize()
-        s.init_iterate_default()
-        s.enable_timing(False)
-        best = None
-
-        def step(k):
-            nonlocal best
-            tick(k, stream)
-            s.solve(stream=stream)
-            if gather:
-                j = k & 1
-                if done[j] is not None:
-                    main.wait_event(done[j])          # the gather that last read this staging buffer has finished
-                stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
-                ready = torch.cuda.Event()
-                ready.record(main)
-                side.wait_event(ready)
+        def run(s, tick, steps, warmup, timing, select):
+            """`steps` timed RTI steps.  With more than one rank every step's result records are all-gathered -- on a side stream,
+            from a staging copy, so that the collective of step k (one small latency-bound ring all-gather over xGMI) overlaps the solve
+            of step k + 1; the timed region ends when the last gather has landed on every rank."""
+            main = torch.cuda.current_stream()
+            stream = main.cuda_stream
+            res_view = D.records_tensor_from_solver(s) if gather else None
+            stage = [torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
+            gathered = [torch.empty(world * D.RECORD_BYTES * Bmax, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
+            done = [None, None]
+            gev = []   # (before gather, after gather, after select) events on the side stream, one triple per timed step
+            if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
                 with torch.cuda.stream(side):
-                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
-                    e0.record(side)
-                    dist.all_gather_into_tensor(gathered[j], stage[j])
-                    e1.record(side)
-                    if select:
-                        best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
-                    e2.record(side)
-                    if k >= warmup:
-                        gev.append((e0, e1, e2))
-                    done[j] = e2
-        for k in range(warmup):
-            step(k)
-        s.enable_timing(timing)
-        ksec = np.zeros(2)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(warmup, warmup + steps):
-            step(k)
-            if timing:  # HIP events on the launch stream; read back after the step (host-side wait only)
-                _, k2 = s.last_solve_seconds()
-                ksec += k2
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        info = dict(per_rank_ms=[dt / max(steps, 1) * 1e3])
-        if gev:   # side-stream event pairs: the collective itself and the device-side arg-min, per step
-            info["gather_ms"] = float(np.mean([a.elapsed_time(b) for a, b, _ in gev]))
-            info["select_ms"] = float(np.mean([b.elapsed_time(c) for _, b, c in gev])) if select else None
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            every = torch.empty(world, dtype=torch.float64, device="cuda")
-            dist.all_gather_into_tensor(every, tt)
-            info["per_rank_ms"] = [float(v) / max(steps, 1) * 1e3 for v in every.cpu()]
-            dt = float(every.max().item())
-        return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best, info)
+                    dist.all_gather_into_tensor(gathered[0], stage[0])
+                torch.cuda.synchronize()
+            s.init_iterate_default()
+            s.enable_timing(False)
+            best = None
 
-    early = 0 if args.force_ipm else 1
-    select = bool(wl.get("always_gather", False))
-    legs, out = [], None
-    for (N, Ts) in wl["horizons"]:
-        s, tick, shared = wl["make"](N, Ts, early)
-        # pass 1: the timed region that defines `value` (no per-kernel events inside)
-        dt, _, (_, _, info) = run(s, tick, K, W, False, select)
-        n_bad = int((s.results()["status"] != 0).sum())
-        # pass 2: same steps again with HIP events around each kernel for the roofline numbers
-        _, ksec, (gathered, best, _) = run(s, tick, K, W, True, select)
-        res2 = s.results()
-        legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, info=info, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
-                         lds=s.lds_kernel_info(), shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
-        last = (s, gathered, best)
-        if (N, Ts) != wl["horizons"][-1]:
-            s.close()
-    s, gathered, best = last
-    total_dt = sum(l["dt"] for l in legs)
-    value = total * K * len(legs) / total_dt
+            def step(k):
+                nonlocal best
+                tick(k, stream)
+                s.solve(stream=stream)
+                if gather:
+                    j = k & 1
+                    if done[j] is not None:
+                        main.wait_event(done[j])          # the gather that last read this staging buffer has finished
+                    stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+                        e0.record(side)
+                        dist.all_gather_into_tensor(gathered[j], stage[j])
+                        e1.record(side)
+                        if select:
+                            best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
+                        e2.record(side)
+                        if k >= warmup:
+                            gev.append((e0, e1, e2))
+                        done[j] = e2
+            for k in range(warmup):
+                step(k)
+            s.enable_timing(timing)
+            ksec = np.zeros(2)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(warmup, warmup + steps):
+                step(k)
+                if timing:  # HIP events on the launch stream; read back after the step (host-side wait only)
+                    _, k2 = s.last_solve_seconds()
+                    ksec += k2
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            info = dict(per_rank_ms=[dt / max(steps, 1) * 1e3])
+            if gev:   # side-stream event pairs: the collective itself and the device-side arg-min, per step
+                info["gather_ms"] = float(np.mean([a.elapsed_time(b) for a, b, _ in gev]))
+                info["select_ms"] = float(np.mean([b.elapsed_time(c) for _, b, c in gev])) if select else None
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                every = torch.empty(world, dtype=torch.float64, device="cuda")
+                dist.all_gather_into_tensor(every, tt)
+                info["per_rank_ms"] = [float(v) / max(steps, 1) * 1e3 for v in every.cpu()]
+                dt = float(every.max().item())
+            return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best, info)
 
-    ranks_seen = [0]
-    if dist.is_initialized():
-        rk = torch.tensor([rank], dtype=torch.int64, device=dev)
-        allr = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allr, rk)
-        ranks_seen = sorted(int(v) for v in allr.cpu())
+        early = 0 if args.force_ipm else 1
+        select = bool(wl.get("always_gather", False))
+        legs, out = [], None
+        for (N, Ts) in wl["horizons"]:
+            s, tick, shared = wl["make"](N, Ts, early)
+            # pass 1: the timed region that defines `value` (no per-kernel events inside)
+            dt, _, (_, _, info) = run(s, tick, K, W, False, select)
+            n_bad = int((s.results()["status"] != 0).sum())
+            # pass 2: same steps again with HIP events around each kernel for the roofline numbers
+            _, ksec, (gathered, best, _) = run(s, tick, K, W, True, select)
+            res2 = s.results()
+            legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, info=info, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
+                             lds=s.lds_kernel_info(), shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
+            last = (s, gathered, best)
+            if (N, Ts) != wl["horizons"][-1]:
+                s.close()
+        s, gathered, best = last
+        total_dt = sum(l["dt"] for l in legs)
+        value = total * K * len(legs) / total_dt
 
-    if rank == 0:
-        lg = legs[-1] if len(legs) == 1 else max(legs, key=lambda l: l["dt"])   # roofline: the (slowest) leg's dominant kernel
-        N = lg["N"]
-        qp_fl = qp_flops(lg["qp_iter"], N)
-        lin_fl = B * N * F_LIN
-        ksec = lg["ksec"]
-        if lg["path"] in KERNEL_NAMES:  # one kernel does both phases
-            dom, dom_fl, dom_t = KERNEL_NAMES[lg["path"]], qp_fl + lin_fl, ksec[1]
-            kernel_ms = {dom: ksec[1] * 1e3}
-        else:
-            dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_wave_kernel"
-            dom_fl, dom_t = (qp_fl, ksec[1]) if dom == "qp_kernel" else (lin_fl, ksec[0])
-            kernel_ms = {"lin_wave_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3}
-        achieved = dom_fl / dom_t / 1e12
-        alg_bytes = algorithmic_bytes(N, lg["shared"])
-        traffic, traffic_src = None, None
-        for pj in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
-                ent = pm.get("runs", {}).get(f"cfg{args.config}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
-                t = ent.get("hbm_bytes_per_launch", {}).get(dom) if B == BATCH_PER_GPU and not args.force_ipm and args.path == 0 else None
-                if t is not None:
-                    traffic, traffic_src = t, f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run"
-                    break
-            except Exception:
-                pass
-        per_gpu_rate = B * K / lg["dt"]
-        out = {
-            "metric": "NMPC RTI solves/s (N=20, 12 states / 4 inputs), batch 4096 per GPU" if args.config == 2 and N == 20 and B == 4096
-            else f"NMPC RTI solves/s (12 states / 4 inputs), config {args.config}",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": total_dt / (K * len(legs)) * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "total_instances": total, "instances_per_rank": counts,
-            "per_rank_ms": lg["info"]["per_rank_ms"], "gather_ms": lg["info"].get("gather_ms"), "select_ms": lg["info"].get("select_ms"),
-            "config": {"workload": wl["name"] + ", default options " +
-                       ("with qp_early_exit=0 (forced interior point)" if args.force_ipm else
-                        "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
-                       "batch_per_gpu": B, "N": [l["N"] for l in legs] if len(legs) > 1 else N, "Ts": lg["Ts"] if len(legs) == 1 else "1/N",
-                       "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
-                                       "records per step (side stream, overlapped with the next step's solve)") if world > 1 else "single GPU"},
-            "ranks_seen": ranks_seen,
-            "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
-            "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),
-            "kernel_ms": kernel_ms, "device_bytes": lg["device_bytes"],
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "N": N, "algorithmic_flops_per_launch": dom_fl,
-                         "note": "FP64; algorithmic flops = factorisations/solves actually required by each instance "
-                                 "(DESIGN.md Accounting), not the MFMA-issued flops"},
-            "roofline_hbm": {"bound": "hbm", "achieved": per_gpu_rate * alg_bytes / 1e9, "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "frac": per_gpu_rate * alg_bytes / 1e9 / PEAK_HBM_GBS,
-                             "algorithmic_bytes_per_solve": alg_bytes,
-                             "formula": "8*[12 + (0 if one window is shared by the batch else 16(N+1)) + 16(N+1) + 2*(12(N+1)+4N)] + 104"},
-        }
-        if len(legs) > 1:
-            out["sweep"] = {f"N{l['N']}": dict(solves_per_s=total * K / l["dt"], ms_per_step=l["dt"] / K * 1e3,
-                                               per_rank_ms=l["info"]["per_rank_ms"], gather_ms=l["info"].get("gather_ms"),
-                                               kernel_path={1: "streaming", 2: "fused", 3: "windowed"}.get(l["path"], "?"),
-                                               stage_solves_per_s=total * K / l["dt"] * l["N"],
-                                               # the LDS-occupancy crossover BASELINE configs[4] asks for: what one instance in flight
-                                               # takes of a CU's 160 KB, and how many the occupancy query lets a CU hold
-                                               kernel=l["lds"]["kind"], lds_bytes_per_instance=l["lds"]["lds_bytes_per_block"],
-                                               instances_in_flight_per_cu=l["lds"]["blocks_per_cu"],
-                                               status_nonzero=l["n_bad"], mean_qp_iter=float(l["qp_iter"].mean()))
-                            for l in legs}
-    if gather:
-        fin = torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev)
-        fin[: B * D.RECORD_BYTES].copy_(D.records_tensor_from_solver(s))
-        allrec = D.gather_records(fin)  # every rank takes part in the collective
+        ranks_seen = [0]
+        if dist.is_initialized():
+            rk = torch.tensor([rank], dtype=torch.int64, device=dev)
+            allr = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allr, rk)
+            ranks_seen = sorted(int(v) for v in allr.cpu())
+
         if rank == 0:
-            idx, brec = D.select_best(allrec)
-            idx = D.padded_to_global(idx, counts)
-            out["select_best"] = {"index": idx, "cost": None if brec is None else float(brec["cost"]),
-                                  "u0": None if brec is None else [float(v) for v in brec["u0"]],
-                                  "thrust": None if brec is None else [float(v) for v in brec["thrust"]],
-                                  "records_gathered": int(sum(counts)), "record_slots_gathered": int(allrec.numel() // D.RECORD_BYTES),
-                                  "selected_every_step_on_device": select}
-            if select and best is not None:
-                out["select_best"]["last_step_index_on_device"] = D.padded_to_global(int(best[0].item()), counts)
-    s.close()
+            lg = legs[-1] if len(legs) == 1 else max(legs, key=lambda l: l["dt"])   # roofline: the (slowest) leg's dominant kernel
+            N = lg["N"]
+            qp_fl = qp_flops(lg["qp_iter"], N)
+            lin_fl = B * N * F_LIN
+            ksec = lg["ksec"]
+            if lg["path"] in KERNEL_NAMES:  # one kernel does both phases
+                dom, dom_fl, dom_t = KERNEL_NAMES[lg["path"]], qp_fl + lin_fl, ksec[1]
+                kernel_ms = {dom: ksec[1] * 1e3}
+            else:
+                dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_wave_kernel"
+                dom_fl, dom_t = (qp_fl, ksec[1]) if dom == "qp_kernel" else (lin_fl, ksec[0])
+                kernel_ms = {"lin_wave_kernel": ksec[0] * 1e3, "qp_kernel": ksec[1] * 1e3}
+            achieved = dom_fl / dom_t / 1e12
+            alg_bytes = algorithmic_bytes(N, lg["shared"])
+            traffic, traffic_src = None, None
+            for pj in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
+                    ent = pm.get("runs", {}).get(f"cfg{args.config}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
+                    t = ent.get("hbm_bytes_per_launch", {}).get(dom) if B == BATCH_PER_GPU and not args.force_ipm and args.path == 0 else None
+                    if t is not None:
+                        traffic, traffic_src = t, f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run"
+                        break
+                except Exception:
+                    pass
+            per_gpu_rate = B * K / lg["dt"]
+            out = {
+                "metric": "NMPC RTI solves/s (N=20, 12 states / 4 inputs), batch 4096 per GPU" if args.config == 2 and N == 20 and B == 4096
+                else f"NMPC RTI solves/s (12 states / 4 inputs), config {args.config}",
+                "value": value, "unit": "solves/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": total_dt / (K * len(legs)) * 1e3,
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "total_instances": total, "instances_per_rank": counts,
+                "per_rank_ms": lg["info"]["per_rank_ms"], "gather_ms": lg["info"].get("gather_ms"), "select_ms": lg["info"].get("select_ms"),
+                "config": {"workload": wl["name"] + ", default options " +
+                           ("with qp_early_exit=0 (forced interior point)" if args.force_ipm else
+                            "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
+                           "batch_per_gpu": B, "N": [l["N"] for l in legs] if len(legs) > 1 else N, "Ts": lg["Ts"] if len(legs) == 1 else "1/N",
+                           "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
+                                           "records per step (side stream, overlapped with the next step's solve)") if world > 1 else "single GPU"},
+                "ranks_seen": ranks_seen,
+                "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
+                "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),
+                "kernel_ms": kernel_ms, "device_bytes": lg["device_bytes"],
+                "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                             "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                             "N": N, "algorithmic_flops_per_launch": dom_fl,
+                             "note": "FP64; algorithmic flops = factorisations/solves actually required by each instance "
+                                     "(DESIGN.md Accounting), not the MFMA-issued flops"},
+                "roofline_hbm": {"bound": "hbm", "achieved": per_gpu_rate * alg_bytes / 1e9, "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": per_gpu_rate * alg_bytes / 1e9 / PEAK_HBM_GBS,
+                                 "algorithmic_bytes_per_solve": alg_bytes,
+                                 "formula": "8*[12 + (0 if one window is shared by the batch else 16(N+1)) + 16(N+1) + 2*(12(N+1)+4N)] + 104"},
+            }
+            if len(legs) > 1:
+                out["sweep"] = {f"N{l['N']}": dict(solves_per_s=total * K / l["dt"], ms_per_step=l["dt"] / K * 1e3,
+                                                   per_rank_ms=l["info"]["per_rank_ms"], gather_ms=l["info"].get("gather_ms"),
+                                                   kernel_path={1: "streaming", 2: "fused", 3: "windowed"}.get(l["path"], "?"),
+                                                   stage_solves_per_s=total * K / l["dt"] * l["N"],
+                                                   # the LDS-occupancy crossover BASELINE configs[4] asks for: what one instance in flight
+                                                   # takes of a CU's 160 KB, and how many the occupancy query lets a CU hold
+                                                   kernel=l["lds"]["kind"], lds_bytes_per_instance=l["lds"]["lds_bytes_per_block"],
+                                                   instances_in_flight_per_cu=l["lds"]["blocks_per_cu"],
+                                                   status_nonzero=l["n_bad"], mean_qp_iter=float(l["qp_iter"].mean()))
+                                for l in legs}
+        if gather:
+            fin = torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev)
+            fin[: B * D.RECORD_BYTES].copy_(D.records_tensor_from_solver(s))
+            allrec = D.gather_records(fin)  # every rank takes part in the collective
+            if rank == 0:
+                idx, brec = D.select_best(allrec)
+                idx = D.padded_to_global(idx, counts)
+                out["select_best"] = {"index": idx, "cost": None if brec is None else float(brec["cost"]),
+                                      "u0": None if brec is None else [float(v) for v in brec["u0"]],
+                                      "thrust": None if brec is None else [float(v) for v in brec["thrust"]],
+                                      "records_gathered": int(sum(counts)), "record_slots_gathered": int(allrec.numel() // D.RECORD_BYTES),
+                                      "selected_every_step_on_device": select}
+                if select and best is not None:
+                    out["select_best"]["last_step_index_on_device"] = D.padded_to_global(int(best[0].item()), counts)
+        s.close()
 
-    extra = rank == 0 and world == 1 and args.config == 2 and not args.force_ipm and not args.no_extra
-    if extra:
-        # the headline never runs an interior-point iteration (no bound is active on the nominal circle): report the legs that do
-        (N, Ts) = wl["horizons"][0]
-        s2, tick2, _ = wl["make"](N, Ts, 0)
-        dt2, _, _ = run(s2, tick2, K, W, False, False)
-        r2 = s2.results()
-        out["forced_ipm"] = dict(value=B * K / dt2, unit="solves/s", ms_per_step=dt2 / K * 1e3, mean_qp_iter=float(r2["qp_iter"].mean()),
-                                 status_nonzero=int((r2["status"] != 0).sum()),
-                                 note="same workload with qp_early_exit=0: every instance goes through the QP loop (active-set tries, interior-point fallback) although no bound is active")
-        s2.close()
-        s3, tick3, _ = wl["make"](N, Ts, 1, sat=0.25)
-        dt3, _, _ = run(s3, tick3, K, W, False, False)
-        r3 = s3.results()
-        out["mixed_batch_25pct_saturated"] = dict(value=B * K / dt3, unit="solves/s", ms_per_step=dt3 / K * 1e3,
-                                                  ipm_instance_fraction=float((r3["qp_iter"] > 0).mean()),
-                                                  mean_qp_iter=float(r3["qp_iter"].mean()), max_qp_iter_last_tick=int(r3["qp_iter"].max()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
-                                                  note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
-                                                       "14 % of the batch runs the QP loop (active-set tries, interior-point fallback)")
-        s3.close()
-        # the same instances in a random order (the leg above has the saturated quarter FIRST, an artefact of the generator: the slow
-        # instances then start in the first round anyway).  The kernels reorder the work themselves -- instances whose QP had active
-        # bounds in the previous tick are handed out first (qp_kernel.hip, sched_map)
-        s4, tick4, _ = wl["make"](N, Ts, 1, sat=0.25, shuffle=True)
-        dt4, _, _ = run(s4, tick4, K, W, False, False)
-        r4 = s4.results()
-        out["mixed_batch_25pct_saturated_shuffled"] = dict(value=B * K / dt4, unit="solves/s", ms_per_step=dt4 / K * 1e3,
-                                                           ipm_instance_fraction=float((r4["qp_iter"] > 0).mean()),
-                                                           max_qp_iter_last_tick=int(r4["qp_iter"].max()),
-                                                           status_histogram=np.bincount(r4["status"], minlength=5).tolist(),
-                                                           note="the mixed batch with its instances in random order")
-        s4.close()
-    if extra:
-        out["batch1_tick"] = batch1_tick(ba)
-        out["host_boundary"] = host_boundary(ba, B)
+        extra = extras_ok and rank == 0 and world == 1 and args.config == 2 and not args.force_ipm and not args.no_extra
+        if extra:
+            # the headline never runs an interior-point iteration (no bound is active on the nominal circle): report the legs that do
+            (N, Ts) = wl["horizons"][0]
+            s2, tick2, _ = wl["make"](N, Ts, 0)
+            dt2, _, _ = run(s2, tick2, K, W, False, False)
+            r2 = s2.results()
+            out["forced_ipm"] = dict(value=B * K / dt2, unit="solves/s", ms_per_step=dt2 / K * 1e3, mean_qp_iter=float(r2["qp_iter"].mean()),
+                                     status_nonzero=int((r2["status"] != 0).sum()),
+                                     note="same workload with qp_early_exit=0: every instance goes through the QP loop (active-set tries, interior-point fallback) although no bound is active")
+            s2.close()
+            s3, tick3, _ = wl["make"](N, Ts, 1, sat=0.25)
+            dt3, _, _ = run(s3, tick3, K, W, False, False)
+            r3 = s3.results()
+            out["mixed_batch_25pct_saturated"] = dict(value=B * K / dt3, unit="solves/s", ms_per_step=dt3 / K * 1e3,
+                                                      ipm_instance_fraction=float((r3["qp_iter"] > 0).mean()),
+                                                      mean_qp_iter=float(r3["qp_iter"].mean()), max_qp_iter_last_tick=int(r3["qp_iter"].max()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
+                                                      note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
+                                                           "14 % of the batch runs the QP loop (active-set tries, interior-point fallback)")
+            s3.close()
+            # the same instances in a random order (the leg above has the saturated quarter FIRST, an artefact of the generator: the slow
+            # instances then start in the first round anyway).  The kernels reorder the work themselves -- instances whose QP had active
+            # bounds in the previous tick are handed out first (qp_kernel.hip, sched_map)
+            s4, tick4, _ = wl["make"](N, Ts, 1, sat=0.25, shuffle=True)
+            dt4, _, _ = run(s4, tick4, K, W, False, False)
+            r4 = s4.results()
+            out["mixed_batch_25pct_saturated_shuffled"] = dict(value=B * K / dt4, unit="solves/s", ms_per_step=dt4 / K * 1e3,
+                                                               ipm_instance_fraction=float((r4["qp_iter"] > 0).mean()),
+                                                               max_qp_iter_last_tick=int(r4["qp_iter"].max()),
+                                                               status_histogram=np.bincount(r4["status"], minlength=5).tolist(),
+                                                               note="the mixed batch with its instances in random order")
+            s4.close()
+        if extra:
+            out["batch1_tick"] = batch1_tick(ba)
+            out["host_boundary"] = host_boundary(ba, B)
+        return out if rank == 0 else None
+
+    out = measure(args)
+    default_run = args.config == 2 and args.scaling == "weak" and not args.force_ipm and not args.no_extra and not args.batch and not args.horizon
+    if default_run and world == 1 and rank == 0:
+        # BASELINE.json configs[2..4] in the SAME line the driver records (round 3 had them in builder-run side files only)
+        out["configs"] = configs_block(ba, args, local_rank)
+    if default_run and world > 1:
+        # a multi-GPU run of the default command also measures BASELINE configs[3] and configs[4] as they are stated: the config's
+        # TOTAL split over the ranks (65 536 candidates / 32 768 sweep instances), gather + global arg-min every step
+        for cfg in (4, 5):
+            ns = argparse.Namespace(**vars(args))
+            ns.config, ns.scaling, ns.no_extra = cfg, "strong", True
+            leg = measure(ns, extras_ok=False)
+            if rank == 0:
+                keep = ("value", "unit", "ms_per_step", "scaling", "total_instances", "instances_per_rank", "per_rank_ms", "gather_ms", "select_ms",
+                        "ranks_seen", "solver_status_nonzero", "status_histogram", "kernel_ms", "roofline", "sweep", "select_best")
+                out[f"config{cfg}_strong"] = {k: leg[k] for k in keep if k in leg}
+                out[f"config{cfg}_strong"]["workload"] = leg["config"]["workload"]
+    extra = default_run and rank == 0 and world == 1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(BATCH_PER_GPU)
         if extra:

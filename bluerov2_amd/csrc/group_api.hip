@@ -1,0 +1,400 @@
+// group_api.hip -- several GPUs behind the C ABI (BASELINE.json north_star: "the batch dimension shards
+// trivially across 8 GPUs with an RCCL all-gather over xGMI only to collect per-instance optimal thrusts/costs for selection").
+//
+// ONE process, n devices: a brov_group owns one brov_solver per device (a contiguous shard of the batch, the first total % n
+// shards one instance larger -- the partition of bluerov2_amd/distributed.py), one non-blocking stream per device and one RCCL
+// communicator per device (ncclCommInitAll).  No communication during the solve.  brov_group_gather issues ONE ncclAllGather per
+// device inside ncclGroupStart / ncclGroupEnd, on the devices' own streams, behind the solve:
+//     BROV_GATHER_RECORDS   the 104-byte result records {u0, cost, kkt, status, qp_iter, thrusts} of every instance, to every device
+//     BROV_GATHER_PACKED    one packed (cost, global index) pair per device (16 B): the local arg-min, for callers that need only
+//                           the winner (SURVEY.md 8e's alternative)
+// and brov_group_select_best finishes with the global arg-min of cost over the successful instances (BASELINE configs[3],
+// "best-trajectory select").  This is the route for the reference's C++ callers (bluerov2_dob.cpp:270-451 runs in one process);
+// bluerov2_amd/distributed.py (one process PER GPU on torch.distributed) stays as the second route.
+//
+// RCCL is resolved at run time (dlopen of librccl.so.1, the copy PyTorch may already have mapped): a process that never creates a
+// group never loads it, and libbluerov2_nmpc.so has no link-time dependency on it.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bluerov2_nmpc.h"
+
+static thread_local std::string g_gerr;
+extern "C" const char* brov_group_last_error(void) { return g_gerr.c_str(); }
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    if (r.handle || !r.why.empty()) return r;
+    // quiet by default: RCCL prints its WARN / INFO lines to stdout, which belongs to the caller (bench.py prints ONE JSON line there)
+    if (!getenv("NCCL_DEBUG")) setenv("NCCL_DEBUG", "ERROR", 0);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { r.why = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+#define SYM(field, name) r.field = (decltype(r.field))dlsym(r.handle, name); if (!r.field) { r.why = std::string("RCCL symbol missing: ") + name; r.handle = nullptr; return r; }
+    SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetVersion, "ncclGetVersion") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return r;
+}
+
+}  // namespace
+
+struct brov_group {
+    int n = 0, total = 0, Bmax = 0;
+    bool even = true;                     // all shards equally large: the records are gathered straight from the solvers' own arrays
+    std::vector<int> dev, lo, cnt;
+    std::vector<brov_solver*> sol;
+    std::vector<hipStream_t> st;
+    std::vector<ncclComm_t> comm;
+    std::vector<brov_result*> stage;      // [Bmax] per device (uneven shards only): the shard's records + never-selectable padding
+    std::vector<brov_result*> gathered;   // [n * Bmax] per device
+    std::vector<double*> pair, pairs;     // [2] local (cost, global index) and [n * 2] gathered, per device
+    std::vector<int*> best;               // [2] per device: arg-min scratch
+    std::vector<hipEvent_t> ev;           // 4 per device: solve start / end = gather start / gather end / select end
+    int last_mode = -1;
+    bool timing = true;
+};
+
+#define GHIP(call)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            g_gerr = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? BROV_ERR_NO_DEVICE : BROV_ERR_HIP; \
+        }                                                                                   \
+    } while (0)
+#define GNCCL(call)                                                                         \
+    do {                                                                                    \
+        ncclResult_t r_ = (call);                                                           \
+        if (r_ != ncclSuccess) { g_gerr = std::string(#call) + ": " + rccl().GetErrorString(r_); return BROV_ERR_HIP; } \
+    } while (0)
+
+// arg-min of cost over the successful records of a (padded) record array: slot -> (rank = slot / Bmax, i = slot % Bmax), valid while
+// i < cnt[rank]; ties go to the lowest slot = lowest global index.  One block.  out[0] = winning slot or -1.
+__global__ void group_select_kernel(const brov_result* __restrict__ rec, int slots, int* __restrict__ out) {
+    __shared__ double sc[256];
+    __shared__ int si[256];
+    double best = 1e300;
+    int bi = -1;
+    for (int k = threadIdx.x; k < slots; k += blockDim.x) {
+        const double c = rec[k].cost;
+        if (rec[k].status == BROV_STATUS_SUCCESS && c == c && (bi < 0 || c < best)) { best = c; bi = k; }
+    }
+    sc[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double c2 = sc[threadIdx.x + o];
+            const int i2 = si[threadIdx.x + o];
+            if (i2 >= 0 && (si[threadIdx.x] < 0 || c2 < sc[threadIdx.x] || (c2 == sc[threadIdx.x] && i2 < si[threadIdx.x]))) {
+                sc[threadIdx.x] = c2; si[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = si[0];
+}
+// the local arg-min as a packed pair: pair[0] = cost (+inf when no record qualifies), pair[1] = global index (exact in a double)
+__global__ void group_pack_kernel(const brov_result* __restrict__ rec, int n, int lo, double* __restrict__ pair) {
+    __shared__ double sc[256];
+    __shared__ int si[256];
+    double best = 1e300;
+    int bi = -1;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double c = rec[k].cost;
+        if (rec[k].status == BROV_STATUS_SUCCESS && c == c && (bi < 0 || c < best)) { best = c; bi = k; }
+    }
+    sc[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double c2 = sc[threadIdx.x + o];
+            const int i2 = si[threadIdx.x + o];
+            if (i2 >= 0 && (si[threadIdx.x] < 0 || c2 < sc[threadIdx.x] || (c2 == sc[threadIdx.x] && i2 < si[threadIdx.x]))) {
+                sc[threadIdx.x] = c2; si[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pair[0] = si[0] >= 0 ? sc[0] : __builtin_inf();
+        pair[1] = si[0] >= 0 ? (double)(lo + si[0]) : -1.0;
+    }
+}
+
+extern "C" {
+
+int brov_group_rccl_version(int* version) {
+    Rccl& r = rccl();
+    if (!r.handle) { g_gerr = r.why; return BROV_ERR_HIP; }
+    int v = 0;
+    if (r.GetVersion(&v) != ncclSuccess) { g_gerr = "ncclGetVersion failed"; return BROV_ERR_HIP; }
+    if (version) *version = v;
+    return BROV_OK;
+}
+
+void brov_group_destroy(brov_group* g) {
+    if (!g) return;
+    for (int d = 0; d < g->n; d++) {
+        if (d < (int)g->dev.size()) hipSetDevice(g->dev[d]);
+        if (d < (int)g->st.size() && g->st[d]) hipStreamSynchronize(g->st[d]);
+        if (d < (int)g->comm.size() && g->comm[d] && rccl().handle) rccl().CommDestroy(g->comm[d]);
+        if (d < (int)g->sol.size()) brov_destroy(g->sol[d]);
+        if (d < (int)g->stage.size() && g->stage[d]) hipFree(g->stage[d]);
+        if (d < (int)g->gathered.size() && g->gathered[d]) hipFree(g->gathered[d]);
+        if (d < (int)g->pair.size() && g->pair[d]) hipFree(g->pair[d]);
+        if (d < (int)g->best.size() && g->best[d]) hipFree(g->best[d]);
+        for (int k = 0; k < 4; k++)
+            if (4 * d + k < (int)g->ev.size() && g->ev[4 * d + k]) hipEventDestroy(g->ev[4 * d + k]);
+        if (d < (int)g->st.size() && g->st[d]) hipStreamDestroy(g->st[d]);
+    }
+    delete g;
+}
+
+int brov_group_create(brov_group** out, const int* devices, int n, int total, const brov_opts* opts) {
+    if (!out || !devices || !opts || n < 1 || n > 64 || total < n) { g_gerr = "brov_group_create: bad argument (1 <= n <= 64 devices, at least one instance each)"; return BROV_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_gerr = "brov_group_create: no usable HIP device (this library has no CPU fallback)"; return BROV_ERR_NO_DEVICE; }
+    for (int d = 0; d < n; d++) {
+        if (devices[d] < 0 || devices[d] >= ndev) { g_gerr = "brov_group_create: device ordinal out of range"; return BROV_ERR_NO_DEVICE; }
+        for (int e = 0; e < d; e++)
+            if (devices[e] == devices[d]) { g_gerr = "brov_group_create: a device may appear once (one RCCL rank per GPU)"; return BROV_ERR_ARG; }
+    }
+    Rccl& R = rccl();
+    if (!R.handle) { g_gerr = "brov_group_create: " + R.why; return BROV_ERR_HIP; }
+    brov_group* g = new brov_group();
+    g->n = n; g->total = total;
+    g->dev.assign(devices, devices + n);
+    g->lo.resize(n); g->cnt.resize(n);
+    const int base = total / n, rem = total % n;
+    for (int d = 0; d < n; d++) {
+        g->lo[d] = d * base + (d < rem ? d : rem);
+        g->cnt[d] = base + (d < rem ? 1 : 0);
+        if (g->cnt[d] > g->Bmax) g->Bmax = g->cnt[d];
+    }
+    g->even = rem == 0;
+    g->sol.assign(n, nullptr); g->st.assign(n, nullptr); g->comm.assign(n, nullptr);
+    g->stage.assign(n, nullptr); g->gathered.assign(n, nullptr); g->pair.assign(n, nullptr); g->pairs.assign(n, nullptr);
+    g->best.assign(n, nullptr); g->ev.assign(4 * (size_t)n, nullptr);
+    auto fail = [&](int rc) { brov_group_destroy(g); return rc; };
+    for (int d = 0; d < n; d++) {
+        if (hipSetDevice(g->dev[d]) != hipSuccess) { g_gerr = "brov_group_create: hipSetDevice failed"; return fail(BROV_ERR_HIP); }
+        const int rc = brov_create(&g->sol[d], g->dev[d], g->cnt[d], opts);
+        if (rc != BROV_OK) { g_gerr = std::string("brov_group_create: shard ") + std::to_string(d) + ": " + brov_last_error(); return fail(rc); }
+        bool ok = hipStreamCreateWithFlags(&g->st[d], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMalloc((void**)&g->gathered[d], (size_t)n * g->Bmax * sizeof(brov_result)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&g->pair[d], (2 + 2 * (size_t)n) * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&g->best[d], 2 * sizeof(int)) == hipSuccess;
+        if (ok && !g->even) {
+            ok = hipMalloc((void**)&g->stage[d], (size_t)g->Bmax * sizeof(brov_result)) == hipSuccess;
+            // padding records: status -1, cost NaN -- never selectable; only the first cnt[d] slots are ever rewritten
+            ok = ok && hipMemset(g->stage[d], 0xFF, (size_t)g->Bmax * sizeof(brov_result)) == hipSuccess;
+        }
+        for (int k = 0; k < 4 && ok; k++) ok = hipEventCreate(&g->ev[4 * d + k]) == hipSuccess;
+        if (!ok) { g_gerr = "brov_group_create: allocation of the gather buffers failed"; return fail(BROV_ERR_ALLOC); }
+        g->pairs[d] = g->pair[d] + 2;
+    }
+    const ncclResult_t nr = R.CommInitAll(g->comm.data(), n, g->dev.data());
+    if (nr != ncclSuccess) { g_gerr = std::string("brov_group_create: ncclCommInitAll: ") + R.GetErrorString(nr); return fail(BROV_ERR_HIP); }
+    *out = g;
+    return BROV_OK;
+}
+
+int brov_group_size(const brov_group* g) { return g ? g->n : 0; }
+int brov_group_total(const brov_group* g) { return g ? g->total : 0; }
+brov_solver* brov_group_solver(brov_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->sol[rank] : nullptr; }
+void* brov_group_stream(brov_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? (void*)g->st[rank] : nullptr; }
+int brov_group_shard(const brov_group* g, int rank, int* lo, int* hi) {
+    if (!g || rank < 0 || rank >= g->n) return BROV_ERR_ARG;
+    if (lo) *lo = g->lo[rank];
+    if (hi) *hi = g->lo[rank] + g->cnt[rank];
+    return BROV_OK;
+}
+
+// ---- whole-batch setters: global HOST arrays, sliced per shard -------------------------------------------------------------
+int brov_group_set_x0_host(brov_group* g, const double* x0) {
+    if (!g || !x0) return BROV_ERR_ARG;
+    for (int d = 0; d < g->n; d++)
+        if (int rc = brov_set_x0_host(g->sol[d], x0 + (size_t)g->lo[d] * 12)) { g_gerr = brov_last_error(); return rc; }
+    return BROV_OK;
+}
+int brov_group_set_params_host(brov_group* g, const double* p, int per_stage) {
+    if (!g || !p) return BROV_ERR_ARG;
+    const size_t row = per_stage ? (size_t)(brov_horizon(g->sol[0]) + 1) * 16 : 16;
+    for (int d = 0; d < g->n; d++)
+        if (int rc = brov_set_params_host(g->sol[d], p + (size_t)g->lo[d] * row, per_stage)) { g_gerr = brov_last_error(); return rc; }
+    return BROV_OK;
+}
+int brov_group_set_yref_host(brov_group* g, const double* yref, int shared) {
+    if (!g || !yref) return BROV_ERR_ARG;
+    const size_t row = (size_t)(brov_horizon(g->sol[0]) + 1) * 16;
+    for (int d = 0; d < g->n; d++)
+        if (int rc = brov_set_yref_host(g->sol[d], shared ? yref : yref + (size_t)g->lo[d] * row, shared)) { g_gerr = brov_last_error(); return rc; }
+    return BROV_OK;
+}
+int brov_group_set_candidate_params_host(brov_group* g, int kind, const double* p0, const double* p1, const double* phase) {
+    if (!g || !p0 || !p1 || !phase) return BROV_ERR_ARG;
+    for (int d = 0; d < g->n; d++)
+        if (int rc = brov_set_candidate_params_host(g->sol[d], kind, p0 + g->lo[d], p1 + g->lo[d], phase + g->lo[d])) { g_gerr = brov_last_error(); return rc; }
+    return BROV_OK;
+}
+int brov_group_set_yref_candidates(brov_group* g, double t0, double dt) {   // one window kernel per device, on the device's stream
+    if (!g) return BROV_ERR_ARG;
+    for (int d = 0; d < g->n; d++)
+        if (int rc = brov_set_yref_candidates(g->sol[d], t0, dt, g->st[d])) { g_gerr = brov_last_error(); return rc; }
+    return BROV_OK;
+}
+
+int brov_group_enable_timing(brov_group* g, int on) { if (!g) return BROV_ERR_ARG; g->timing = on != 0; return BROV_OK; }
+
+int brov_group_solve(brov_group* g) {
+    if (!g) return BROV_ERR_ARG;
+    for (int d = 0; d < g->n; d++) {
+        GHIP(hipSetDevice(g->dev[d]));
+        if (g->timing) GHIP(hipEventRecord(g->ev[4 * d + 0], g->st[d]));
+        if (int rc = brov_solve(g->sol[d], g->st[d])) { g_gerr = brov_last_error(); return rc; }
+        if (g->timing) GHIP(hipEventRecord(g->ev[4 * d + 1], g->st[d]));
+    }
+    g->last_mode = -1;
+    return BROV_OK;
+}
+
+int brov_group_gather(brov_group* g, int mode) {
+    if (!g || (mode != BROV_GATHER_RECORDS && mode != BROV_GATHER_PACKED)) return BROV_ERR_ARG;
+    Rccl& R = rccl();
+    const size_t rec = sizeof(brov_result);
+    // what each device contributes, produced on its own stream behind the solve
+    for (int d = 0; d < g->n; d++) {
+        GHIP(hipSetDevice(g->dev[d]));
+        // (timing: the solve's end event doubles as the gather's start)
+        if (mode == BROV_GATHER_RECORDS) {
+            if (!g->even) GHIP(hipMemcpyAsync(g->stage[d], brov_results_device(g->sol[d]), (size_t)g->cnt[d] * rec, hipMemcpyDeviceToDevice, g->st[d]));
+        } else {
+            hipLaunchKernelGGL(group_pack_kernel, dim3(1), dim3(256), 0, g->st[d], brov_results_device(g->sol[d]), g->cnt[d], g->lo[d], g->pair[d]);
+            GHIP(hipGetLastError());
+        }
+    }
+    GNCCL(R.GroupStart());
+    for (int d = 0; d < g->n; d++) {
+        ncclResult_t r;
+        if (mode == BROV_GATHER_RECORDS) {
+            const void* src = g->even ? (const void*)brov_results_device(g->sol[d]) : (const void*)g->stage[d];
+            r = R.AllGather(src, g->gathered[d], (size_t)g->Bmax * rec, ncclUint8, g->comm[d], g->st[d]);
+        } else {
+            r = R.AllGather(g->pair[d], g->pairs[d], 2, ncclDouble, g->comm[d], g->st[d]);
+        }
+        if (r != ncclSuccess) { R.GroupEnd(); g_gerr = std::string("ncclAllGather: ") + R.GetErrorString(r); return BROV_ERR_HIP; }
+    }
+    GNCCL(R.GroupEnd());
+    if (g->timing)
+        for (int d = 0; d < g->n; d++) { GHIP(hipSetDevice(g->dev[d])); GHIP(hipEventRecord(g->ev[4 * d + 2], g->st[d])); }
+    g->last_mode = mode;
+    return BROV_OK;
+}
+
+int brov_group_synchronize(brov_group* g) {
+    if (!g) return BROV_ERR_ARG;
+    for (int d = 0; d < g->n; d++) { GHIP(hipSetDevice(g->dev[d])); GHIP(hipStreamSynchronize(g->st[d])); }
+    return BROV_OK;
+}
+
+static int slot_to_global(const brov_group* g, int slot) {
+    if (slot < 0) return -1;
+    const int r = slot / g->Bmax, i = slot % g->Bmax;
+    return (r < g->n && i < g->cnt[r]) ? g->lo[r] + i : -1;
+}
+
+int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
+    if (!g || !best_index) return BROV_ERR_ARG;
+    if (g->last_mode < 0) { g_gerr = "brov_group_select_best: call brov_group_gather first"; return BROV_ERR_ARG; }
+    *best_index = -1;
+    if (g->last_mode == BROV_GATHER_RECORDS) {
+        // every device holds all records: device 0 selects (any would do), the others only finish their gather
+        GHIP(hipSetDevice(g->dev[0]));
+        hipLaunchKernelGGL(group_select_kernel, dim3(1), dim3(256), 0, g->st[0], g->gathered[0], g->n * g->Bmax, g->best[0]);
+        GHIP(hipGetLastError());
+        if (g->timing) GHIP(hipEventRecord(g->ev[3], g->st[0]));
+        int slot = -1;
+        GHIP(hipMemcpyAsync(&slot, g->best[0], sizeof(int), hipMemcpyDeviceToHost, g->st[0]));
+        if (int rc = brov_group_synchronize(g)) return rc;
+        *best_index = slot_to_global(g, slot);
+        if (best && slot >= 0) { GHIP(hipSetDevice(g->dev[0])); GHIP(hipMemcpy(best, g->gathered[0] + slot, sizeof(brov_result), hipMemcpyDeviceToHost)); }
+    } else {
+        std::vector<double> pr(2 * (size_t)g->n);
+        GHIP(hipSetDevice(g->dev[0]));
+        if (g->timing) GHIP(hipEventRecord(g->ev[3], g->st[0]));
+        GHIP(hipMemcpyAsync(pr.data(), g->pairs[0], pr.size() * sizeof(double), hipMemcpyDeviceToHost, g->st[0]));
+        if (int rc = brov_group_synchronize(g)) return rc;
+        int owner = -1;
+        for (int d = 0; d < g->n; d++)   // shards hold ascending index ranges: the first minimal cost is the lowest index
+            if (pr[2 * d + 1] >= 0.0 && (owner < 0 || pr[2 * d] < pr[2 * owner])) owner = d;
+        if (owner >= 0) {
+            *best_index = (int)pr[2 * owner + 1];
+            if (best) {
+                GHIP(hipSetDevice(g->dev[owner]));
+                GHIP(hipMemcpy(best, brov_results_device(g->sol[owner]) + (*best_index - g->lo[owner]), sizeof(brov_result), hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    return BROV_OK;
+}
+
+int brov_group_get_results_host(brov_group* g, brov_result* res) {
+    if (!g || !res) return BROV_ERR_ARG;
+    if (g->last_mode != BROV_GATHER_RECORDS) { g_gerr = "brov_group_get_results_host: needs a BROV_GATHER_RECORDS gather"; return BROV_ERR_ARG; }
+    if (int rc = brov_group_synchronize(g)) return rc;
+    GHIP(hipSetDevice(g->dev[0]));
+    for (int d = 0; d < g->n; d++)   // strip the padding slots of uneven shards
+        GHIP(hipMemcpy(res + g->lo[d], g->gathered[0] + (size_t)d * g->Bmax, (size_t)g->cnt[d] * sizeof(brov_result), hipMemcpyDeviceToHost));
+    return BROV_OK;
+}
+const brov_result* brov_group_gathered_device(const brov_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->gathered[rank] : nullptr; }
+int brov_group_slots_per_rank(const brov_group* g) { return g ? g->Bmax : 0; }
+
+int brov_group_last_seconds(brov_group* g, double* solve, double* gather, double* select) {
+    if (!g || !g->timing) return BROV_ERR_ARG;
+    double ts = 0, tg = 0, tsel = 0;
+    for (int d = 0; d < g->n; d++) {
+        GHIP(hipSetDevice(g->dev[d]));
+        float a = 0, b = 0;
+        GHIP(hipEventSynchronize(g->ev[4 * d + 1]));
+        GHIP(hipEventElapsedTime(&a, g->ev[4 * d + 0], g->ev[4 * d + 1]));
+        if (g->last_mode >= 0) { GHIP(hipEventSynchronize(g->ev[4 * d + 2])); GHIP(hipEventElapsedTime(&b, g->ev[4 * d + 1], g->ev[4 * d + 2])); }
+        if (a * 1e-3 > ts) ts = a * 1e-3;
+        if (b * 1e-3 > tg) tg = b * 1e-3;
+    }
+    if (g->last_mode >= 0 && hipEventQuery(g->ev[3]) == hipSuccess) {
+        float c = 0;
+        GHIP(hipSetDevice(g->dev[0]));
+        if (hipEventElapsedTime(&c, g->ev[2], g->ev[3]) == hipSuccess) tsel = c * 1e-3;
+    }
+    if (solve) *solve = ts;
+    if (gather) *gather = tg;
+    if (select) *select = tsel;
+    return BROV_OK;
+}
+
+}  // extern "C"

@@ -248,6 +248,46 @@ int brov_plant_set_rp_disturbance_host(brov_solver* s, const double* d /*[B][2];
  * and its record; runs on the GPU, result copied to HOST */
 int brov_select_best_host(brov_solver* s, int* best_index, brov_result* best);
 
+/* ---- several GPUs in ONE process (BASELINE.json configs[3]: 65 536 candidates over 8 GPUs, all-gather of the
+ * optimal cost / u* for best-trajectory select) ------------------------------------------------------------------------------------
+ * A group owns one brov_solver per device -- a contiguous shard of `total_instances`, the first total % n shards one instance
+ * larger --, one stream and one RCCL communicator per device.  There is no communication during the solve; brov_group_gather is ONE
+ * ncclAllGather per device (inside ncclGroupStart / ncclGroupEnd, on the devices' own streams, behind the solve) of
+ *     BROV_GATHER_RECORDS  every instance's 104-byte result record, to every device (uneven shards: padded with never-selectable slots)
+ *     BROV_GATHER_PACKED   one (cost, global index) pair per device (16 B): the local arg-min -- when only the winner is wanted
+ * and brov_group_select_best returns the global arg-min of cost over the instances with status SUCCESS (ties: lowest index) and waits
+ * for it -- the only host wait of a step.  Per-shard inputs go through the shard's own handle (brov_group_solver: every brov_set_* /
+ * brov_get_* above works on it, with brov_group_stream(rank) as the stream) or through the whole-batch setters below, which slice a
+ * global HOST array.  RCCL is loaded at run time (dlopen) by brov_group_create; a process that never creates a group never loads it.
+ * The reference's callers live in one C++ process (bluerov2_dob.cpp:270-451): this is their route to several GPUs; one process per
+ * GPU on torch.distributed (bluerov2_amd/distributed.py, bench.py --gpus N) is the other. */
+typedef struct brov_group brov_group;
+#define BROV_GATHER_RECORDS 0
+#define BROV_GATHER_PACKED 1
+int  brov_group_create(brov_group** out, const int* devices /*[n] distinct HIP ordinals*/, int n, int total_instances, const brov_opts* opts);
+void brov_group_destroy(brov_group* g);
+const char* brov_group_last_error(void);
+int  brov_group_rccl_version(int* version);          /* loads RCCL if need be; BROV_ERR_HIP when it cannot be loaded */
+int  brov_group_size(const brov_group* g);
+int  brov_group_total(const brov_group* g);
+int  brov_group_shard(const brov_group* g, int rank, int* lo, int* hi);   /* global instance range [lo, hi) of shard `rank` */
+brov_solver* brov_group_solver(brov_group* g, int rank);
+void* brov_group_stream(brov_group* g, int rank);    /* hipStream_t of shard `rank` */
+int brov_group_set_x0_host(brov_group* g, const double* x0 /*[total][12]*/);
+int brov_group_set_params_host(brov_group* g, const double* p /*[total][16] or [total][N+1][16]*/, int per_stage);
+int brov_group_set_yref_host(brov_group* g, const double* yref /*shared [N+1][16] or [total][N+1][16]*/, int shared);
+int brov_group_set_candidate_params_host(brov_group* g, int kind, const double* p0, const double* p1, const double* phase /*[total]*/);
+int brov_group_set_yref_candidates(brov_group* g, double t0, double dt);   /* one window kernel per device, no host traffic */
+int brov_group_solve(brov_group* g);                 /* one RTI step of every shard, enqueued; returns after the launches */
+int brov_group_gather(brov_group* g, int mode);      /* enqueued behind the solve */
+int brov_group_select_best(brov_group* g, int* best_index /*global; -1: no instance qualifies*/, brov_result* best /*or NULL*/);
+int brov_group_synchronize(brov_group* g);
+int brov_group_get_results_host(brov_group* g, brov_result* res /*[total]*/);   /* after a BROV_GATHER_RECORDS gather: device 0's copy */
+const brov_result* brov_group_gathered_device(const brov_group* g, int rank);   /* DEVICE: [n][slots_per_rank] records on shard `rank`'s GPU */
+int brov_group_slots_per_rank(const brov_group* g);
+int brov_group_enable_timing(brov_group* g, int on);  /* HIP events around solve / gather / select (default on) */
+int brov_group_last_seconds(brov_group* g, double* solve, double* gather, double* select);   /* slowest device each */
+
 /* thrust allocation (bluerov2_dob.cpp:390-395): t[B][6] = the `thrust` field the solve kernel wrote into every result record */
 int brov_get_thrusts_host(brov_solver* s, double* t6 /*[B][6]*/);
 

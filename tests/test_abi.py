@@ -94,3 +94,18 @@ def test_thrust_allocation_host_helper():
     c = 0.026546960744430276
     t = bluerov2_amd.thrust_allocation(np.array([1.0, -2.0, 3.0, 0.5]))
     assert np.allclose(t, [(-1 - 2 + 0.5) / c, (-1 + 2 - 0.5) / c, (1 - 2 - 0.5) / c, (1 + 2 + 0.5) / c, -3 / c, -3 / c])
+
+
+def test_group_api_links_rccl_and_refuses_without_a_gpu():
+    """brov_group_* (several GPUs in one process): RCCL is resolved at run time -- the library loads without it being linked, the
+    loader finds it, and without a GPU the create call refuses (no CPU fallback)"""
+    import subprocess
+    import torch
+    import bluerov2_amd
+    out = subprocess.run(["ldd", bluerov2_amd.library_path()], capture_output=True, text=True).stdout
+    assert "rccl" not in out                                  # no link-time dependency
+    assert bluerov2_amd.rccl_version() > 20000                # dlopen + ncclGetVersion
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bluerov2_amd.NoDeviceError):
+        bluerov2_amd.SolverGroup([0], 8, bluerov2_amd.SolverOptions(20))

@@ -3,7 +3,7 @@ reference CasADi model (oracle/_ref, the reference's generated C compiled by ora
 the other built libraries) -> textbook RK4 + numpy condensing -> scipy BVLS, the recipe of scripts/make_golden.py.  Options drawn
 like the randomised-options test; fused, windowed and streaming kernels; every instance of every batch has its own BVLS answer.
 
-Round 4: 64 instances per option draw at N <= 24, 16 at N = 40 / 57 (round 3: 6), half of them far off, so that the absolute 1e-8 / 1e-9 claim demonstrably
+Round 4: 64 instances per option draw at N <= 23, 32 at N = 24, 8 at N = 40 / 57 (round 3: 6; BVLS itself is the cost), half of them far off, so that the absolute 1e-8 / 1e-9 claim demonstrably
 spans entering KKT values up to ~1e4 -- the histogram of the entering KKT it covered is printed and recorded
 (gpurun_out/parity_excused.json -> profiles/).  The BVLS answers are independent of the GPU (each tick continues from the
 independent iterate), so they are computed by a pool of worker processes without a GPU while the kernels run."""
@@ -20,7 +20,7 @@ from conftest import KKT_EDGES, _parity_note
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
-NB, NB_LONG, TICKS = 64, 16, 2   # BVLS itself is the cost: ~2 s per instance and tick at N >= 40 with hundreds of active bounds
+NB, NB_MID, NB_LONG, TICKS = 64, 32, 8, 2   # BVLS itself is the cost: ~2 s per instance and tick at N >= 40 with hundreds of active bounds
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +57,7 @@ def test_random_problems_against_independent_answers(ba, recipe, golden_traj, se
     lbu, ubu = -rng.uniform(5, 60, size=4), rng.uniform(5, 60, size=4)
     if seed % 3 == 0:
         lbu[1], ubu[1] = 2.0, 30.0
-    nb = NB if N < 40 else NB_LONG
+    nb = NB if N < 24 else (NB_MID if N < 40 else NB_LONG)
     x0 = np.zeros((nb, 12)); x0[:, :6] = circ[0, :6]; x0 += rng.normal(size=(nb, 12)) * 0.05
     x0[::2, :3] += rng.uniform(-4, 4, size=(nb // 2, 3)); x0[::2, 5] += rng.uniform(-0.3, 0.3, size=nb // 2)
     p = np.tile(G.P_NOMINAL, (nb, N + 1, 1))

@@ -1,0 +1,88 @@
+"""Several GPUs behind the C ABI (brov_group_*, include/bluerov2_nmpc.h): one process, one shard + stream + RCCL communicator per
+device, ncclAllGather of the result records (or of one packed (cost, index) pair per device), global arg-min.  Runs with every
+visible device: one on the 1-GPU box (RCCL with one rank: the collective is a copy, the code path is the real one), two or more
+where the driver's multi-GPU node provides them.  Workload: BASELINE configs[3]'s lemniscate candidates (a slice)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N, TS = 20, 0.05
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import bluerov2_amd
+    return bluerov2_amd
+
+
+def _candidates(total):
+    rng = np.random.default_rng(3)
+    amp, frq, ph = rng.uniform(1, 3, total), rng.uniform(0.25, 0.75, total), rng.uniform(0, 2 * np.pi, total)
+    x0 = np.zeros((total, 12)); x0[:, 0] = 2.0; x0[:, 2] = -20.0
+    return amp, frq, ph, x0
+
+
+def _devices():
+    import torch
+    return list(range(torch.cuda.device_count()))
+
+
+@pytest.mark.parametrize("total", [4096, 4099])   # even shards: gathered straight from the solvers' arrays; uneven: padded staging
+def test_group_equals_one_solver_and_selects_the_global_minimum(ba, total):
+    devs = _devices()
+    amp, frq, ph, x0 = _candidates(total)
+    g = ba.SolverGroup(devs, total, ba.SolverOptions(N, TS))
+    assert [hi - lo for lo, hi in g.bounds] == [total // len(devs) + (1 if r < total % len(devs) else 0) for r in range(len(devs))]
+    g.set_x0(x0); g.set_params(ba.P_NOMINAL); g.set_candidate_params("lemniscate", amp, frq, ph)
+    one = ba.BatchSolver(total, ba.SolverOptions(N, TS), device=devs[0])
+    one.set_x0(x0); one.set_params(ba.P_NOMINAL); one.set_candidate_params("lemniscate", amp, frq, ph)
+    for k in range(3):
+        g.set_yref_candidates_tick(TS * k, TS); g.solve()
+        one.set_yref_candidates_tick(TS * k, TS); one.solve()
+        g.gather(ba.GATHER_RECORDS)
+        idx, rec = g.select_best()
+        r1 = one.results()
+        rg = g.results()
+        assert rg.tobytes() == r1.tobytes(), k          # what the all-gather delivers == the whole batch solved at once, bit for bit
+        ok = r1["status"] == 0
+        want = int(np.argmin(np.where(ok, r1["cost"], np.inf)))
+        assert idx == want and rec["cost"] == r1["cost"][want] and np.array_equal(rec["u0"], r1["u0"][want])
+        g.gather(ba.GATHER_PACKED)                      # 16 bytes per device instead of 104 per instance: same winner
+        idx2, rec2 = g.select_best()
+        assert idx2 == want and rec2.tobytes() == rec.tobytes()
+        t = g.last_seconds()
+        assert t["solve"] > 0 and t["gather"] >= 0
+    # every device holds every record after the gather
+    import torch
+    from bluerov2_amd import distributed as D
+    g.gather(ba.GATHER_RECORDS); g.synchronize()
+    slots = int(g._L.brov_group_slots_per_rank(g._h))
+    for r, dev in enumerate(devs):
+        ptr = int(g._L.brov_group_gathered_device(g._h, r))
+        view = torch.as_tensor(D.DevicePointerView(ptr, 104 * slots * len(devs)), device=f"cuda:{dev}").cpu().numpy().tobytes()
+        allrec = np.frombuffer(view, dtype=ba.RESULT_DTYPE)
+        for q, (lo, hi) in enumerate(g.bounds):
+            assert allrec[q * slots:q * slots + hi - lo].tobytes() == r1[lo:hi].tobytes()
+            assert np.all(allrec[q * slots + hi - lo:(q + 1) * slots]["status"] == -1)     # padding: never selectable
+    g.close(); one.close()
+
+
+def test_group_arguments_and_failed_instances_are_skipped(ba):
+    devs = _devices()
+    with pytest.raises(RuntimeError):
+        ba.SolverGroup(devs + devs, 64, ba.SolverOptions(N, TS))     # a device may appear once
+    total = 64 * len(devs)
+    g = ba.SolverGroup(devs, total, ba.SolverOptions(N, TS))
+    x0 = np.zeros((total, 12)); x0[:, 2] = -20.0
+    x0[5, 0] = np.nan                                                  # instance 5 fails (status 1): it must not win
+    yref = np.zeros((N + 1, 16)); yref[:, 2] = -20.0
+    g.set_x0(x0); g.set_params(ba.P_NOMINAL); g.set_yref(yref)
+    g.solve(); g.gather(); idx, rec = g.select_best()
+    r = g.results()
+    assert r["status"][5] != 0 and idx != 5 and idx == int(np.argmin(np.where(r["status"] == 0, r["cost"], np.inf)))
+    g.gather(ba.GATHER_PACKED); idx2, _ = g.select_best()
+    assert idx2 == idx
+    assert ba.rccl_version() > 20000
+    g.close()
