@@ -318,6 +318,25 @@ def cpu_single_thread(ticks=1000):
     return out
 
 
+class quiet_c_stdout:
+    """file descriptor 1 points at /dev/null while the block runs, and whatever C stdio buffered in it is flushed there: stdout of this
+    script carries ONE JSON line (the driver parses it), and libraries that printf a banner (RCCL at communicator set-up) must not add to it"""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self.libc = ctypes.CDLL(None)
+        self.libc.fflush(None)
+        self.saved, self.null = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+
+    def __exit__(self, *exc):
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved); os.close(self.null)
+        return False
+
+
 def pmc_traffic(tag, kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary that has an entry `tag` (profiles/r*_pmc_summary.json,
     written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes): (bytes or None, source or None)"""
@@ -338,6 +357,7 @@ def configs_block(ba, args, device):
     import torch
     K, W = args.steps, args.warmup
     out = {}
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")   # RCCL's own lines must not land on stdout (ONE JSON line there)
 
     def timed(step, K=K, W=W):
         for k in range(W):
@@ -410,7 +430,8 @@ def configs_block(ba, args, device):
     B = CAND_TOTAL // CAND_SHARDS
     amp, frq, ph = (a[:B] for a in candidate_params())
     x0 = np.zeros((B, NX)); x0[:, 0] = 2.0; x0[:, 2] = -20.0
-    g = ba.SolverGroup([device], B, ba.SolverOptions(N, TS))
+    with quiet_c_stdout():   # RCCL's communicator set-up prints a version banner through C stdio
+        g = ba.SolverGroup([device], B, ba.SolverOptions(N, TS))
     g.set_x0(x0); g.set_params(ba.P_NOMINAL); g.set_candidate_params("lemniscate", amp, frq, ph)
     sh = g.shards[0]
     sh.init_iterate_default()

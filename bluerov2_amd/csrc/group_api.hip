@@ -46,8 +46,6 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl r;
     if (r.handle || !r.why.empty()) return r;
-    // quiet by default: RCCL prints its WARN / INFO lines to stdout, which belongs to the caller (bench.py prints ONE JSON line there)
-    if (!getenv("NCCL_DEBUG")) setenv("NCCL_DEBUG", "ERROR", 0);
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
