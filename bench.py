@@ -937,6 +937,18 @@ def main(argv=None):
                                      status_nonzero=int((r2["status"] != 0).sum()),
                                      note="same workload with qp_early_exit=0: every instance goes through the QP loop (active-set tries, interior-point fallback) although no bound is active")
             s2.close()
+            def per_tick_kernel_ms(sx, tickx):
+                """kernel time of every timed step (HIP events): a launch ends with its slowest instance, so ONE instance with 13..21
+                Newton systems makes its tick 2..3 times as long as the others and pulls the mean"""
+                sx.init_iterate_default(); sx.enable_timing(True)
+                ms = []
+                for k in range(W + K):
+                    tickx(k, torch.cuda.current_stream().cuda_stream); sx.solve(stream=torch.cuda.current_stream().cuda_stream)
+                    if k >= W:
+                        ms.append(sum(sx.last_solve_seconds()[1]) * 1e3)
+                sx.enable_timing(False)
+                return dict(median_tick_kernel_ms=float(np.median(ms)), max_tick_kernel_ms=float(np.max(ms)),
+                            median_tick_solves_per_s=B / float(np.median(ms)) * 1e3)
             s3, tick3, _ = wl["make"](N, Ts, 1, sat=0.25)
             dt3, _, _ = run(s3, tick3, K, W, False, False)
             r3 = s3.results()
@@ -945,6 +957,7 @@ def main(argv=None):
                                                       mean_qp_iter=float(r3["qp_iter"].mean()), max_qp_iter_last_tick=int(r3["qp_iter"].max()), status_histogram=np.bincount(r3["status"], minlength=5).tolist(),
                                                       note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
                                                            "14 % of the batch runs the QP loop (active-set tries, interior-point fallback)")
+            out["mixed_batch_25pct_saturated"].update(per_tick_kernel_ms(s3, tick3))
             s3.close()
             # the same instances in a random order (the leg above has the saturated quarter FIRST, an artefact of the generator: the slow
             # instances then start in the first round anyway).  The kernels reorder the work themselves -- instances whose QP had active
@@ -957,6 +970,7 @@ def main(argv=None):
                                                                max_qp_iter_last_tick=int(r4["qp_iter"].max()),
                                                                status_histogram=np.bincount(r4["status"], minlength=5).tolist(),
                                                                note="the mixed batch with its instances in random order")
+            out["mixed_batch_25pct_saturated_shuffled"].update(per_tick_kernel_ms(s4, tick4))
             s4.close()
         if extra:
             out["batch1_tick"] = batch1_tick(ba)

@@ -109,6 +109,7 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 struct Inst {
     int lane, rg, cl, N, nv;   // N = stages the sweeps run over (the whole horizon, or the resident window of it)
     int i0, NT;                // windowed kernel: global index of the window's first stage, total horizon (else 0, N)
+    int ckpt;                  // fused kernels: the step-0 factor sweep leaves (P, p) entering stage ckpt - 1 in HBM (partial refactorisation); 0 = off
     const double* x;     // [N+1][12] entering iterate
     const double* u;     // [N][4]
     const double* yref;  // [N+1][16]
@@ -422,13 +423,15 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
     S.pv = d4{tl[0], tl[4], tl[8], 0.0};
 }
 
+// hi / lo: the sweep runs over the stages hi-1 .. lo of the resident block (default: all I.N of them); explicit arguments, not fields of
+// Inst -- a horizon that changes under the compiler's eyes costs every sweep of the kernel its loop-invariant addressing
 template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
-__device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
+__device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -1, int lo = 0) {
     if constexpr (!FACTOR && LDS != 0) {
         bwd_solve_v<LDS>(I, S);
         return;
     }
-    const int lane = I.lane, rg = I.rg, cl = I.cl, N = I.N;
+    const int lane = I.lane, rg = I.rg, cl = I.cl, N = hi < 0 ? I.N : hi;
     const double* gam = I.ipm + (size_t)IPM_GAM * I.nv;
     const double* rt = I.ipm + (size_t)IPM_RT * I.nv;
     BwdIn nx;
@@ -601,11 +604,12 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S) {
         }
     };
     if constexpr (LDS) {
+        const int cnt = N - lo;   // stages N-1 .. lo
         if constexpr (LDS == 2) {   // two-wave kernel: the other wave fills those slots, and the variant below costs it registers it does not have
-            pipelined<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+            pipelined<kLdsDist<LDS>, BwdIn>(cnt, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
                                 [&](int k, const BwdIn& in) { stage(N - 1 - k, in, [] {}); });
         } else {
-            pipelined_mid<kLdsDist<LDS>, BwdIn>(N, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+            pipelined_mid<kLdsDist<LDS>, BwdIn>(cnt, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
                                 [&](int k, const BwdIn& in, auto&& issue) { stage(N - 1 - k, in, issue); });
         }
     } else {
@@ -626,6 +630,38 @@ __device__ bool riccati_backward(const Inst& I) {
     wave_fence();
     bwd_init<FACTOR, LDS>(I, S);
     bwd_chunk<FACTOR, LDS, STORE_IPM, STEP0>(I, S);
+    return S.ok;
+}
+
+// Partial refactorisation (round 4; fused kernels).  P_i and p_i of the backward sweep depend only on the stages >= i.  An active-set
+// try pins inputs of the first few stages almost always (a far-off instance saturates the START of its horizon: measured on the
+// mixed batch, the last pinned stage is <= 4 for 98 % of the QPs that run the loop), so everything the step-0 sweep computed for the
+// stages >= ckpt -- P, p, the gains and feed-forward terms in LDS -- is what a full sweep of the try would compute again, bit for
+// bit (Gamma = 0 and the same right-hand side there).  The try restarts at stage ckpt - 1 from the checkpoint the step-0 sweep
+// left in HBM: ckpt of N stages instead of N.  Valid while (a) no pinned input sits at a stage >= ckpt and (b) the LDS gains of
+// those stages are still the step-0 ones (no full factor sweep has run inside the QP loop); the feed-forward terms, which every
+// adjoint sweep overwrites with the input gradient, are restored from the register copy taken at loop entry.  The K^T area of the
+// stages < ckpt = ceil(N / 4) is where the adjoint sweeps stage the multipliers: those stages are refactored in any case.
+// part = false: a full sweep (what riccati_backward<true, LDS> does).  ONE call site of the stage loop for both.
+template <int LDS>
+__device__ __forceinline__ bool riccati_backward_tries(const Inst& I, bool part, const double (&kff0)[2]) {
+    static_assert(LDS == 1 || LDS == 2, "fused kernels");
+    wave_fence();
+    BwdState S;
+    if (part) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {   // out-of-range lanes rewrite element 0 (stage 0: recomputed by this sweep anyway)
+            const int j = I.lane + 64 * t;
+            I.lds_kff[j < I.nv ? j : 0] = kff0[t];
+        }
+        const double* ck = I.Kt;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { S.P[r] = ck[r * 64 + I.lane]; S.pv[r] = ck[192 + r * 64 + I.lane]; }
+        S.P[3] = 0.0; S.pv[3] = 0.0; S.ok = true;
+    } else {
+        bwd_init<true, LDS>(I, S);
+    }
+    bwd_chunk<true, LDS, true, false>(I, S, part ? I.ckpt : I.N, 0);
     return S.ok;
 }
 
@@ -1430,6 +1466,12 @@ __device__ __forceinline__ void sched_note(const DevParams& P, int b, int p) {
     if (p >= 0 && p < Bc) Wr[kSchedClasses * kSchedCntStride + k * Bc + p] = b;
     Wr[kSchedClasses * kSchedCntStride + kSchedClasses * Bc + b] = p;
 }
+// did instance b run the QP loop in the previous solve?  (pos[b] of the buffer that solve wrote; all zero before the first solve: yes)
+__device__ __forceinline__ bool sched_listed(const DevParams& P, int b) {
+    if (!P.sched) return true;
+    const int32_t* Rd = uniform_ptr(P.sched + (size_t)P.sched_r * P.sched_stride);
+    return Rd[kSchedClasses * kSchedCntStride + kSchedClasses * sched_class_len(P.B) + b] >= 0;
+}
 __device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) {   // one wave of the launch
     if (P.sched && lane < kSchedClasses) P.sched[(size_t)P.sched_z * P.sched_stride + lane * kSchedCntStride] = 0;
 }
@@ -1516,7 +1558,35 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     bool early = false, polished = false, use_vhat = false;
     int sched_p = -1;   // this instance's place in the next solve's list of expensive instances (work ordering; wave-uniform)
     bool ok = pre_ok;
-    if constexpr (LDS < 3) ok = riccati_backward<true, LDS, false, true>(I);
+    // partial refactorisation of the active-set tries (fused kernels, riccati_backward_partial): checkpoint stage = ceil(N / 4), off for
+    // horizons too short to gain from it
+    constexpr bool PART = EL;
+    bool split0 = false;
+    if constexpr (PART) split0 = I.ckpt > 0;   // set by the kernel body: only instances that ran the QP loop in the previous solve
+    if constexpr (PART) { if (split0) {
+        // the step-0 factor sweep in two parts with the checkpoint between them.  Measured: inside the stage loop a wave-uniform
+        // `if (i == ckpt)` with the six stores costs the loop 7 % (registers and scheduling, taken or not); the split sweep still
+        // costs 2 % (the software pipeline drains and refills once) + 1 % (the stores) -- so only the instances that are LIKELY to run
+        // the QP loop pay it: those that ran it in the previous solve (the work ordering's own prediction, sched_listed).  Everybody
+        // else runs the unsplit sweep below and, should it enter the loop after all, full factor sweeps as in round 3.
+        BwdState S;
+        wave_fence();
+        bwd_init<true, LDS>(I, S);
+        // ... out of ONE copy of the stage loop (a second inlined copy costs instruction-cache misses on every instance)
+#pragma clang loop unroll(disable)
+        for (int ph = 0; ph < 2; ph++) {
+            if (ph == 1) {
+                if (I.ckpt == 0) break;
+                double* ck = I.Kt;     // the register images of P and p entering stage ckpt - 1: six coalesced 512-byte stores into the
+#pragma unroll                         // (otherwise unused) K^T array of the streaming path, never waited for
+                for (int r = 0; r < 3; r++) { ck[r * 64 + lane] = S.P[r]; ck[192 + r * 64 + lane] = S.pv[r]; }
+            }
+            // stages N-1 .. ckpt (all of them when ckpt = 0), then ckpt-1 .. 0
+            bwd_chunk<true, LDS, false, true>(I, S, ph == 0 ? N : I.ckpt, ph == 0 ? I.ckpt : 0);
+        }
+        ok = S.ok;
+    } }
+    if constexpr (LDS < 3) { if (!split0) ok = riccati_backward<true, LDS, false, true>(I); }
     d4 d0;
     double kkt = 0.0;
     {
@@ -1622,6 +1692,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
             }
             status = BROV_STATUS_MAXITER;
+            // partial refactorisation: the feed-forward terms of the step-0 sweep, before the first adjoint sweep overwrites them
+            double kff0[2] = {0.0, 0.0};
+            bool hi_step0 = false;   // gains / feed-forward terms of the stages >= ckpt in LDS are the step-0 ones
+            if constexpr (PART) {
+                hi_step0 = I.ckpt > 0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) kff0[t] = I.lds_kff[lane + 64 * t < nv ? lane + 64 * t : 0];
+            }
             // this instance runs the QP loop: first in line in the next solve.  (BROV_SCHED_TICKET_LATE: the ticket at the end of the wave
             // instead -- the statement order that makes hipcc 7.2 build the exec-restore defect into rti_window_kernel, at a join block of
             // the first-guess stores above; kept as the canary of tests/test_kernel_resources.py: the build gate must reject it.)
@@ -1689,8 +1767,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 }
                 iters++;
                 double s = 0.0;
+                bool part = false;   // this Newton system restarts its factor sweep from the step-0 checkpoint
                 if (try_mode) {   // pin: Gamma = POL_BIG and a right-hand side that lands the input on its bound
                     round_k++;
+                    bool deep = false;   // a pinned input at a stage >= ckpt
                     {
                         GROUP_LANE;
                         vACT.fetch(lane, nv);
@@ -1705,8 +1785,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                             const double gm = ac != 0.0 ? POL_BIG : 0.0;
                             GAM[j] = gm;
                             RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj);
+                            if constexpr (PART) deep = deep | ((ac != 0.0) & ((int)j >= 4 * I.ckpt));
                         }
                     }
+                    if constexpr (PART) part = hi_step0 && __ballot(deep) == 0ull;
                 } else {   // group A of an interior-point iteration: Gamma and the predictor's right-hand side
                     {   // group A: Gamma and the predictor's right-hand side
                         GROUP_LANE;
@@ -1728,7 +1810,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     mu = wave_sum(s) * inv2nv;
                 }
                 IPM_T(1);
-                ok = sw_backward<true, LDS>(I, W);
+                if constexpr (PART) {
+                    ok = riccati_backward_tries<LDS>(I, part, kff0);
+                    if (!part) hi_step0 = false;   // a full sweep: the LDS gains are no longer step 0's
+                } else {
+                    ok = sw_backward<true, LDS>(I, W);
+                }
                 IPM_T(2);
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
                 sw_forward<LDS>(I, W, d0);
@@ -2173,7 +2260,7 @@ __device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, i
     const int N = P.N, nv = 4 * N;
     const double* __restrict__ cst = P.cst;
     I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
-    I.i0 = 0; I.NT = N;
+    I.i0 = 0; I.NT = N; I.ckpt = 0;
     I.x = P.x + (size_t)b * (N + 1) * 12;
     I.u = P.u + (size_t)b * N * 4;
     I.yref = P.yref + (size_t)b * P.yref_stride;
@@ -2558,6 +2645,7 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
     const int lane = threadIdx.x;
     const int N = P.N;
+    const bool listed = sched_listed(P, b);   // requested here, used after the linearisation
     if (blockIdx.x == 0) sched_zero_next(P, lane);
     DBG_STAMP(0);
     // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
@@ -2581,6 +2669,9 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
     Inst I;
     setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr);
+    // partial refactorisation of the active-set tries (riccati_backward_tries): checkpoint stage = ceil(N / 4); off for horizons too
+    // short to gain from it and for instances the previous solve did not list as expensive
+    I.ckpt = (N >= 8 && P.partial_refactor && listed) ? (N + 3) >> 2 : 0;
     I.lds_ba = (const lds_f64*)ba_s;
     I.lds_bv = (const lds_f64*)bv_s;
     I.lds_kt = (lds_f64*)kt_s;
