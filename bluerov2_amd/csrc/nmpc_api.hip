@@ -743,6 +743,7 @@ static DevParams make_params(const brov_solver* s) {
     P.B = s->B; P.N = s->N;
     P.qp_iter_max = s->opts.qp_iter_max; P.early_exit = s->opts.qp_early_exit;
     P.on_failure = s->opts.on_failure; P.dump_lin = s->dump_lin ? 1 : 0;
+    P.robust_pivot = getenv("BROV_ROBUST_PIVOT") ? atoi(getenv("BROV_ROBUST_PIVOT")) : 1;   // development knob: 0 off, 1 on demand (default), 2 every instance
     P.partial_refactor = !(getenv("BROV_PARTIAL_REFACTOR") && atoi(getenv("BROV_PARTIAL_REFACTOR")) == 0);   // development knob (A/B, tests)
     P.Ts = s->opts.Ts; P.tol_mu = s->opts.qp_tol_mu; P.tol_stat = s->opts.qp_tol_stat;
     for (int j = 0; j < 16; j++) P.W[j] = s->opts.W[j];

@@ -20,7 +20,7 @@ namespace brov {
 struct DevParams {
     int32_t B, N;
     int32_t qp_iter_max, early_exit;
-    int32_t partial_refactor, pad0_;   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
+    int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)
     double Ts, tol_mu, tol_stat;
     double W[16], We[12], lbu[4], ubu[4];

@@ -216,6 +216,14 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return fma(y, e, y);
 }
 
+// 1/sqrt(d) for a positive, normal d: v_rsq_f64 seed + 2 Newton steps (the robust pivot path below)
+__device__ __forceinline__ double fast_rsq(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    return y * fma(-h * y, y, 1.5);
+}
+
 // acc += a * (src of lane K of this lane's 16-lane row): v_fmac_f64_dpp with row_newbcast, the one DPP control gfx950 has for
 // 64-bit operands.  The broadcast costs nothing beyond the FMA (5.3 cycles against 4.9, scripts/dev/dpp_fmac_rate.hip) -- a
 // v_readlane pair into SGPRs costs 8 plus the SGPR hazard.  A DPP read needs two wait states behind a VALU write of the register
@@ -344,7 +352,19 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
 // FACTOR = false: reuse the stored factors (Ks, Mt, Pb) and solve for a new rhs.  Returns false if a pivot block is
 // not positive definite.  The sweep is split into bwd_init (terminal cost -> P, p) and bwd_chunk (the stages of the resident
 // window, state carried in registers) so that the windowed kernel can run it window by window.
-struct BwdState { d4 P, pv; bool ok; };
+// illc: a pivot block of the sweep was ill-conditioned (see kPivotRho); wave-uniform like ok
+struct BwdState { d4 P, pv; bool ok; bool illc = false; };
+// The 4x4 pivot block Huu is inverted EXPLICITLY by 2x2 block elimination (two reciprocals on the serial chain of every stage).  That is
+// as accurate as a Cholesky solve while the block is well conditioned after diagonal scaling, and loses a factor cond(Huu) against
+// it otherwise (round 4, scripts/dev/riccati_pivot_variants.py: on QPs whose condensed Hessian has cond 1e11..1e13 the explicit
+// inverse leaves u 1e-2 off, the Cholesky form 1e-7).  Well conditioned is the rule: the relative pivots rho of the elimination --
+// det E / (a00 a11), s00 / a22, s11 / a33, det Sc / (s00 s11) -- are 0.94..1 on every instance of the standard workloads and
+// 1e-6..1e-4 on the ill-conditioned ones (iterates of a diverging full-step SQP).  So the fast sweep only WATCHES them (four
+// compares per stage, off the chain), and an instance with a relative pivot below kPivotRho repeats the sweep -- and runs all its
+// later ones -- in the ROBUST form: Cholesky factor L of Huu (four reciprocal square roots in sequence), its triangular inverse,
+//     Y = L^-1 Hu,   S = H - Y'Y,   K = -L^-T Y,   kff = -L^-T (L^-1 gu)        (+2 MFMAs per stage)
+// which is the oracle's algebra (chol4 / chol4_solve) in tile form.
+constexpr double kPivotRho = 1.0 / 64.0;
 
 template <bool FACTOR, int LDS>
 __device__ __forceinline__ void bwd_init(const Inst& I, BwdState& S) {
@@ -425,7 +445,7 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
 
 // hi / lo: the sweep runs over the stages hi-1 .. lo of the resident block (default: all I.N of them); explicit arguments, not fields of
 // Inst -- a horizon that changes under the compiler's eyes costs every sweep of the kernel its loop-invariant addressing
-template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false>
 __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -1, int lo = 0) {
     if constexpr (!FACTOR && LDS != 0) {
         bwd_solve_v<LDS>(I, S);
@@ -438,6 +458,7 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -
     d4& P = S.P;
     d4& pv = S.pv;
     bool& ok = S.ok;
+    bool& illc = S.illc;
     const d4 z4 = {0, 0, 0, 0};
     const unsigned mk_col0 = cl == 0 ? ~0u : 0u;
     constexpr bool kMaskPvAtUse = (LDS == 1 || LDS == 2);
@@ -513,24 +534,49 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -
             const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
             const double a30 = readlane_f64(H[3], 60), a31 = readlane_f64(H[3], 61), a32 = readlane_f64(H[3], 62),
                          a33 = readlane_f64(H[3], 63);
-            // M = Huu^-1 by 2x2 block elimination (all lanes redundantly; the values are wave-uniform):
-            //   Huu = [E F; F' G],  X = E^-1 F,  Sc = G - F'X,  M22 = Sc^-1,  M12 = -X M22,  M11 = E^-1 - M12 X'
-            // Two reciprocals in sequence instead of the four of an LDL^T: this algebra is the serial critical path of
-            // every Riccati stage (~26 dependent FP64 operations instead of ~48).  SPD <=> e00, det E, s00, det Sc > 0.
-            const double detE = a00 * a11 - a10 * a10, iE = fast_rcp(detE);
-            const double e00 = a11 * iE, e01 = -a10 * iE, e11 = a00 * iE;           // E^-1
-            // F = [a20 a30; a21 a31]^T block: rows 0,1 x cols 2,3 -> F = [[a20, a30], [a21, a31]]
-            const double x00 = e00 * a20 + e01 * a21, x01 = e00 * a30 + e01 * a31;   // X = E^-1 F
-            const double x10 = e01 * a20 + e11 * a21, x11 = e01 * a30 + e11 * a31;
-            const double s00 = a22 - (a20 * x00 + a21 * x10), s01 = a32 - (a20 * x01 + a21 * x11);
-            const double s11 = a33 - (a30 * x01 + a31 * x11);                          // Sc = G - F'X
-            const double detS = s00 * s11 - s01 * s01, iS = fast_rcp(detS);
-            const double m22 = s11 * iS, m32 = -s01 * iS, m33 = s00 * iS;            // M22 = Sc^-1
-            const double m20 = -(x00 * m22 + x01 * m32), m30 = -(x00 * m32 + x01 * m33);  // M12' (rows 2,3 x cols 0,1)
-            const double m21 = -(x10 * m22 + x11 * m32), m31 = -(x10 * m32 + x11 * m33);
-            const double m00 = e00 - (m20 * x00 + m30 * x01), m10 = e01 - (m20 * x10 + m30 * x11);
-            const double m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
-            if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
+            double m00, m10, m11, m20, m21, m22, m30, m31, m32, m33;   // M = Huu^-1 (lower triangle)
+            double li00 = 0, li10 = 0, li11 = 0, li20 = 0, li21 = 0, li22 = 0, li30 = 0, li31 = 0, li32 = 0, li33 = 0;   // ROBUST: L^-1
+            if constexpr (ROBUST) {
+                // Cholesky Huu = L L' (all lanes redundantly), L^-1 by forward substitution, M = L^-T L^-1 for the stored operand
+                const double i0 = fast_rsq(a00);
+                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+                const double d1 = a11 - l10 * l10, i1 = fast_rsq(d1);
+                const double l21 = (a21 - l20 * l10) * i1, l31 = (a31 - l30 * l10) * i1;
+                const double d2 = a22 - (l20 * l20 + l21 * l21), i2 = fast_rsq(d2);
+                const double l32 = (a32 - (l30 * l20 + l31 * l21)) * i2;
+                const double d3 = a33 - (l30 * l30 + l31 * l31 + l32 * l32), i3 = fast_rsq(d3);
+                if (!(a00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
+                li00 = i0; li11 = i1; li22 = i2; li33 = i3;
+                li10 = -(l10 * li00) * i1;
+                li20 = -(l20 * li00 + l21 * li10) * i2; li21 = -(l21 * li11) * i2;
+                li30 = -(l30 * li00 + l31 * li10 + l32 * li20) * i3; li31 = -(l31 * li11 + l32 * li21) * i3; li32 = -(l32 * li22) * i3;
+                m00 = li00 * li00 + li10 * li10 + li20 * li20 + li30 * li30;
+                m10 = li10 * li11 + li20 * li21 + li30 * li31; m11 = li11 * li11 + li21 * li21 + li31 * li31;
+                m20 = li20 * li22 + li30 * li32; m21 = li21 * li22 + li31 * li32; m22 = li22 * li22 + li32 * li32;
+                m30 = li30 * li33; m31 = li31 * li33; m32 = li32 * li33; m33 = li33 * li33;
+            } else {
+                // M = Huu^-1 by 2x2 block elimination (all lanes redundantly; the values are wave-uniform):
+                //   Huu = [E F; F' G],  X = E^-1 F,  Sc = G - F'X,  M22 = Sc^-1,  M12 = -X M22,  M11 = E^-1 - M12 X'
+                // Two reciprocals in sequence instead of the four of an LDL^T: this algebra is the serial critical path of
+                // every Riccati stage (~26 dependent FP64 operations instead of ~48).  SPD <=> e00, det E, s00, det Sc > 0.
+                const double detE = a00 * a11 - a10 * a10, iE = fast_rcp(detE);
+                const double e00 = a11 * iE, e01 = -a10 * iE, e11 = a00 * iE;           // E^-1
+                // F = [a20 a30; a21 a31]^T block: rows 0,1 x cols 2,3 -> F = [[a20, a30], [a21, a31]]
+                const double x00 = e00 * a20 + e01 * a21, x01 = e00 * a30 + e01 * a31;   // X = E^-1 F
+                const double x10 = e01 * a20 + e11 * a21, x11 = e01 * a30 + e11 * a31;
+                const double s00 = a22 - (a20 * x00 + a21 * x10), s01 = a32 - (a20 * x01 + a21 * x11);
+                const double s11 = a33 - (a30 * x01 + a31 * x11);                          // Sc = G - F'X
+                const double detS = s00 * s11 - s01 * s01, iS = fast_rcp(detS);
+                m22 = s11 * iS; m32 = -s01 * iS; m33 = s00 * iS;            // M22 = Sc^-1
+                m20 = -(x00 * m22 + x01 * m32); m30 = -(x00 * m32 + x01 * m33);  // M12' (rows 2,3 x cols 0,1)
+                m21 = -(x10 * m22 + x11 * m32); m31 = -(x10 * m32 + x11 * m33);
+                m00 = e00 - (m20 * x00 + m30 * x01); m10 = e01 - (m20 * x10 + m30 * x11);
+                m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
+                if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
+
+                // the relative pivots of the elimination (kPivotRho): four compares, off the chain
+                illc = illc | (detE < kPivotRho * (a00 * a11)) | (s00 < kPivotRho * a22) | (s11 < kPivotRho * a33) | (detS < kPivotRho * (s00 * s11));
+            }
             // Mtile: lane (rg = m, cl = n < 4) = M[m][n]; msel: the same element for every column n = cl & 3
             double mt = 0.0, msel;
             {
@@ -548,16 +594,40 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -
             H[2] = blend(mk_col0, t2, H[2]);
             H[3] = blend(mk_col0, t3, H[3]);
             // T = M Hu (rows 0..3 in reg 0), S = H - Hu^T T, Kt = -(Hu^T M), kff = -M gu, p = gx + K^T gu
-            d4 T = tn1(mt, H[3], z4);
-            const double ks = -T[0];
-            d4 S = tn1(H[3], ks, H);
+            d4 T, S;
+            double ks, liT = 0.0, li = 0.0;
+            if constexpr (ROBUST) {
+                // L^-1 as operand tiles: element L^-1[max][min] selected per lane like M above; liT: (k, m) = L^-1[m][k] (so that the
+                // product forms L^-1 y), li: (k, m) = L^-1[k][m] (forms L^-T y)
+                const int cq = cl & 3;
+                const int a = rg > cq ? rg : cq, c = rg > cq ? cq : rg;
+                const double r1 = (c == 0) ? li10 : li11;
+                const double r2 = (c == 0) ? li20 : ((c == 1) ? li21 : li22);
+                const double r3 = (c == 0) ? li30 : ((c == 1) ? li31 : ((c == 2) ? li32 : li33));
+                const double lsel = (a == 0) ? li00 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
+                liT = (cl < 4 && cl >= rg) ? lsel : 0.0;
+                li = (cl < 4 && rg >= cl) ? lsel : 0.0;
+                const d4 Y = tn1(liT, H[3], z4);     // Y = L^-1 Hu (rows 0..3 in register 0)
+                S = tn1(Y[0], -Y[0], H);             // S = H - Y'Y: a difference of the stage Hessian and a Gram matrix
+                T = tn1(li, Y[0], z4);               // L^-T Y = M Hu through the factor, not through the explicit inverse
+                ks = -T[0];
+            } else {
+                T = tn1(mt, H[3], z4);
+                ks = -T[0];
+                S = tn1(H[3], ks, H);
+            }
             // kff = -M gu and p = gx + K^T gu in ONE product: the operand carries the gain in columns 0..11 and M in columns
             // 12..15, so rows 0..11 of the result are p and rows 12..15 are M gu (M is symmetric)
             // (windowed kernel.  In the fused kernels the separate M gu product is what fills the issue slot behind T while S and
             // p wait for the gain: merged, the stage measured 110 cycles SLOWER there and 125 cycles faster in the windowed kernel.)
             const double xt2 = (cl < NX) ? ks : msel;
             d4 pn;
-            if constexpr (LDS == 3) {
+            if constexpr (ROBUST) {
+                const d4 yg = tn1(liT, g[3], z4);    // L^-1 gu, then L^-T of it
+                const d4 kf = tn1(li, yg[0], z4);
+                pn = tn1(ks, g[3], g);
+                pn[3] = kf[0];
+            } else if constexpr (LDS == 3) {
                 const d4 gC = {g[0], g[1], g[2], 0.0};
                 pn = tn1(xt2, g[3], gC);
             } else {
@@ -624,12 +694,13 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -
     }
 }
 
-template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false>
-__device__ bool riccati_backward(const Inst& I) {
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false>
+__device__ bool riccati_backward(const Inst& I, bool* illc = nullptr) {
     BwdState S;
     wave_fence();
     bwd_init<FACTOR, LDS>(I, S);
-    bwd_chunk<FACTOR, LDS, STORE_IPM, STEP0>(I, S);
+    bwd_chunk<FACTOR, LDS, STORE_IPM, STEP0, ROBUST>(I, S);
+    if (illc) *illc = S.illc;
     return S.ok;
 }
 
@@ -644,7 +715,7 @@ __device__ bool riccati_backward(const Inst& I) {
 // stages < ckpt = ceil(N / 4) is where the adjoint sweeps stage the multipliers: those stages are refactored in any case.
 // part = false: a full sweep (what riccati_backward<true, LDS> does).  ONE call site of the stage loop for both.
 template <int LDS>
-__device__ __forceinline__ bool riccati_backward_tries(const Inst& I, bool part, const double (&kff0)[2]) {
+__device__ __forceinline__ bool riccati_backward_tries(const Inst& I, bool part, const double (&kff0)[2], bool& illc) {
     static_assert(LDS == 1 || LDS == 2, "fused kernels");
     wave_fence();
     BwdState S;
@@ -662,6 +733,7 @@ __device__ __forceinline__ bool riccati_backward_tries(const Inst& I, bool part,
         bwd_init<true, LDS>(I, S);
     }
     bwd_chunk<true, LDS, true, false>(I, S, part ? I.ckpt : I.N, 0);
+    illc = S.illc;
     return S.ok;
 }
 
@@ -1324,10 +1396,12 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
     wave_fence();
 }
 
-template <bool FACTOR, int LDS>
-__device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
+// STEP0: the equality-constrained system (Gamma = 0, right-hand side r; nothing is read from or stored to the interior-point
+// arrays); ROBUST: the Cholesky pivot form (kPivotRho); illc: an ill-conditioned pivot block was seen (fast form only)
+template <bool FACTOR, int LDS, bool STEP0 = false, bool ROBUST = false>
+__device__ __forceinline__ bool sw_backward(Inst& I, Win* W, bool* illc = nullptr) {
     if constexpr (LDS < 3) {
-        return riccati_backward<FACTOR, LDS>(I);
+        return riccati_backward<FACTOR, LDS, !STEP0, STEP0, ROBUST>(I, illc);
     } else {
         opaque_lane(I);
         wave_fence();
@@ -1335,7 +1409,7 @@ __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
         for (int c = W->nc - 1; c >= 0; c--) {
             win_need(I, *W, c, WM_LIN, nullptr);
             if (c == W->nc - 1) bwd_init<FACTOR, 3>(I, S);
-            bwd_chunk<FACTOR, 3, true, false>(I, S);
+            bwd_chunk<FACTOR, 3, !STEP0, STEP0, ROBUST>(I, S);
             __syncthreads();
             // park what the sweep produced: K^T | kff (contiguous), or kff alone after a solve-only sweep.  The resident K^T stays
             // valid in both cases (a solve-only sweep does not touch it) unless an adjoint sweep has overwritten the area since.
@@ -1347,6 +1421,7 @@ __device__ __forceinline__ bool sw_backward(Inst& I, Win* W) {
             if (FACTOR) W->valid |= WM_GAIN;
         }
         wave_fence();
+        if (illc) *illc = S.illc;
         return S.ok;
     }
 }
@@ -1508,7 +1583,7 @@ __device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) { 
 // step-0 factorisation has already run, fused with the linearisation: pre_ok)
 template <int LDS>
 __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan, Win* W = nullptr,
-                                        bool pre_ok = true) {
+                                        bool pre_ok = true, bool pre_illc = false) {
     constexpr bool EL = (LDS == 1 || LDS == 2);
     const double* __restrict__ cst = P.cst;
     const int lane = I.lane, N = I.NT, nv = I.nv;
@@ -1561,6 +1636,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     // partial refactorisation of the active-set tries (fused kernels, riccati_backward_partial): checkpoint stage = ceil(N / 4), off for
     // horizons too short to gain from it
     constexpr bool PART = EL;
+    bool illc0 = pre_illc;
     bool split0 = false;
     if constexpr (PART) split0 = I.ckpt > 0;   // set by the kernel body: only instances that ran the QP loop in the previous solve
     if constexpr (PART) { if (split0) {
@@ -1585,8 +1661,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             bwd_chunk<true, LDS, false, true>(I, S, ph == 0 ? N : I.ckpt, ph == 0 ? I.ckpt : 0);
         }
         ok = S.ok;
+        illc0 = S.illc;
     } }
-    if constexpr (LDS < 3) { if (!split0) ok = riccati_backward<true, LDS, false, true>(I); }
+    if constexpr (LDS < 3) { if (!split0) ok = riccati_backward<true, LDS, false, true>(I, &illc0); }
     d4 d0;
     double kkt = 0.0;
     {
@@ -1601,6 +1678,23 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         if (kkt != kkt) nanp = true;
         kkt = wave_max(fmax(part, (kkt != kkt) ? 0.0 : kkt));
         if (__ballot(nanp) != 0ull) kkt = __builtin_nan("");
+    }
+    // an ill-conditioned pivot block (kPivotRho): this instance repeats the sweep, and runs every later one, in the Cholesky form
+    // (not in the two-waves-per-SIMD kernel of the short horizons, N <= 13: its 256 registers do not hold the second pivot form
+    // without scratch, which the build forbids in a solver kernel)
+    constexpr bool ROB = LDS != 2;
+    bool robust = false, robust_ok = false;
+    if constexpr (ROB) {
+        // Only while the step is numerically meaningful (entering KKT <= 1e6, the bound of the parity rules): the iterate of a diverged
+        // full-step SQP is ill-conditioned without end, and with pivots that never fail its interior-point loop grinds through all
+        // qp_iter_max systems (measured: 50 instead of the 1..19 after which the fast form gives up or fails -- one such instance
+        // made its whole launch 2.6 times as long).
+        robust_ok = kkt <= 1e6;
+        if ((__ballot(illc0) != 0ull && P.robust_pivot && robust_ok) || P.robust_pivot == 2) {   // (2: development knob, every instance)
+            robust = true;
+            I.ckpt = 0;   // (no partial refactorisation: the checkpoint belongs to the fast sweep)
+            ok = sw_backward<true, LDS, true, true>(I, W);
+        }
     }
     DBG_STAMP(2);
     // bounds of this lane's elements of the check below (element j = lane + 64 t belongs to input lane & 3): requested before
@@ -1810,12 +1904,17 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                     mu = wave_sum(s) * inv2nv;
                 }
                 IPM_T(1);
-                if constexpr (PART) {
-                    ok = riccati_backward_tries<LDS>(I, part, kff0);
-                    if (!part) hi_step0 = false;   // a full sweep: the LDS gains are no longer step 0's
-                } else {
-                    ok = sw_backward<true, LDS>(I, W);
+                if (!robust) {
+                    bool ill = false;
+                    if constexpr (PART) {
+                        ok = riccati_backward_tries<LDS>(I, part, kff0, ill);
+                        if (!part) hi_step0 = false;   // a full sweep: the LDS gains are no longer step 0's
+                    } else {
+                        ok = sw_backward<true, LDS>(I, W, &ill);
+                    }
+                    if constexpr (ROB) { if (__ballot(ill) != 0ull && P.robust_pivot && robust_ok) { robust = true; hi_step0 = false; } }   // ... and this system is factorised again
                 }
+                if constexpr (ROB) { if (robust) ok = sw_backward<true, LDS, false, true>(I, W); }
                 IPM_T(2);
                 if (__ballot(!ok) != 0ull) { status = BROV_STATUS_QP_FAILURE; break; }
                 sw_forward<LDS>(I, W, d0);
@@ -2906,7 +3005,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         W.t_fetch = 0; W.n_fetch = 0;
 #endif
 #if !defined(BROV_WIN_EXP) || BROV_WIN_EXP != 1
-        qp_body<(RES ? 4 : 3)>(P, I, b, part, nanp, &W, S.ok);
+        qp_body<(RES ? 4 : 3)>(P, I, b, part, nanp, &W, S.ok, S.illc);
 #endif
 #ifdef BROV_DBG_WIN
         if (P.dbg && lane == 0) { P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 3] = W.t_fetch; P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 4] = W.n_fetch; }
