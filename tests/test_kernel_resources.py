@@ -153,4 +153,6 @@ def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
                        check=True, capture_output=True, timeout=900)
         out[name] = chk.scan(open(asm).read().split("\n"))
     assert out["product"] == []
-    assert len(out["late"]) >= 1 and all("rti_window" in h[0] for h in out["late"]), out["late"]
+    # which kernel hosts the defect moves with every change of the source (round 4 saw it in rti_window_kernel, then, three features
+    # later, in rti_fused_kernel): any hit counts
+    assert len(out["late"]) >= 1, "the canary order no longer builds the defect: pick a new canary or retire it"
