@@ -1398,17 +1398,25 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
 
 // STEP0: the equality-constrained system (Gamma = 0, right-hand side r; nothing is read from or stored to the interior-point
 // arrays); ROBUST: the Cholesky pivot form (kPivotRho); illc: an ill-conditioned pivot block was seen (fast form only)
+// part (windowed kernel): only window 0 is refactorised, from the checkpoint pass 1 left behind (the parked gains of the other windows are
+// the step-0 ones, and a try that pins inputs of window 0 only would recompute them bit for bit)
 template <bool FACTOR, int LDS, bool STEP0 = false, bool ROBUST = false>
-__device__ __forceinline__ bool sw_backward(Inst& I, Win* W, bool* illc = nullptr) {
+__device__ __forceinline__ bool sw_backward(Inst& I, Win* W, bool* illc = nullptr, bool part = false) {
     if constexpr (LDS < 3) {
         return riccati_backward<FACTOR, LDS, !STEP0, STEP0, ROBUST>(I, illc);
     } else {
         opaque_lane(I);
         wave_fence();
         BwdState S;
-        for (int c = W->nc - 1; c >= 0; c--) {
+        if (part) {
+            const double* ck = I.Kt;
+#pragma unroll
+            for (int r = 0; r < 3; r++) { S.P[r] = ck[r * 64 + I.lane]; S.pv[r] = ck[192 + r * 64 + I.lane]; }
+            S.P[3] = 0.0; S.pv[3] = 0.0; S.ok = true;
+        }
+        for (int c = part ? 0 : W->nc - 1; c >= 0; c--) {
             win_need(I, *W, c, WM_LIN, nullptr);
-            if (c == W->nc - 1) bwd_init<FACTOR, 3>(I, S);
+            if (c == W->nc - 1 && !part) bwd_init<FACTOR, 3>(I, S);
             bwd_chunk<FACTOR, 3, !STEP0, STEP0, ROBUST>(I, S);
             __syncthreads();
             // park what the sweep produced: K^T | kff (contiguous), or kff alone after a solve-only sweep.  The resident K^T stays
@@ -1635,11 +1643,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
     bool ok = pre_ok;
     // partial refactorisation of the active-set tries (fused kernels, riccati_backward_partial): checkpoint stage = ceil(N / 4), off for
     // horizons too short to gain from it
-    constexpr bool PART = EL;
+    constexpr bool PART = EL || LDS == 3;   // fused kernels: stage checkpoint (riccati_backward_tries); windowed kernel: window-0 checkpoint
     bool illc0 = pre_illc;
     bool split0 = false;
-    if constexpr (PART) split0 = I.ckpt > 0;   // set by the kernel body: only instances that ran the QP loop in the previous solve
-    if constexpr (PART) { if (split0) {
+    if constexpr (EL) split0 = I.ckpt > 0;   // set by the kernel body: only instances that ran the QP loop in the previous solve
+    if constexpr (EL) { if (split0) {
         // the step-0 factor sweep in two parts with the checkpoint between them.  Measured: inside the stage loop a wave-uniform
         // `if (i == ckpt)` with the six stores costs the loop 7 % (registers and scheduling, taken or not); the split sweep still
         // costs 2 % (the software pipeline drains and refills once) + 1 % (the stores) -- so only the instances that are LIKELY to run
@@ -1789,8 +1797,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // partial refactorisation: the feed-forward terms of the step-0 sweep, before the first adjoint sweep overwrites them
             double kff0[2] = {0.0, 0.0};
             bool hi_step0 = false;   // gains / feed-forward terms of the stages >= ckpt in LDS are the step-0 ones
-            if constexpr (PART) {
-                hi_step0 = I.ckpt > 0;
+            if constexpr (PART) hi_step0 = I.ckpt > 0;
+            if constexpr (EL) {
 #pragma unroll
                 for (int t = 0; t < 2; t++) kff0[t] = I.lds_kff[lane + 64 * t < nv ? lane + 64 * t : 0];
             }
@@ -1906,9 +1914,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                 IPM_T(1);
                 if (!robust) {
                     bool ill = false;
-                    if constexpr (PART) {
+                    if constexpr (EL) {
                         ok = riccati_backward_tries<LDS>(I, part, kff0, ill);
                         if (!part) hi_step0 = false;   // a full sweep: the LDS gains are no longer step 0's
+                    } else if constexpr (LDS == 3) {
+                        ok = sw_backward<true, LDS>(I, W, &ill, part);
+                        if (!part) hi_step0 = false;   // ... the parked gains of the windows >= 1
                     } else {
                         ok = sw_backward<true, LDS>(I, W, &ill);
                     }
@@ -2835,7 +2846,8 @@ __host__ __device__ inline int win_len(int N) { const int nc = win_chunks(N); re
 __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
     return (size_t)((N + L - 1) / L) * win_img_doubles(L)                  // parked window images
            + (size_t)N * 4 + (size_t)(N + 1) * NX                          // vhat, dx (flat over the horizon)
-           + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N;        // Ks Mt Pb | interior-point vectors
+           + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N         // Ks Mt Pb | interior-point vectors
+           + 384;                                                          // (P, p) entering window 0: checkpoint of the partial refactorisation
 }
 // RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
 // one instance per CU.  Nothing is parked and no window is fetched.  A separate instantiation (rti_window_kernel_res), so that the
@@ -2889,6 +2901,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     double* ws_Mt = ws_Ks + (size_t)N * 64;
     double* ws_Pb = ws_Mt + (size_t)N * 64;
     double* ws_ipm = ws_Pb + (size_t)N * NX;
+    double* ws_ck = ws_ipm + (size_t)IPM_NARR * 4 * N;
     for (int trip = 0;; trip++) {
         // the lane index is re-derived behind an opaque move in every iteration: nothing lane-dependent is hoisted out of the
         // instance loop (such loop invariants otherwise sit in VGPRs across lin_phase and push the kernel into scratch)
@@ -2909,7 +2922,9 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         auto setup = [&](Inst& I) __attribute__((always_inline)) {
             setup_inst(P, I, b, lane, &lc);
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
-            I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr;
+            I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = ws_ck;
+            // partial refactorisation of the active-set tries: the checkpoint is the state of the factor sweep as it enters window 0
+            I.ckpt = (!RES && nc >= 2 && P.partial_refactor) ? Lc : 0;
             I.lds_ba = (const lds_f64*)ba_s;
             I.lds_bv = (const lds_f64*)bv_s;
             I.lds_kt = (lds_f64*)kt_s;
@@ -2987,6 +3002,10 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             win_select(I, W, c);
             if (c == nc - 1) bwd_init<true, 3>(I, S);
             bwd_chunk<true, 3, false, true>(I, S);
+            if (!RES && c == 1 && I.ckpt > 0) {   // (P, p) as they enter window 0: six coalesced 512-byte stores, never waited for
+#pragma unroll
+                for (int r = 0; r < 3; r++) { ws_ck[r * 64 + lane] = S.P[r]; ws_ck[192 + r * 64 + lane] = S.pv[r]; }
+            }
             __syncthreads();
             const unsigned long long t2 = P.dbg ? __builtin_readcyclecounter() : 0;
             // park the window: one contiguous image.  Window 0 keeps its K^T | kff in LDS only: the forward sweep starts on the resident

@@ -440,7 +440,11 @@ def _condensed_hessian_cond(oracle, op, N, Ts, W, We, x0, yref, p, xe, ue):
         return float(np.linalg.cond(H)) if np.isfinite(H).all() else np.inf
 
 
-COND_LIMIT = 1e9   # cond(H) * 2^-52 * |u| = 1e9 * 2.2e-16 * 50 = 1.1e-5: beyond it the QP itself does not pin u to the north star's 1e-5
+# cond(H) * 2^-52 * |u| = 1e9 * 2.2e-16 * 50 = 1.1e-5: beyond 1e9 the QP itself does not pin u to the north star's 1e-5 any more.  The
+# limit held here is ten times that: since the on-demand Cholesky pivot form (qp_kernel.hip, kPivotRho) the kernels track the oracle
+# far into that range -- measured: the best-conditioned QP on which the two still disagree has cond 1.6e11 (with the explicit pivot
+# inverse alone: 1e10, and 1037 instead of 984 instance-ticks)
+COND_LIMIT = 1e10
 
 
 def test_nominal_model_fuzz_at_the_headline_step(ba, oracle, golden_traj):
@@ -458,8 +462,8 @@ def test_nominal_model_fuzz_at_the_headline_step(ba, oracle, golden_traj):
     KKT residuals of 1e-5..1e+1 and oracle and kernels land 1e-7..1e-1 apart.  Which of those instances FP64 can decide is a
     property of the QP, not of a solver: for every disagreeing instance the condensed Hessian is formed from the ORACLE's
     linearisation of the entering iterate (numpy, no build code on the kernel side) and its condition number taken.  cond(H) >=
-    1e9 (an answer of ANY backward-stable solver is then uncertain by cond * 2^-52 * |u| >= 1e-5, the north star's own bar): left
-    out of that tick's comparison, counted and recorded with its cond.  cond(H) < 1e9: a DISAGREEMENT, and none is tolerated.
+    1e10 (an answer of ANY backward-stable solver is then uncertain by cond * 2^-52 * |u| >= 1e-4, ten times the north star's bar):
+    left out of that tick's comparison, counted and recorded with its cond.  cond(H) < 1e10: a DISAGREEMENT, and none is tolerated.
     The draws of the headline regime itself (N = 20, the shipped +-50 box, config-2 noise only; weights and disturbances still
     drawn) are counted separately: first GPU run 1 left out of 1920 (drawn weights under which the SQP diverges by tick 2)."""
     Ts, nb = 0.05, 32
@@ -508,11 +512,11 @@ def test_nominal_model_fuzz_at_the_headline_step(ba, oracle, golden_traj):
             n_ipm_draws += int(n_ipm > 0)
         s.close()
     lo = np.array(left_out).reshape(-1, 12)
-    cond_hist = np.histogram(np.minimum(lo[:, 5], 1e299), bins=[1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e16, 1e300])[0].tolist() if len(lo) else []
+    cond_hist = np.histogram(np.minimum(lo[:, 5], 1e299), bins=[1e10, 1e11, 1e12, 1e13, 1e14, 1e16, 1e300])[0].tolist() if len(lo) else []
     vmax_hist = np.histogram(np.nan_to_num(lo[:, 11], nan=1e9, posinf=1e9), bins=[0, 5, 10, 15, 20, 50, 1e300])[0].tolist() if len(lo) else []
     print(f"[nominal fuzz] 512 draws at Ts = 0.05 s, {checked} instance-ticks, every one compared: {len(bad)} disagreements on QPs that FP64 "
           f"determines (cond(H) < {COND_LIMIT:g}); {len(lo)} instance-ticks disagree on QPs it does not -- cond(H) histogram over "
-          f"[1e9,1e10,1e11,1e12,1e13,1e14,1e16,inf]: {cond_hist}; largest body velocity of their entering iterates over [0,5,10,15,20,50,inf]: "
+          f"[1e10,1e11,1e12,1e13,1e14,1e16,inf]: {cond_hist}; largest body velocity of their entering iterates over [0,5,10,15,20,50,inf]: "
           f"{vmax_hist}; {n_ipm_draws} draws ran the QP loop; headline regime (N = 20, shipped box, config-2 noise, drawn weights / "
           f"disturbances): {checked_headline} instance-ticks, {headline_left_out} of them among the left-out")
     from conftest import _parity_note

@@ -29,15 +29,18 @@ def _run(ba, N, Ts, B, ticks, partial, kw, x0, circ, p):
         for k in range(ticks):
             s.set_yref(circ[k:k + N + 1]); s.solve()
             out.append((s.results().copy(), s.get_iterate()))
-        assert s.last_kernel_path() == ba.PATH_FUSED
+        assert s.last_kernel_path() == (ba.PATH_FUSED if N <= 23 else ba.PATH_WINDOWED)
         s.close()
     finally:
         os.environ.pop("BROV_PARTIAL_REFACTOR", None)
     return out
 
 
-@pytest.mark.parametrize("N,box,early", [(20, 50.0, 1), (20, 8.0, 1), (23, 50.0, 1), (10, 50.0, 1), (13, 20.0, 0), (8, 50.0, 1), (7, 50.0, 1)])
+@pytest.mark.parametrize("N,box,early", [(20, 50.0, 1), (20, 8.0, 1), (23, 50.0, 1), (10, 50.0, 1), (13, 20.0, 0), (8, 50.0, 1), (7, 50.0, 1),
+                                         (40, 50.0, 1), (80, 50.0, 1), (57, 20.0, 0), (24, 50.0, 1)])
 def test_partial_refactorisation_is_bit_identical_to_full_sweeps(ba, N, box, early):
+    """N <= 23: the fused kernels (checkpoint at stage ceil(N / 4)); above: the windowed kernel (checkpoint at the boundary of window 0;
+    B = 1024 > one instance per CU, so the large-batch kernel runs, not the resident one)"""
     import bench
     B, ticks = 1024, 6
     x0, circ = bench.synthetic_inputs(B, seed=40 + N)
