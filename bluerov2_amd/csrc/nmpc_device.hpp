@@ -84,6 +84,7 @@ bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
 // windowed LDS-resident kernel for longer horizons: persistent blocks (one wavefront each) that take instances from a counter
 void launch_windowed(const DevParams& P, hipStream_t st);
 void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]);   // LDS bytes per block, blocks per CU, threads, kernel kind
+bool windowed_is_resident(int win_L);      // one window = the whole horizon (small batches): no general-grid instantiation
 int windowed_stage_count(int N, int B);   // stages per window (= N for batches of at most one instance per CU: resident mode)
 int windowed_blocks(int N, int B, int L); // persistent blocks that will be launched on the current device
 size_t windowed_ws_doubles(int N, int L); // per-block workspace

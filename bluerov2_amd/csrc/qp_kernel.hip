@@ -26,6 +26,8 @@
 // work ordering (sched_*) -> qp_body (QP solve, multiplier recovery, full step; shared by all kernels) -> lin_phase (wave-wide
 // linearisation) -> kernels (qp_kernel + lin_wave_kernel[_grid] streaming pair, rti_fused_kernel / _w2, rti_window_kernel and its
 // resident-mode instantiation rti_window_kernel_res for small batches) and their launchers.
+#include <type_traits>
+
 #include "lin_device.hpp"
 #include "nmpc_device.hpp"
 
@@ -135,7 +137,12 @@ struct Inst {
     double Wer[3];  // We[row]
     double Wq, Weq, Wuq;  // adjoint sweep (lane = (column c, row group)): W[c], We[c] for c = min(lane >> 2, 11); W[12 + (lane >> 2 & 3)]
     double lbm, ubm;  // bounds of input m = rg
+    static constexpr bool kGrid = false;
 };
+// General grid (round 4: also on the LDS-resident kernels): per-stage time steps and scaled weights (DevParams::tsv / wst).  The sweeps
+// are generic in the instance type; where a loop-invariant Ts * W turns into a per-stage load they ask `IT::kGrid`, so the uniform-grid
+// kernels are compiled exactly as before.
+struct InstGrid : Inst { static constexpr bool kGrid = true; };
 
 __device__ __forceinline__ d4 load_tile3(const double* base, int lane) {  // rows 0..11
     d4 t;
@@ -320,8 +327,8 @@ struct BwdIn {
     double ks, mt;        // stored factors (only !FACTOR)
 };
 
-template <bool FACTOR, int LDS, bool STEP0 = false>
-__device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* gam, const double* rt) {
+template <bool FACTOR, int LDS, bool STEP0 = false, class IT = Inst>
+__device__ __forceinline__ BwdIn load_bwd(const IT& I, int i, const double* gam, const double* rt) {
     BwdIn s;
     s.ba = get_ba<LDS>(I, i);
     const int ig = I.i0 + i;   // HBM-resident operands are indexed by the global stage
@@ -345,6 +352,12 @@ __device__ __forceinline__ BwdIn load_bwd(const Inst& I, int i, const double* ga
     }
     s.ks = FACTOR ? 0.0 : I.Ks[(size_t)ig * 64 + I.lane];
     s.mt = 0.0;   // M rides in columns 12..15 of the stored gain operand
+    if constexpr (IT::kGrid && LDS != 0 && FACTOR) {
+        // general grid on the LDS-resident kernels: the stage's scaled weights ts_i * W (stage 0: W_0) for this lane's four rows,
+        // requested with the stage's other operands (the two fields are unused in LDS mode otherwise)
+        const double* ws = I.wst + (size_t)ig * 16 + I.rg;
+        s.yv[0] = ws[0]; s.yv[1] = ws[4]; s.yv[2] = ws[8]; s.mt = ws[12];
+    }
     return s;
 }
 
@@ -445,8 +458,8 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
 
 // hi / lo: the sweep runs over the stages hi-1 .. lo of the resident block (default: all I.N of them); explicit arguments, not fields of
 // Inst -- a horizon that changes under the compiler's eyes costs every sweep of the kernel its loop-invariant addressing
-template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false>
-__device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -1, int lo = 0) {
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false, class IT = Inst>
+__device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1, int lo = 0) {
     if constexpr (!FACTOR && LDS != 0) {
         bwd_solve_v<LDS>(I, S);
         return;
@@ -474,6 +487,10 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -
         for (int r = 0; r < 3; r++) qr[r] = LDS ? in.xv[r] : I.Ts * I.Wr[r] * (in.xv[r] - in.yv[r]);
         qr[3] = (!LDS && STEP0) ? I.Ts * I.Wr[3] * in.rtv : in.rtv;
         d4 dg = diagm;   // stage cost diagonal: loop-invariant ...
+        if constexpr (IT::kGrid && LDS != 0 && FACTOR) {   // ... except on a general grid
+            dg[0] = (rg == cl) ? in.yv[0] : 0.0; dg[1] = (rg + 4 == cl) ? in.yv[1] : 0.0; dg[2] = (rg + 8 == cl) ? in.yv[2] : 0.0;
+            dg[3] = (12 + rg == cl) ? in.mt : 0.0;
+        }
         if constexpr (!LDS) {
             // ... except on the streaming kernel's general grid (per-stage time steps / a separate stage-0 weight): the stage's scaled
             // weights come from DevParams::wst, loaded here -- a wave-uniform branch, taken only by solvers that use the feature
@@ -694,8 +711,8 @@ __device__ __forceinline__ void bwd_chunk(const Inst& I, BwdState& S, int hi = -
     }
 }
 
-template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false>
-__device__ bool riccati_backward(const Inst& I, bool* illc = nullptr) {
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false, class IT = Inst>
+__device__ bool riccati_backward(const IT& I, bool* illc = nullptr) {
     BwdState S;
     wave_fence();
     bwd_init<FACTOR, LDS>(I, S);
@@ -714,8 +731,8 @@ __device__ bool riccati_backward(const Inst& I, bool* illc = nullptr) {
 // adjoint sweep overwrites with the input gradient, are restored from the register copy taken at loop entry.  The K^T area of the
 // stages < ckpt = ceil(N / 4) is where the adjoint sweeps stage the multipliers: those stages are refactored in any case.
 // part = false: a full sweep (what riccati_backward<true, LDS> does).  ONE call site of the stage loop for both.
-template <int LDS>
-__device__ __forceinline__ bool riccati_backward_tries(const Inst& I, bool part, const double (&kff0)[2], bool& illc) {
+template <int LDS, class IT = Inst>
+__device__ __forceinline__ bool riccati_backward_tries(const IT& I, bool part, const double (&kff0)[2], bool& illc) {
     static_assert(LDS == 1 || LDS == 2, "fused kernels");
     wave_fence();
     BwdState S;
@@ -941,8 +958,9 @@ __device__ __forceinline__ AdjIn load_adj(const Inst& I, int i, const double* va
 // With COMMIT the multipliers pi are written to pi_out (the iterate).
 // LDS path: both outputs go to LDS regions that are dead at this point (g -> the feed-forward array, pi -> the K^T array,
 // 12 of its 48 doubles per stage); per-stage global stores would sit on vmcnt in front of every prefetch wait.
-struct AdjV { double m[4], dxc, qc, vm, rm; };
-__device__ __forceinline__ AdjV load_adj_v(const Inst& I, int om, int ox, int ou, int i) {
+struct AdjV { double m[4], dxc, qc, vm, rm, wq, wr; };
+template <class IT = Inst>
+__device__ __forceinline__ AdjV load_adj_v(const IT& I, int om, int ox, int ou, int i) {
     AdjV s;
     // column c of [A_i B_i], rows 4q..4q+3 (columns 0..2 are e_c: not stored)
     const lds_f64* col = I.lds_ba + i * kBaStage + om;
@@ -952,10 +970,15 @@ __device__ __forceinline__ AdjV load_adj_v(const Inst& I, int om, int ox, int ou
     s.qc = I.lds_q[(i + 1) * NX + ox];
     s.vm = I.lds_vhat[i * 4 + ou];
     s.rm = I.lds_r[i * 4 + ou];
+    s.wq = 0.0; s.wr = 0.0;
+    if constexpr (IT::kGrid) {   // general grid: scaled weights of node i + 1 (row NT = [We | 0]) and of the inputs of stage i
+        s.wq = I.wst[(size_t)(I.i0 + i + 1) * 16 + ox];
+        s.wr = I.wst[(size_t)(I.i0 + i) * 16 + 12 + ou];
+    }
     return s;
 }
-template <bool COMMIT, int LDS>
-__device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double* varr, double* garr, double* pi_out) {
+template <bool COMMIT, int LDS, class IT = Inst>
+__device__ __forceinline__ void adj_chunk(const IT& I, d4& atpi, const double* varr, double* garr, double* pi_out) {
     const int rg = I.rg, cl = I.cl, N = I.N;
     if constexpr (LDS) {
         // VALU form (see fwd_chunk): lane (c, q) = (lane >> 2, lane & 3) <-> column c of [A B], rows 4q..4q+3 (q < 3).
@@ -979,7 +1002,7 @@ __device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double*
         const double rd = I.Ts * I.Wuq;
         pipelined<kLdsDist<LDS>, AdjV>(N, [&](int kk) { return load_adj_v(I, om, ox, ou, N - 1 - kk); }, [&](int kk, const AdjV& in) {
             const int i = N - 1 - kk;
-            const double qd = (I.i0 + i + 1 == I.NT) ? I.Weq : I.Ts * I.Wq;
+            const double qd = IT::kGrid ? in.wq : ((I.i0 + i + 1 == I.NT) ? I.Weq : I.Ts * I.Wq);
             const double pic = fma(qd, in.dxc, in.qc + gq);
             ppark[i * pstr] = rowx ? pic : 0.0;
             const lds_f64* pr = I.lds_kt + i * NX + 4 * q3;
@@ -990,7 +1013,7 @@ __device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double*
             acc = fma(m1, p1, acc); acc = fma(m2, p2, acc); acc = fma(m3, p3, acc);
             acc = colx ? acc : 0.0;
             const double G = quad_sum(acc);
-            gpark[i * gstr] = rowx ? 0.0 : fma(rd, in.vm, in.rm + G);
+            gpark[i * gstr] = rowx ? 0.0 : fma(IT::kGrid ? in.wr : rd, in.vm, in.rm + G);
             gq = G;
         });
         // hand A'pi of this window's first stage on, row-replicated
@@ -1026,8 +1049,8 @@ __device__ __forceinline__ void adj_chunk(const Inst& I, d4& atpi, const double*
     pipelined<3, AdjIn>(N, [&](int k) { return load_adj<LDS>(I, N - 1 - k, varr); },
                         [&](int k, const AdjIn& in) { stage(N - 1 - k, in); });
 }
-template <bool COMMIT, int LDS>
-__device__ void adjoint(const Inst& I, const double* varr, double* garr, double* pi_out) {
+template <bool COMMIT, int LDS, class IT = Inst>
+__device__ void adjoint(const IT& I, const double* varr, double* garr, double* pi_out) {
     wave_fence();
     d4 atpi = {0, 0, 0, 0};  // A_{i+1}' pi_{i+1}, rows 0..11
     adj_chunk<COMMIT, LDS>(I, atpi, varr, garr, pi_out);
@@ -1264,8 +1287,8 @@ __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const 
         wave_fence();
     }
 }
-template <bool COMMIT, int LDS>
-__device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, double* garr, double* pi_out) {
+template <bool COMMIT, int LDS, class IT = Inst>
+__device__ __forceinline__ void sw_adjoint(IT& I, Win* W, const double* varr, double* garr, double* pi_out) {
     if constexpr (LDS < 3) {
         adjoint<COMMIT, LDS>(I, varr, garr, pi_out);
     } else {
@@ -1287,8 +1310,8 @@ __device__ __forceinline__ void sw_adjoint(Inst& I, Win* W, const double* varr, 
 // steps, inputs, input gradient and multipliers are all in LDS; the iterate rows and the reference of the window are requested
 // before the window is fetched and swept, so the step costs no exposed HBM round trip.  cost: this lane's share of the NLS
 // objective at the updated iterate; u0v: lanes 0..3 the new first input.
-template <bool RES, class Mid>
-__device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, Win& W, int b, const double* vfin, bool early,
+template <bool RES, class Mid, class IT = Inst>
+__device__ __forceinline__ void win_adjoint_commit(const DevParams& P, IT& I, Win& W, int b, const double* vfin, bool early,
                                                    double& cost, double& u0v, bool deliver_first, Mid&& mid) {
     const int lane = I.lane, NT = I.NT, L = W.Lc;
     const double* __restrict__ cst = P.cst;
@@ -1311,7 +1334,7 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
             const int j = lane + 64 * t, jj = j < nu ? j : 0;
             uo[t] = u_it[i0 * 4 + jj];
             ur[t] = I.yref[(size_t)(i0 + (jj >> 2)) * 16 + 12 + (jj & 3)];
-            wu[t] = cst[12 + (jj & 3)];
+            wu[t] = IT::kGrid ? I.wst[(size_t)(i0 + (jj >> 2)) * 16 + 12 + (jj & 3)] : P.Ts * cst[12 + (jj & 3)];   // scaled input weight of the stage
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -1319,7 +1342,7 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
             const int i = jj / 12, cc = jj - i * 12;
             xo[t] = x_it[i0 * 12 + jj];
             yr[t] = I.yref[(size_t)(i0 + i) * 16 + cc];
-            wx[t] = (i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc];
+            wx[t] = IT::kGrid ? I.wst[(size_t)(i0 + i) * 16 + cc] : ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc]);
         }
         auto adjoint_part = [&]() __attribute__((always_inline)) {
             win_need(I, W, c, WM_AB | WM_QR | WM_DX, vfin);
@@ -1341,7 +1364,7 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
                     u_it[i0 * 4 + j] = un;
                     if (i0 == 0 && j < 4) { P.res[b].u0[j] = un; u0v = un; }
                     const double e = un - ur[t];
-                    cost += 0.5 * P.Ts * wu[t] * e * e;
+                    cost += 0.5 * wu[t] * e * e;
                 }
             }
 #pragma unroll
@@ -1400,8 +1423,8 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, Inst& I, 
 // arrays); ROBUST: the Cholesky pivot form (kPivotRho); illc: an ill-conditioned pivot block was seen (fast form only)
 // part (windowed kernel): only window 0 is refactorised, from the checkpoint pass 1 left behind (the parked gains of the other windows are
 // the step-0 ones, and a try that pins inputs of window 0 only would recompute them bit for bit)
-template <bool FACTOR, int LDS, bool STEP0 = false, bool ROBUST = false>
-__device__ __forceinline__ bool sw_backward(Inst& I, Win* W, bool* illc = nullptr, bool part = false) {
+template <bool FACTOR, int LDS, bool STEP0 = false, bool ROBUST = false, class IT = Inst>
+__device__ __forceinline__ bool sw_backward(IT& I, Win* W, bool* illc = nullptr, bool part = false) {
     if constexpr (LDS < 3) {
         return riccati_backward<FACTOR, LDS, !STEP0, STEP0, ROBUST>(I, illc);
     } else {
@@ -1589,8 +1612,8 @@ __device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) { 
 // LDS = 0 streaming kernels, 1 / 2 fused kernels (whole horizon resident; element arrays in LDS / registers: EL), 3 windowed
 // kernel (sweeps on the resident window through the sw_* wrappers, element loops on the flat HBM arrays like LDS = 0; the
 // step-0 factorisation has already run, fused with the linearisation: pre_ok)
-template <int LDS>
-__device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, double lin_part, bool lin_nan, Win* W = nullptr,
+template <int LDS, class IT = Inst>
+__device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double lin_part, bool lin_nan, Win* W = nullptr,
                                         bool pre_ok = true, bool pre_illc = false) {
     constexpr bool EL = (LDS == 1 || LDS == 2);
     const double* __restrict__ cst = P.cst;
@@ -1781,6 +1804,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
             // ... per stage on the streaming kernel's general grid (time steps / stage-0 weight differ from stage to stage)
             auto rd_el = [&](unsigned j) __attribute__((always_inline)) -> double {
                 if constexpr (LDS == 0) return I.wst ? I.wst[(size_t)(j >> 2) * 16 + 12 + mI] : rdI;
+                else if constexpr (IT::kGrid) return I.wst[(size_t)(j >> 2) * 16 + 12 + mI];
                 else return rdI;
             };
             {   // first guess: the inputs of the Newton point that violate their bounds
@@ -2273,7 +2297,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         if (j < 4) { P.res[b].u0[j] = un; u0v = un; }
                         const double e = un - ur[t];
                         const double wgt = (LDS == 1 && j0 == lane) ? wupre[LDS == 1 ? t : 0] : cst[12 + m];
-                        const double sw = (LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + 12 + m] : P.Ts * wgt;
+                        const double sw = (IT::kGrid || (LDS == 0 && I.wst)) ? I.wst[(size_t)i * 16 + 12 + m] : P.Ts * wgt;
                         cost += 0.5 * sw * e * e;
                     }
                 }
@@ -2310,7 +2334,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
                         x_it[j] = xn;
                         const double e = xn - yr[t];
                         const double wgt = (LDS == 1 && j0 == lane) ? wxpre[LDS == 1 ? t : 0] : cst[(i == N) ? 16 + c : c];
-                        const double sw = (LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + c] : ((i == N) ? wgt : P.Ts * wgt);
+                        const double sw = (IT::kGrid || (LDS == 0 && I.wst)) ? I.wst[(size_t)i * 16 + c] : ((i == N) ? wgt : P.Ts * wgt);
                         cost += 0.5 * sw * e * e;
                     }
                 }
@@ -2328,13 +2352,13 @@ __device__ __forceinline__ void qp_body(const DevParams& P, Inst& I, int b, doub
         for (int j = lane; j < nv; j += 64) {
             const int i = j >> 2, m = j & 3;
             const double e = u_it[j] - I.yref[(size_t)i * 16 + 12 + m];
-            cost += 0.5 * ((LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + 12 + m] : P.Ts * cst[12 + m]) * e * e;
+            cost += 0.5 * ((IT::kGrid || (LDS == 0 && I.wst)) ? I.wst[(size_t)i * 16 + 12 + m] : P.Ts * cst[12 + m]) * e * e;
             if (restart) { u_it[j] = 0.0; lam_it[i * 8 + m] = 0.0; lam_it[i * 8 + 4 + m] = 0.0; }
         }
         for (int j = lane; j < nxe; j += 64) {
             const int i = j / 12, c = j - i * 12;
             const double e = x_it[j] - I.yref[(size_t)i * 16 + c];
-            cost += 0.5 * ((LDS == 0 && I.wst) ? I.wst[(size_t)i * 16 + c] : ((i == N) ? cst[16 + c] : P.Ts * cst[c])) * e * e;
+            cost += 0.5 * ((IT::kGrid || (LDS == 0 && I.wst)) ? I.wst[(size_t)i * 16 + c] : ((i == N) ? cst[16 + c] : P.Ts * cst[c])) * e * e;
             if (restart) { x_it[j] = x0[c]; if (i < N) pi_it[j] = 0.0; }
         }
     }
@@ -2749,7 +2773,7 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel_grid(DevParams P) { lin
 // are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
 // (interior-point) instance does not pin the LDS of three finished ones.
 constexpr int kFusedMaxN = 23;
-template <int W>
+template <int W, bool GRID = false>
 __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
@@ -2774,10 +2798,10 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     bool nanp = false;
     LaneCst lc;
     if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
-    lin_phase<W == 1>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
+    lin_phase<W == 1, GRID>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
-    Inst I;
+    std::conditional_t<GRID, InstGrid, Inst> I;
     setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr);
     // partial refactorisation of the active-set tries (riccati_backward_tries): checkpoint stage = ceil(N / 4); off for horizons too
     // short to gain from it and for instances the previous solve did not list as expensive
@@ -2820,6 +2844,8 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fus
 // Two waves per SIMD (256 VGPRs, some spilled): short horizons (N <= 13, at least six blocks per CU by LDS), where the
 // second wave fills the first one's MFMA / LDS / dependent-issue waits.
 __global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body<2>(P); }
+// General grid (per-stage time steps / a separate stage-0 weight), every N <= 23: one wave per SIMD
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel_grid(DevParams P) { rti_fused_body<1, true>(P); }
 
 // function attributes are per device (a process may hold solvers on several GPUs): one flag per (launcher, device)
 static bool first_launch_on_device(int which) {
@@ -2852,8 +2878,10 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
 // one instance per CU.  Nothing is parked and no window is fetched.  A separate instantiation (rti_window_kernel_res), so that the
 // large-batch kernel carries none of its code.
-template <bool RES>
+template <bool RES, bool GRID = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
+    static_assert(!(RES && GRID), "the resident mode has no general-grid instantiation (such solvers run on the streaming kernels)");
+    using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;       // (RES: four waves per block, see below)
     const int N = P.N, Lc = P.win_L, nc = (N + Lc - 1) / Lc;
@@ -2919,7 +2947,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
         // lin_phase (which needs the whole architectural register file)
         const LaneCst lc = load_lane_cst(P.cst, lane);
-        auto setup = [&](Inst& I) __attribute__((always_inline)) {
+        auto setup = [&](InstT& I) __attribute__((always_inline)) {
             setup_inst(P, I, b, lane, &lc);
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
             I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = ws_ck;
@@ -2966,7 +2994,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             if (c < nc - 1 && lane < NX) {
                 xq = P.x[((size_t)b * (N + 1) + i0 + n) * NX + lane];
                 yq = P.yref[(size_t)b * P.yref_stride + (size_t)(i0 + n) * NY + lane];
-                wq = P.cst[lane];
+                wq = GRID ? P.wst[(size_t)(i0 + n) * 16 + lane] : P.Ts * P.cst[lane];   // scaled state weight of stage i0 + n
             }
             __syncthreads();
             if (RES && trip == 0) {
@@ -2980,7 +3008,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                     part = fmax(part, v);
                 }
             } else if (!RES || n <= kLinMaxIntervals) {
-                lin_phase<true>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+                lin_phase<true, GRID>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
             } else {
                 // resident mode (one window = the whole horizon in a 160 KB slice, small batches): the wave-wide linearisation takes
                 // at most 23 intervals at a time -- sub-chunks, each into its own part of the slice (row n_j of a sub-chunk's q is
@@ -2993,11 +3021,11 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                     __syncthreads();
                 }
             }
-            if (c < nc - 1 && lane < NX) q_s[n * NX + lane] = P.Ts * wq * (xq - yq);
+            if (c < nc - 1 && lane < NX) q_s[n * NX + lane] = wq * (xq - yq);
             __syncthreads();
             if (P.dump_lin) copy_out_linearisation(P, b, i0, n, lane, ba_s, bv_s);
             const unsigned long long t1 = P.dbg ? __builtin_readcyclecounter() : 0;
-            Inst I;
+            InstT I;
             setup(I);
             win_select(I, W, c);
             if (c == nc - 1) bwd_init<true, 3>(I, S);
@@ -3015,7 +3043,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             if (P.dbg) { const unsigned long long t3 = __builtin_readcyclecounter(); t_lin += t1 - t0; t_bwd += t2 - t1; t_fl += t3 - t2; }
         }
         if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + 7] = (t_lin & 0xFFFFF) | ((t_bwd & 0xFFFFF) << 20) | ((t_fl & 0xFFFFF) << 40);
-        Inst I;
+        InstT I;
         setup(I);
         W.cur = -1;
         win_select(I, W, 0);
@@ -3033,6 +3061,8 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     }
 }
 __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_window_body<false>(P); }
+// the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
+__global__ __launch_bounds__(64, 1) void rti_window_kernel_grid(DevParams P) { rti_window_body<false, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
@@ -3073,6 +3103,7 @@ int windowed_blocks(int N, int B, int L) {
     if (first_launch_on_device(2)) {
         (void)hipFuncSetAttribute((const void*)rti_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     int dev = 0, cus = 256, per_cu = 4;
     (void)hipGetDevice(&dev);
@@ -3088,8 +3119,10 @@ int windowed_blocks(int N, int B, int L) {
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
     if (windowed_resident(P.win_L)) hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+    else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }
+bool windowed_is_resident(int win_L) { return windowed_resident(win_L); }
 
 
 static size_t fused_lds_bytes(int N) { return ((size_t)N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(N + 1) * NX + 2 + 17) * sizeof(double); }
@@ -3127,11 +3160,13 @@ void launch_fused(const DevParams& P, hipStream_t st) {
     if (first_launch_on_device(1)) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
     static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;
     const bool w2 = fused_two_wave(lds);
-    if (w2) hipLaunchKernelGGL(rti_fused_kernel_w2, dim3(P.B), dim3(64), lds + pad, st, P);
+    if (P.tsv) hipLaunchKernelGGL(rti_fused_kernel_grid, dim3(P.B), dim3(64), lds + pad, st, P);
+    else if (w2) hipLaunchKernelGGL(rti_fused_kernel_w2, dim3(P.B), dim3(64), lds + pad, st, P);
     else hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds + pad, st, P);
 }
 

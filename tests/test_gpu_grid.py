@@ -1,7 +1,7 @@
 """Boundary corners of the reference API on the GPU (SURVEY.md section 8 row b): non-uniform grids -- per-stage time steps as
 bluerov2_acados_create_with_discretization / bluerov2_acados_update_time_steps set them (c_generated_code/acados_solver_bluerov2.h:
-141,146; .c:111-131: ERK4 step AND cost scaling of stage i) -- and a separate stage-0 weight W_0 (.c:422-441).  Implemented by the
-streaming kernels; against the oracle on the same grid and against the independent recipe (reference CasADi model -> numpy
+141,146; .c:111-131: ERK4 step AND cost scaling of stage i) -- and a separate stage-0 weight W_0 (.c:422-441).  Round 4: on the
+LDS-resident kernels (fused, windowed) as well as on the streaming pair; against the oracle on the same grid and against the independent recipe (reference CasADi model -> numpy
 condensing -> scipy BVLS)."""
 import os
 import sys
@@ -33,15 +33,22 @@ def _inputs(golden_traj, B, seed):
     return x0, circ
 
 
-@pytest.mark.parametrize("N,grow,with_w0", [(20, 1.08, True), (40, 1.04, False), (80, 1.01, True), (7, 1.3, True)])
-def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_traj, N, grow, with_w0):
-    B = 48
+# (N, growth factor of the geometric grid, separate W_0, batch, kernel path asked for, kernel path that must run): round 4 runs general grids on
+# the LDS-resident kernels -- fused for N <= 23, windowed above for batches beyond one instance per CU; the windowed kernel's resident mode
+# (small batches at N > 23) and BROV_PATH_STREAMING keep the streaming pair
+GRID_CASES = [(20, 1.08, True, 48, 0, 2), (7, 1.3, True, 48, 0, 2), (13, 1.1, False, 300, 2, 2), (23, 1.05, True, 64, 0, 2),
+              (40, 1.04, False, 320, 0, 3), (80, 1.01, True, 320, 2, 3), (57, 1.02, True, 300, 0, 3),
+              (40, 1.04, False, 48, 0, 1), (80, 1.01, True, 48, 0, 1), (20, 1.08, True, 48, 1, 1)]
+
+
+@pytest.mark.parametrize("N,grow,with_w0,B,path,ran", GRID_CASES)
+def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_traj, N, grow, with_w0, B, path, ran):
     x0, circ = _inputs(golden_traj, B, seed=N)
     ts = (0.5 / N) * grow ** np.arange(N)
     rng = np.random.default_rng(N + 1)
     W0 = np.array(ba.SolverOptions(N).W) * rng.uniform(0.5, 2.0, 16) if with_w0 else None
     kw = dict(lbu=[-25.0] * 4, ubu=[25.0] * 4)
-    s = ba.BatchSolver(B, ba.SolverOptions(N, float(ts[0]), **kw))     # BROV_PATH_AUTO
+    s = ba.BatchSolver(B, ba.SolverOptions(N, float(ts[0]), kernel_path=path, **kw))
     s.set_time_steps(ts)
     if with_w0:
         s.set_stage0_weight(W0)
@@ -53,7 +60,7 @@ def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_
     for k in range(3):
         yref = circ[k:k + N + 1]
         s.set_yref(yref); s.solve()
-        assert s.last_kernel_path() == 1          # the streaming kernels implement the general grid
+        assert s.last_kernel_path() == ran
         res = s.results(); gx, gu, gpi, glam = s.get_iterate()
         _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
         kk = ro["kkt"]
@@ -117,14 +124,23 @@ def test_feature_gating(ba, golden_traj):
         assert s.last_kernel_path() == 2
         outs.append(s.get_iterate()[1].copy()); s.close()
     assert np.array_equal(outs[0], outs[1])
-    # BROV_PATH_FUSED cannot honour a general grid: refused, not silently ignored
+    # round 4: BROV_PATH_FUSED honours a general grid (rti_fused_kernel_grid) ...
     s = ba.BatchSolver(B, ba.SolverOptions(N, 0.05, kernel_path=ba.PATH_FUSED))
     s.set_time_steps(0.04 * 1.05 ** np.arange(N))
     s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1])
-    with pytest.raises(RuntimeError):
-        s.solve()
+    s.solve()
+    assert s.last_kernel_path() == 2 and s.lds_kernel_info()["kind"] == "fused"
     s.set_time_steps(None); s.solve()          # back to the uniform grid
     assert s.last_kernel_path() == 2
+    # ... except where the windowed kernel runs in its resident mode (at most one instance per CU at N > 23), which has no grid
+    # instantiation: refused under BROV_PATH_FUSED, not silently ignored (BROV_PATH_AUTO takes the streaming kernels there)
+    s2 = ba.BatchSolver(B, ba.SolverOptions(40, 0.025, kernel_path=ba.PATH_FUSED))
+    s2.set_time_steps(0.02 * 1.03 ** np.arange(40))
+    s2.set_x0(x0); s2.set_params(ba.P_NOMINAL); s2.set_yref(circ[:41])
+    with pytest.raises(RuntimeError):
+        s2.solve()
+    assert s2.lds_kernel_info()["kind"] == "streaming"
+    s2.close()
     with pytest.raises(RuntimeError):
         s.set_time_steps(np.array([0.05] * (N - 1) + [-0.01]))
     s.close()
