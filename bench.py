@@ -463,6 +463,47 @@ def configs_block(ba, args, device):
         note="solves_per_s includes one host wait per step (the selected record comes back to the host every step); solve_only = the same steps without gather / select")
     g.close()
 
+    # ---- configs[1] through the group entry points: what the one-process multi-GPU route costs the 0.155 ms step on the host side
+    # (one brov_group_solve + one ncclAllGather enqueue per step, no host wait inside the timed region)
+    B = BATCH_PER_GPU
+    x0, circ = synthetic_inputs(B, seed=1)
+    with quiet_c_stdout():
+        g = ba.SolverGroup([device], B, ba.SolverOptions(HORIZON, TS))
+    g.set_x0(x0); g.set_params(ba.P_NOMINAL)
+    sh = g.shards[0]
+    sh.set_trajectory(circ)
+    st = g.stream(0)
+    g.enable_timing(False)
+    sh.init_iterate_default()
+    dt_s = timed(lambda k: (sh.set_yref_from_trajectory(k, 16, stream=st), g.solve()))
+    g.synchronize(); sh.init_iterate_default()
+    dt_g = timed(lambda k: (sh.set_yref_from_trajectory(k, 16, stream=st), g.solve(), g.gather(ba.GATHER_RECORDS)))
+    g.synchronize(); sh.init_iterate_default()
+    dt_p = timed(lambda k: (sh.set_yref_from_trajectory(k, 16, stream=st), g.solve(), g.gather(ba.GATHER_PACKED)))
+    g.synchronize()
+    g.enable_timing(True)
+    sh.set_yref_from_trajectory(0, 16, stream=st); g.solve(); g.gather(ba.GATHER_RECORDS); g.synchronize()
+    tsec = g.last_seconds()
+    out["config2_group"] = dict(
+        workload="the headline workload (BASELINE.json configs[1], 4096 instances) through brov_group_* on one device",
+        solve_only_solves_per_s=B / dt_s, solve_only_ms_per_step=dt_s * 1e3, with_record_gather_solves_per_s=B / dt_g, with_record_gather_ms_per_step=dt_g * 1e3,
+        with_packed_gather_solves_per_s=B / dt_p, gather_ms=tsec["gather"] * 1e3, step_growth_with_record_gather=dt_g / dt_s - 1.0,
+        note="no host wait inside the timed region; the gather is one ncclAllGather per device on the device's stream behind the solve")
+    g.close()
+
+    # ---- a non-uniform grid (bluerov2_acados_create_with_discretization, acados_solver_bluerov2.c:111-131) at the headline size: since round 4
+    # on the LDS-resident kernels (rti_fused_kernel_grid), before on the streaming pair only
+    x0, circ = synthetic_inputs(B, seed=1)
+    grid = {}
+    for path, name in ((0, "lds_resident_kernel"), (1, "streaming_pair")):
+        s = ba.BatchSolver(B, ba.SolverOptions(HORIZON, TS, kernel_path=path), device=device)
+        s.set_time_steps(TS * 1.01 ** np.arange(HORIZON)); s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
+        dtg = timed(lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()))
+        grid[name] = dict(solves_per_s=B / dtg, ms_per_step=dtg * 1e3, kernel_path={1: "streaming", 2: "fused", 3: "windowed"}[s.last_kernel_path()],
+                          status_nonzero=int((s.results()["status"] != 0).sum()))
+        s.close()
+    out["general_grid_N20"] = dict(workload="headline workload on a geometric grid ts_i = 0.05 * 1.01^i (per-stage ERK4 step and cost scaling)", **grid)
+
     # ---- configs[4], one of its 8 shards: horizon sweep at 4096 instances, Ts = 1/N, with the LDS-occupancy crossover
     sweep = {}
     for N in (10, 20, 40, 80):
@@ -474,6 +515,8 @@ def configs_block(ba, args, device):
         lds = s.lds_kernel_info()
         leg.update(kernel_kind=lds["kind"], lds_bytes_per_instance=lds["lds_bytes_per_block"], instances_in_flight_per_cu=lds["blocks_per_cu"],
                    stage_solves_per_s=leg["solves_per_s"] * N, device_bytes=s.device_bytes)
+        if lds["kind"].startswith("fused, two"):
+            leg["kernel"] = "rti_fused_kernel_w2"
         leg["traffic"], leg["traffic_source"] = pmc_traffic(f"cfg5_N{N}", leg["kernel"])
         if leg["traffic"] is not None:
             leg["traffic_over_algorithmic"] = leg["traffic"] / (B * algorithmic_bytes(N, True))

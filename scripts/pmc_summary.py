@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-KEEP = ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel", "rti_fused_kernel_w2", "rti_window_kernel", "rti_window_kernel_res", "plant_kernel", "candidates_kernel",
+KEEP = ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel", "rti_fused_kernel_w2", "rti_fused_kernel_grid", "rti_window_kernel", "rti_window_kernel_grid", "rti_window_kernel_res", "plant_kernel", "candidates_kernel",
         "window_kernel", "ekf_update_kernel_dpp")
 
 

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun): bench lines of every config, rocprofv3 kernel-trace stats of the default bench command,
 # counter passes (HBM traffic, SQ, LDS) of the headline and of the long-horizon kernels, FETCH_SIZE/WRITE_SIZE calibration.
 # Outputs land in gpurun_out/prof_$1/ ; scripts/collect_profiles.py turns them into the committed summaries under profiles/.
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -21,6 +21,7 @@ $R/scripts/pmc_pass.sh $OUT/pmc_cfg2_N20
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80 --config 5 --horizon 80
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N40 --config 5 --horizon 40
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N10 --config 5 --horizon 10
+$R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N20 --config 5 --horizon 20
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_streaming --config 5 --horizon 80 --path 1
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg2_N20_forced_ipm --force-ipm
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_forced_ipm --config 5 --horizon 80 --force-ipm
@@ -29,6 +30,8 @@ $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_B64_resident --config 5 --horizon 80 --
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch -o f -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o w -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
+python $R/scripts/dev/phase_stamps.py 4096 20 1 0 > $OUT/phase_stamps_N20.txt 2>/dev/null
+python $R/scripts/dev/phase_stamps.py 4096 80 1 0 > $OUT/phase_stamps_N80.txt 2>/dev/null
 python $R/scripts/bench_ekf.py > $OUT/bench_ekf.json 2> $OUT/bench_ekf.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ekf -o stats -- python $R/scripts/bench_ekf.py --no-cpu-baseline > /dev/null 2> $OUT/stats_ekf.err
 python $R/scripts/bench_batch_sweep.py > $OUT/batch_sweep.log 2>&1
