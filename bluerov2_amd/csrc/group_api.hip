@@ -74,6 +74,7 @@ struct brov_group {
     std::vector<hipEvent_t> ev;           // 4 per device: solve start / end = gather start / gather end / select end
     int last_mode = -1;
     bool timing = true;
+    bool ev_sel = false;                  // the select-end event of the current step has been recorded
 };
 
 #define GHIP(call)                                                                          \
@@ -277,6 +278,7 @@ int brov_group_solve(brov_group* g) {
         if (g->timing) GHIP(hipEventRecord(g->ev[4 * d + 1], g->st[d]));
     }
     g->last_mode = -1;
+    g->ev_sel = false;
     return BROV_OK;
 }
 
@@ -334,7 +336,7 @@ int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
         GHIP(hipSetDevice(g->dev[0]));
         hipLaunchKernelGGL(group_select_kernel, dim3(1), dim3(256), 0, g->st[0], g->gathered[0], g->n * g->Bmax, g->best[0]);
         GHIP(hipGetLastError());
-        if (g->timing) GHIP(hipEventRecord(g->ev[3], g->st[0]));
+        if (g->timing) { GHIP(hipEventRecord(g->ev[3], g->st[0])); g->ev_sel = true; }
         int slot = -1;
         GHIP(hipMemcpyAsync(&slot, g->best[0], sizeof(int), hipMemcpyDeviceToHost, g->st[0]));
         if (int rc = brov_group_synchronize(g)) return rc;
@@ -343,7 +345,7 @@ int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
     } else {
         std::vector<double> pr(2 * (size_t)g->n);
         GHIP(hipSetDevice(g->dev[0]));
-        if (g->timing) GHIP(hipEventRecord(g->ev[3], g->st[0]));
+        if (g->timing) { GHIP(hipEventRecord(g->ev[3], g->st[0])); g->ev_sel = true; }
         GHIP(hipMemcpyAsync(pr.data(), g->pairs[0], pr.size() * sizeof(double), hipMemcpyDeviceToHost, g->st[0]));
         if (int rc = brov_group_synchronize(g)) return rc;
         int owner = -1;
@@ -384,10 +386,12 @@ int brov_group_last_seconds(brov_group* g, double* solve, double* gather, double
         if (a * 1e-3 > ts) ts = a * 1e-3;
         if (b * 1e-3 > tg) tg = b * 1e-3;
     }
-    if (g->last_mode >= 0 && hipEventQuery(g->ev[3]) == hipSuccess) {
-        float c = 0;
+    if (g->last_mode >= 0 && g->ev_sel) {   // (an event that was never recorded makes hipEventElapsedTime fail, and the failure would stay
+        float c = 0;                        // behind as the thread's "last error" for the next hipGetLastError of an unrelated call)
         GHIP(hipSetDevice(g->dev[0]));
-        if (hipEventElapsedTime(&c, g->ev[2], g->ev[3]) == hipSuccess) tsel = c * 1e-3;
+        GHIP(hipEventSynchronize(g->ev[3]));
+        GHIP(hipEventElapsedTime(&c, g->ev[2], g->ev[3]));
+        tsel = c * 1e-3;
     }
     if (solve) *solve = ts;
     if (gather) *gather = tg;

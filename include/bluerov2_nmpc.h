@@ -87,6 +87,9 @@ typedef struct brov_opts {
 
 #define BROV_PATH_WINDOWED 3  /* reported by brov_last_kernel_path only: the windowed flavour of BROV_PATH_FUSED / _AUTO (N >= 24) */
 
+/* Longest horizon.  The reference's create_with_discretization takes any N (acados_solver_bluerov2.c:734-783); here the QP loop keeps the
+ * 4 N inputs of an instance as 8 elements per lane of its wavefront (4 N <= 8 * 64), in every kernel family: 128 is structural, not a
+ * tuning choice.  (The reference ships N = 80; brov_create refuses N > 128 with BROV_ERR_ARG and the drop-in's create returns non-zero.) */
 #define BROV_MAX_N 128
 
 /* 104-byte per-instance result record; this is also the record all-gathered across GPUs ("optimal
@@ -221,7 +224,9 @@ int brov_debug_dump_linearisation(brov_solver* s, int enable);
  * new_time_steps[i].  brov_set_time_steps does the same for the whole batch (ts[N]; NULL or a uniform vector = the uniform grid
  * with brov_opts::Ts).  Separate stage-0 weight: the generated solver carries W_0 next to W (.c:422-441, same numbers as
  * shipped); brov_set_stage0_weight(W0[16]) gives stage 0 its own (NULL or W itself = one stage weight).
- * Either feature is implemented by the streaming kernels: BROV_PATH_AUTO selects them, BROV_PATH_FUSED is refused (BROV_ERR_ARG). */
+ * Round 4: either feature runs on the LDS-resident kernels (grid instantiations of the fused and of the windowed kernel) as well as on
+ * the streaming pair; only the windowed kernel's resident mode (batches of at most one instance per CU at N > 23) has none --
+ * BROV_PATH_AUTO takes the streaming kernels there, BROV_PATH_FUSED is refused (BROV_ERR_ARG). */
 int brov_set_time_steps(brov_solver* s, const double* ts /*[N] or NULL*/);
 int brov_set_stage0_weight(brov_solver* s, const double* W0 /*[16] or NULL*/);
 int brov_general_grid(const brov_solver* s);   /* 1 while either feature is in force */

@@ -85,4 +85,9 @@ def test_group_arguments_and_failed_instances_are_skipped(ba):
     g.gather(ba.GATHER_PACKED); idx2, _ = g.select_best()
     assert idx2 == idx
     assert ba.rccl_version() > 20000
+    # timing of a step WITHOUT a select (round 4 regression: an unrecorded event left an error behind that the next unrelated call reported)
+    g.solve(); g.gather(); g.synchronize()
+    t = g.last_seconds()
+    assert t["solve"] > 0 and t["select"] == 0.0
     g.close()
+    s = ba.BatchSolver(8, ba.SolverOptions(N, TS)); s.set_params(ba.P_NOMINAL); s.close()
