@@ -592,7 +592,9 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
 
                 // the relative pivots of the elimination (kPivotRho): four compares, off the chain
+#ifndef BROV_EXP_NO_WATCH
                 illc = illc | (detE < kPivotRho * (a00 * a11)) | (s00 < kPivotRho * a22) | (s11 < kPivotRho * a33) | (detS < kPivotRho * (s00 * s11));
+#endif
             }
             // Mtile: lane (rg = m, cl = n < 4) = M[m][n]; msel: the same element for every column n = cl & 3
             double mt = 0.0, msel;
@@ -1669,7 +1671,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
     constexpr bool PART = EL || LDS == 3;   // fused kernels: stage checkpoint (riccati_backward_tries); windowed kernel: window-0 checkpoint
     bool illc0 = pre_illc;
     bool split0 = false;
+#ifndef BROV_EXP_NO_SPLIT
     if constexpr (EL) split0 = I.ckpt > 0;   // set by the kernel body: only instances that ran the QP loop in the previous solve
+#endif
     if constexpr (EL) { if (split0) {
         // the step-0 factor sweep in two parts with the checkpoint between them.  Measured: inside the stage loop a wave-uniform
         // `if (i == ckpt)` with the six stores costs the loop 7 % (registers and scheduling, taken or not); the split sweep still
@@ -2805,7 +2809,11 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr);
     // partial refactorisation of the active-set tries (riccati_backward_tries): checkpoint stage = ceil(N / 4); off for horizons too
     // short to gain from it and for instances the previous solve did not list as expensive
+#ifndef BROV_EXP_NO_SPLIT
     I.ckpt = (N >= 8 && P.partial_refactor && listed) ? (N + 3) >> 2 : 0;
+#else
+    I.ckpt = 0; (void)listed;
+#endif
     I.lds_ba = (const lds_f64*)ba_s;
     I.lds_bv = (const lds_f64*)bv_s;
     I.lds_kt = (lds_f64*)kt_s;

@@ -45,6 +45,17 @@ def main(tag, rnd):
         lines = [ln for ln in open(sweep).read().splitlines() if ln.startswith("{")]
         if lines:
             json.dump(json.loads(lines[-1]), open(os.path.join(dst, f"{rnd}_batch_sweep.json"), "w"), indent=1)
+    # what the parity rules of the last full `pytest -m gpu` run checked and excused (tests/conftest.py session hook)
+    pe = os.path.join(ROOT, "gpurun_out", "parity_excused.json")
+    if os.path.exists(pe):
+        d = json.load(open(pe))
+        d["entries_with_excused"] = [{k: v for k, v in e.items() if k != "disagreements" or v} for e in d.get("entries_with_excused", [])][:40]
+        d["note"] = ("summary of gpurun_out/parity_excused.json: per rule, the number of rule calls, instances checked and instances excused in ONE run of "
+                     "`pytest tests -m gpu`; entries_with_excused lists the calls that excused anything (first 40)")
+        json.dump(d, open(os.path.join(dst, f"{rnd}_parity_excused.json"), "w"), indent=1)
+    for txt in ("phase_stamps_N20.txt", "phase_stamps_N80.txt"):
+        if os.path.exists(os.path.join(src, txt)):
+            shutil.copy(os.path.join(src, txt), os.path.join(dst, f"{rnd}_{txt}"))
     print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(rnd + "_")))
 
 
