@@ -789,16 +789,14 @@ def main(argv=None):
         side = torch.cuda.Stream(device=dev) if gather else None
 
         def run(s, tick, steps, warmup, timing, select):
-            """`steps` timed RTI steps.  With more than one rank every step's result records are all-gathered -- on a side stream,
-            from a staging copy, so that the collective of step k (one small latency-bound ring all-gather over xGMI) overlaps the solve
-            of step k + 1; the timed region ends when the last gather has landed on every rank."""
+            """`steps` timed RTI steps.  With more than one rank every step's result records are all-gathered (one small latency-bound
+            ring all-gather over xGMI) behind the solve; the timed region ends when the last gather has landed on every rank."""
             main = torch.cuda.current_stream()
             stream = main.cuda_stream
             res_view = D.records_tensor_from_solver(s) if gather else None
             stage = [torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
             gathered = [torch.empty(world * D.RECORD_BYTES * Bmax, dtype=torch.uint8, device=dev) for _ in range(2)] if gather else None
-            done = [None, None]
-            gev = []   # (before gather, after gather, after select) events on the side stream, one triple per timed step
+            gev = []   # (before gather, after gather, after select) events, one triple per timed step of the pass that times kernels
             if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
                 with torch.cuda.stream(side):
                     dist.all_gather_into_tensor(gathered[0], stage[0])
@@ -806,6 +804,18 @@ def main(argv=None):
             s.init_iterate_default()
             s.enable_timing(False)
             best = None
+            # The host side of a step must stay well below the 0.155 ms the GPU needs for it, or the ranks of a multi-GPU run wait for
+            # python: every event is created here, outside the steps, the per-step timing events exist only in the pass that times
+            # kernels (not in the pass that defines `value`), and the default route is the LEAN one: the all-gather is enqueued on the
+            # solve's own stream straight from the solver's record array (equal shards; a padded staging copy otherwise) -- one
+            # collective call per step, no side stream, no cross-stream events.  (Measured with one rank, forced gather: side-stream
+            # choreography with per-step events 0.202 ms per step, lean 0.16x; BROV_BENCH_GATHER=side selects the overlapped route.)
+            lean = os.environ.get("BROV_BENCH_GATHER", "lean") != "side"
+            direct = lean and B == Bmax                      # equal shards: gather from the record array itself
+            ready = [torch.cuda.Event() for _ in range(2)]
+            done = [torch.cuda.Event() for _ in range(2)]
+            used = [False, False]
+            tev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps)] if (gather and timing) else None
 
             def step(k):
                 nonlocal best
@@ -813,23 +823,31 @@ def main(argv=None):
                 s.solve(stream=stream)
                 if gather:
                     j = k & 1
-                    if done[j] is not None:
-                        main.wait_event(done[j])          # the gather that last read this staging buffer has finished
-                    stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    side.wait_event(ready)
-                    with torch.cuda.stream(side):
-                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
-                        e0.record(side)
-                        dist.all_gather_into_tensor(gathered[j], stage[j])
-                        e1.record(side)
+                    te = tev[k - warmup] if (tev is not None and k >= warmup) else None
+                    if lean:
+                        if not direct:
+                            stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
+                        if te: te[0].record(main)
+                        dist.all_gather_into_tensor(gathered[j], res_view if direct else stage[j])
+                        if te: te[1].record(main)
                         if select:
                             best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
-                        e2.record(side)
-                        if k >= warmup:
-                            gev.append((e0, e1, e2))
-                        done[j] = e2
+                        if te: te[2].record(main); gev.append(te)
+                        return
+                    if used[j]:
+                        main.wait_event(done[j])          # the gather that last read this staging buffer has finished
+                    stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
+                    ready[j].record(main)
+                    side.wait_event(ready[j])
+                    with torch.cuda.stream(side):
+                        if te: te[0].record(side)
+                        dist.all_gather_into_tensor(gathered[j], stage[j])
+                        if te: te[1].record(side)
+                        if select:
+                            best = D.select_best_device(gathered[j])
+                        if te: te[2].record(side); gev.append(te)
+                        done[j].record(side)
+                        used[j] = True
             for k in range(warmup):
                 step(k)
             s.enable_timing(timing)
@@ -869,7 +887,8 @@ def main(argv=None):
             dt, _, (_, _, info) = run(s, tick, K, W, False, select)
             n_bad = int((s.results()["status"] != 0).sum())
             # pass 2: same steps again with HIP events around each kernel for the roofline numbers
-            _, ksec, (gathered, best, _) = run(s, tick, K, W, True, select)
+            _, ksec, (gathered, best, info2) = run(s, tick, K, W, True, select)
+            info["gather_ms"], info["select_ms"] = info2.get("gather_ms"), info2.get("select_ms")   # per-step event pairs exist in this pass only
             res2 = s.results()
             legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, info=info, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
                              lds=s.lds_kernel_info(), shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
@@ -927,7 +946,7 @@ def main(argv=None):
                             "(qp_early_exit=1: exact equality-constrained shortcut when no bound is active)"),
                            "batch_per_gpu": B, "N": [l["N"] for l in legs] if len(legs) > 1 else N, "Ts": lg["Ts"] if len(legs) == 1 else "1/N",
                            "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
-                                           "records per step (side stream, overlapped with the next step's solve)") if world > 1 else "single GPU"},
+                                           "records per step, enqueued behind the solve on its stream") if world > 1 else "single GPU"},
                 "ranks_seen": ranks_seen,
                 "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
                 "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),
@@ -1022,10 +1041,11 @@ def main(argv=None):
 
     out = measure(args)
     default_run = args.config == 2 and args.scaling == "weak" and not args.force_ipm and not args.no_extra and not args.batch and not args.horizon
-    if default_run and world == 1 and rank == 0:
+    if default_run and world == 1 and rank == 0 and os.environ.get("BROV_BENCH_STRONG_LEGS") != "1":
         # BASELINE.json configs[2..4] in the SAME line the driver records (round 3 had them in builder-run side files only)
         out["configs"] = configs_block(ba, args, local_rank)
-    if default_run and world > 1:
+    # (BROV_BENCH_STRONG_LEGS=1: run the legs with one rank too -- the only way to exercise this path on a 1-GPU box; use with --force-gather)
+    if default_run and (world > 1 or os.environ.get("BROV_BENCH_STRONG_LEGS") == "1"):
         # a multi-GPU run of the default command also measures BASELINE configs[3] and configs[4] as they are stated: the config's
         # TOTAL split over the ranks (65 536 candidates / 32 768 sweep instances), gather + global arg-min every step
         for cfg in (4, 5):
