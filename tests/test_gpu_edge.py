@@ -352,3 +352,35 @@ def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mai
     if B >= 12:
         assert (ra["qp_iter"] > 0).any()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("N,B", [(80, 4), (20, 8), (40, 64)])
+def test_tick_followed_by_calls_on_another_stream_is_ordered(ba, golden_traj, N, B):
+    """brov_tick_host runs on the solver's own non-blocking stream and, for small batches, returns as soon as the
+    records are in the mailbox -- while the tail of its kernel (the last adjoint sweep, the multipliers) may still be running.  A
+    brov_solve / brov_plant_step / device setter that follows on ANOTHER stream (here: the null stream) must not overlap it (they
+    share the iterate, the work-ordering buffers, the hand-out counters): since round 4 every such call first waits for the stream
+    the solver used last.  The interleaved sequence tick, solve, plant_step, tick, solve ... must give the same bits as the same
+    sequence with a device-wide synchronisation after every call."""
+    import torch
+    x0, circ = _inputs(golden_traj, B, seed=33, big=2.0)
+    win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])
+    outs = []
+    for serial in (False, True):
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
+        s.set_params(ba.P_NOMINAL)
+        sync = (lambda: torch.cuda.synchronize()) if serial else (lambda: None)
+        rec = []
+        xk = x0.copy()
+        for k in range(6):
+            r = s.tick(x0=xk, yref=win[k:k + N + 1]); sync()
+            s.set_yref(win[k + 1:k + N + 2]); s.solve(); sync()          # null stream, straight behind the tick
+            s.plant_step(0.05, 1); sync()                                    # x0 <- plant(x0, u0) on the device, null stream
+            rec.append((r.copy(), s.results().copy()))
+            xk = s.get_x0()
+        rec.append(s.get_iterate())
+        outs.append(rec); s.close()
+    for (ra, sa), (rb, sb) in zip(outs[0][:-1], outs[1][:-1]):
+        assert ra.tobytes() == rb.tobytes() and sa.tobytes() == sb.tobytes()
+    for ia, ib in zip(outs[0][-1], outs[1][-1]):
+        assert np.array_equal(ia, ib)
