@@ -8,7 +8,7 @@ from .solver import (BatchSolver, SolverOptions, RESULT_DTYPE, P_NOMINAL, build_
                      NoDeviceError, thrust_allocation, PATH_AUTO, PATH_STREAMING, PATH_FUSED, PATH_WINDOWED)
 
 from .ekf import BatchEkf, EkfParams  # noqa: F401,E402
-from .group import SolverGroup, GATHER_RECORDS, GATHER_PACKED, rccl_version  # noqa: F401,E402
+from .group import SolverGroup, GATHER_RECORDS, GATHER_PACKED, rccl_version, unique_id  # noqa: F401,E402
 
-__all__ = ["SolverGroup", "GATHER_RECORDS", "GATHER_PACKED", "rccl_version", "BatchEkf", "EkfParams", "BatchSolver", "SolverOptions", "RESULT_DTYPE", "P_NOMINAL", "build_library", "library_path",
+__all__ = ["SolverGroup", "GATHER_RECORDS", "GATHER_PACKED", "rccl_version", "unique_id", "BatchEkf", "EkfParams", "BatchSolver", "SolverOptions", "RESULT_DTYPE", "P_NOMINAL", "build_library", "library_path",
            "NoDeviceError", "thrust_allocation", "PATH_AUTO", "PATH_STREAMING", "PATH_FUSED", "PATH_WINDOWED"]

@@ -34,6 +34,8 @@ namespace {
 struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -52,7 +54,7 @@ Rccl& rccl() {
     }
     if (!r.handle) { r.why = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
 #define SYM(field, name) r.field = (decltype(r.field))dlsym(r.handle, name); if (!r.field) { r.why = std::string("RCCL symbol missing: ") + name; r.handle = nullptr; return r; }
-    SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
+    SYM(CommInitAll, "ncclCommInitAll") SYM(CommInitRank, "ncclCommInitRank") SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetVersion, "ncclGetVersion") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     return r;
@@ -61,7 +63,9 @@ Rccl& rccl() {
 }  // namespace
 
 struct brov_group {
-    int n = 0, total = 0, Bmax = 0;
+    // n = devices of THIS process; W = ranks of the whole group (= n for the one-process form; one process per GPU: n = 1, W = world),
+    // r0 = global rank of local device 0.  lo / cnt are indexed by GLOBAL rank; everything else by local device.
+    int n = 0, W = 0, r0 = 0, total = 0, Bmax = 0;
     bool even = true;                     // all shards equally large: the records are gathered straight from the solvers' own arrays
     std::vector<int> dev, lo, cnt;
     std::vector<brov_solver*> sol;
@@ -173,8 +177,9 @@ void brov_group_destroy(brov_group* g) {
     delete g;
 }
 
-int brov_group_create(brov_group** out, const int* devices, int n, int total, const brov_opts* opts) {
-    if (!out || !devices || !opts || n < 1 || n > 64 || total < n) { g_gerr = "brov_group_create: bad argument (1 <= n <= 64 devices, at least one instance each)"; return BROV_ERR_ARG; }
+// common part of the two creators: local devices dev[0..n), global ranks r0 .. r0 + n - 1 of W, instances per global rank in cnt[W]
+static int group_build(brov_group** out, const int* devices, int n, int W, int r0, const std::vector<int>& cnt, const brov_opts* opts,
+                       const ncclUniqueId* id) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_gerr = "brov_group_create: no usable HIP device (this library has no CPU fallback)"; return BROV_ERR_NO_DEVICE; }
     for (int d = 0; d < n; d++) {
@@ -185,49 +190,84 @@ int brov_group_create(brov_group** out, const int* devices, int n, int total, co
     Rccl& R = rccl();
     if (!R.handle) { g_gerr = "brov_group_create: " + R.why; return BROV_ERR_HIP; }
     brov_group* g = new brov_group();
-    g->n = n; g->total = total;
+    g->n = n; g->W = W; g->r0 = r0;
     g->dev.assign(devices, devices + n);
-    g->lo.resize(n); g->cnt.resize(n);
-    const int base = total / n, rem = total % n;
-    for (int d = 0; d < n; d++) {
-        g->lo[d] = d * base + (d < rem ? d : rem);
-        g->cnt[d] = base + (d < rem ? 1 : 0);
-        if (g->cnt[d] > g->Bmax) g->Bmax = g->cnt[d];
+    g->cnt = cnt; g->lo.assign(W, 0);
+    g->even = true;
+    for (int r = 0; r < W; r++) {
+        g->lo[r] = r ? g->lo[r - 1] + g->cnt[r - 1] : 0;
+        if (g->cnt[r] > g->Bmax) g->Bmax = g->cnt[r];
+        g->even = g->even && g->cnt[r] == g->cnt[0];
     }
-    g->even = rem == 0;
+    g->total = g->lo[W - 1] + g->cnt[W - 1];
     g->sol.assign(n, nullptr); g->st.assign(n, nullptr); g->comm.assign(n, nullptr);
     g->stage.assign(n, nullptr); g->gathered.assign(n, nullptr); g->pair.assign(n, nullptr); g->pairs.assign(n, nullptr);
     g->best.assign(n, nullptr); g->ev.assign(4 * (size_t)n, nullptr);
     auto fail = [&](int rc) { brov_group_destroy(g); return rc; };
     for (int d = 0; d < n; d++) {
         if (hipSetDevice(g->dev[d]) != hipSuccess) { g_gerr = "brov_group_create: hipSetDevice failed"; return fail(BROV_ERR_HIP); }
-        const int rc = brov_create(&g->sol[d], g->dev[d], g->cnt[d], opts);
-        if (rc != BROV_OK) { g_gerr = std::string("brov_group_create: shard ") + std::to_string(d) + ": " + brov_last_error(); return fail(rc); }
+        const int rc = brov_create(&g->sol[d], g->dev[d], g->cnt[r0 + d], opts);
+        if (rc != BROV_OK) { g_gerr = std::string("brov_group_create: shard ") + std::to_string(r0 + d) + ": " + brov_last_error(); return fail(rc); }
         bool ok = hipStreamCreateWithFlags(&g->st[d], hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipMalloc((void**)&g->gathered[d], (size_t)n * g->Bmax * sizeof(brov_result)) == hipSuccess;
-        ok = ok && hipMalloc((void**)&g->pair[d], (2 + 2 * (size_t)n) * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&g->gathered[d], (size_t)W * g->Bmax * sizeof(brov_result)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&g->pair[d], (2 + 2 * (size_t)W) * sizeof(double)) == hipSuccess;
         ok = ok && hipMalloc((void**)&g->best[d], 2 * sizeof(int)) == hipSuccess;
         if (ok && !g->even) {
             ok = hipMalloc((void**)&g->stage[d], (size_t)g->Bmax * sizeof(brov_result)) == hipSuccess;
-            // padding records: status -1, cost NaN -- never selectable; only the first cnt[d] slots are ever rewritten
+            // padding records: status -1, cost NaN -- never selectable; only the first cnt slots are ever rewritten
             ok = ok && hipMemset(g->stage[d], 0xFF, (size_t)g->Bmax * sizeof(brov_result)) == hipSuccess;
         }
         for (int k = 0; k < 4 && ok; k++) ok = hipEventCreate(&g->ev[4 * d + k]) == hipSuccess;
         if (!ok) { g_gerr = "brov_group_create: allocation of the gather buffers failed"; return fail(BROV_ERR_ALLOC); }
         g->pairs[d] = g->pair[d] + 2;
     }
-    const ncclResult_t nr = R.CommInitAll(g->comm.data(), n, g->dev.data());
-    if (nr != ncclSuccess) { g_gerr = std::string("brov_group_create: ncclCommInitAll: ") + R.GetErrorString(nr); return fail(BROV_ERR_HIP); }
+    ncclResult_t nr;
+    if (id) {   // one process per GPU: this process is rank r0 of W
+        if (hipSetDevice(g->dev[0]) != hipSuccess) { g_gerr = "brov_group_create_rank: hipSetDevice failed"; return fail(BROV_ERR_HIP); }
+        nr = R.CommInitRank(&g->comm[0], W, *id, r0);
+    } else {
+        nr = R.CommInitAll(g->comm.data(), n, g->dev.data());
+    }
+    if (nr != ncclSuccess) { g_gerr = std::string("brov_group_create: RCCL communicator set-up: ") + R.GetErrorString(nr); return fail(BROV_ERR_HIP); }
     *out = g;
     return BROV_OK;
 }
 
-int brov_group_size(const brov_group* g) { return g ? g->n : 0; }
+int brov_group_create(brov_group** out, const int* devices, int n, int total, const brov_opts* opts) {
+    if (!out || !devices || !opts || n < 1 || n > 64 || total < n) { g_gerr = "brov_group_create: bad argument (1 <= n <= 64 devices, at least one instance each)"; return BROV_ERR_ARG; }
+    std::vector<int> cnt(n);
+    for (int d = 0; d < n; d++) cnt[d] = total / n + (d < total % n ? 1 : 0);
+    return group_build(out, devices, n, n, 0, cnt, opts, nullptr);
+}
+
+// ---- one process per GPU: the same group, each process holding ONE rank of it ----------------------------------------------------
+int brov_group_unique_id(char id[128]) {
+    Rccl& R = rccl();
+    if (!R.handle) { g_gerr = R.why; return BROV_ERR_HIP; }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    if (!id || R.GetUniqueId(&u) != ncclSuccess) { g_gerr = "ncclGetUniqueId failed"; return BROV_ERR_HIP; }
+    std::memcpy(id, &u, 128);
+    return BROV_OK;
+}
+int brov_group_create_rank(brov_group** out, int device, int rank, int world, const char id[128], const int* counts, const brov_opts* opts) {
+    if (!out || !id || !counts || !opts || world < 1 || rank < 0 || rank >= world) { g_gerr = "brov_group_create_rank: bad argument"; return BROV_ERR_ARG; }
+    std::vector<int> cnt(counts, counts + world);
+    for (int r = 0; r < world; r++)
+        if (cnt[r] < 1) { g_gerr = "brov_group_create_rank: every rank needs at least one instance"; return BROV_ERR_ARG; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    return group_build(out, &device, 1, world, rank, cnt, opts, &u);
+}
+
+int brov_group_size(const brov_group* g) { return g ? g->n : 0; }          /* devices of this process */
+int brov_group_world(const brov_group* g) { return g ? g->W : 0; }         /* ranks of the whole group */
+int brov_group_first_rank(const brov_group* g) { return g ? g->r0 : 0; }
 int brov_group_total(const brov_group* g) { return g ? g->total : 0; }
 brov_solver* brov_group_solver(brov_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->sol[rank] : nullptr; }
 void* brov_group_stream(brov_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? (void*)g->st[rank] : nullptr; }
 int brov_group_shard(const brov_group* g, int rank, int* lo, int* hi) {
-    if (!g || rank < 0 || rank >= g->n) return BROV_ERR_ARG;
+    if (!g || rank < 0 || rank >= g->W) return BROV_ERR_ARG;   /* GLOBAL rank */
     if (lo) *lo = g->lo[rank];
     if (hi) *hi = g->lo[rank] + g->cnt[rank];
     return BROV_OK;
@@ -237,27 +277,27 @@ int brov_group_shard(const brov_group* g, int rank, int* lo, int* hi) {
 int brov_group_set_x0_host(brov_group* g, const double* x0) {
     if (!g || !x0) return BROV_ERR_ARG;
     for (int d = 0; d < g->n; d++)
-        if (int rc = brov_set_x0_host(g->sol[d], x0 + (size_t)g->lo[d] * 12)) { g_gerr = brov_last_error(); return rc; }
+        if (int rc = brov_set_x0_host(g->sol[d], x0 + (size_t)g->lo[g->r0 + d] * 12)) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
 }
 int brov_group_set_params_host(brov_group* g, const double* p, int per_stage) {
     if (!g || !p) return BROV_ERR_ARG;
     const size_t row = per_stage ? (size_t)(brov_horizon(g->sol[0]) + 1) * 16 : 16;
     for (int d = 0; d < g->n; d++)
-        if (int rc = brov_set_params_host(g->sol[d], p + (size_t)g->lo[d] * row, per_stage)) { g_gerr = brov_last_error(); return rc; }
+        if (int rc = brov_set_params_host(g->sol[d], p + (size_t)g->lo[g->r0 + d] * row, per_stage)) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
 }
 int brov_group_set_yref_host(brov_group* g, const double* yref, int shared) {
     if (!g || !yref) return BROV_ERR_ARG;
     const size_t row = (size_t)(brov_horizon(g->sol[0]) + 1) * 16;
     for (int d = 0; d < g->n; d++)
-        if (int rc = brov_set_yref_host(g->sol[d], shared ? yref : yref + (size_t)g->lo[d] * row, shared)) { g_gerr = brov_last_error(); return rc; }
+        if (int rc = brov_set_yref_host(g->sol[d], shared ? yref : yref + (size_t)g->lo[g->r0 + d] * row, shared)) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
 }
 int brov_group_set_candidate_params_host(brov_group* g, int kind, const double* p0, const double* p1, const double* phase) {
     if (!g || !p0 || !p1 || !phase) return BROV_ERR_ARG;
     for (int d = 0; d < g->n; d++)
-        if (int rc = brov_set_candidate_params_host(g->sol[d], kind, p0 + g->lo[d], p1 + g->lo[d], phase + g->lo[d])) { g_gerr = brov_last_error(); return rc; }
+        if (int rc = brov_set_candidate_params_host(g->sol[d], kind, p0 + g->lo[g->r0 + d], p1 + g->lo[g->r0 + d], phase + g->lo[g->r0 + d])) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
 }
 int brov_group_set_yref_candidates(brov_group* g, double t0, double dt) {   // one window kernel per device, on the device's stream
@@ -291,9 +331,9 @@ int brov_group_gather(brov_group* g, int mode) {
         GHIP(hipSetDevice(g->dev[d]));
         // (timing: the solve's end event doubles as the gather's start)
         if (mode == BROV_GATHER_RECORDS) {
-            if (!g->even) GHIP(hipMemcpyAsync(g->stage[d], brov_results_device(g->sol[d]), (size_t)g->cnt[d] * rec, hipMemcpyDeviceToDevice, g->st[d]));
+            if (!g->even) GHIP(hipMemcpyAsync(g->stage[d], brov_results_device(g->sol[d]), (size_t)g->cnt[g->r0 + d] * rec, hipMemcpyDeviceToDevice, g->st[d]));
         } else {
-            hipLaunchKernelGGL(group_pack_kernel, dim3(1), dim3(256), 0, g->st[d], brov_results_device(g->sol[d]), g->cnt[d], g->lo[d], g->pair[d]);
+            hipLaunchKernelGGL(group_pack_kernel, dim3(1), dim3(256), 0, g->st[d], brov_results_device(g->sol[d]), g->cnt[g->r0 + d], g->lo[g->r0 + d], g->pair[d]);
             GHIP(hipGetLastError());
         }
     }
@@ -324,7 +364,7 @@ int brov_group_synchronize(brov_group* g) {
 static int slot_to_global(const brov_group* g, int slot) {
     if (slot < 0) return -1;
     const int r = slot / g->Bmax, i = slot % g->Bmax;
-    return (r < g->n && i < g->cnt[r]) ? g->lo[r] + i : -1;
+    return (r < g->W && i < g->cnt[r]) ? g->lo[r] + i : -1;
 }
 
 int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
@@ -334,7 +374,7 @@ int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
     if (g->last_mode == BROV_GATHER_RECORDS) {
         // every device holds all records: device 0 selects (any would do), the others only finish their gather
         GHIP(hipSetDevice(g->dev[0]));
-        hipLaunchKernelGGL(group_select_kernel, dim3(1), dim3(256), 0, g->st[0], g->gathered[0], g->n * g->Bmax, g->best[0]);
+        hipLaunchKernelGGL(group_select_kernel, dim3(1), dim3(256), 0, g->st[0], g->gathered[0], g->W * g->Bmax, g->best[0]);
         GHIP(hipGetLastError());
         if (g->timing) { GHIP(hipEventRecord(g->ev[3], g->st[0])); g->ev_sel = true; }
         int slot = -1;
@@ -343,19 +383,25 @@ int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
         *best_index = slot_to_global(g, slot);
         if (best && slot >= 0) { GHIP(hipSetDevice(g->dev[0])); GHIP(hipMemcpy(best, g->gathered[0] + slot, sizeof(brov_result), hipMemcpyDeviceToHost)); }
     } else {
-        std::vector<double> pr(2 * (size_t)g->n);
+        std::vector<double> pr(2 * (size_t)g->W);
         GHIP(hipSetDevice(g->dev[0]));
         if (g->timing) { GHIP(hipEventRecord(g->ev[3], g->st[0])); g->ev_sel = true; }
         GHIP(hipMemcpyAsync(pr.data(), g->pairs[0], pr.size() * sizeof(double), hipMemcpyDeviceToHost, g->st[0]));
         if (int rc = brov_group_synchronize(g)) return rc;
         int owner = -1;
-        for (int d = 0; d < g->n; d++)   // shards hold ascending index ranges: the first minimal cost is the lowest index
-            if (pr[2 * d + 1] >= 0.0 && (owner < 0 || pr[2 * d] < pr[2 * owner])) owner = d;
+        for (int r = 0; r < g->W; r++)   // shards hold ascending index ranges: the first minimal cost is the lowest index
+            if (pr[2 * r + 1] >= 0.0 && (owner < 0 || pr[2 * r] < pr[2 * owner])) owner = r;
         if (owner >= 0) {
             *best_index = (int)pr[2 * owner + 1];
             if (best) {
-                GHIP(hipSetDevice(g->dev[owner]));
-                GHIP(hipMemcpy(best, brov_results_device(g->sol[owner]) + (*best_index - g->lo[owner]), sizeof(brov_result), hipMemcpyDeviceToHost));
+                std::memset(best, 0, sizeof(*best));
+                const int d = owner - g->r0;
+                if (d >= 0 && d < g->n) {   // the winner lives in this process: its whole record
+                    GHIP(hipSetDevice(g->dev[d]));
+                    GHIP(hipMemcpy(best, brov_results_device(g->sol[d]) + (*best_index - g->lo[owner]), sizeof(brov_result), hipMemcpyDeviceToHost));
+                } else {                    // ... in another process (one process per GPU): the pair carries its cost only
+                    best->cost = pr[2 * owner]; best->status = BROV_STATUS_SUCCESS;
+                }
             }
         }
     }
@@ -367,8 +413,8 @@ int brov_group_get_results_host(brov_group* g, brov_result* res) {
     if (g->last_mode != BROV_GATHER_RECORDS) { g_gerr = "brov_group_get_results_host: needs a BROV_GATHER_RECORDS gather"; return BROV_ERR_ARG; }
     if (int rc = brov_group_synchronize(g)) return rc;
     GHIP(hipSetDevice(g->dev[0]));
-    for (int d = 0; d < g->n; d++)   // strip the padding slots of uneven shards
-        GHIP(hipMemcpy(res + g->lo[d], g->gathered[0] + (size_t)d * g->Bmax, (size_t)g->cnt[d] * sizeof(brov_result), hipMemcpyDeviceToHost));
+    for (int r = 0; r < g->W; r++)   // strip the padding slots of uneven shards
+        GHIP(hipMemcpy(res + g->lo[r], g->gathered[0] + (size_t)r * g->Bmax, (size_t)g->cnt[r] * sizeof(brov_result), hipMemcpyDeviceToHost));
     return BROV_OK;
 }
 const brov_result* brov_group_gathered_device(const brov_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->gathered[rank] : nullptr; }

@@ -27,7 +27,11 @@ def _lib():
         L.brov_group_stream.restype = vp
         L.brov_group_gathered_device.argtypes = [vp, C.c_int]
         L.brov_group_gathered_device.restype = vp
-        for name, args in {"brov_group_rccl_version": [ip], "brov_group_size": [vp], "brov_group_total": [vp], "brov_group_shard": [vp, C.c_int, ip, ip],
+        L.brov_group_unique_id.argtypes = [C.c_char_p]
+        L.brov_group_unique_id.restype = C.c_int
+        L.brov_group_create_rank.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_char_p, ip, vp]
+        L.brov_group_create_rank.restype = C.c_int
+        for name, args in {"brov_group_world": [vp], "brov_group_first_rank": [vp], "brov_group_rccl_version": [ip], "brov_group_size": [vp], "brov_group_total": [vp], "brov_group_shard": [vp, C.c_int, ip, ip],
                            "brov_group_set_x0_host": [vp, dp], "brov_group_set_params_host": [vp, dp, C.c_int],
                            "brov_group_set_yref_host": [vp, dp, C.c_int], "brov_group_set_candidate_params_host": [vp, C.c_int, dp, dp, dp],
                            "brov_group_set_yref_candidates": [vp, C.c_double, C.c_double], "brov_group_solve": [vp], "brov_group_gather": [vp, C.c_int],
@@ -63,26 +67,50 @@ class _Shard(BatchSolver):
     __del__ = close
 
 
+def unique_id():
+    """128 opaque bytes (ncclGetUniqueId): rank 0 of a one-process-per-GPU group creates them, every rank needs them"""
+    L = _lib()
+    buf = C.create_string_buffer(128)
+    if L.brov_group_unique_id(buf) != 0:
+        raise RuntimeError(L.brov_group_last_error().decode())
+    return buf.raw
+
+
 class SolverGroup:
-    def __init__(self, devices, total, opts=None):
+    """devices + total: ONE process holds every device of the group.  rank= / world= / uid= / counts= (with devices = [this process's
+    device]): one process per GPU, this process holds rank `rank` of `world` (uid: unique_id() of rank 0, handed to every rank by the
+    launcher).  The whole-batch setters take GLOBAL arrays in both forms (every process uses the slice of its own shard);
+    `shards[0]` is the local shard's solver for everything else."""
+
+    def __init__(self, devices, total=None, opts=None, rank=None, world=None, uid=None, counts=None):
         L = _lib()
         self.opts = opts if opts is not None else SolverOptions()
         self.devices = [int(d) for d in devices]
-        self.total, self.N = int(total), int(self.opts.N)
-        arr = (C.c_int * len(self.devices))(*self.devices)
+        self.N = int(self.opts.N)
         h = C.c_void_p()
-        rc = L.brov_group_create(C.byref(h), arr, len(self.devices), self.total, C.byref(self.opts._o))
+        if rank is None:
+            self.total = int(total)
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            rc = L.brov_group_create(C.byref(h), arr, len(self.devices), self.total, C.byref(self.opts._o))
+        else:
+            cnt = (C.c_int * int(world))(*[int(c) for c in counts])
+            rc = L.brov_group_create_rank(C.byref(h), self.devices[0], int(rank), int(world), C.c_char_p(bytes(uid)), cnt, C.byref(self.opts._o))
+            self.total = int(sum(counts))
         if rc == -2:
             raise NoDeviceError(L.brov_group_last_error().decode() or "no HIP device")
         if rc != 0:
             raise RuntimeError(f"brov_group_create failed ({rc}): {L.brov_group_last_error().decode()}")
         self._h, self._L = h, L
-        self.shards, self.bounds = [], []
-        for r in range(len(self.devices)):
+        self.world, self.first_rank = int(L.brov_group_world(h)), int(L.brov_group_first_rank(h))
+        self.bounds = []
+        for r in range(self.world):
             lo, hi = C.c_int(0), C.c_int(0)
             L.brov_group_shard(h, r, C.byref(lo), C.byref(hi))
             self.bounds.append((lo.value, hi.value))
-            self.shards.append(_Shard(L.brov_group_solver(h, r), hi.value - lo.value, self.opts, self.devices[r], L))
+        self.shards = []
+        for d in range(len(self.devices)):
+            lo, hi = self.bounds[self.first_rank + d]
+            self.shards.append(_Shard(L.brov_group_solver(h, d), hi - lo, self.opts, self.devices[d], L))
 
     def close(self):
         if getattr(self, "_h", None):

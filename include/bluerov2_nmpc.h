@@ -270,14 +270,23 @@ typedef struct brov_group brov_group;
 #define BROV_GATHER_RECORDS 0
 #define BROV_GATHER_PACKED 1
 int  brov_group_create(brov_group** out, const int* devices /*[n] distinct HIP ordinals*/, int n, int total_instances, const brov_opts* opts);
+/* The same group with ONE PROCESS PER GPU (the launcher's route, e.g. torchrun): every process creates its rank of the group on its own
+ * device.  Rank 0 calls brov_group_unique_id and hands the 128 bytes to the other ranks by whatever means the launcher has (a file, MPI,
+ * torch.distributed.broadcast); counts[world] = instances per rank.  All entry points below then act on the local shard, the gather
+ * spans all ranks; brov_group_select_best returns the global index everywhere and the full record where the winner is local or the
+ * 104-byte records were gathered (with BROV_GATHER_PACKED and a remote winner: cost and status only). */
+int  brov_group_unique_id(char id[128]);
+int  brov_group_create_rank(brov_group** out, int device, int rank, int world, const char id[128], const int* counts /*[world]*/, const brov_opts* opts);
 void brov_group_destroy(brov_group* g);
 const char* brov_group_last_error(void);
 int  brov_group_rccl_version(int* version);          /* loads RCCL if need be; BROV_ERR_HIP when it cannot be loaded */
-int  brov_group_size(const brov_group* g);
+int  brov_group_size(const brov_group* g);           /* devices held by THIS process (local indices 0 .. size-1 address solver / stream below) */
+int  brov_group_world(const brov_group* g);          /* ranks of the whole group (= size in the one-process form) */
+int  brov_group_first_rank(const brov_group* g);     /* global rank of local device 0 */
 int  brov_group_total(const brov_group* g);
-int  brov_group_shard(const brov_group* g, int rank, int* lo, int* hi);   /* global instance range [lo, hi) of shard `rank` */
-brov_solver* brov_group_solver(brov_group* g, int rank);
-void* brov_group_stream(brov_group* g, int rank);    /* hipStream_t of shard `rank` */
+int  brov_group_shard(const brov_group* g, int rank, int* lo, int* hi);   /* global instance range [lo, hi) of GLOBAL rank `rank` */
+brov_solver* brov_group_solver(brov_group* g, int local);   /* shard handle of local device `local` */
+void* brov_group_stream(brov_group* g, int local);    /* its hipStream_t */
 int brov_group_set_x0_host(brov_group* g, const double* x0 /*[total][12]*/);
 int brov_group_set_params_host(brov_group* g, const double* p /*[total][16] or [total][N+1][16]*/, int per_stage);
 int brov_group_set_yref_host(brov_group* g, const double* yref /*shared [N+1][16] or [total][N+1][16]*/, int shared);

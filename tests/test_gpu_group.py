@@ -91,3 +91,51 @@ def test_group_arguments_and_failed_instances_are_skipped(ba):
     assert t["solve"] > 0 and t["select"] == 0.0
     g.close()
     s = ba.BatchSolver(8, ba.SolverOptions(N, TS)); s.set_params(ba.P_NOMINAL); s.close()
+
+
+def _rank_worker(rank, world, uid, total, q):
+    """one process per GPU: rank `rank` of a group of `world` (test below; needs `world` visible devices)"""
+    import numpy as np
+    import bluerov2_amd as ba
+    amp, frq, ph, x0 = _candidates(total)
+    counts = [total // world + (1 if r < total % world else 0) for r in range(world)]
+    g = ba.SolverGroup([rank], opts=ba.SolverOptions(N, TS), rank=rank, world=world, uid=uid, counts=counts)
+    g.set_x0(x0); g.set_params(ba.P_NOMINAL); g.set_candidate_params("lemniscate", amp, frq, ph)
+    for k in range(3):
+        g.set_yref_candidates_tick(TS * k, TS); g.solve()
+    g.gather(ba.GATHER_RECORDS); idx, rec = g.select_best(); res = g.results()
+    g.gather(ba.GATHER_PACKED); idx2, rec2 = g.select_best()
+    q.put((rank, idx, float(rec["cost"]), idx2, float(rec2["cost"]), res.tobytes()))
+    g.close()
+
+
+def test_group_one_process_per_gpu(ba):
+    """brov_group_create_rank: every process holds one rank; rank 0's unique id reaches the others through the launcher (here: the
+    argument list of spawned processes).  With one visible device: one rank in this process (RCCL communicator of size one through
+    ncclCommInitRank); with two or more: two spawned processes, whose gathered records and selections must agree with each other and
+    with the whole batch solved on one device."""
+    import multiprocessing as mp
+    total = 1027
+    amp, frq, ph, x0 = _candidates(total)
+    one = ba.BatchSolver(total, ba.SolverOptions(N, TS))
+    one.set_x0(x0); one.set_params(ba.P_NOMINAL); one.set_candidate_params("lemniscate", amp, frq, ph)
+    for k in range(3):
+        one.set_yref_candidates_tick(TS * k, TS); one.solve()
+    r1 = one.results(); one.close()
+    want = int(np.argmin(np.where(r1["status"] == 0, r1["cost"], np.inf)))
+    world = 2 if len(_devices()) >= 2 else 1
+    uid = ba.unique_id()
+    assert len(uid) == 128
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    if world == 1:
+        _rank_worker(0, 1, uid, total, q)
+        outs = [q.get(timeout=60)]
+    else:
+        ps = [ctx.Process(target=_rank_worker, args=(r, world, uid, total, q)) for r in range(world)]
+        for p in ps: p.start()
+        outs = [q.get(timeout=300) for _ in ps]
+        for p in ps: p.join(60)
+    for rank, idx, cost, idx2, cost2, blob in outs:
+        assert blob == r1.tobytes(), rank
+        assert idx == idx2 == want and cost == cost2 == r1["cost"][want], rank
