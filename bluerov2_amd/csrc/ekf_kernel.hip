@@ -827,6 +827,7 @@ static thread_local std::string g_ekf_err;
         hipError_t e_ = (call);                                                                               \
         if (e_ != hipSuccess) {                                                                               \
             g_ekf_err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+            (void)hipGetLastError();                                                                              \
             return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) \
                        ? BROV_ERR_NO_DEVICE                                                                   \
                        : BROV_ERR_HIP;                                                                        \

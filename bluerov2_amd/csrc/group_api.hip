@@ -79,6 +79,7 @@ struct brov_group {
     int last_mode = -1;
     bool timing = true;
     bool ev_sel = false;                  // the select-end event of the current step has been recorded
+    bool ev_solve = false, ev_gather = false;   // ... the solve's pair, the gather's end
 };
 
 #define GHIP(call)                                                                          \
@@ -86,6 +87,7 @@ struct brov_group {
         hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) {                                                             \
             g_gerr = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            (void)hipGetLastError();   /* reported here: do not leave it behind as the thread's "last error" for an unrelated call */ \
             return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? BROV_ERR_NO_DEVICE : BROV_ERR_HIP; \
         }                                                                                   \
     } while (0)
@@ -318,7 +320,7 @@ int brov_group_solve(brov_group* g) {
         if (g->timing) GHIP(hipEventRecord(g->ev[4 * d + 1], g->st[d]));
     }
     g->last_mode = -1;
-    g->ev_sel = false;
+    g->ev_sel = false; g->ev_gather = false; g->ev_solve = g->timing;
     return BROV_OK;
 }
 
@@ -351,6 +353,7 @@ int brov_group_gather(brov_group* g, int mode) {
     GNCCL(R.GroupEnd());
     if (g->timing)
         for (int d = 0; d < g->n; d++) { GHIP(hipSetDevice(g->dev[d])); GHIP(hipEventRecord(g->ev[4 * d + 2], g->st[d])); }
+    g->ev_gather = g->timing && g->ev_solve;
     g->last_mode = mode;
     return BROV_OK;
 }
@@ -421,18 +424,18 @@ const brov_result* brov_group_gathered_device(const brov_group* g, int rank) { r
 int brov_group_slots_per_rank(const brov_group* g) { return g ? g->Bmax : 0; }
 
 int brov_group_last_seconds(brov_group* g, double* solve, double* gather, double* select) {
-    if (!g || !g->timing) return BROV_ERR_ARG;
+    if (!g || !g->timing || !g->ev_solve) { g_gerr = "brov_group_last_seconds: no timed solve yet (timing must be on before brov_group_solve)"; return BROV_ERR_ARG; }
     double ts = 0, tg = 0, tsel = 0;
     for (int d = 0; d < g->n; d++) {
         GHIP(hipSetDevice(g->dev[d]));
         float a = 0, b = 0;
         GHIP(hipEventSynchronize(g->ev[4 * d + 1]));
         GHIP(hipEventElapsedTime(&a, g->ev[4 * d + 0], g->ev[4 * d + 1]));
-        if (g->last_mode >= 0) { GHIP(hipEventSynchronize(g->ev[4 * d + 2])); GHIP(hipEventElapsedTime(&b, g->ev[4 * d + 1], g->ev[4 * d + 2])); }
+        if (g->last_mode >= 0 && g->ev_gather) { GHIP(hipEventSynchronize(g->ev[4 * d + 2])); GHIP(hipEventElapsedTime(&b, g->ev[4 * d + 1], g->ev[4 * d + 2])); }
         if (a * 1e-3 > ts) ts = a * 1e-3;
         if (b * 1e-3 > tg) tg = b * 1e-3;
     }
-    if (g->last_mode >= 0 && g->ev_sel) {   // (an event that was never recorded makes hipEventElapsedTime fail, and the failure would stay
+    if (g->last_mode >= 0 && g->ev_sel && g->ev_gather) {   // (an event that was never recorded makes hipEventElapsedTime fail, and the failure would stay
         float c = 0;                        // behind as the thread's "last error" for the next hipGetLastError of an unrelated call)
         GHIP(hipSetDevice(g->dev[0]));
         GHIP(hipEventSynchronize(g->ev[3]));

@@ -27,6 +27,7 @@ extern "C" const char* brov_last_error(void) { return g_err.c_str(); }
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
             g_err = std::string(#call) + ": " + hipGetErrorString(e_);                                 \
+            (void)hipGetLastError(); /* reported here: not left behind as the "last error" of a later call */ \
             return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice || e_ == hipErrorInsufficientDriver) \
                        ? BROV_ERR_NO_DEVICE                                                            \
                        : BROV_ERR_HIP;                                                                 \
