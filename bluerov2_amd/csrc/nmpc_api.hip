@@ -85,6 +85,9 @@ struct brov_solver {
     hipStream_t tick_stream = nullptr;   // brov_tick_host: the solver's own stream and pinned staging buffer
     double* pin = nullptr;
     size_t pin_doubles = 0;
+    // brov_tick_host, mailbox path: inputs passed with the tick are read by THIS launch straight from the pinned staging buffer (no copy
+    // command ahead of the kernel); their device copies are refreshed behind the kernel.  Non-null only while that launch is built.
+    const double *tick_x0 = nullptr, *tick_yref = nullptr, *tick_par = nullptr;
     brov_result* mail = nullptr;     // host mailbox of the tick in flight (device-visible pinned memory), else nullptr
     int32_t* mail_flag = nullptr;
     int32_t mail_seq = 0;
@@ -750,10 +753,10 @@ static DevParams make_params(const brov_solver* s) {
     for (int j = 0; j < 16; j++) P.W[j] = s->opts.W[j];
     for (int j = 0; j < 12; j++) P.We[j] = s->opts.We[j];
     for (int j = 0; j < 4; j++) { P.lbu[j] = s->opts.lbu[j]; P.ubu[j] = s->opts.ubu[j]; }
-    P.x0 = s->x0;
-    P.yref = s->yref_shared ? shared_window(s) : s->yref;
+    P.x0 = s->tick_x0 ? s->tick_x0 : s->x0;
+    P.yref = s->tick_yref ? s->tick_yref : (s->yref_shared ? shared_window(s) : s->yref);
     P.yref_stride = s->yref_shared ? 0 : (int64_t)(s->N + 1) * 16;
-    P.par = s->par;
+    P.par = s->tick_par ? s->tick_par : s->par;
     P.par_rp = s->dist6 ? s->par_rp : nullptr;
     P.tsv = general_grid(s) ? s->tsv : nullptr;
     P.sched = s->sched_on ? s->sched : nullptr;
@@ -842,17 +845,26 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         s->yref_shared = true;
     }
     if (par_stage) { std::memcpy(pp, par_stage, n_p * sizeof(double)); s->pplant_stale = true; }
-    if (x0 && yref_shared && par_stage) {   // device side: one allocation in the same order (brov_create)
-        HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, st));
-    } else {
-        if (x0) HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, st));
-        if (yref_shared) HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, st));
-        if (par_stage) HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, st));
-    }
+    // Small batches with the mailbox: the kernel reads the inputs of this tick where the host has just put them (pinned, device-visible
+    // memory: 21 KB over PCIe inside the linearisation's staging loads) instead of waiting for a copy command ahead of it; the device
+    // copies every other entry point works on are refreshed by the same copies, enqueued BEHIND the launch (BROV_TICK_ZEROCOPY=0: ahead).
+    const bool mailbox = rti_phase != 1 && B <= kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0);
+    const bool zerocopy = mailbox && rti_phase == 0 && !(getenv("BROV_TICK_ZEROCOPY") && atoi(getenv("BROV_TICK_ZEROCOPY")) == 0);
+    auto upload = [&]() -> int {
+        if (x0 && yref_shared && par_stage) {   // device side: one allocation in the same order (brov_create)
+            HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, st));
+        } else {
+            if (x0) HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, st));
+            if (yref_shared) HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, st));
+            if (par_stage) HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        return BROV_OK;
+    };
+    if (!zerocopy) { if (int rc = upload()) return rc; }
+    else { s->tick_x0 = x0 ? px : nullptr; s->tick_yref = yref_shared ? py : nullptr; s->tick_par = par_stage ? pp : nullptr; }
     // Results.  Small batches (the ROS node's batch of one): the kernel writes every record into the pinned buffer itself and then the
     // instance's sequence word; the host polls those words -- no copy command, no stream synchronisation on the way back.  The stream
     // is queried now and then: a launch that ended without delivering (a device fault) falls back to the synchronous path's error.
-    const bool mailbox = rti_phase != 1 && B <= kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0);
     if (mailbox) {
         s->mail_seq = s->mail_seq == 0x7fffffff ? 1 : s->mail_seq + 1;
         s->mail = (brov_result*)pr; s->mail_flag = (int32_t*)pf;
@@ -860,7 +872,9 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     const int rc = brov_solve_phase(s, st, rti_phase);
     const int32_t seq = s->mail_seq;
     s->mail = nullptr; s->mail_flag = nullptr;
+    s->tick_x0 = s->tick_yref = s->tick_par = nullptr;
     if (rc) return rc;
+    if (zerocopy) { if (int rc2 = upload()) return rc2; }   // the device copies, behind the kernel that has read the pinned ones
     if (mailbox) {
         size_t done = 0;
         for (unsigned long spin = 1; done < B; spin++) {
