@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,9 @@ Rccl& rccl() {
 
 }  // namespace
 
+constexpr int kSelBlocks = 64;   // blocks of group_select_kernel
+struct GroupMail { brov_result rec; int32_t slot; int32_t seq; int32_t owner; int32_t pad; };   // what the select kernels deliver to the host (pinned), seq last
+
 struct brov_group {
     // n = devices of THIS process; W = ranks of the whole group (= n for the one-process form; one process per GPU: n = 1, W = world),
     // r0 = global rank of local device 0.  lo / cnt are indexed by GLOBAL rank; everything else by local device.
@@ -74,7 +78,13 @@ struct brov_group {
     std::vector<brov_result*> stage;      // [Bmax] per device (uneven shards only): the shard's records + never-selectable padding
     std::vector<brov_result*> gathered;   // [n * Bmax] per device
     std::vector<double*> pair, pairs;     // [2] local (cost, global index) and [n * 2] gathered, per device
-    std::vector<int*> best;               // [2] per device: arg-min scratch
+    std::vector<int*> best;               // [2] per device: arg-min scratch (winning slot, ticket of the select kernel)
+    double* sel_cost = nullptr;           // device 0: partial results of the select kernel's blocks, the winning record
+    int* sel_idx = nullptr;
+    brov_result* sel_rec = nullptr;
+    GroupMail* mail = nullptr;            // pinned host mailbox the select kernels deliver into (device 0)
+    std::vector<GroupMail*> pmail;        // per device (pinned): the local winner's record, written by the pack kernel
+    int32_t mail_seq = 0;
     std::vector<hipEvent_t> ev;           // 4 per device: solve start / end = gather start / gather end / select end
     int last_mode = -1;
     bool timing = true;
@@ -98,32 +108,66 @@ struct brov_group {
     } while (0)
 
 // arg-min of cost over the successful records of a (padded) record array: slot -> (rank = slot / Bmax, i = slot % Bmax), valid while
-// i < cnt[rank]; ties go to the lowest slot = lowest global index.  One block.  out[0] = winning slot or -1.
-__global__ void group_select_kernel(const brov_result* __restrict__ rec, int slots, int* __restrict__ out) {
+// i < cnt[rank]; ties go to the lowest slot = lowest global index.  Up to kSelBlocks blocks scan the array (65 536 records of 104 B at
+// BASELINE configs[3]: one block needs ~0.1 ms for them), the block that draws the last ticket reduces the partial results, and -- so
+// that the host needs no copy command and no second round trip for the winner -- writes the winning slot AND its record into a pinned
+// host mailbox, the sequence word last.  out[0] = winning slot or -1, best_dev = the record on the device.
+__device__ __forceinline__ bool sel_better(double c2, int i2, double c1, int i1) { return i2 >= 0 && (i1 < 0 || c2 < c1 || (c2 == c1 && i2 < i1)); }
+__global__ __launch_bounds__(256) void group_select_kernel(const brov_result* __restrict__ rec, int slots, int* __restrict__ out, double* pc, int* pi,
+                                                             unsigned* ticket, brov_result* best_dev, GroupMail* mail, int seq) {
     __shared__ double sc[256];
     __shared__ int si[256];
+    __shared__ bool last;
     double best = 1e300;
     int bi = -1;
-    for (int k = threadIdx.x; k < slots; k += blockDim.x) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < slots; k += gridDim.x * blockDim.x) {
         const double c = rec[k].cost;
         if (rec[k].status == BROV_STATUS_SUCCESS && c == c && (bi < 0 || c < best)) { best = c; bi = k; }
     }
-    sc[threadIdx.x] = best; si[threadIdx.x] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const double c2 = sc[threadIdx.x + o];
-            const int i2 = si[threadIdx.x + o];
-            if (i2 >= 0 && (si[threadIdx.x] < 0 || c2 < sc[threadIdx.x] || (c2 == sc[threadIdx.x] && i2 < si[threadIdx.x]))) {
-                sc[threadIdx.x] = c2; si[threadIdx.x] = i2;
-            }
-        }
+    auto block_reduce = [&]() {
+        sc[threadIdx.x] = best; si[threadIdx.x] = bi;
         __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o && sel_better(sc[threadIdx.x + o], si[threadIdx.x + o], sc[threadIdx.x], si[threadIdx.x])) {
+                sc[threadIdx.x] = sc[threadIdx.x + o]; si[threadIdx.x] = si[threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+    };
+    block_reduce();
+    if (threadIdx.x == 0) {
+        pc[blockIdx.x] = sc[0]; pi[blockIdx.x] = si[0];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
-    if (threadIdx.x == 0) out[0] = si[0];
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    best = 1e300; bi = -1;
+    if (threadIdx.x < gridDim.x) { best = ((volatile double*)pc)[threadIdx.x]; bi = ((volatile int*)pi)[threadIdx.x]; }
+    block_reduce();
+    const int slot = si[0];
+    if (slot >= 0 && threadIdx.x < sizeof(brov_result) / 8) {
+        const double v = ((const double*)(rec + slot))[threadIdx.x];
+        ((double*)best_dev)[threadIdx.x] = v;
+        if (mail) ((double*)&mail->rec)[threadIdx.x] = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = slot;
+        *ticket = 0;   // the next launch on this stream
+        if (mail) {
+            mail->slot = slot;
+            __threadfence_system();
+            *(volatile int32_t*)&mail->seq = seq;
+        }
+    }
 }
-// the local arg-min as a packed pair: pair[0] = cost (+inf when no record qualifies), pair[1] = global index (exact in a double)
-__global__ void group_pack_kernel(const brov_result* __restrict__ rec, int n, int lo, double* __restrict__ pair) {
+// the local arg-min as a packed pair: pair[0] = cost (+inf when no record qualifies), pair[1] = global index (exact in a double).  The
+// winner's whole record goes into the device's own pinned mailbox on the way (system-scope fence ahead of the pair: whoever learns the
+// pair through the all-gather finds the record in place).
+__global__ void group_pack_kernel(const brov_result* __restrict__ rec, int n, int lo, double* __restrict__ pair, GroupMail* mail) {
     __shared__ double sc[256];
     __shared__ int si[256];
     double best = 1e300;
@@ -135,19 +179,34 @@ __global__ void group_pack_kernel(const brov_result* __restrict__ rec, int n, in
     sc[threadIdx.x] = best; si[threadIdx.x] = bi;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            const double c2 = sc[threadIdx.x + o];
-            const int i2 = si[threadIdx.x + o];
-            if (i2 >= 0 && (si[threadIdx.x] < 0 || c2 < sc[threadIdx.x] || (c2 == sc[threadIdx.x] && i2 < si[threadIdx.x]))) {
-                sc[threadIdx.x] = c2; si[threadIdx.x] = i2;
-            }
+        if ((int)threadIdx.x < o && sel_better(sc[threadIdx.x + o], si[threadIdx.x + o], sc[threadIdx.x], si[threadIdx.x])) {
+            sc[threadIdx.x] = sc[threadIdx.x + o]; si[threadIdx.x] = si[threadIdx.x + o];
         }
         __syncthreads();
     }
+    const int w = si[0];
+    if (w >= 0 && threadIdx.x < sizeof(brov_result) / 8) ((double*)&mail->rec)[threadIdx.x] = ((const double*)(rec + w))[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
     if (threadIdx.x == 0) {
-        pair[0] = si[0] >= 0 ? sc[0] : __builtin_inf();
-        pair[1] = si[0] >= 0 ? (double)(lo + si[0]) : -1.0;
+        mail->slot = w >= 0 ? lo + w : -1;
+        __threadfence_system();
+        pair[0] = w >= 0 ? sc[0] : __builtin_inf();
+        pair[1] = w >= 0 ? (double)(lo + w) : -1.0;
     }
+}
+// the gathered pairs -> owner rank, global index and cost of the global winner, into the host mailbox (one wave; shards hold ascending
+// index ranges, so the first minimal cost in rank order is the lowest index)
+__global__ void group_pairs_kernel(const double* __restrict__ pairs, int W, GroupMail* mail, int seq) {
+    if (threadIdx.x != 0) return;
+    int owner = -1;
+    for (int r = 0; r < W; r++)
+        if (pairs[2 * r + 1] >= 0.0 && (owner < 0 || pairs[2 * r] < pairs[2 * owner])) owner = r;
+    mail->owner = owner;
+    mail->slot = owner >= 0 ? (int)pairs[2 * owner + 1] : -1;
+    mail->rec.cost = owner >= 0 ? pairs[2 * owner] : 0.0;
+    __threadfence_system();
+    *(volatile int32_t*)&mail->seq = seq;
 }
 
 extern "C" {
@@ -172,6 +231,13 @@ void brov_group_destroy(brov_group* g) {
         if (d < (int)g->gathered.size() && g->gathered[d]) hipFree(g->gathered[d]);
         if (d < (int)g->pair.size() && g->pair[d]) hipFree(g->pair[d]);
         if (d < (int)g->best.size() && g->best[d]) hipFree(g->best[d]);
+        if (d < (int)g->pmail.size() && g->pmail[d]) hipHostFree(g->pmail[d]);
+        if (d == 0) {
+            if (g->sel_cost) hipFree(g->sel_cost);
+            if (g->sel_idx) hipFree(g->sel_idx);
+            if (g->sel_rec) hipFree(g->sel_rec);
+            if (g->mail) hipHostFree(g->mail);
+        }
         for (int k = 0; k < 4; k++)
             if (4 * d + k < (int)g->ev.size() && g->ev[4 * d + k]) hipEventDestroy(g->ev[4 * d + k]);
         if (d < (int)g->st.size() && g->st[d]) hipStreamDestroy(g->st[d]);
@@ -204,7 +270,7 @@ static int group_build(brov_group** out, const int* devices, int n, int W, int r
     g->total = g->lo[W - 1] + g->cnt[W - 1];
     g->sol.assign(n, nullptr); g->st.assign(n, nullptr); g->comm.assign(n, nullptr);
     g->stage.assign(n, nullptr); g->gathered.assign(n, nullptr); g->pair.assign(n, nullptr); g->pairs.assign(n, nullptr);
-    g->best.assign(n, nullptr); g->ev.assign(4 * (size_t)n, nullptr);
+    g->best.assign(n, nullptr); g->ev.assign(4 * (size_t)n, nullptr); g->pmail.assign(n, nullptr);
     auto fail = [&](int rc) { brov_group_destroy(g); return rc; };
     for (int d = 0; d < n; d++) {
         if (hipSetDevice(g->dev[d]) != hipSuccess) { g_gerr = "brov_group_create: hipSetDevice failed"; return fail(BROV_ERR_HIP); }
@@ -214,6 +280,16 @@ static int group_build(brov_group** out, const int* devices, int n, int W, int r
         ok = ok && hipMalloc((void**)&g->gathered[d], (size_t)W * g->Bmax * sizeof(brov_result)) == hipSuccess;
         ok = ok && hipMalloc((void**)&g->pair[d], (2 + 2 * (size_t)W) * sizeof(double)) == hipSuccess;
         ok = ok && hipMalloc((void**)&g->best[d], 2 * sizeof(int)) == hipSuccess;
+        ok = ok && hipMemset(g->best[d], 0, 2 * sizeof(int)) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&g->pmail[d], sizeof(GroupMail), hipHostMallocDefault) == hipSuccess;
+        if (ok) std::memset(g->pmail[d], 0, sizeof(GroupMail));
+        if (ok && d == 0) {   // the select runs on local device 0
+            ok = hipMalloc((void**)&g->sel_cost, kSelBlocks * sizeof(double)) == hipSuccess;
+            ok = ok && hipMalloc((void**)&g->sel_idx, kSelBlocks * sizeof(int)) == hipSuccess;
+            ok = ok && hipMalloc((void**)&g->sel_rec, sizeof(brov_result)) == hipSuccess;
+            ok = ok && hipHostMalloc((void**)&g->mail, sizeof(GroupMail), hipHostMallocDefault) == hipSuccess;
+            if (ok) std::memset(g->mail, 0, sizeof(GroupMail));
+        }
         if (ok && !g->even) {
             ok = hipMalloc((void**)&g->stage[d], (size_t)g->Bmax * sizeof(brov_result)) == hipSuccess;
             // padding records: status -1, cost NaN -- never selectable; only the first cnt slots are ever rewritten
@@ -335,7 +411,7 @@ int brov_group_gather(brov_group* g, int mode) {
         if (mode == BROV_GATHER_RECORDS) {
             if (!g->even) GHIP(hipMemcpyAsync(g->stage[d], brov_results_device(g->sol[d]), (size_t)g->cnt[g->r0 + d] * rec, hipMemcpyDeviceToDevice, g->st[d]));
         } else {
-            hipLaunchKernelGGL(group_pack_kernel, dim3(1), dim3(256), 0, g->st[d], brov_results_device(g->sol[d]), g->cnt[g->r0 + d], g->lo[g->r0 + d], g->pair[d]);
+            hipLaunchKernelGGL(group_pack_kernel, dim3(1), dim3(256), 0, g->st[d], brov_results_device(g->sol[d]), g->cnt[g->r0 + d], g->lo[g->r0 + d], g->pair[d], g->pmail[d]);
             GHIP(hipGetLastError());
         }
     }
@@ -370,40 +446,68 @@ static int slot_to_global(const brov_group* g, int slot) {
     return (r < g->W && i < g->cnt[r]) ? g->lo[r] + i : -1;
 }
 
+// poll the sequence word of device 0's mailbox; the stream is queried now and then, so that a launch that ended without delivering (a
+// device fault) turns into an error instead of a hang
+static int mail_wait(brov_group* g, int32_t seq) {
+    volatile int32_t* pf = (volatile int32_t*)&g->mail->seq;
+    for (unsigned long spin = 1; *pf != seq; spin++) {
+        if ((spin & 0x3ff) == 0) {
+            const hipError_t q = hipStreamQuery(g->st[0]);
+            if (q == hipSuccess) {   // the launch is over: everything it wrote is visible
+                if (*pf != seq) { g_gerr = "brov_group_select_best: the select kernel ended without delivering"; return BROV_ERR_HIP; }
+            } else if (q != hipErrorNotReady) {
+                g_gerr = std::string("brov_group_select_best: ") + hipGetErrorString(q);
+                (void)hipGetLastError();
+                return BROV_ERR_HIP;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return BROV_OK;
+}
+
 int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
     if (!g || !best_index) return BROV_ERR_ARG;
     if (g->last_mode < 0) { g_gerr = "brov_group_select_best: call brov_group_gather first"; return BROV_ERR_ARG; }
     *best_index = -1;
     if (g->last_mode == BROV_GATHER_RECORDS) {
-        // every device holds all records: device 0 selects (any would do), the others only finish their gather
+        // every device holds all records: device 0 selects (any would do).  The kernel delivers the winning slot and its record into
+        // the pinned mailbox and the host polls the sequence word: no copy command, no stream synchronisation on the way back (the
+        // other devices only finish their gather -- their streams order whatever is enqueued next behind it).
         GHIP(hipSetDevice(g->dev[0]));
-        hipLaunchKernelGGL(group_select_kernel, dim3(1), dim3(256), 0, g->st[0], g->gathered[0], g->W * g->Bmax, g->best[0]);
+        const int slots = g->W * g->Bmax;
+        int nb = (slots + 1023) / 1024;
+        nb = nb < 1 ? 1 : (nb > kSelBlocks ? kSelBlocks : nb);
+        g->mail_seq = g->mail_seq == 0x7fffffff ? 1 : g->mail_seq + 1;
+        const int32_t seq = g->mail_seq;
+        hipLaunchKernelGGL(group_select_kernel, dim3(nb), dim3(256), 0, g->st[0], g->gathered[0], slots, g->best[0], g->sel_cost, g->sel_idx,
+                           (unsigned*)(g->best[0] + 1), g->sel_rec, g->mail, seq);
         GHIP(hipGetLastError());
         if (g->timing) { GHIP(hipEventRecord(g->ev[3], g->st[0])); g->ev_sel = true; }
-        int slot = -1;
-        GHIP(hipMemcpyAsync(&slot, g->best[0], sizeof(int), hipMemcpyDeviceToHost, g->st[0]));
-        if (int rc = brov_group_synchronize(g)) return rc;
+        if (int rc = mail_wait(g, seq)) return rc;
+        const int slot = g->mail->slot;
         *best_index = slot_to_global(g, slot);
-        if (best && slot >= 0) { GHIP(hipSetDevice(g->dev[0])); GHIP(hipMemcpy(best, g->gathered[0] + slot, sizeof(brov_result), hipMemcpyDeviceToHost)); }
+        if (best && slot >= 0) std::memcpy(best, &g->mail->rec, sizeof(brov_result));
     } else {
-        std::vector<double> pr(2 * (size_t)g->W);
+        // the gathered pairs are reduced on device 0 and the winner's (owner rank, global index, cost) comes back through the mailbox;
+        // its whole record is already in the owner's own mailbox (group_pack_kernel) when the owner is a device of this process
         GHIP(hipSetDevice(g->dev[0]));
+        g->mail_seq = g->mail_seq == 0x7fffffff ? 1 : g->mail_seq + 1;
+        const int32_t seq = g->mail_seq;
+        hipLaunchKernelGGL(group_pairs_kernel, dim3(1), dim3(64), 0, g->st[0], g->pairs[0], g->W, g->mail, seq);
+        GHIP(hipGetLastError());
         if (g->timing) { GHIP(hipEventRecord(g->ev[3], g->st[0])); g->ev_sel = true; }
-        GHIP(hipMemcpyAsync(pr.data(), g->pairs[0], pr.size() * sizeof(double), hipMemcpyDeviceToHost, g->st[0]));
-        if (int rc = brov_group_synchronize(g)) return rc;
-        int owner = -1;
-        for (int r = 0; r < g->W; r++)   // shards hold ascending index ranges: the first minimal cost is the lowest index
-            if (pr[2 * r + 1] >= 0.0 && (owner < 0 || pr[2 * r] < pr[2 * owner])) owner = r;
+        if (int rc = mail_wait(g, seq)) return rc;
+        const int owner = g->mail->owner;
         if (owner >= 0) {
-            *best_index = (int)pr[2 * owner + 1];
+            *best_index = g->mail->slot;
             if (best) {
                 std::memset(best, 0, sizeof(*best));
                 const int d = owner - g->r0;
                 if (d >= 0 && d < g->n) {   // the winner lives in this process: its whole record
-                    GHIP(hipSetDevice(g->dev[d]));
-                    GHIP(hipMemcpy(best, brov_results_device(g->sol[d]) + (*best_index - g->lo[owner]), sizeof(brov_result), hipMemcpyDeviceToHost));
+                    std::memcpy(best, &g->pmail[d]->rec, sizeof(brov_result));
                 } else {                    // ... in another process (one process per GPU): the pair carries its cost only
-                    best->cost = pr[2 * owner]; best->status = BROV_STATUS_SUCCESS;
+                    best->cost = g->mail->rec.cost; best->status = BROV_STATUS_SUCCESS;
                 }
             }
         }

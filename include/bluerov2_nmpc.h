@@ -261,7 +261,10 @@ int brov_select_best_host(brov_solver* s, int* best_index, brov_result* best);
  *     BROV_GATHER_RECORDS  every instance's 104-byte result record, to every device (uneven shards: padded with never-selectable slots)
  *     BROV_GATHER_PACKED   one (cost, global index) pair per device (16 B): the local arg-min -- when only the winner is wanted
  * and brov_group_select_best returns the global arg-min of cost over the instances with status SUCCESS (ties: lowest index) and waits
- * for it -- the only host wait of a step.  Per-shard inputs go through the shard's own handle (brov_group_solver: every brov_set_* /
+ * for it -- the only host wait of a step.  With BROV_GATHER_RECORDS the winner comes back through a pinned host mailbox the select kernel
+ * (up to 64 blocks over the gathered records) writes itself: no copy command and no stream synchronisation on the way back; the call
+ * returns when local device 0 has delivered, the other devices may still be finishing their gather (their streams order whatever is
+ * enqueued next behind it; brov_group_synchronize waits for all of them).  Per-shard inputs go through the shard's own handle (brov_group_solver: every brov_set_* /
  * brov_get_* above works on it, with brov_group_stream(rank) as the stream) or through the whole-batch setters below, which slice a
  * global HOST array.  RCCL is loaded at run time (dlopen) by brov_group_create; a process that never creates a group never loads it.
  * The reference's callers live in one C++ process (bluerov2_dob.cpp:270-451): this is their route to several GPUs; one process per

@@ -93,6 +93,37 @@ def test_group_arguments_and_failed_instances_are_skipped(ba):
     s = ba.BatchSolver(8, ba.SolverOptions(N, TS)); s.set_params(ba.P_NOMINAL); s.close()
 
 
+def test_select_over_many_blocks_breaks_ties_towards_the_lowest_index(ba):
+    """the select kernel scans with several blocks (one per 1024 slots) and reduces their partial results in the block that finishes last:
+    identical instances have identical costs, so the winner is the lowest index that solved -- wherever in the array it sits -- and the
+    record in the host mailbox is that instance's"""
+    devs = _devices()
+    total = 9000 + len(devs)
+    x0 = np.zeros((total, 12)); x0[:, 2] = -20.0
+    yref = np.zeros((N + 1, 16)); yref[:, 2] = -20.0; yref[:, 0] = 0.3
+    g = ba.SolverGroup(devs, total, ba.SolverOptions(N, TS))
+    g.set_params(ba.P_NOMINAL); g.set_yref(yref)
+    for first_ok in (0, 3, 1500, 7777):
+        x = x0.copy(); x[:first_ok, 0] = np.nan
+        g.set_x0(x)
+        for s in g.shards: s.init_iterate_default()
+        g.solve(); g.gather(ba.GATHER_RECORDS)
+        idx, rec = g.select_best()
+        r = g.results()
+        assert np.all(r["status"][:first_ok] != 0) and np.all(r["status"][first_ok:] == 0)
+        assert np.all(r["cost"][first_ok:] == r["cost"][first_ok])          # a tie among all that solved
+        assert idx == first_ok and rec.tobytes() == r[first_ok].tobytes()
+        g.gather(ba.GATHER_PACKED); idx2, _ = g.select_best()
+        assert idx2 == first_ok
+    x = x0.copy(); x[:, 0] = np.nan                                           # nobody qualifies
+    g.set_x0(x)
+    for s in g.shards: s.init_iterate_default()
+    g.solve(); g.gather(ba.GATHER_RECORDS)
+    idx, rec = g.select_best()
+    assert idx == -1 and rec is None
+    g.close()
+
+
 def _rank_worker(rank, world, uid, total, q):
     """one process per GPU: rank `rank` of a group of `world` (test below; needs `world` visible devices)"""
     import numpy as np
