@@ -4,6 +4,8 @@ on the same seeded inputs and against the committed known answers.
 Tolerances: FP64 end to end.  Linearisation (A, B, b) 1e-11 relative; iterates after an RTI step 1e-7 absolute (the north
 star asks 1e-5 on u*; summation order differs between the MFMA tiles and the oracle's loops and the condensed Hessian has
 cond ~1e5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -400,7 +402,8 @@ def test_randomised_options_against_oracle(ba, oracle, golden_traj, seed):
 def _nominal_draws(ba, nb=32):
     """the 512 option draws of test_nominal_model_fuzz_at_the_headline_step (also replayed by scripts/dev/nominal_fuzz_*.py)"""
     draws = []
-    for seed in range(512):
+    base = int(os.environ.get("BROV_FUZZ_SEED_BASE", "0"))   # extra samples on demand (scripts/gpu_r4_r.sh); the suite runs base 0
+    for seed in range(base, base + 512):
         rng = np.random.default_rng(70000 + seed)
         N = int(rng.choice([1, 3, 7, 10, 13, 14, 19, 20, 20, 20, 23, 24, 31, 40, 57, 80]))
         W = ba.SolverOptions(N).W * rng.uniform(0.3, 3.0, size=16)
