@@ -351,6 +351,57 @@ def pmc_traffic(tag, kernel):
     return None, None
 
 
+def live_pmc_traffic(args, kernel, timeout=150):
+    """HBM bytes per launch of `kernel`, measured NOW: two child runs of this command's headline leg under rocprofv3 --pmc -- FETCH_SIZE and
+    WRITE_SIZE, each in its own pass with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- and counts x unit,
+    the units (bytes per count on gfx950 for this project's access pattern) from the committed calibration (profiles/r*_pmc_summary.json
+    "calibration", measured with scripts/dev/pmc_calib.hip).  (bytes, source) or (None, why)."""
+    import csv, glob, shutil, subprocess, tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return None, "rocprofv3 not found"
+    cal = None
+    for pj in ("r4_pmc_summary.json", "r3_pmc_summary.json"):
+        try:
+            c = json.load(open(os.path.join(ROOT, "profiles", pj)))["calibration"]
+            if c.get("bytes_per_FETCH_SIZE_count") and c.get("bytes_per_WRITE_SIZE_count"):
+                cal = (c["bytes_per_FETCH_SIZE_count"], c["bytes_per_WRITE_SIZE_count"], pj)
+                break
+        except Exception:
+            pass
+    if cal is None:
+        return None, "no committed counter calibration"
+    fwd = ["--config", str(args.config), "--batch", str(args.batch), "--horizon", str(args.horizon), "--path", str(args.path), "--scaling", args.scaling]
+    if args.force_ipm:
+        fwd.append("--force-ipm")
+    tmp = tempfile.mkdtemp(prefix="brov_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BROV_BENCH_PMC_CHILD="1")
+    counts = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [tool, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "c", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-extra", "--no-traffic"] + fwd
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].split("(")[0].replace("brov::", "").replace("void ", "").strip()
+                    if row["Counter_Name"] == counter and name == kernel:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {counter}: no rows for {kernel} (rc {r.returncode}: {r.stderr.decode(errors='replace')[-200:]})"
+            tail = vals[10:] if len(vals) > 10 else vals   # the first launches (warm-up of the two passes) start from a cold iterate
+            counts[counter] = (sum(tail) / len(tail), len(vals))
+    except Exception as e:   # a profiler that hangs or is refused must not cost the bench line
+        return None, f"rocprofv3 pass failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    t = counts["FETCH_SIZE"][0] * cal[0] + counts["WRITE_SIZE"][0] * cal[1]
+    return t, (f"measured in this run: two child runs of this workload under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (--kernel-trace only), mean over "
+               f"{counts['FETCH_SIZE'][1] - 10} / {counts['WRITE_SIZE'][1] - 10} launches; {cal[0]:.0f} / {cal[1]:.0f} B per count from the calibration in profiles/{cal[2]}")
+
+
 def configs_block(ba, args, device):
     """BASELINE.json configs[2], configs[3] (one of its 8 shards) and configs[4] (one of its 8 shards) on this GPU, with the same W / K
     as the headline: what round 3 reported from builder-run side files, now inside the line the driver records.  ~6 s."""
@@ -540,6 +591,7 @@ def parse_args(argv=None):
     ap.add_argument("--horizon", type=int, default=0, help="N for configs 2/3 (0 = 20); config 5: run this horizon only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the forced-IPM / mixed-batch legs of the default run")
+    ap.add_argument("--no-traffic", action="store_true", help="roofline.traffic from the committed counter summary instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--force-ipm", action="store_true", help="qp_early_exit=0 as the headline variant")
     ap.add_argument("--force-gather", action="store_true", help="run the result all-gather even with one rank")
     ap.add_argument("--path", type=int, default=0, help="0 auto (LDS-resident kernels), 1 streaming, 2 fused")
@@ -922,13 +974,20 @@ def main(argv=None):
             achieved = dom_fl / dom_t / 1e12
             alg_bytes = algorithmic_bytes(N, lg["shared"])
             traffic, traffic_src = None, None
-            for pj in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+            why_not_live = None
+            profiled = bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")   # this run is itself under rocprofv3
+            if world == 1 and len(legs) == 1 and not args.no_traffic and not args.no_extra and not profiled and not os.environ.get("BROV_BENCH_PMC_CHILD"):
+                traffic, traffic_src = live_pmc_traffic(args, dom)
+                if traffic is None:
+                    why_not_live, traffic_src = traffic_src, None
+            for pj in (() if traffic is not None else ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json")):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
                     ent = pm.get("runs", {}).get(f"cfg{args.config}_N{N}", pm if (pm.get("batch") == B and pm.get("N") == N) else {})
                     t = ent.get("hbm_bytes_per_launch", {}).get(dom) if B == BATCH_PER_GPU and not args.force_ipm and args.path == 0 else None
                     if t is not None:
-                        traffic, traffic_src = t, f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run"
+                        traffic, traffic_src = t, (f"profiles/{pj}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run" +
+                                                   (f" (live passes: {why_not_live})" if why_not_live else ""))
                         break
                 except Exception:
                     pass
