@@ -820,13 +820,10 @@ extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phas
 // changed go through ONE pinned staging buffer and asynchronous copies on the solver's own stream, the step is enqueued behind them,
 // the result records come back the same way, and the host waits once.  The separate setters + brov_solve + brov_get_results_host
 // cost five blocking pageable copies and three synchronisations per tick -- 0.2 .. 0.4 ms at batch 1, more than the kernels.
-extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
-                              brov_result* res) {
-    if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
-    HIPCHK(hipSetDevice(s->device));
+// the pinned staging buffer of brov_tick_host (x0 | shared window | stage parameters | records | sequence words), (re)allocated on demand
+static int tick_pin(brov_solver* s) {
     const size_t B = s->B, N1 = s->N + 1;
     const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8, n_f = (B * sizeof(int32_t) + 7) / 8;
-    if (!s->tick_stream) HIPCHK(hipStreamCreateWithFlags(&s->tick_stream, hipStreamNonBlocking));
     if (s->pin_doubles < n_x0 + n_y + n_p + n_r + n_f) {
         if (s->pin) hipHostFree(s->pin);
         s->pin = nullptr; s->pin_doubles = 0;
@@ -834,17 +831,41 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         s->pin_doubles = n_x0 + n_y + n_p + n_r + n_f;
         std::memset(s->pin, 0, s->pin_doubles * sizeof(double));
     }
+    return BROV_OK;
+}
+// A caller that builds its inputs and reads its records IN these buffers (device-visible pinned host memory, valid until brov_destroy)
+// saves brov_tick_host the host-side copies: pass the pointers returned here as x0 / yref_shared / par_stage and NULL as res.
+extern "C" int brov_tick_buffers(brov_solver* s, double** x0, double** yref_shared, double** par_stage, const brov_result** res) {
+    if (!s) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    if (int rc = tick_pin(s)) return rc;
+    const size_t B = s->B, N1 = s->N + 1;
+    if (x0) *x0 = s->pin;
+    if (yref_shared) *yref_shared = s->pin + B * 12;
+    if (par_stage) *par_stage = s->pin + B * 12 + N1 * 16;
+    if (res) *res = (const brov_result*)(s->pin + B * 12 + N1 * 16 + B * N1 * 16);
+    return BROV_OK;
+}
+
+extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
+                              brov_result* res) {
+    if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    const size_t B = s->B, N1 = s->N + 1;
+    const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8;
+    if (!s->tick_stream) HIPCHK(hipStreamCreateWithFlags(&s->tick_stream, hipStreamNonBlocking));
+    if (int rc = tick_pin(s)) return rc;
     hipStream_t st = s->tick_stream;
     if (s->last_stream != st) HIPCHK(hipStreamSynchronize(s->last_stream));   // an earlier solve on the caller's stream
     double* px = s->pin; double* py = px + n_x0; double* pp = py + n_y; double* pr = pp + n_p;
     volatile int32_t* pf = (volatile int32_t*)(pr + n_r);
-    if (x0) std::memcpy(px, x0, n_x0 * sizeof(double));
+    if (x0 && x0 != px) std::memcpy(px, x0, n_x0 * sizeof(double));   // (equal: the caller wrote into the staging buffer, brov_tick_buffers)
     if (yref_shared) {
-        std::memcpy(py, yref_shared, n_y * sizeof(double));
+        if (yref_shared != py) std::memcpy(py, yref_shared, n_y * sizeof(double));
         s->yref_view = nullptr;
         s->yref_shared = true;
     }
-    if (par_stage) { std::memcpy(pp, par_stage, n_p * sizeof(double)); s->pplant_stale = true; }
+    if (par_stage) { if (par_stage != pp) std::memcpy(pp, par_stage, n_p * sizeof(double)); s->pplant_stale = true; }
     // Small batches with the mailbox: the kernel reads the inputs of this tick where the host has just put them (pinned, device-visible
     // memory: 21 KB over PCIe inside the linearisation's staging loads) instead of waiting for a copy command ahead of it; the device
     // copies every other entry point works on are refreshed by the same copies, enqueued BEHIND the launch (BROV_TICK_ZEROCOPY=0: ahead).
@@ -865,9 +886,15 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     // Results.  Small batches (the ROS node's batch of one): the kernel writes every record into the pinned buffer itself and then the
     // instance's sequence word; the host polls those words -- no copy command, no stream synchronisation on the way back.  The stream
     // is queried now and then: a launch that ended without delivering (a device fault) falls back to the synchronous path's error.
+    // Larger batches: the kernel still writes the records into the pinned buffer itself (no copy command behind it), without the
+    // per-instance sequence words -- the host waits for the stream once.
+    const bool bulk = !mailbox && rti_phase != 1 && B > kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0) &&
+                      !(getenv("BROV_TICK_BULK") && atoi(getenv("BROV_TICK_BULK")) == 0);
     if (mailbox) {
         s->mail_seq = s->mail_seq == 0x7fffffff ? 1 : s->mail_seq + 1;
         s->mail = (brov_result*)pr; s->mail_flag = (int32_t*)pf;
+    } else if (bulk) {
+        s->mail = (brov_result*)pr; s->mail_flag = nullptr;
     }
     const int rc = brov_solve_phase(s, st, rti_phase);
     const int32_t seq = s->mail_seq;
@@ -892,10 +919,10 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     } else {
-        HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
+        if (!bulk) HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    if (res) std::memcpy(res, pr, B * sizeof(brov_result));
+    if (res && res != (brov_result*)pr) std::memcpy(res, pr, B * sizeof(brov_result));
     return BROV_OK;
 }
 

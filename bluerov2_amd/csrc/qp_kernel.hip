@@ -2194,8 +2194,10 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             if (lane < 4) m->u0[lane] = u0r;
             if (lane < 6) m->thrust[lane] = th;
             if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = status; m->qp_iter = early ? 0 : iters; }
-            __threadfence_system();
-            if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (P.mail_flag) {   // (no sequence words: a large batch, the host waits for the launch)
+                __threadfence_system();
+                if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         emitted = true;
     };

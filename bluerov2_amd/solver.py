@@ -99,6 +99,7 @@ def _load():
         "brov_set_candidate_params_host": [vp, C.c_int, dp, dp, dp], "brov_set_yref_candidates": [vp, C.c_double, C.c_double, vp],
         "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
         "brov_tick_host": [vp, dp, dp, dp, C.c_int, vp],
+        "brov_tick_buffers": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
         "brov_set_time_steps": [vp, dp], "brov_set_stage0_weight": [vp, dp], "brov_general_grid": [vp],
         "brov_enable_dist6": [vp, C.c_int], "brov_dist6_enabled": [vp], "brov_set_rp_disturbance_host": [vp, dp, C.c_int],
         "brov_set_params18_host": [vp, dp, C.c_int], "brov_plant_set_rp_disturbance_host": [vp, dp], "brov_get_rp_disturbance_host": [vp, dp],
@@ -275,6 +276,28 @@ class BatchSolver:
         self._chk(self._L.brov_tick_host(self._h, None if a is None else _dp(a), None if b is None else _dp(b),
                                          None if c is None else _dp(c), int(rti_phase), C.c_void_p(res.ctypes.data)), "tick")
         return res
+
+    def tick_buffers(self):
+        """numpy views of brov_tick_host's pinned staging buffers (brov_tick_buffers): dict(x0 [B,12], yref [N+1,16], params [B,N+1,16],
+        results [B] records).  Fill the inputs in place, call tick_inplace(), read `results` in place: no host-side copies."""
+        if getattr(self, "_tick_views", None) is None:
+            p = [C.c_void_p() for _ in range(4)]
+            self._chk(self._L.brov_tick_buffers(self._h, *[C.byref(q) for q in p]), "tick_buffers")
+
+            def view(ptr, shape, dtype=np.float64):
+                n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+                return np.frombuffer((C.c_char * n).from_address(ptr.value), dtype=dtype).reshape(shape)
+            self._tick_ptrs = [C.cast(q, C.POINTER(C.c_double)) for q in p[:3]]
+            self._tick_views = dict(x0=view(p[0], (self.B, NX)), yref=view(p[1], (self.N + 1, NY)), params=view(p[2], (self.B, self.N + 1, NP)),
+                                    results=view(p[3], (self.B,), RESULT_DTYPE))
+        return self._tick_views
+
+    def tick_inplace(self, x0=True, yref=True, params=False, rti_phase=0):
+        """brov_tick_host on the staging buffers themselves: which of the inputs the caller has rewritten there; returns the results view"""
+        v = self.tick_buffers()
+        p = self._tick_ptrs
+        self._chk(self._L.brov_tick_host(self._h, p[0] if x0 else None, p[1] if yref else None, p[2] if params else None, int(rti_phase), None), "tick")
+        return v["results"]
 
     # ---- non-uniform grid / separate stage-0 weight (acados_solver_bluerov2.h:141,146; .c:422-441): streaming kernels ------------
     def set_time_steps(self, ts):

@@ -199,6 +199,13 @@ int brov_order_stream(brov_solver* s, void* stream);
  * HOST pointers. */
 int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
                    brov_result* res /*[B] or NULL*/);
+/* The staging buffers brov_tick_host copies its arguments into / its records out of: device-visible pinned host memory, valid until
+ * brov_destroy.  A caller that builds its inputs in them and reads its records from them -- pass exactly these pointers as x0 /
+ * yref_shared / par_stage, and NULL as res -- saves the tick its host-side copies (0.8 MB per step at a batch of 4096).  The result
+ * records are written there by the solve kernel itself (no copy command behind the launch; batches <= 64: with a sequence word per
+ * instance that the host polls, larger ones: the host waits for the launch once; BROV_TICK_BULK=0: the copy command of round 3). */
+int brov_tick_buffers(brov_solver* s, double** x0 /*[B][12]*/, double** yref_shared /*[N+1][16]*/, double** par_stage /*[B][N+1][16]*/,
+                      const brov_result** res /*[B]*/);
 /* replace weights / bounds / Ts / QP options of an existing solver (N must not change) */
 int brov_set_opts(brov_solver* s, const brov_opts* opts);
 int brov_get_opts(const brov_solver* s, brov_opts* opts);

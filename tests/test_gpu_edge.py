@@ -320,18 +320,23 @@ def test_work_ordering_changes_nothing_but_the_order(ba, golden_traj, N, B, path
     assert n_qp > B // 4
 
 
-@pytest.mark.parametrize("N,B,mailbox", [(20, 12, True), (20, 12, False), (20, 70, True), (40, 3, True), (80, 1, True), (10, 1, True)])
+@pytest.mark.parametrize("N,B,mailbox", [(20, 12, True), (20, 12, False), (20, 70, True), (20, 70, False), (20, 300, True), (40, 3, True), (80, 1, True),
+                                         (10, 1, True)])
 def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mailbox):
     """brov_tick_host (what the acados-shaped drop-in makes of one bluerov2_acados_solve): pinned staging, ONE upload when all inputs
     are rewritten, and -- for up to 64 instances -- the records written by the kernel straight into pinned host memory, each followed
     by a sequence word the host polls (no copy back, no stream synchronisation; BROV_TICK_MAILBOX=0 and larger batches take the
-    copy + synchronise path).  The same records and the same iterate, bit for bit, as the separate setters + brov_solve +
-    brov_get_results_host on every kernel family; inputs passed as None keep their values"""
+    copy + synchronise path; round 4: larger batches have their records written into the pinned buffer by the kernel as well, without
+    sequence words, and wait for the launch).  The same records and the same iterate, bit for bit, as the separate setters +
+    brov_solve + brov_get_results_host on every kernel family; inputs passed as None keep their values.  A third solver is driven
+    through the staging buffers themselves (brov_tick_buffers: inputs written in place, records read in place)."""
     x0, circ = _inputs(golden_traj, B, seed=21, big=2.5)
     win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])
     p = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16))).copy()
     p[:, :, 0] = np.linspace(-50, 50, B)[:, None]
-    a = ba.BatchSolver(B, ba.SolverOptions(N)); b = ba.BatchSolver(B, ba.SolverOptions(N))
+    a = ba.BatchSolver(B, ba.SolverOptions(N)); b = ba.BatchSolver(B, ba.SolverOptions(N)); c = ba.BatchSolver(B, ba.SolverOptions(N))
+    buf = c.tick_buffers()
+    assert buf["x0"].shape == (B, 12) and buf["yref"].shape == (N + 1, 16) and buf["params"].shape == (B, N + 1, 16) and buf["results"].shape == (B,)
     if not mailbox:
         os.environ["BROV_TICK_MAILBOX"] = "0"
     try:
@@ -347,11 +352,20 @@ def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mai
             assert np.array_equal(b.results()["u0"], rb["u0"])   # the device-side records are the same ones
             for ia, ib in zip(a.get_iterate(), b.get_iterate()):
                 assert np.array_equal(ia, ib)
+            if k != 2:
+                buf["x0"][...] = x0
+            buf["yref"][...] = win[k:k + N + 1]
+            if k in (0, 3):
+                buf["params"][...] = p
+            rc = c.tick_inplace(x0=k != 2, yref=True, params=k in (0, 3))
+            assert rc.tobytes() == rb.tobytes(), k
+            for ia, ic in zip(a.get_iterate(), c.get_iterate()):
+                assert np.array_equal(ia, ic)
     finally:
         os.environ.pop("BROV_TICK_MAILBOX", None)
     if B >= 12:
         assert (ra["qp_iter"] > 0).any()
-    a.close(); b.close()
+    a.close(); b.close(); c.close()
 
 
 @pytest.mark.parametrize("N,B", [(80, 4), (20, 8), (40, 64)])
