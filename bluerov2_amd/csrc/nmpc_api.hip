@@ -90,6 +90,8 @@ struct brov_solver {
     const double *tick_x0 = nullptr, *tick_yref = nullptr, *tick_par = nullptr;
     brov_result* mail = nullptr;     // host mailbox of the tick in flight (device-visible pinned memory), else nullptr
     int32_t* mail_flag = nullptr;
+    bool pit_ran = false;            // the last solve launched rti_pit_kernel
+    int32_t* pit_done = nullptr;     // [B]: written by rti_pit_kernel (parallel-in-time step-0 solve), read by the resident kernel launched behind it
     int32_t mail_seq = 0;
 };
 
@@ -238,6 +240,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(lines, Bz);
     AL(pplant, Bz * 16);
     AL(counter, 64);   // two hand-out counters of the windowed kernel, 128 bytes apart, used alternately
+    AL(pit_done, Bz);   // rti_pit_kernel's per-instance verdict
     AL(sched, 3 * (size_t)sched_buffer_ints_host(B));
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
     s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
@@ -781,7 +784,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     if (int rc = order_behind_last(s, st)) return rc;   // e.g. a brov_tick_host whose kernel is still finishing on the solver's own stream
-    const DevParams P = make_params(s);
+    DevParams P = make_params(s);
     const int path = s->opts.kernel_path;
     // LDS-resident kernels (one launch): whole horizon for N <= 23, windowed above.  rti_phase 1 / 2 (preparation and feedback as
     // separate calls) need the linearisation in HBM between the calls: streaming kernels.
@@ -796,11 +799,21 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING && !grid_resident;
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
     const bool windowed = lds_path && !fused && s->ws != nullptr;
+    s->pit_ran = false;
     if (s->timing) hipEventRecord(s->ev[0], st);
     if (fused || windowed) {
         if (s->timing) hipEventRecord(s->ev[1], st);
         if (fused) launch_fused(P, st);
-        else { launch_windowed(P, st); s->win_tick++; }   // persistent blocks; the two hand-out counters alternate
+        else {
+            // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
+            // instance is tried, not only those whose previous step was an early exit)
+            const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
+            if (pit && s->pit_done && pit_supported(s->N, s->win_L) && !general_grid(s) && s->opts.qp_early_exit && !s->dump_lin && !s->dbg) {
+                P.pit = pit; P.pit_done = s->pit_done;
+            }
+            s->pit_ran = P.pit != 0;
+            launch_windowed(P, st); s->win_tick++;   // persistent blocks; the two hand-out counters alternate
+        }
     } else {
         if (rti_phase != 2) launch_linearise(P, st);
         if (s->timing) hipEventRecord(s->ev[1], st);
@@ -953,6 +966,16 @@ extern "C" int brov_synchronize(brov_solver* s, void* stream) {
 }
 extern "C" int brov_last_kernel_path(const brov_solver* s) {
     return s ? (s->last_fused ? BROV_PATH_FUSED : (s->last_windowed ? BROV_PATH_WINDOWED : BROV_PATH_STREAMING)) : BROV_ERR_ARG;
+}
+// which instances of the LAST solve were completed by the parallel-in-time kernel (rti_pit_kernel, batches the resident windowed mode
+// serves): done[b] = 1, else 0 -- all zero when that kernel did not run.  Test / bench instrumentation.
+extern "C" int brov_pit_last(brov_solver* s, int32_t* done) {
+    if (!s || !done) return BROV_ERR_ARG;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->last_stream));
+    if (!s->pit_ran) { std::memset(done, 0, (size_t)s->B * sizeof(int32_t)); return BROV_OK; }
+    HIPCHK(hipMemcpy(done, s->pit_done, (size_t)s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return BROV_OK;
 }
 extern "C" int brov_lds_kernel_info(const brov_solver* s, int32_t info[4]) {
     if (!s || !info) return BROV_ERR_ARG;

@@ -20,6 +20,8 @@ namespace brov {
 struct DevParams {
     int32_t B, N;
     int32_t qp_iter_max, early_exit;
+    int32_t pit;             // parallel-in-time step-0 solve ahead of the resident windowed kernel: 0 off, 1 instances whose previous step was an early exit, 2 every instance (tests)
+    int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
     int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)
     double Ts, tol_mu, tol_stat;
@@ -84,6 +86,7 @@ bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
 // windowed LDS-resident kernel for longer horizons: persistent blocks (one wavefront each) that take instances from a counter
 void launch_windowed(const DevParams& P, hipStream_t st);
 void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]);   // LDS bytes per block, blocks per CU, threads, kernel kind
+bool pit_supported(int N, int win_L);       // rti_pit_kernel ahead of the resident kernel
 bool windowed_is_resident(int win_L);      // one window = the whole horizon (small batches): no general-grid instantiation
 int windowed_stage_count(int N, int B);   // stages per window (= N for batches of at most one instance per CU: resident mode)
 int windowed_blocks(int N, int B, int L); // persistent blocks that will be launched on the current device

@@ -366,7 +366,12 @@ __device__ __forceinline__ BwdIn load_bwd(const IT& I, int i, const double* gam,
 // not positive definite.  The sweep is split into bwd_init (terminal cost -> P, p) and bwd_chunk (the stages of the resident
 // window, state carried in registers) so that the windowed kernel can run it window by window.
 // illc: a pivot block of the sweep was ill-conditioned (see kPivotRho); wave-uniform like ok
-struct BwdState { d4 P, pv; bool ok; bool illc = false; };
+struct PitAcc { d4 Psi, G; };
+struct BwdState { d4 P, pv; bool ok; bool illc = false; PitAcc acc; };   // acc: bwd_chunk<..., ACC = true> only (see PitAcc)
+// Parallel-in-time step-0 solve (rti_pit_kernel): what a segment's factor sweep accumulates next to its Riccati recursion, so that the
+// segment can be condensed to its two ends -- Psi = Phi' (Phi: closed-loop transition from the current stage to the segment end, 12 x 12
+// in columns 0..11), G rows 0..11 = sum Z M Z' (Z = Phi_{i+1} B_i: how the segment's end state answers to a costate at that end), G row 12 =
+// c' (c: the forced response of the segment end).  Filled by bwd_chunk<..., ACC = true> (struct PitAcc, a member of BwdState).
 // The 4x4 pivot block Huu is inverted EXPLICITLY by 2x2 block elimination (two reciprocals on the serial chain of every stage).  That is
 // as accurate as a Cholesky solve while the block is well conditioned after diagonal scaling, and loses a factor cond(Huu) against
 // it otherwise (round 4, scripts/dev/riccati_pivot_variants.py: on QPs whose condensed Hessian has cond 1e11..1e13 the explicit
@@ -458,8 +463,10 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
 
 // hi / lo: the sweep runs over the stages hi-1 .. lo of the resident block (default: all I.N of them); explicit arguments, not fields of
 // Inst -- a horizon that changes under the compiler's eyes costs every sweep of the kernel its loop-invariant addressing
-template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false, class IT = Inst>
+template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false, class IT = Inst, bool ACC = false>
 __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1, int lo = 0) {
+    PitAcc* const acc = &S.acc;
+    static_assert(!ACC || (FACTOR && STEP0 && LDS == 3 && !ROBUST && !STORE_IPM), "ACC: the step-0 factor sweep of rti_pit_kernel");
     if constexpr (!FACTOR && LDS != 0) {
         bwd_solve_v<LDS>(I, S);
         return;
@@ -675,6 +682,22 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             } else if (cl == 0) {
                 I.kff[i * 4 + rg] = -pn[3];
             }
+            if constexpr (ACC) {
+                // off the Riccati chain (nothing of it feeds P or p): six products per stage
+                d4 R = tn<3>(ba1, acc->Psi, z4);               // [b | A(:,1:) B]' Psi: rows 1..11 = A'Psi, rows 12..15 = Z' = B'Psi, row 0 = b'Psi
+                const double bPsi = R[0];
+                R[0] = (rg == 0) ? acc->Psi[0] : R[0];         // the true row 0 of A'Psi is row 0 of Psi (column 0 of A is e_0)
+                const d4 MZ = tn1(mt, R[3], z4);               // rows 0..3: M Z' -- what a costate at the segment end adds to this stage's feed-forward term
+                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = MZ[0];  // (the gain | M tile of the in-loop sweeps lives there otherwise: no loop in this kernel)
+                const double kffb = dpp_f64<0x150>(-pn[3]);    // row_newbcast:0 -- kff_m in every lane of row m
+                const double Xg = (cl < NX) ? MZ[0] : ((cl == NX) ? kffb : 0.0);
+                d4 Gn = tn1(Xg, R[3], acc->G);                 // rows 0..11 += Z M Z', row 12 += kff' Z'
+                Gn[3] += (rg == 0) ? bPsi : 0.0;               // row 12 += b'Psi
+                acc->G = Gn;
+                d4 Pn = tn1(ks, R[3], d4{R[0], R[1], R[2], 0.0});   // (A + B K)' Psi
+                Pn[3] = 0.0;
+                acc->Psi = Pn;
+            }
             P = S;
 #pragma unroll
             for (int r = 0; r < 3; r++) pv[r] = kMaskPvAtUse ? pn[r] : blend(mk_col0, pn[r], 0.0);
@@ -802,10 +825,13 @@ __device__ __forceinline__ FwdV load_fwd_v(const lds_f64* mrow, const lds_f64* k
     s.cv = *cvec;
     return s;
 }
+// first: where the entering state step is staged for the sweep (default: row 0 of the block's state steps, which it IS; rti_pit_kernel:
+// a scratch slot -- a segment's row 0 is the last row of the segment before it and is written by that segment's sweep only)
 template <int LDS>
-__device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
+__device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx, lds_f64* first = nullptr) {
     const int rg = I.rg, cl = I.cl, N = I.N;
-    if constexpr (LDS) store_vec12_lds(I.lds_dxb, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
+    lds_f64* const x_in = first ? first : I.lds_dxb;
+    if constexpr (LDS) store_vec12_lds(x_in, xx, rg, cl); else store_vec12(I.dxb, xx, rg, cl);
     if constexpr (LDS) {
         const int k = I.lane & 15;
         const bool rowx = k < NX;
@@ -826,7 +852,7 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx) {
         // ONE 16-lane row runs the sweep.  Every row would compute the same thing, and every row's LDS reads cost LDS clocks: a
         // 64-lane ds_read_b64 occupies the CU's LDS (shared by the four resident waves, all of them in the same phase) for 4
         // clocks, a 16-lane one for 1 -- with 17 reads per stage that is the difference between 9.2 k and 7.7 k cycles per sweep.
-        double xcur = I.lds_dxb[rowx ? k : 0];
+        double xcur = x_in[rowx ? k : 0];
         if (I.lane < 16)
         pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(mrow0 + kk * mstr, klo0 + kk * kKtStage, brow0 + kk * kBaStage, cvec0 + kk * cstr); },
                                        [&](int i, const FwdV& in) {
@@ -2859,7 +2885,7 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel_grid(DevParams P) { rt
 
 // function attributes are per device (a process may hold solvers on several GPUs): one flag per (launcher, device)
 static bool first_launch_on_device(int which) {
-    static bool done[3][64] = {};
+    static bool done[4][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
     const bool first = !done[which][dev];
@@ -2912,6 +2938,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         if (threadIdx.x >= 64) {
             const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
             const int b = __builtin_amdgcn_readfirstlane(sched_map(P, (int)blockIdx.x));
+            if (P.pit_done && P.pit_done[b]) return;   // rti_pit_kernel has completed this instance's step (wave 0 takes the same decision)
             const int lsub = (N + 3) >> 2, j0 = wv * lsub, nj = N - j0 < lsub ? N - j0 : lsub;
             double part = 0.0;
             bool nanp = false;
@@ -2948,6 +2975,15 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         int b = 0;
         if (RES && trip == 0) {
             b = (int)blockIdx.x;   // the helper waves work on this ticket
+            if constexpr (RES) {
+                if (P.pit_done) {
+                    const int bm = __builtin_amdgcn_readfirstlane(sched_map(P, b));
+                    if (P.pit_done[bm]) {   // done by rti_pit_kernel: nothing to do but to keep the work-ordering tables consistent
+                        sched_note(P, bm, -1);
+                        continue;
+                    }
+                }
+            }
         } else {
             if (lane == 0) b = atomicAdd(P.counter, 1) + (RES ? (int)gridDim.x : 0);
             b = __builtin_amdgcn_readfirstlane(b);
@@ -3075,6 +3111,429 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_wi
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_grid(DevParams P) { rti_window_body<false, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Parallel-in-time step-0 solve (round 4): rti_pit_kernel, for the batches the resident mode serves (at most one instance per CU, the
+// whole horizon in one LDS slice; the ROS node's batch of one at the shipped N = 80).  There the step is ONE wave's serial chain:
+// 80 factor stages + 80 forward stages = 78 us of the 90 us to the record.  Here the block's four waves keep the quarter of the
+// horizon they linearised:
+//   1. every wave factorises its segment with the ordinary Riccati sweep from a ZERO terminal cost (the last one: the true terminal cost)
+//      and accumulates, next to it, how the segment maps to its two ends (PitAcc: Psi, G, c);
+//   2. a relay over the three inner boundaries, last to first: the exact cost-to-go (Pc, pc) at a segment's end and the segment's
+//      condensed form give the exact cost-to-go at its start,
+//          W = (Pc^-1 + G)^-1,  Pc' = P0 + Psi W Psi',  pc' = p0 + Psi (W (c - G pc) + pc)
+//      (two 12 x 12 SPD inverses by block sweeps with the factor sweep's own 4 x 4 pivot algebra); then first to last the boundary
+//      states and costates,  lam = W (Phi x + c - G pc) + pc,  x' = Phi x + c - G lam;
+//   3. every wave adds the costate's share to its feed-forward terms (kff_i -= M_i Z_i' lam: independent per stage) and runs the forward
+//      sweep over its own segment from its boundary state.
+// Same minimiser as the sequential sweep (scripts/dev/pit_prototype.py: 1e-14 relative on the oracle's linearisations).  Wave 0 then
+// checks the bounds; an answer inside them is THE answer (early exit): record, adjoint sweep, full step as in the resident kernel, and
+// pit_done[b] = 1 -- the resident kernel, which is launched behind this one in any case, skips the instance.  Anything else (a bound
+// active, a pivot block not positive definite or ill-conditioned, a NaN) leaves the iterate untouched and pit_done[b] = 0: the
+// resident kernel does the whole step.  Instances whose previous step was not an early exit are not tried (their record says so).
+// LDS: the resident slice + 220 doubles (hand-over buffers, one transposition scratch per wave): N <= 80.
+constexpr int kPitExtraDoubles = 8 + 144 + 12 + 12 + 3 * 17 + 1;
+__host__ __device__ constexpr int pit_off_flags(int L) { return win_off_const(L) + 2 + 17; }   // 4 + 4 doubles: per-wave KKT partial, verdict
+__host__ __device__ constexpr int pit_off_P(int L) { return pit_off_flags(L) + 8; }
+__host__ __device__ constexpr int pit_off_p(int L) { return pit_off_P(L) + 144; }
+__host__ __device__ constexpr int pit_off_x(int L) { return pit_off_p(L) + 12; }
+__host__ __device__ constexpr int pit_off_tr(int L) { return pit_off_x(L) + 12; }            // waves 1..3 (wave 0 uses the slice's own)
+
+// inverse of an SPD 4 x 4 block given by its lower triangle (the 2 x 2 block elimination of the factor sweep)
+struct Sym4 { double m00, m10, m11, m20, m21, m22, m30, m31, m32, m33; };
+__device__ __forceinline__ Sym4 inv4_spd(double a00, double a10, double a11, double a20, double a21, double a22, double a30, double a31, double a32,
+                                         double a33, bool& ok) {
+    Sym4 m;
+    const double detE = a00 * a11 - a10 * a10, iE = fast_rcp(detE);
+    const double e00 = a11 * iE, e01 = -a10 * iE, e11 = a00 * iE;
+    const double x00 = e00 * a20 + e01 * a21, x01 = e00 * a30 + e01 * a31;
+    const double x10 = e01 * a20 + e11 * a21, x11 = e01 * a30 + e11 * a31;
+    const double s00 = a22 - (a20 * x00 + a21 * x10), s01 = a32 - (a20 * x01 + a21 * x11);
+    const double s11 = a33 - (a30 * x01 + a31 * x11);
+    const double detS = s00 * s11 - s01 * s01, iS = fast_rcp(detS);
+    m.m22 = s11 * iS; m.m32 = -s01 * iS; m.m33 = s00 * iS;
+    m.m20 = -(x00 * m.m22 + x01 * m.m32); m.m30 = -(x00 * m.m32 + x01 * m.m33);
+    m.m21 = -(x10 * m.m22 + x11 * m.m32); m.m31 = -(x10 * m.m32 + x11 * m.m33);
+    m.m00 = e00 - (m.m20 * x00 + m.m30 * x01); m.m10 = e01 - (m.m20 * x10 + m.m30 * x11);
+    m.m11 = e11 - (m.m21 * x10 + m.m31 * x11);
+    if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
+    return m;
+}
+// Inverse of an SPD 12 x 12 matrix held as a tile (rows rg + 4r, columns cl < 12; everything else zero) by three symmetric block sweeps:
+//   sweep k:  M = S_kk^-1,  Y = M S_k:,  S <- S - S_k:' Y,  block row k <- Y,  block column k <- Y',  S_kk <- -M;     after all three: -S^-1.
+// Block row k of the tile is its register k: the products are single 16x16x4 tiles.
+__device__ __forceinline__ d4 sweep12(d4 S, int rg, int cl, bool& ok) {
+    const d4 z4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c0 = 4 * k;
+        const double Rk = S[k];
+        const Sym4 m = inv4_spd(readlane_f64(Rk, c0), readlane_f64(Rk, 16 + c0), readlane_f64(Rk, 17 + c0), readlane_f64(Rk, 32 + c0),
+                                readlane_f64(Rk, 33 + c0), readlane_f64(Rk, 34 + c0), readlane_f64(Rk, 48 + c0), readlane_f64(Rk, 49 + c0),
+                                readlane_f64(Rk, 50 + c0), readlane_f64(Rk, 51 + c0), ok);
+        const int cq = cl & 3;
+        const int a = rg > cq ? rg : cq, c = rg > cq ? cq : rg;   // element (max, min) of the symmetric block for this lane
+        const double r1 = (c == 0) ? m.m10 : m.m11;
+        const double r2 = (c == 0) ? m.m20 : ((c == 1) ? m.m21 : m.m22);
+        const double r3 = (c == 0) ? m.m30 : ((c == 1) ? m.m31 : ((c == 2) ? m.m32 : m.m33));
+        const double msel = (a == 0) ? m.m00 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));   // M[rg][cl & 3]
+        const double mt = (cl < 4) ? msel : 0.0;
+        const d4 Y4 = tn1(mt, Rk, z4);                 // rows 0..3: Y = M S_k:
+        const double Y = Y4[0];
+        d4 Sn = tn1(Rk, -Y, S);                        // S - S_k:' Y
+        const double ek = (cl == c0 + rg) ? 1.0 : 0.0;
+        const d4 Yt = tn1(Y, ek, z4);                  // Y' placed in block column k
+        const bool inblk = (cl >= c0) && (cl < c0 + 4);
+#pragma unroll
+        for (int r = 0; r < 3; r++) Sn[r] = inblk ? Yt[r] : Sn[r];
+        Sn[k] = inblk ? -msel : Y;
+        Sn[3] = 0.0;
+        S = Sn;
+    }
+    return d4{-S[0], -S[1], -S[2], 0.0};
+}
+// the result record of an early exit (what qp_body's emit_record writes): device copy, thrust allocation epilogue
+// (bluerov2_dob.cpp:390-395), and -- brov_tick_host -- the host mailbox
+__device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int lane, double cost_lane, double u0_lane, double kkt) {
+    const double cs = wave_sum(cost_lane);
+    if (lane == 0) {
+        brov_result* r = P.res + b;
+        r->cost = cs; r->kkt = kkt; r->status = BROV_STATUS_SUCCESS; r->qp_iter = 0;
+    }
+    const double a0 = readlane_f64(u0_lane, 0), a1 = readlane_f64(u0_lane, 1), a2 = readlane_f64(u0_lane, 2), a3 = readlane_f64(u0_lane, 3);
+    const double s0 = (lane == 0 || lane == 1) ? -a0 : a0;
+    const double s1 = (lane == 0 || lane == 2) ? a1 : -a1;
+    const double s3 = (lane == 0 || lane == 3) ? a3 : -a3;
+    const double th = ((lane < 4) ? (s0 + s1) + s3 : -a2) / kRotor;
+    if (lane < 6) P.res[b].thrust[lane] = th;
+    if (P.mail) {
+        brov_result* m = P.mail + b;
+        if (lane < 4) m->u0[lane] = u0_lane;
+        if (lane < 6) m->thrust[lane] = th;
+        if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = BROV_STATUS_SUCCESS; m->qp_iter = 0; }
+        if (P.mail_flag) {
+            __threadfence_system();
+            if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane0 = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int N = P.N, Lc = P.win_L;   // resident mode: Lc = N
+    const int b = __builtin_amdgcn_readfirstlane(sched_map(P, (int)blockIdx.x));
+    if (b >= P.B) return;
+    {   // worth trying?  The previous step of this instance was an early exit (its record says so; a fresh solver: zeros = yes)
+        const brov_result* prev = P.res + b;
+        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter == 0);
+        if (!try_it) { if (threadIdx.x == 0) P.pit_done[b] = 0; return; }
+    }
+    double* ba_s = smem;
+    double* bv_s = smem + win_off_bv(Lc);
+    double* q_s = smem + win_off_q(Lc);
+    double* r_s = smem + win_off_r(Lc);
+    double* kt_s = smem + win_off_kt(Lc);
+    double* kff_s = smem + win_off_kff(Lc);
+    double* vh_s = smem + win_off_vh(Lc);
+    double* dx_s = smem + win_off_dx(Lc);
+    double* const_s = smem + win_off_const(Lc);
+    lds_f64* flag_s = (lds_f64*)(smem + pit_off_flags(Lc));
+    lds_f64* mailP = (lds_f64*)(smem + pit_off_P(Lc));
+    lds_f64* mailp = (lds_f64*)(smem + pit_off_p(Lc));
+    lds_f64* mailx = (lds_f64*)(smem + pit_off_x(Lc));
+    lds_f64* tr_w = wv == 0 ? (lds_f64*)const_s + 2 : (lds_f64*)(smem + pit_off_tr(Lc)) + (wv - 1) * 17;
+    if (threadIdx.x == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
+    // ---- segments = the quarters of the linearisation
+    const int lsub = (N + 3) >> 2;
+    const int s0 = wv * lsub, nseg = (N - s0 < lsub) ? N - s0 : lsub;
+    const bool last = s0 + nseg == N;
+    double part = 0.0;
+    bool nanp = false;
+    const LaneCst lc = load_lane_cst(P.cst, lane);
+    __syncthreads();
+    lin_phase<true>(P, b, s0, nseg, lane, ba_s + (size_t)s0 * kBaStage, bv_s + (size_t)s0 * NX, kt_s + (size_t)s0 * kRecInterval, q_s + (size_t)s0 * NX,
+                    r_s + (size_t)s0 * NU, part, nanp, false);
+    {
+        const double pw = wave_max(part);
+        const bool nw = __ballot(nanp) != 0ull;
+        if (lane == 0) flag_s[wv] = nw ? __builtin_nan("") : pw;
+    }
+    __syncthreads();   // (the stage-record scratch of the linearisation is the K^T .. dx area the sweeps write next)
+    // ---- this wave's view of its segment
+    // (the block's workspace as the resident kernel lays it out: one parked image -- unused here --, candidate inputs, state steps, and the
+    // gain | M tiles of the in-loop sweeps, where this kernel keeps its M Z' tiles; nothing else of it is touched)
+    double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
+    double* ws_vhat = ws + (size_t)1 * win_img_doubles(Lc);
+    double* ws_dxb = ws_vhat + (size_t)N * 4;
+    double* ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
+    auto setup = [&](Inst& I, int seg0, int nst, lds_f64* tr) __attribute__((always_inline)) {
+        setup_inst(P, I, b, lane, &lc);
+        I.Ks = ws_Ks; I.Mt = nullptr; I.Pb = nullptr; I.ipm = nullptr;
+        I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr; I.ckpt = 0;
+        I.BA = nullptr; I.bvec = nullptr;
+        I.i0 = seg0; I.N = nst; I.NT = N;
+        const double* ba = ba_s + (size_t)seg0 * kBaStage;
+        I.lds_ba = (const lds_f64*)ba;
+        I.lds_bv = (const lds_f64*)(bv_s + (size_t)seg0 * NX);
+        I.lds_kt = (lds_f64*)(kt_s + (size_t)seg0 * kKtStage);
+        I.lds_q = (const lds_f64*)(q_s + (size_t)seg0 * NX);
+        I.lds_r = (const lds_f64*)(r_s + (size_t)seg0 * NU);
+        I.lds_kff = (lds_f64*)(kff_s + (size_t)seg0 * 4);
+        I.lds_vhat = (lds_f64*)(vh_s + (size_t)seg0 * 4);
+        I.lds_dxb = (lds_f64*)(dx_s + (size_t)seg0 * NX);
+        I.lds_zero = (lds_f64*)const_s;
+        I.lds_tr = tr;
+        const int rg = I.rg, cl = I.cl;
+        const int zero = (int)(const_s - ba), one = zero + 1, kt0 = (int)((kt_s + (size_t)seg0 * kKtStage) - ba);
+        for (int r = 0; r < 3; r++) I.ba_off[r] = cl >= 3 ? (rg + 4 * r) * kBaStride + cl - 3 : ((r == 0 && rg == cl) ? one : zero);
+        I.ba_str = cl >= 3 ? kBaStage : 0;
+        for (int r = 0; r < 4; r++) {
+            const int c = rg + 4 * r;
+            I.bat_off[r] = cl >= NX ? zero : (c >= 3 ? cl * kBaStride + c - 3 : (c == cl ? one : zero));
+        }
+        I.bat_str = cl >= NX ? 0 : kBaStage;
+        I.bat_str0 = (cl < NX && rg == 3) ? kBaStage : 0;
+        for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
+        I.kt_str = cl < 4 ? kKtStage : 0;
+    };
+    Inst I;
+    setup(I, s0, nseg, tr_w);
+    const int rg = I.rg, cl = I.cl;
+    const d4 z4 = {0, 0, 0, 0};
+    // d0 = x0 - x_0 (wave 0 rolls out from it; everybody needs it for nothing else)
+    double x0v[3], xiv[3];
+    {
+        const double* x0 = P.x0 + (size_t)b * 12;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { x0v[r] = x0[rg + 4 * r]; xiv[r] = I.x[rg + 4 * r]; }
+    }
+    // ---- 1. local factor sweep with the condensing accumulators
+    BwdState S;
+    PitAcc& acc = S.acc;
+    wave_fence();
+    if (last) bwd_init<true, 3>(I, S);
+    else { S.P = z4; S.pv = z4; S.ok = true; }
+#pragma unroll
+    for (int r = 0; r < 3; r++) acc.Psi[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
+    acc.Psi[3] = 0.0;
+    acc.G = z4;
+    bwd_chunk<true, 3, false, true, false, Inst, true>(I, S);
+    wave_fence();
+    bool good = S.ok && !S.illc;
+    // vectors travel row-replicated (lane (rg, cl): elements rg, rg + 4, rg + 8)
+    d4 p0;   // p of the segment start: column 0 of S.pv -> every column
+#pragma unroll
+    for (int r = 0; r < 3; r++) p0[r] = dpp_f64<0x150>(S.pv[r]);
+    p0[3] = 0.0;
+    d4 cbar;   // row 12 of G (lanes rg == 0) -> row-replicated
+    {
+        lds_f64* t = (rg == 0 && cl < NX) ? tr_w + cl : tr_w + 16;
+        *t = acc.G[3];
+        cbar = d4{tr_w[rg], tr_w[rg + 4], tr_w[rg + 8], 0.0};
+    }
+    d4 G = acc.G;
+    G[3] = 0.0;
+    const d4 Psi = acc.Psi;
+    d4 idt;
+#pragma unroll
+    for (int r = 0; r < 3; r++) idt[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
+    idt[3] = 0.0;
+    const d4 Phi = tn<3>(Psi, idt, z4);   // the transpose
+    // ---- 2a. coarse relay, last boundary to first: wave j + 1 publishes the cost-to-go at its start, wave j takes it to its own start
+    d4 W = z4, vv = z4, pcn = z4, Pcn = z4;   // this segment's W, c - G pc, and the (Pc, pc) it was built with (the forward relay needs them)
+    auto publish = [&](const d4& Pt, const d4& pt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            lds_f64* t = cl < NX ? mailP + (rg + 4 * r) * NX + cl : tr_w + 16;   // (the wave's parking slot)
+            *t = Pt[r];
+        }
+        store_vec12_lds(mailp, pt, rg, cl);
+    };
+    d4 Pst = S.P, pst = p0;   // the exact cost-to-go at this segment's start once the relay has passed (the last segment: already)
+    Pst[3] = 0.0;
+    for (int j = 3; j >= 1; j--) {
+        if (wv == j) publish(Pst, pst);
+        __syncthreads();
+        if (wv == j - 1) {
+            d4 Pc;
+#pragma unroll
+            for (int r = 0; r < 3; r++) Pc[r] = cl < NX ? (double)mailP[(rg + 4 * r) * NX + cl] : 0.0;
+            Pc[3] = 0.0;
+            Pcn = Pc;
+            pcn = d4{mailp[rg], mailp[rg + 4], mailp[rg + 8], 0.0};
+            d4 Pi = sweep12(Pc, rg, cl, good);
+#pragma unroll
+            for (int r = 0; r < 3; r++) Pi[r] += G[r];
+            W = sweep12(Pi, rg, cl, good);
+            const d4 Gp = tn<3>(G, pcn, z4);                    // G pc (G symmetric)
+#pragma unroll
+            for (int r = 0; r < 3; r++) vv[r] = cbar[r] - Gp[r];
+            d4 Pe, Ce;                                          // [Phi | v] and [0 | pc]: the vectors ride in column 12
+#pragma unroll
+            for (int r = 0; r < 3; r++) { Pe[r] = (cl == NX) ? vv[r] : Phi[r]; Ce[r] = (cl == NX) ? pcn[r] : 0.0; }
+            Pe[3] = 0.0; Ce[3] = 0.0;
+            d4 in = tn<3>(W, Pe, Ce);                           // [W Phi | W v + pc]
+            in[3] = 0.0;
+            const d4 out = tn<3>(Phi, in, z4);                  // Psi [W Phi | W v + pc]
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                Pst[r] = S.P[r] + ((cl < NX) ? out[r] : 0.0);
+                pst[r] = p0[r] + dpp_f64<0x15C>(out[r]);        // row_newbcast:12
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 2b. first boundary to last: boundary states and the costates at the segment ends
+    d4 xh = z4, lam = z4;
+    if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) xh[r] = x0v[r] - xiv[r];
+    }
+    for (int j = 0; j < 3; j++) {
+        if (wv == j) {
+            const d4 y1 = tn<3>(Psi, xh, z4);                   // Phi x
+            d4 y2;
+#pragma unroll
+            for (int r = 0; r < 3; r++) y2[r] = y1[r] + vv[r];
+            y2[3] = 0.0;
+            lam = tn<3>(W, y2, pcn);                            // W (Phi x + c - G pc) + pc
+            lam[3] = 0.0;
+            const d4 gl = tn<3>(G, lam, z4);
+            d4 xn;
+#pragma unroll
+            for (int r = 0; r < 3; r++) xn[r] = y1[r] + cbar[r] - gl[r];
+            xn[3] = 0.0;
+            store_vec12_lds(mailx, xn, rg, cl);
+            // What the two explicit inverses behind W are worth on THIS problem: the costate at the boundary must be the gradient of the
+            // cost-to-go there, lam = Pc x' + pc -- exactly so for the exact W, and off by (I + Pc G) times the error of lam otherwise.  An
+            // iterate on its way out of the physical regime (cond(Pc) 1e8 and more) fails this; its step is left to the resident kernel's
+            // sequential sweep, which needs no such inverse (tests/test_gpu_parity.py, the nominal-model fuzz, found such instances).
+            const d4 l2 = tn<3>(Pcn, xn, pcn);
+            double mis = 0.0, sc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) { mis = fmax(mis, fabs(l2[r] - lam[r])); sc = fmax(sc, fabs(lam[r])); }
+            mis = wave_max(mis); sc = wave_max(sc);
+            if (!(mis <= 1e-9 * sc + 1e-300)) good = false;
+        }
+        __syncthreads();
+        if (wv == j + 1) xh = d4{mailx[rg], mailx[rg + 4], mailx[rg + 8], 0.0};
+        __syncthreads();
+    }
+    // ---- 3. the costate's share of the feed-forward terms, then the forward sweep of the segment
+    if (!last) {
+        store_vec12_lds(tr_w, lam, rg, cl);
+        const double lc_ = tr_w[cl < NX ? cl : 0];
+        const double lcl = cl < NX ? lc_ : 0.0;
+        // (a rolled loop over batches of four stages, the next batch requested before the current one is used: fully unrolled, the 20 stages
+        // cost the kernel 18 more SGPR spills than its one lane-spill register holds, and the rest went to scratch)
+        const double* kb = I.Ks + (size_t)s0 * 64 + lane;
+        const int nlast = nseg - 1;
+        double mz[4], mn[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) mz[t] = kb[(t < nlast ? t : nlast) * 64];
+#pragma clang loop unroll(disable)
+        for (int i0 = 0; i0 < nseg; i0 += 4) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int i = i0 + 4 + t; mn[t] = kb[(i < nlast ? i : nlast) * 64]; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i = i0 + t < nlast ? i0 + t : nlast;       // (past the end: the last stage again, same value written twice)
+                double v = mz[t] * lcl;                              // (M Z')[rg][cl] lam[cl]
+                v += dpp_f64<0xB1>(v);
+                v += dpp_f64<0x4E>(v);
+                v += dpp_f64<0x141>(v);
+                v += dpp_f64<0x140>(v);                              // the row's sum in every lane
+                lds_f64* kp = (cl == 0 && i0 + t < nseg) ? I.lds_kff + i * 4 + rg : tr_w + 16;
+                const double k0 = I.lds_kff[i * 4 + rg];
+                *kp = k0 - v;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) mz[t] = mn[t];
+        }
+    }
+    wave_fence();
+    {
+        d4 xx = xh;
+        fwd_chunk<3>(I, xx, wv == 0 ? nullptr : tr_w);
+    }
+    wave_fence();
+    if (lane == 0) flag_s[4 + wv] = good ? 1.0 : 0.0;
+    __syncthreads();
+    if (wv != 0) return;
+    // ---- wave 0: the checks of the forward sweep's wrapper over the whole horizon, then the early exit or nothing
+    bool all_good = true;
+    double kkt_lin = 0.0;
+    bool nan_lin = false;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        all_good = all_good && (flag_s[4 + w] == 1.0);
+        const double v = flag_s[w];
+        nan_lin = nan_lin | !(v == v);
+        kkt_lin = fmax(kkt_lin, v);
+    }
+    // (everything the record and the full step address is derived from an opaque copy of the instance index HERE: formed from `b` itself the
+    // base addresses are loop invariants of the whole kernel, computed up front and spilled -- one SGPR spill more than the kernel's
+    // lane-spill register holds, and the build then reserves scratch)
+    int bq = b;
+    asm volatile("s_mov_b32 %0, %0" : "+s"(bq));
+    setup_inst(P, I, bq, lane, &lc);
+    I.Ks = ws_Ks; I.Mt = nullptr; I.Pb = nullptr; I.ipm = nullptr; I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr; I.ckpt = 0;
+    {   // the whole horizon as one block
+        I.i0 = 0; I.N = N; I.NT = N;
+        I.lds_ba = (const lds_f64*)ba_s; I.lds_bv = (const lds_f64*)bv_s; I.lds_kt = (lds_f64*)kt_s; I.lds_q = (const lds_f64*)q_s;
+        I.lds_r = (const lds_f64*)r_s; I.lds_kff = (lds_f64*)kff_s; I.lds_vhat = (lds_f64*)vh_s; I.lds_dxb = (lds_f64*)dx_s;
+        I.lds_zero = (lds_f64*)const_s; I.lds_tr = (lds_f64*)const_s + 2;
+        const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
+        for (int r = 0; r < 3; r++) I.ba_off[r] = cl >= 3 ? (rg + 4 * r) * kBaStride + cl - 3 : ((r == 0 && rg == cl) ? one : zero);
+        I.ba_str = cl >= 3 ? kBaStage : 0;
+        for (int r = 0; r < 4; r++) {
+            const int c = rg + 4 * r;
+            I.bat_off[r] = cl >= NX ? zero : (c >= 3 ? cl * kBaStride + c - 3 : (c == cl ? one : zero));
+        }
+        I.bat_str = cl >= NX ? 0 : kBaStage;
+        I.bat_str0 = (cl < NX && rg == 3) ? kBaStage : 0;
+        for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
+        I.kt_str = cl < 4 ? kKtStage : 0;
+    }
+    Win Wn;
+    Wn.nc = 1; Wn.Lc = Lc; Wn.cur = 0; Wn.valid = WM_LIN | WM_GAIN | WM_DX; Wn.lds = smem; Wn.img = ws; Wn.nan = false; Wn.feas = true;
+    d4 d0;
+    double kkt = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { d0[r] = x0v[r] - xiv[r]; kkt_upd(kkt, d0[r]); }
+    d0[3] = 0.0;
+    bool nanp2 = nan_lin;
+    if (kkt != kkt) nanp2 = true;
+    kkt = wave_max(fmax(kkt_lin, (kkt != kkt) ? 0.0 : kkt));
+    const bool kkt_nan = __ballot(nanp2) != 0ull;
+    win_flush_small(I.vhat, smem + win_off_vh(Lc), N * 4, lane);
+    win_flush_small(I.dxb, smem + win_off_dx(Lc), (N + 1) * NX, lane);
+    const bool bad = win_nan_check<true>(I, Wn, true);
+    bool infeas = false;
+    {
+        const double lbm = P.cst[32 + (lane & 3)], ubm = P.cst[36 + (lane & 3)];
+        const lds_f64* vh = (const lds_f64*)(smem + win_off_vh(Lc));
+        for (int j = lane; j < N * 4; j += 64) {
+            const double vj = vh[j], uj = I.u[j];
+            infeas = infeas | !(vj >= lbm - uj && vj <= ubm - uj);
+        }
+    }
+    const bool accept = all_good && !kkt_nan && __ballot(bad) == 0ull && __ballot(infeas) == 0ull && P.early_exit;
+    if (!accept) {
+        if (lane == 0) P.pit_done[bq] = 0;
+        return;
+    }
+    double cost = 0.0, u0v = 0.0;
+    bool emitted = false;
+    win_adjoint_commit<true>(P, I, Wn, bq, I.vhat, true, cost, u0v, P.mail != nullptr && P.mail_early != 0,
+                             [&](double cost_lane, double u0_lane) __attribute__((always_inline)) { pit_emit_record(P, bq, lane, cost_lane, u0_lane, kkt); emitted = true; });
+    if (!emitted) pit_emit_record(P, bq, lane, cost, u0v, kkt);
+    if (lane == 0) P.pit_done[bq] = 1;
+}
+
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
     const size_t lds = ((size_t)C * (kBaStage + NX + kRecInterval + NU) + (size_t)(C + 1) * NX + 64) * sizeof(double);
@@ -3127,8 +3586,17 @@ int windowed_blocks(int N, int B, int L) {
     if (const char* e = getenv("BROV_DEV_WIN_BLOCKS")) { const long long v = atoll(e); if (v >= 1 && v < fit) fit = v; }
     return (int)(B < fit ? B : fit);
 }
+bool pit_supported(int N, int win_L) {
+    return windowed_resident(win_L) && win_L == N && N >= 24 && N <= 80 && windowed_lds_bytes(win_L) + kPitExtraDoubles * sizeof(double) <= 160 * 1024;
+}
 void launch_windowed(const DevParams& P, hipStream_t st) {
-    if (windowed_resident(P.win_L)) hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+    if (windowed_resident(P.win_L)) {
+        if (P.pit && P.pit_done) {   // parallel-in-time step-0 solve first; the resident kernel skips what it completed
+            if (first_launch_on_device(3)) (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(rti_pit_kernel, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+        }
+        hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+    }
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }

@@ -100,6 +100,7 @@ def _load():
         "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
         "brov_tick_host": [vp, dp, dp, dp, C.c_int, vp],
         "brov_tick_buffers": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
+        "brov_pit_last": [vp, C.POINTER(C.c_int32)],
         "brov_set_time_steps": [vp, dp], "brov_set_stage0_weight": [vp, dp], "brov_general_grid": [vp],
         "brov_enable_dist6": [vp, C.c_int], "brov_dist6_enabled": [vp], "brov_set_rp_disturbance_host": [vp, dp, C.c_int],
         "brov_set_params18_host": [vp, dp, C.c_int], "brov_plant_set_rp_disturbance_host": [vp, dp], "brov_get_rp_disturbance_host": [vp, dp],
@@ -276,6 +277,12 @@ class BatchSolver:
         self._chk(self._L.brov_tick_host(self._h, None if a is None else _dp(a), None if b is None else _dp(b),
                                          None if c is None else _dp(c), int(rti_phase), C.c_void_p(res.ctypes.data)), "tick")
         return res
+
+    def pit_last(self):
+        """[B] int32: 1 where the parallel-in-time kernel completed the instance's last step (resident windowed mode only)"""
+        d = np.zeros(self.B, dtype=np.int32)
+        self._chk(self._L.brov_pit_last(self._h, d.ctypes.data_as(C.POINTER(C.c_int32))), "pit_last")
+        return d
 
     def tick_buffers(self):
         """numpy views of brov_tick_host's pinned staging buffers (brov_tick_buffers): dict(x0 [B,12], yref [N+1,16], params [B,N+1,16],

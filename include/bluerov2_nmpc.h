@@ -204,6 +204,8 @@ int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, 
  * yref_shared / par_stage, and NULL as res -- saves the tick its host-side copies (0.8 MB per step at a batch of 4096).  The result
  * records are written there by the solve kernel itself (no copy command behind the launch; batches <= 64: with a sequence word per
  * instance that the host polls, larger ones: the host waits for the launch once; BROV_TICK_BULK=0: the copy command of round 3). */
+/* instrumentation: which instances of the last solve were completed by the parallel-in-time kernel */
+int brov_pit_last(brov_solver* s, int32_t* done /*[B]*/);
 int brov_tick_buffers(brov_solver* s, double** x0 /*[B][12]*/, double** yref_shared /*[N+1][16]*/, double** par_stage /*[B][N+1][16]*/,
                       const brov_result** res /*[B]*/);
 /* replace weights / bounds / Ts / QP options of an existing solver (N must not change) */

@@ -1,0 +1,148 @@
+"""The parallel-in-time step-0 kernel (rti_pit_kernel): batches the resident windowed mode serves (at most one
+instance per CU, 24 <= N <= 80 -- the ROS node's batch of one at the shipped N = 80).  The block's four waves factorise a quarter of
+the horizon each, a relay over the three inner boundaries joins them, and an answer without active bounds is committed; everything
+else is left to the resident kernel launched behind it.  Held here: the same records and iterates as the oracle -- and, to rounding,
+as the resident kernel alone -- whoever completed the instance; the verdict per instance (brov_pit_last); the hand-over to the
+resident kernel for instances with active bounds, failed pivots and NaN inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import status_agreement, u0_abs_ok, values_agree
+
+pytestmark = pytest.mark.gpu
+P_NOMINAL = np.array([0, 0, 0, 0, 1.7182, 0, 5.468, 0.4006, -11.7391, -20, -31.8678, -5, -18.18, -21.66, -36.99, -1.55])
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import bluerov2_amd
+    return bluerov2_amd
+
+
+@pytest.fixture(autouse=True)
+def _restore_env():
+    old = os.environ.get("BROV_PIT")
+    yield
+    if old is None:
+        os.environ.pop("BROV_PIT", None)
+    else:
+        os.environ["BROV_PIT"] = old
+
+
+def _inputs(golden_traj, B, seed, far=0.0):
+    rng = np.random.default_rng(seed)
+    circ = golden_traj["circle"]
+    x0 = np.zeros((B, 12)); x0[:, :6] = circ[0, :6]
+    x0 += rng.normal(size=(B, 12)) * np.array([0.05] * 3 + [0.02] * 3 + [0.05] * 3 + [0.02] * 3)
+    nfar = int(round(far * B))
+    if nfar:
+        x0[:nfar, :3] += rng.uniform(2.0, 4.0, size=(nfar, 3)) * rng.choice([-1.0, 1.0], size=(nfar, 3))
+    return x0, circ
+
+
+def _compare(r, it, ro, xo, uo, pio, lamo, what):
+    live = status_agreement(r["status"], ro["status"], ro["kkt"])
+    kk = np.maximum(1.0, np.nan_to_num(ro["kkt"], nan=1.0, posinf=1e300))
+    for name, a, b in (("x", it[0], xo), ("u", it[1], uo), ("pi", it[2], pio), ("lam", it[3], lamo)):
+        err = np.abs(a - b).reshape(len(kk), -1).max(axis=1)
+        scale = kk * (max(1.0, np.abs(b).max()) if name in ("pi", "lam") else 1.0)
+        values_agree((err <= 1e-7 * scale) | ~live, ro["kkt"], (what, name), err=err)
+    u0_abs_ok(r["u0"], ro["u0"], r["status"], ro["status"], ro["kkt"], what)
+    ok = live & (ro["status"] == 0)
+    assert np.allclose(r["cost"][ok], ro["cost"][ok], rtol=1e-9) and np.allclose(r["kkt"][ok], ro["kkt"][ok], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(r["qp_iter"][ok] == 0, ro["qp_iter"][ok] == 0)
+
+
+@pytest.mark.parametrize("N,B,far", [(80, 1, 0.0), (80, 7, 0.0), (40, 5, 0.0), (24, 3, 0.0), (25, 3, 0.0), (57, 9, 0.0), (79, 2, 0.0), (80, 16, 0.5), (47, 12, 0.34)])
+@pytest.mark.parametrize("mode", ["2", "1"])
+def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B, far, mode):
+    """every tick of six against the oracle, with every instance tried (BROV_PIT=2) and with the product's rule (1: only instances whose
+    previous step was an early exit); far-off instances saturate their inputs, are NOT completed by the kernel, and come out of the
+    resident kernel behind it exactly as without it"""
+    os.environ["BROV_PIT"] = mode
+    Ts = 1.0 / N
+    x0, circ = _inputs(golden_traj, B, seed=500 + N, far=far)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    assert s.window_stages() == N                          # resident mode
+    s.set_x0(x0); s.set_params(P_NOMINAL)
+    op = oracle.opts(N, Ts)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
+    prev, n_done, n_loop = None, 0, 0
+    for k in range(6):
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        s.set_yref(yref); s.solve()
+        r, it, done = s.results(), s.get_iterate(), s.pit_last()
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        prev = ro
+        _compare(r, it, ro, x, u, pi, lam, (N, B, far, mode, k))
+        early = (ro["status"] == 0) & (ro["qp_iter"] == 0)
+        assert not np.any(done.astype(bool) & ~early), "an instance with active bounds must be left to the resident kernel"
+        if mode == "2":
+            assert np.array_equal(done.astype(bool), early), (k, done, early)     # every early exit is found
+        n_done += int(done.sum()); n_loop += int((~early).sum())
+    assert n_done > 0
+    if far:
+        assert n_loop > 0
+    s.close()
+
+
+def test_off_is_the_resident_kernel_alone_and_on_agrees_with_it(ba, golden_traj):
+    """BROV_PIT=0: the kernel is not launched (no instance reported); with it the records agree to rounding (different summation order
+    inside the factorisation: 1e-11 on the inputs), bit for bit where the kernel did not complete the instance"""
+    N, B = 80, 6
+    x0, circ = _inputs(golden_traj, B, seed=77, far=0.34)
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["BROV_PIT"] = mode
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); s.set_x0(x0); s.set_params(P_NOMINAL)
+        rec = []
+        for k in range(5):
+            s.set_yref(np.ascontiguousarray(circ[k:k + N + 1])); s.solve()
+            rec.append((s.results(), s.get_iterate(), s.pit_last()))
+        out[mode] = rec; s.close()
+    assert all(d.sum() == 0 for _, _, d in out["0"])
+    assert sum(int(d.sum()) for _, _, d in out["1"]) > 0
+    for (r0, it0, _), (r1, it1, d1) in zip(out["0"], out["1"]):
+        assert np.array_equal(r0["status"], r1["status"]) and np.array_equal(r0["qp_iter"], r1["qp_iter"])
+        assert np.abs(r0["u0"] - r1["u0"]).max() < 1e-10
+        for a, b in zip(it0, it1):
+            assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(a).max())
+
+
+def test_nan_inputs_and_both_failure_policies_go_through_the_resident_kernel(ba, oracle, golden_traj):
+    N, B = 40, 8
+    for pol in (0, 1):
+        os.environ["BROV_PIT"] = "2"
+        x0, circ = _inputs(golden_traj, B, seed=9)
+        x0[2, 4] = np.nan
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, on_failure=pol)); s.set_x0(x0); s.set_params(P_NOMINAL)
+        for k in range(3):
+            s.set_yref(np.ascontiguousarray(circ[k:k + N + 1])); s.solve()
+            r, done = s.results(), s.pit_last()
+            assert r["status"][2] == 1 and done[2] == 0
+            assert np.all(r["status"][np.arange(B) != 2] == 0) and done.sum() == B - 1
+        s.close()
+
+
+def test_tick_host_mailbox_delivers_the_parallel_in_time_record(ba, golden_traj):
+    """the drop-in's path: batch of one at the shipped horizon through brov_tick_host (mailbox); the record of the parallel-in-time kernel
+    equals the one of separate setters + solve"""
+    N = 80
+    os.environ["BROV_PIT"] = "1"
+    x0, circ = _inputs(golden_traj, 1, seed=3)
+    a = ba.BatchSolver(1, ba.SolverOptions(N, 1.0 / N)); b = ba.BatchSolver(1, ba.SolverOptions(N, 1.0 / N))
+    a.set_params(P_NOMINAL); b.set_params(P_NOMINAL)
+    for k in range(6):
+        y = np.ascontiguousarray(circ[k:k + N + 1])
+        a.set_x0(x0); a.set_yref(y); a.solve(); ra = a.results()
+        rb = b.tick(x0=x0, yref=y)
+        assert rb.tobytes() == ra.tobytes(), k
+        assert a.pit_last()[0] == 1 and b.pit_last()[0] == 1
+        for ia, ib in zip(a.get_iterate(), b.get_iterate()):
+            assert np.array_equal(ia, ib)
+    a.close(); b.close()

@@ -28,7 +28,7 @@ def _report(src):
 def test_solver_kernels_use_no_scratch_and_keep_their_occupancy():
     rep = _report("qp_kernel.hip")
     want = {"rti_fused_kernel": 1, "rti_fused_kernel_w2": 2, "rti_fused_kernel_grid": 1, "rti_window_kernel": 1, "rti_window_kernel_grid": 1,
-            "rti_window_kernel_res": 1, "qp_kernel": 2, "lin_wave_kernel": 1, "lin_wave_kernel_grid": 1}
+            "rti_window_kernel_res": 1, "rti_pit_kernel": 1, "qp_kernel": 2, "lin_wave_kernel": 1, "lin_wave_kernel_grid": 1}
     seen = {}
     for mangled, r in rep.items():
         for short in want:
@@ -136,11 +136,17 @@ def test_shipped_library_has_no_vector_code_ahead_of_an_exec_restore():
 
 
 def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
-    """The canary (round 4): qp_kernel.hip compiled with -DBROV_SCHED_TICKET_LATE -- the work-ordering ticket taken at the end of the
-    wave instead of ahead of the QP loop, a harmless reordering -- makes hipcc (ROCm 7.2) place AGPR copies of live registers ahead
-    of an exec restore in rti_window_kernel.  The checker must find it in the compiler's own assembly (if a future compiler stops
-    producing it this test says so, and the canary can go), and must find nothing in the product order."""
+    """The checker against REAL compiler output.  (1) A committed excerpt of hipcc 7.2's own assembly of this repository's qp_kernel.hip
+    (commit da0d7bb with -DBROV_SCHED_TICKET_LATE: the work-ordering ticket taken at the end of the wave, a harmless reordering) in which
+    the register allocator's AGPR copies sit ahead of an exec restore in rti_fused_kernel: the checker must find it.  (2) The product
+    order compiled now: nothing.  (3) The canary order compiled now: reported, not asserted -- which statement order builds the defect
+    moves with every change of the source (rti_window_kernel, then rti_fused_kernel, then -- with the parallel-in-time kernel in the
+    file -- nowhere), which is the reason the link rule runs the checker on every build."""
     chk = _checker()
+    fixture = os.path.join(ROOT, "tests", "golden", "exec_restore_defect_hipcc72.s")
+    hits = chk.scan(open(fixture).read().split("\n"))
+    assert len(hits) == 1 and hits[0][0].endswith("rti_fused_kernelENS_9DevParamsE") and hits[0][2] == ".LBB3_47", hits
+    assert all("v_accvgpr_write_b32" in ins for _, ins in hits[0][4])
     src = os.path.join(ROOT, "bluerov2_amd", "csrc", "qp_kernel.hip")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -153,6 +159,4 @@ def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
                        check=True, capture_output=True, timeout=900)
         out[name] = chk.scan(open(asm).read().split("\n"))
     assert out["product"] == []
-    # which kernel hosts the defect moves with every change of the source (round 4 saw it in rti_window_kernel, then, three features
-    # later, in rti_fused_kernel): any hit counts
-    assert len(out["late"]) >= 1, "the canary order no longer builds the defect: pick a new canary or retire it"
+    print(f"canary order (-DBROV_SCHED_TICKET_LATE) compiled now: {len(out['late'])} join block(s) with the defect", [h[0] for h in out["late"]])
