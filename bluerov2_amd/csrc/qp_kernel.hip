@@ -525,6 +525,8 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             for (int r = 0; r < 3; r++) ba1[r] = blend(mk_col0, in.bv[r], in.ba[r]);
             ba1[3] = 0.0;
             const d4 Pb = tn<3>(P, ba1, z4);
+            d4 Racc = z4;
+            if constexpr (ACC) Racc = tn<3>(ba1, acc->Psi, z4);   // [b | A(:,1:) B]' Psi: rows 1..11 = A'Psi, rows 12..15 = Z' = B'Psi, row 0 = b'Psi
             // the operand requests of stage i - 2 go here, into the wait for the product (18 idle cycles otherwise)
             __builtin_amdgcn_sched_barrier(0);
             mid();
@@ -683,8 +685,8 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 I.kff[i * 4 + rg] = -pn[3];
             }
             if constexpr (ACC) {
-                // off the Riccati chain (nothing of it feeds P or p): six products per stage
-                d4 R = tn<3>(ba1, acc->Psi, z4);               // [b | A(:,1:) B]' Psi: rows 1..11 = A'Psi, rows 12..15 = Z' = B'Psi, row 0 = b'Psi
+                // off the Riccati chain (nothing of it feeds P or p): six products per stage (the first three requested at the head of the stage)
+                d4 R = Racc;
                 const double bPsi = R[0];
                 R[0] = (rg == 0) ? acc->Psi[0] : R[0];         // the true row 0 of A'Psi is row 0 of Psi (column 0 of A is e_0)
                 const d4 MZ = tn1(mt, R[3], z4);               // rows 0..3: M Z' -- what a costate at the segment end adds to this stage's feed-forward term
@@ -3244,6 +3246,8 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     lds_f64* mailx = (lds_f64*)(smem + pit_off_x(Lc));
     lds_f64* tr_w = wv == 0 ? (lds_f64*)const_s + 2 : (lds_f64*)(smem + pit_off_tr(Lc)) + (wv - 1) * 17;
     if (threadIdx.x == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
+#define PIT_STAMP(slot) do { if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)b * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+    PIT_STAMP(0);
     int lane;
     asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane0));
     // ---- segments = the quarters of the linearisation
@@ -3262,6 +3266,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         if (lane == 0) flag_s[wv] = nw ? __builtin_nan("") : pw;
     }
     __syncthreads();   // (the stage-record scratch of the linearisation is the K^T .. dx area the sweeps write next)
+    PIT_STAMP(1);
     // ---- this wave's view of its segment
     // (the block's workspace as the resident kernel lays it out: one parked image -- unused here --, candidate inputs, state steps, and the
     // gain | M tiles of the in-loop sweeps, where this kernel keeps its M Z' tiles; nothing else of it is touched)
@@ -3323,6 +3328,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     bwd_chunk<true, 3, false, true, false, Inst, true>(I, S);
     wave_fence();
     bool good = S.ok && !S.illc;
+    const unsigned long long t_fac = P.dbg ? __builtin_readcyclecounter() : 0;
     // vectors travel row-replicated (lane (rg, cl): elements rg, rg + 4, rg + 8)
     d4 p0;   // p of the segment start: column 0 of S.pv -> every column
 #pragma unroll
@@ -3342,6 +3348,13 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     for (int r = 0; r < 3; r++) idt[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
     idt[3] = 0.0;
     const d4 Phi = tn<3>(Psi, idt, z4);   // the transpose
+    // the iterate's inputs for the bound check (wave 0; N * 4 <= 320 elements, five per lane): requested here, used behind the forward sweeps
+    double ubk[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (wv == 0) {
+        const double* uall = P.u + (size_t)b * N * NU;
+#pragma unroll
+        for (int t = 0; t < 5; t++) { const int j = lane + 64 * t; ubk[t] = uall[j < N * 4 ? j : 0]; }
+    }
     // ---- 2a. coarse relay, last boundary to first: wave j + 1 publishes the cost-to-go at its start, wave j takes it to its own start
     d4 W = z4, vv = z4, pcn = z4, Pcn = z4;   // this segment's W, c - G pc, and the (Pc, pc) it was built with (the forward relay needs them)
     auto publish = [&](const d4& Pt, const d4& pt) __attribute__((always_inline)) {
@@ -3386,6 +3399,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         }
         __syncthreads();
     }
+    const unsigned long long t_cb = P.dbg ? __builtin_readcyclecounter() : 0;
     // ---- 2b. first boundary to last: boundary states and the costates at the segment ends
     d4 xh = z4, lam = z4;
     if (wv == 0) {
@@ -3422,6 +3436,8 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         if (wv == j + 1) xh = d4{mailx[rg], mailx[rg + 4], mailx[rg + 8], 0.0};
         __syncthreads();
     }
+    PIT_STAMP(2);
+    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)b * 8 + 7] = ((t_fac - P.dbg[(size_t)b * 8 + 1]) & 0xFFFFF) | (((t_cb - t_fac) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - t_cb) & 0xFFFFF) << 40);
     // ---- 3. the costate's share of the feed-forward terms, then the forward sweep of the segment
     if (!last) {
         store_vec12_lds(tr_w, lam, rg, cl);
@@ -3463,6 +3479,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     if (lane == 0) flag_s[4 + wv] = good ? 1.0 : 0.0;
     __syncthreads();
     if (wv != 0) return;
+    PIT_STAMP(3);
     // ---- wave 0: the checks of the forward sweep's wrapper over the whole horizon, then the early exit or nothing
     bool all_good = true;
     double kkt_lin = 0.0;
@@ -3509,16 +3526,18 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     if (kkt != kkt) nanp2 = true;
     kkt = wave_max(fmax(kkt_lin, (kkt != kkt) ? 0.0 : kkt));
     const bool kkt_nan = __ballot(nanp2) != 0ull;
-    win_flush_small(I.vhat, smem + win_off_vh(Lc), N * 4, lane);
-    win_flush_small(I.dxb, smem + win_off_dx(Lc), (N + 1) * NX, lane);
+    // (candidate inputs and state steps stay where the forward sweeps left them, in LDS: the resident kernel's wrappers park them in HBM
+    // and the adjoint pass fetches the inputs back -- one slice, nothing to park)
     const bool bad = win_nan_check<true>(I, Wn, true);
     bool infeas = false;
     {
         const double lbm = P.cst[32 + (lane & 3)], ubm = P.cst[36 + (lane & 3)];
         const lds_f64* vh = (const lds_f64*)(smem + win_off_vh(Lc));
-        for (int j = lane; j < N * 4; j += 64) {
-            const double vj = vh[j], uj = I.u[j];
-            infeas = infeas | !(vj >= lbm - uj && vj <= ubm - uj);
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const int j = lane + 64 * t;
+            const double vj = vh[j < N * 4 ? j : 0], uj = ubk[t];
+            infeas = infeas | ((j < N * 4) & !(vj >= lbm - uj && vj <= ubm - uj));
         }
     }
     const bool accept = all_good && !kkt_nan && __ballot(bad) == 0ull && __ballot(infeas) == 0ull && P.early_exit;
@@ -3526,12 +3545,15 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         if (lane == 0) P.pit_done[bq] = 0;
         return;
     }
+    PIT_STAMP(4);
     double cost = 0.0, u0v = 0.0;
     bool emitted = false;
-    win_adjoint_commit<true>(P, I, Wn, bq, I.vhat, true, cost, u0v, P.mail != nullptr && P.mail_early != 0,
-                             [&](double cost_lane, double u0_lane) __attribute__((always_inline)) { pit_emit_record(P, bq, lane, cost_lane, u0_lane, kkt); emitted = true; });
+    win_adjoint_commit<true>(P, I, Wn, bq, nullptr, true, cost, u0v, P.mail != nullptr && P.mail_early != 0,
+                             [&](double cost_lane, double u0_lane) __attribute__((always_inline)) { pit_emit_record(P, bq, lane, cost_lane, u0_lane, kkt); emitted = true; PIT_STAMP(5); });
     if (!emitted) pit_emit_record(P, bq, lane, cost, u0v, kkt);
     if (lane == 0) P.pit_done[bq] = 1;
+    PIT_STAMP(6);
+#undef PIT_STAMP
 }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
