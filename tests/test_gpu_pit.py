@@ -146,3 +146,44 @@ def test_tick_host_mailbox_delivers_the_parallel_in_time_record(ba, golden_traj)
         for ia, ib in zip(a.get_iterate(), b.get_iterate()):
             assert np.array_equal(ia, ib)
     a.close(); b.close()
+
+
+def test_long_closed_loop_with_reference_jumps_switches_between_the_two_kernels(ba, golden_traj):
+    """1200 ticks of ONE instance at the shipped horizon, closed on the plant model on the device, with a reference that jumps every 150
+    ticks (saturated inputs for a while after every jump: the resident kernel's ticks; tracking in between: the parallel-in-time
+    kernel's).  A second solver without the parallel kernel is fed the same measured states: same status on every tick, the applied
+    input to 1e-8 of its own scale, and both kinds of tick occur many times."""
+    N, T = 80, 1200
+    circ = golden_traj["circle"]
+    rows = np.repeat(circ[:1], T + N + 2, axis=0).copy()
+    for k0 in range(0, T + N + 2, 150):                       # piecewise constant pose reference with jumps of 1.5 .. 3 m
+        j = (k0 // 150) % 4
+        rows[k0:k0 + 150, 0] = circ[0, 0] + (0.0, 2.5, -1.5, 3.0)[j]
+        rows[k0:k0 + 150, 1] = circ[0, 1] + (0.0, -2.0, 1.5, 0.5)[j]
+        rows[k0:k0 + 150, 6:] = 0.0
+    x0 = np.zeros((1, 12)); x0[0, :6] = rows[0, :6]
+    os.environ["BROV_PIT"] = "1"
+    a = ba.BatchSolver(1, ba.SolverOptions(N, 1.0 / N)); a.set_params(P_NOMINAL); a.set_x0(x0); a.set_trajectory(rows)
+    os.environ["BROV_PIT"] = "0"
+    b = ba.BatchSolver(1, ba.SolverOptions(N, 1.0 / N)); b.set_params(P_NOMINAL); b.set_trajectory(rows)
+    n_pit = n_res = n_loop = 0
+    worst = 0.0
+    for k in range(T):
+        xk = a.get_x0()
+        os.environ["BROV_PIT"] = "1"
+        a.set_yref_from_trajectory(k, 16); a.solve()
+        ra, done = a.results(), a.pit_last()
+        os.environ["BROV_PIT"] = "0"
+        b.set_x0(xk); b.set_yref_from_trajectory(k, 16); b.solve()
+        rb = b.results()
+        assert ra["status"][0] == rb["status"][0] == 0, k
+        assert (ra["qp_iter"][0] == 0) == (rb["qp_iter"][0] == 0), k
+        err = np.abs(ra["u0"] - rb["u0"]).max() / max(1.0, np.abs(rb["u0"]).max())
+        worst = max(worst, err)
+        assert err < 1e-8, (k, err, done)
+        assert bool(done[0]) <= (ra["qp_iter"][0] == 0)
+        n_pit += int(done[0]); n_res += int(not done[0]); n_loop += int(ra["qp_iter"][0] > 0)
+        a.plant_step(1.0 / N)
+    print(f"[pit soak] {T} ticks: {n_pit} by the parallel-in-time kernel, {n_res} by the resident kernel ({n_loop} with active bounds), worst relative |du0| {worst:.1e}")
+    assert n_pit > T // 3 and n_loop > 30 and n_res >= n_loop
+    a.close(); b.close()
