@@ -3348,12 +3348,29 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     for (int r = 0; r < 3; r++) idt[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
     idt[3] = 0.0;
     const d4 Phi = tn<3>(Psi, idt, z4);   // the transpose
-    // the iterate's inputs for the bound check (wave 0; N * 4 <= 320 elements, five per lane): requested here, used behind the forward sweeps
-    double ubk[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (wv == 0) {
-        const double* uall = P.u + (size_t)b * N * NU;
+    // the iterate rows and the reference of the segment, for the bound check and the full step behind the forward sweeps: requested here, ahead
+    // of the relay (lsub <= 20 stages -> 2 / 4 elements per lane)
+    const int nu = nseg * 4, nxr = (last ? nseg + 1 : nseg) * NX;   // the last segment also commits the terminal node
+    double uo[2], ur[2], xo[4], yr[4];
+    {
+        int b2 = b;
+        asm volatile("s_mov_b32 %0, %0" : "+s"(b2));
+        const double* xr = P.x + ((size_t)b2 * (N + 1) + s0) * NX;
+        const double* uu = P.u + ((size_t)b2 * N + s0) * NU;
+        const double* yy = P.yref + (size_t)b2 * P.yref_stride + (size_t)s0 * NY;
 #pragma unroll
-        for (int t = 0; t < 5; t++) { const int j = lane + 64 * t; ubk[t] = uall[j < N * 4 ? j : 0]; }
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t, jj = j < nu ? j : 0;
+            uo[t] = uu[jj];
+            ur[t] = yy[(size_t)(jj >> 2) * NY + 12 + (jj & 3)];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = lane + 64 * t, jj = j < nxr ? j : 0;
+            const int i = jj / 12, cc = jj - i * 12;
+            xo[t] = xr[jj];
+            yr[t] = yy[(size_t)i * NY + cc];
+        }
     }
     // ---- 2a. coarse relay, last boundary to first: wave j + 1 publishes the cost-to-go at its start, wave j takes it to its own start
     d4 W = z4, vv = z4, pcn = z4, Pcn = z4;   // this segment's W, c - G pc, and the (Pc, pc) it was built with (the forward relay needs them)
@@ -3476,11 +3493,38 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         fwd_chunk<3>(I, xx, wv == 0 ? nullptr : tr_w);
     }
     wave_fence();
-    if (lane == 0) flag_s[4 + wv] = good ? 1.0 : 0.0;
+    // ---- 4. checks, full step and adjoint sweep, every wave on its own segment
+    // (everything the record and the full step address is derived from an opaque copy of the instance index HERE: formed from `b` itself the
+    // base addresses are loop invariants of the whole kernel, computed up front and spilled -- and the build then reserves scratch)
+    int bq = b;
+    asm volatile("s_mov_b32 %0, %0" : "+s"(bq));
+    const lds_f64* vh = I.lds_vhat;    // this segment's candidate inputs [nseg][4] and state steps (row 0 = the boundary it starts from)
+    const lds_f64* dxs = I.lds_dxb;
+    double* x_it = P.x + ((size_t)bq * (N + 1) + s0) * NX;
+    double* u_it = P.u + ((size_t)bq * N + s0) * NU;
+    double* pi_it = P.pi + ((size_t)bq * N + s0) * NX;
+    double* lam_it = P.lam + ((size_t)bq * N + s0) * 8;
+    bool bad = false, infeas = false;
+    {   // NaN among what the forward sweep produced; inputs inside their bounds
+        const double lbm = P.cst[32 + (lane & 3)], ubm = P.cst[36 + (lane & 3)];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t;
+            const double vj = vh[j < nu ? j : 0];
+            bad = bad | !(vj == vj);
+            infeas = infeas | ((j < nu) & !(vj >= lbm - uo[t] && vj <= ubm - uo[t]));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = lane + 64 * t + NX;                       // rows 1 .. nseg: the state steps this segment's sweep wrote
+            const double e = dxs[j < (nseg + 1) * NX ? j : NX];
+            bad = bad | !(e == e);
+        }
+    }
+    const bool seg_ok = good && __ballot(bad) == 0ull && __ballot(infeas) == 0ull;
+    if (lane == 0) flag_s[4 + wv] = seg_ok ? 1.0 : 0.0;
     __syncthreads();
-    if (wv != 0) return;
     PIT_STAMP(3);
-    // ---- wave 0: the checks of the forward sweep's wrapper over the whole horizon, then the early exit or nothing
     bool all_good = true;
     double kkt_lin = 0.0;
     bool nan_lin = false;
@@ -3491,68 +3535,73 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         nan_lin = nan_lin | !(v == v);
         kkt_lin = fmax(kkt_lin, v);
     }
-    // (everything the record and the full step address is derived from an opaque copy of the instance index HERE: formed from `b` itself the
-    // base addresses are loop invariants of the whole kernel, computed up front and spilled -- one SGPR spill more than the kernel's
-    // lane-spill register holds, and the build then reserves scratch)
-    int bq = b;
-    asm volatile("s_mov_b32 %0, %0" : "+s"(bq));
-    setup_inst(P, I, bq, lane, &lc);
-    I.Ks = ws_Ks; I.Mt = nullptr; I.Pb = nullptr; I.ipm = nullptr; I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr; I.ckpt = 0;
-    {   // the whole horizon as one block
-        I.i0 = 0; I.N = N; I.NT = N;
-        I.lds_ba = (const lds_f64*)ba_s; I.lds_bv = (const lds_f64*)bv_s; I.lds_kt = (lds_f64*)kt_s; I.lds_q = (const lds_f64*)q_s;
-        I.lds_r = (const lds_f64*)r_s; I.lds_kff = (lds_f64*)kff_s; I.lds_vhat = (lds_f64*)vh_s; I.lds_dxb = (lds_f64*)dx_s;
-        I.lds_zero = (lds_f64*)const_s; I.lds_tr = (lds_f64*)const_s + 2;
-        const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
-        for (int r = 0; r < 3; r++) I.ba_off[r] = cl >= 3 ? (rg + 4 * r) * kBaStride + cl - 3 : ((r == 0 && rg == cl) ? one : zero);
-        I.ba_str = cl >= 3 ? kBaStage : 0;
-        for (int r = 0; r < 4; r++) {
-            const int c = rg + 4 * r;
-            I.bat_off[r] = cl >= NX ? zero : (c >= 3 ? cl * kBaStride + c - 3 : (c == cl ? one : zero));
-        }
-        I.bat_str = cl >= NX ? 0 : kBaStage;
-        I.bat_str0 = (cl < NX && rg == 3) ? kBaStage : 0;
-        for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
-        I.kt_str = cl < 4 ? kKtStage : 0;
-    }
-    Win Wn;
-    Wn.nc = 1; Wn.Lc = Lc; Wn.cur = 0; Wn.valid = WM_LIN | WM_GAIN | WM_DX; Wn.lds = smem; Wn.img = ws; Wn.nan = false; Wn.feas = true;
-    d4 d0;
     double kkt = 0.0;
 #pragma unroll
-    for (int r = 0; r < 3; r++) { d0[r] = x0v[r] - xiv[r]; kkt_upd(kkt, d0[r]); }
-    d0[3] = 0.0;
+    for (int r = 0; r < 3; r++) kkt_upd(kkt, x0v[r] - xiv[r]);
     bool nanp2 = nan_lin;
     if (kkt != kkt) nanp2 = true;
     kkt = wave_max(fmax(kkt_lin, (kkt != kkt) ? 0.0 : kkt));
     const bool kkt_nan = __ballot(nanp2) != 0ull;
-    // (candidate inputs and state steps stay where the forward sweeps left them, in LDS: the resident kernel's wrappers park them in HBM
-    // and the adjoint pass fetches the inputs back -- one slice, nothing to park)
-    const bool bad = win_nan_check<true>(I, Wn, true);
-    bool infeas = false;
-    {
-        const double lbm = P.cst[32 + (lane & 3)], ubm = P.cst[36 + (lane & 3)];
-        const lds_f64* vh = (const lds_f64*)(smem + win_off_vh(Lc));
-#pragma unroll
-        for (int t = 0; t < 5; t++) {
-            const int j = lane + 64 * t;
-            const double vj = vh[j < N * 4 ? j : 0], uj = ubk[t];
-            infeas = infeas | ((j < N * 4) & !(vj >= lbm - uj && vj <= ubm - uj));
-        }
-    }
-    const bool accept = all_good && !kkt_nan && __ballot(bad) == 0ull && __ballot(infeas) == 0ull && P.early_exit;
+    const bool accept = all_good && !kkt_nan && P.early_exit;    // (the same decision in every wave)
     if (!accept) {
-        if (lane == 0) P.pit_done[bq] = 0;
+        if (threadIdx.x == 0) P.pit_done[bq] = 0;
         return;
     }
+    __syncthreads();   // (flag_s is reused for the cost partials)
     PIT_STAMP(4);
+    // full step of the segment and its share of the objective at the new iterate
     double cost = 0.0, u0v = 0.0;
-    bool emitted = false;
-    win_adjoint_commit<true>(P, I, Wn, bq, nullptr, true, cost, u0v, P.mail != nullptr && P.mail_early != 0,
-                             [&](double cost_lane, double u0_lane) __attribute__((always_inline)) { pit_emit_record(P, bq, lane, cost_lane, u0_lane, kkt); emitted = true; PIT_STAMP(5); });
-    if (!emitted) pit_emit_record(P, bq, lane, cost, u0v, kkt);
-    if (lane == 0) P.pit_done[bq] = 1;
-    PIT_STAMP(6);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int j = lane + 64 * t;
+        if (j < nu) {
+            const int i = j >> 2, m = j & 3;
+            lam_it[(size_t)i * 8 + m] = 0.0;          // no active bound: the bound multipliers are zero
+            lam_it[(size_t)i * 8 + 4 + m] = 0.0;
+            const double un = uo[t] + vh[j];
+            u_it[j] = un;
+            if (wv == 0 && j < 4) { P.res[bq].u0[j] = un; u0v = un; }
+            const double e = un - ur[t];
+            cost += 0.5 * (P.Ts * P.cst[12 + m]) * e * e;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int j = lane + 64 * t;
+        if (j < nxr) {
+            const int i = j / 12, cc = j - i * 12;
+            const double xn = xo[t] + dxs[j];
+            x_it[j] = xn;
+            const double e = xn - yr[t];
+            cost += 0.5 * ((s0 + i == N) ? P.cst[16 + cc] : P.Ts * P.cst[cc]) * e * e;
+        }
+    }
+    {
+        const double cw = wave_sum(cost);
+        if (lane == 0) flag_s[4 + wv] = cw;
+    }
+    __syncthreads();
+    if (wv == 0) {   // the record: as soon as the four shares of the objective are in
+        const double ctot = ((flag_s[4] + flag_s[5]) + (flag_s[6] + flag_s[7]));
+        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt);
+        PIT_STAMP(5);
+    }
+    // adjoint sweep of the segment.  The multiplier of its last interval is the costate at its end boundary, which the relay has computed
+    // (lam; the last segment: the terminal gradient, which the sweep forms itself): the sweep enters with A'pi := lam - (Qd dx_e + q_e)
+    d4 atpi = z4;
+    if (!last) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int row = rg + 4 * r;
+            atpi[r] = lam[r] - (P.Ts * I.Wr[r] * (double)dxs[nseg * NX + row] + (double)I.lds_q[nseg * NX + row]);
+        }
+    }
+    wave_fence();
+    adj_chunk<true, 3>(I, atpi, nullptr, nullptr, nullptr);
+    wave_fence();
+    win_flush_small(pi_it, (const double*)I.lds_kt, nseg * NX, lane);
+    if (threadIdx.x == 0) P.pit_done[bq] = 1;
+    if (wv == 0) PIT_STAMP(6);
 #undef PIT_STAMP
 }
 
