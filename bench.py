@@ -97,6 +97,7 @@ def batch1_tick(ba, ticks=300, warm=30):
         x0, circ = synthetic_inputs(1, seed=5)
         p = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (1, N + 1, NP)))
         res = {}
+        n_pit = 0
         for name, gap in (("back_to_back", 0.0), ("idle_200us_between_ticks", 200e-6)):
             wall = []
             for k in range(warm + ticks):
@@ -110,11 +111,14 @@ def batch1_tick(ba, ticks=300, warm=30):
                     pass                                # multipliers behind the record it has already delivered
             wall = np.sort(np.array(wall[warm:])) * 1e6
             res[name] = dict(wall_us_median=float(np.median(wall)), wall_us_p99=float(wall[int(0.99 * len(wall))]))
+            n_pit += int(s.pit_last()[0])   # (the last tick of the leg)
         out[f"N{N}"] = dict(wall_us_median=res["back_to_back"]["wall_us_median"], wall_us_p99=res["back_to_back"]["wall_us_p99"],
-                            idle_200us_between_ticks=res["idle_200us_between_ticks"], status=int(r["status"][0]), kernel_path=int(s.last_kernel_path()))
+                            idle_200us_between_ticks=res["idle_200us_between_ticks"], status=int(r["status"][0]), kernel_path=int(s.last_kernel_path()),
+                            step0_parallel_in_time=bool(n_pit == 2))
         s.close()
     out["note"] = ("one instance through brov_tick_host (python ctypes caller): host -> device upload, RTI step, record back; "
-                   "compare cpu_baseline_single_thread")
+                   "compare cpu_baseline_single_thread.  N80: the step-0 solve runs parallel in time on the block's four wavefronts "
+                   "(rti_pit_kernel, DESIGN.md 4.5; BROV_PIT=0: the sequential resident kernel alone, 132 / 119 us)")
     return out
 
 
