@@ -1466,11 +1466,19 @@ __device__ __forceinline__ bool sw_backward(IT& I, Win* W, bool* illc = nullptr,
 #pragma unroll
             for (int r = 0; r < 3; r++) { S.P[r] = ck[r * 64 + I.lane]; S.pv[r] = ck[192 + r * 64 + I.lane]; }
             S.P[3] = 0.0; S.pv[3] = 0.0; S.ok = true;
+            if constexpr (LDS == 4) {
+                // resident mode: the stages >= ckpt keep their step-0 gains in LDS (the adjoint sweeps stage the multipliers in the K^T area
+                // of the stages < N / 4 <= ckpt only), but their feed-forward terms have been overwritten by an input gradient: back from
+                // the copy qp_body took at loop entry
+                const double* kf = I.Kt + 384;
+                for (int j = I.lane; j < I.NT * 4; j += 64) I.lds_kff[j] = kf[j];
+            }
         }
+        const int hi = (LDS == 4 && part) ? I.ckpt : -1;   // resident mode: the stages ckpt - 1 .. 0 of the one window
         for (int c = part ? 0 : W->nc - 1; c >= 0; c--) {
             win_need(I, *W, c, WM_LIN, nullptr);
             if (c == W->nc - 1 && !part) bwd_init<FACTOR, 3>(I, S);
-            bwd_chunk<FACTOR, 3, !STEP0, STEP0, ROBUST>(I, S);
+            bwd_chunk<FACTOR, 3, !STEP0, STEP0, ROBUST>(I, S, hi, 0);
             __syncthreads();
             // park what the sweep produced: K^T | kff (contiguous), or kff alone after a solve-only sweep.  The resident K^T stays
             // valid in both cases (a solve-only sweep does not touch it) unless an adjoint sweep has overwritten the area since.
@@ -1696,7 +1704,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
     bool ok = pre_ok;
     // partial refactorisation of the active-set tries (fused kernels, riccati_backward_partial): checkpoint stage = ceil(N / 4), off for
     // horizons too short to gain from it
-    constexpr bool PART = EL || LDS == 3;   // fused kernels: stage checkpoint (riccati_backward_tries); windowed kernel: window-0 checkpoint
+    constexpr bool PART = EL || LDS >= 3;   // fused kernels and the windowed kernel's resident mode: stage checkpoint; windowed kernel: window-0 checkpoint
     bool illc0 = pre_illc;
     bool split0 = false;
 #ifndef BROV_EXP_NO_SPLIT
@@ -1858,6 +1866,12 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
 #pragma unroll
                 for (int t = 0; t < 2; t++) kff0[t] = I.lds_kff[lane + 64 * t < nv ? lane + 64 * t : 0];
             }
+            if constexpr (LDS == 4) {   // resident mode: nv <= 324 elements, kept behind the checkpoint in HBM (sw_backward restores them)
+                if (I.ckpt > 0) {
+                    double* kf = I.Kt + 384;
+                    for (int j = lane; j < nv; j += 64) kf[j] = I.lds_kff[j];
+                }
+            }
             // this instance runs the QP loop: first in line in the next solve.  (BROV_SCHED_TICKET_LATE: the ticket at the end of the wave
             // instead -- the statement order that makes hipcc 7.2 build the exec-restore defect into rti_window_kernel, at a join block of
             // the first-guess stores above; kept as the canary of tests/test_kernel_resources.py: the build gate must reject it.)
@@ -1973,11 +1987,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
                     if constexpr (EL) {
                         ok = riccati_backward_tries<LDS>(I, part, kff0, ill);
                         if (!part) hi_step0 = false;   // a full sweep: the LDS gains are no longer step 0's
-                    } else if constexpr (LDS == 3) {
+                    } else if constexpr (LDS >= 3) {
                         ok = sw_backward<true, LDS>(I, W, &ill, part);
-                        if (!part) hi_step0 = false;   // ... the parked gains of the windows >= 1
+                        if (!part) hi_step0 = false;   // ... the parked gains of the windows >= 1 (resident mode: the LDS gains of the stages >= ckpt)
                     } else {
-                        ok = sw_backward<true, LDS>(I, W, &ill);
+                        ok = sw_backward<true, LDS>(I, W, &ill);   // (streaming kernel)
                     }
                     if constexpr (ROB) { if (__ballot(ill) != 0ull && P.robust_pivot && robust_ok) { robust = true; hi_step0 = false; } }   // ... and this system is factorised again
                 }
@@ -2911,7 +2925,8 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
     return (size_t)((N + L - 1) / L) * win_img_doubles(L)                  // parked window images
            + (size_t)N * 4 + (size_t)(N + 1) * NX                          // vhat, dx (flat over the horizon)
            + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N         // Ks Mt Pb | interior-point vectors
-           + 384;                                                          // (P, p) entering window 0: checkpoint of the partial refactorisation
+           + 384 + 512;                                                    // (P, p) entering window 0 (resident mode: stage ckpt): checkpoint of the partial
+                                                                           // refactorisation; resident mode: + the step-0 feed-forward terms (4 N <= 512)
 }
 // RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
 // one instance per CU.  Nothing is parked and no window is fetched.  A separate instantiation (rti_window_kernel_res), so that the
@@ -3000,7 +3015,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
             I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = ws_ck;
             // partial refactorisation of the active-set tries: the checkpoint is the state of the factor sweep as it enters window 0
-            I.ckpt = (!RES && nc >= 2 && P.partial_refactor) ? Lc : 0;
+            I.ckpt = !P.partial_refactor ? 0 : (RES ? (N >= 8 ? (N + 3) >> 2 : 0) : (nc >= 2 ? Lc : 0));   // resident mode: a stage, as in the fused kernels
             I.lds_ba = (const lds_f64*)ba_s;
             I.lds_bv = (const lds_f64*)bv_s;
             I.lds_kt = (lds_f64*)kt_s;
@@ -3077,7 +3092,21 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             setup(I);
             win_select(I, W, c);
             if (c == nc - 1) bwd_init<true, 3>(I, S);
-            bwd_chunk<true, 3, false, true>(I, S);
+            if constexpr (RES) {
+                // resident mode: one window, so the checkpoint of the partial refactorisation is a STAGE (as in the fused kernels): the
+                // sweep in two parts out of one copy of the stage loop, (P, p) entering stage ckpt - 1 stored between them
+#pragma clang loop unroll(disable)
+                for (int ph = 0; ph < 2; ph++) {
+                    if (ph == 1) {
+                        if (I.ckpt == 0) break;
+#pragma unroll
+                        for (int r = 0; r < 3; r++) { ws_ck[r * 64 + lane] = S.P[r]; ws_ck[192 + r * 64 + lane] = S.pv[r]; }
+                    }
+                    bwd_chunk<true, 3, false, true>(I, S, ph == 0 ? n : I.ckpt, ph == 0 ? I.ckpt : 0);
+                }
+            } else {
+                bwd_chunk<true, 3, false, true>(I, S);
+            }
             if (!RES && c == 1 && I.ckpt > 0) {   // (P, p) as they enter window 0: six coalesced 512-byte stores, never waited for
 #pragma unroll
                 for (int r = 0; r < 3; r++) { ws_ck[r * 64 + lane] = S.P[r]; ws_ck[192 + r * 64 + lane] = S.pv[r]; }

@@ -36,13 +36,15 @@ def _run(ba, N, Ts, B, ticks, partial, kw, x0, circ, p):
     return out
 
 
-@pytest.mark.parametrize("N,box,early", [(20, 50.0, 1), (20, 8.0, 1), (23, 50.0, 1), (10, 50.0, 1), (13, 20.0, 0), (8, 50.0, 1), (7, 50.0, 1),
-                                         (40, 50.0, 1), (80, 50.0, 1), (57, 20.0, 0), (24, 50.0, 1)])
-def test_partial_refactorisation_is_bit_identical_to_full_sweeps(ba, N, box, early):
-    """N <= 23: the fused kernels (checkpoint at stage ceil(N / 4)); above: the windowed kernel (checkpoint at the boundary of window 0;
-    B = 1024 > one instance per CU, so the large-batch kernel runs, not the resident one)"""
+@pytest.mark.parametrize("N,box,early,B", [(20, 50.0, 1, 1024), (20, 8.0, 1, 1024), (23, 50.0, 1, 1024), (10, 50.0, 1, 1024), (13, 20.0, 0, 1024), (8, 50.0, 1, 1024),
+                                           (7, 50.0, 1, 1024), (40, 50.0, 1, 1024), (80, 50.0, 1, 1024), (57, 20.0, 0, 1024), (24, 50.0, 1, 1024),
+                                           (80, 50.0, 1, 96), (40, 8.0, 1, 64), (57, 20.0, 0, 48), (25, 50.0, 1, 32), (80, 50.0, 0, 16)])
+def test_partial_refactorisation_is_bit_identical_to_full_sweeps(ba, N, box, early, B):
+    """N <= 23: the fused kernels (checkpoint at stage ceil(N / 4)); above: the windowed kernel -- B = 1024 > one instance per CU: the
+    large-batch kernel (checkpoint at the boundary of window 0); B <= 96: its resident mode (one window: checkpoint at stage
+    ceil(N / 4) again, the feed-forward terms of the later stages restored from a copy in HBM)"""
     import bench
-    B, ticks = 1024, 6
+    ticks = 6
     x0, circ = bench.synthetic_inputs(B, seed=40 + N)
     x0 = bench.saturate(x0, 0.5, seed=41 + N)
     p = np.tile(ba.P_NOMINAL, (B, 1)); p[:, :4] = np.random.default_rng(N).uniform(-200, 200, (B, 4))
