@@ -129,6 +129,28 @@ def test_nan_inputs_and_both_failure_policies_go_through_the_resident_kernel(ba,
         s.close()
 
 
+@pytest.mark.parametrize("N,B", [(40, 70), (80, 9)])
+def test_tick_host_at_small_batches_with_and_without_sequence_words(ba, golden_traj, N, B):
+    """brov_tick_host above and below its 64-instance mailbox limit (sequence words per instance / the records written into the pinned
+    buffer without them): the parallel-in-time kernel writes the records of the instances it completes, the resident kernel the others"""
+    os.environ["BROV_PIT"] = "1"
+    x0, circ = _inputs(golden_traj, B, seed=31, far=0.3)
+    a = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); b = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
+    a.set_params(P_NOMINAL); b.set_params(P_NOMINAL)
+    n_done = n_not = 0
+    for k in range(5):
+        y = np.ascontiguousarray(circ[k:k + N + 1])
+        a.set_x0(x0); a.set_yref(y); a.solve(); ra = a.results()
+        rb = b.tick(x0=x0, yref=y)
+        assert rb.tobytes() == ra.tobytes(), k
+        assert np.array_equal(a.pit_last(), b.pit_last())
+        n_done += int(b.pit_last().sum()); n_not += int(B - b.pit_last().sum())
+        for ia, ib in zip(a.get_iterate(), b.get_iterate()):
+            assert np.array_equal(ia, ib)
+    assert n_done > 0 and n_not > 0
+    a.close(); b.close()
+
+
 def test_tick_host_mailbox_delivers_the_parallel_in_time_record(ba, golden_traj):
     """the drop-in's path: batch of one at the shipped horizon through brov_tick_host (mailbox); the record of the parallel-in-time kernel
     equals the one of separate setters + solve"""
