@@ -810,6 +810,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
             if (pit && s->pit_done && pit_supported(s->N, s->win_L) && !general_grid(s) && s->opts.qp_early_exit && !s->dump_lin) {
                 P.pit = pit; P.pit_done = s->pit_done;
+                P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);
             }
             s->pit_ran = P.pit != 0;
             launch_windowed(P, st); s->win_tick++;   // persistent blocks; the two hand-out counters alternate

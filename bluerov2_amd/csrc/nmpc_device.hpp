@@ -21,6 +21,7 @@ struct DevParams {
     int32_t B, N;
     int32_t qp_iter_max, early_exit;
     int32_t pit;             // parallel-in-time step-0 solve ahead of the resident windowed kernel: 0 off, 1 instances whose previous step was an early exit, 2 every instance (tests)
+    int32_t pit_try;         // ... and, when the step-0 answer leaves the box, ONE active-set try parallel in time as well (default 1; BROV_PIT_TRY=0: A/B)
     int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
     int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)

@@ -466,7 +466,7 @@ __device__ __forceinline__ void bwd_solve_v(const Inst& I, BwdState& S) {
 template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false, class IT = Inst, bool ACC = false>
 __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1, int lo = 0) {
     PitAcc* const acc = &S.acc;
-    static_assert(!ACC || (FACTOR && STEP0 && LDS == 3 && !ROBUST && !STORE_IPM), "ACC: the step-0 factor sweep of rti_pit_kernel");
+    static_assert(!ACC || (FACTOR && LDS == 3 && !ROBUST && !STORE_IPM), "ACC: the factor sweeps of rti_pit_kernel");
     if constexpr (!FACTOR && LDS != 0) {
         bwd_solve_v<LDS>(I, S);
         return;
@@ -3162,9 +3162,9 @@ __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { r
 // active, a pivot block not positive definite or ill-conditioned, a NaN) leaves the iterate untouched and pit_done[b] = 0: the
 // resident kernel does the whole step.  Instances whose previous step was not an early exit are not tried (their record says so).
 // LDS: the resident slice + 220 doubles (hand-over buffers, one transposition scratch per wave): N <= 80.
-constexpr int kPitExtraDoubles = 8 + 144 + 12 + 12 + 3 * 17 + 1;
-__host__ __device__ constexpr int pit_off_flags(int L) { return win_off_const(L) + 2 + 17; }   // 4 + 4 doubles: per-wave KKT partial, verdict
-__host__ __device__ constexpr int pit_off_P(int L) { return pit_off_flags(L) + 8; }
+constexpr int kPitExtraDoubles = 24 + 144 + 12 + 12 + 3 * 17 + 1;
+__host__ __device__ constexpr int pit_off_flags(int L) { return win_off_const(L) + 2 + 17; }   // 6 x 4 doubles: per-wave KKT partial, verdicts, partial sums
+__host__ __device__ constexpr int pit_off_P(int L) { return pit_off_flags(L) + 24; }
 __host__ __device__ constexpr int pit_off_p(int L) { return pit_off_P(L) + 144; }
 __host__ __device__ constexpr int pit_off_x(int L) { return pit_off_p(L) + 12; }
 __host__ __device__ constexpr int pit_off_tr(int L) { return pit_off_x(L) + 12; }            // waves 1..3 (wave 0 uses the slice's own)
@@ -3224,11 +3224,11 @@ __device__ __forceinline__ d4 sweep12(d4 S, int rg, int cl, bool& ok) {
 }
 // the result record of an early exit (what qp_body's emit_record writes): device copy, thrust allocation epilogue
 // (bluerov2_dob.cpp:390-395), and -- brov_tick_host -- the host mailbox
-__device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int lane, double cost_lane, double u0_lane, double kkt) {
+__device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int lane, double cost_lane, double u0_lane, double kkt, int qp_iter) {
     const double cs = wave_sum(cost_lane);
     if (lane == 0) {
         brov_result* r = P.res + b;
-        r->cost = cs; r->kkt = kkt; r->status = BROV_STATUS_SUCCESS; r->qp_iter = 0;
+        r->cost = cs; r->kkt = kkt; r->status = BROV_STATUS_SUCCESS; r->qp_iter = qp_iter;
     }
     const double a0 = readlane_f64(u0_lane, 0), a1 = readlane_f64(u0_lane, 1), a2 = readlane_f64(u0_lane, 2), a3 = readlane_f64(u0_lane, 3);
     const double s0 = (lane == 0 || lane == 1) ? -a0 : a0;
@@ -3240,7 +3240,7 @@ __device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int l
         brov_result* m = P.mail + b;
         if (lane < 4) m->u0[lane] = u0_lane;
         if (lane < 6) m->thrust[lane] = th;
-        if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = BROV_STATUS_SUCCESS; m->qp_iter = 0; }
+        if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = BROV_STATUS_SUCCESS; m->qp_iter = qp_iter; }
         if (P.mail_flag) {
             __threadfence_system();
             if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3257,7 +3257,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     if (b >= P.B) return;
     {   // worth trying?  The previous step of this instance was an early exit (its record says so; a fresh solver: zeros = yes)
         const brov_result* prev = P.res + b;
-        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter == 0);
+        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter <= (P.pit_try ? 1 : 0));
         if (!try_it) { if (threadIdx.x == 0) P.pit_done[b] = 0; return; }
     }
     double* ba_s = smem;
@@ -3303,9 +3303,10 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     double* ws_vhat = ws + (size_t)1 * win_img_doubles(Lc);
     double* ws_dxb = ws_vhat + (size_t)N * 4;
     double* ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
+    double* ws_ipm = ws_Ks + (size_t)N * (64 + 64 + NX);   // (behind Ks | Mt | Pb) Gamma and the right-hand side of the try
     auto setup = [&](Inst& I, int seg0, int nst, lds_f64* tr) __attribute__((always_inline)) {
         setup_inst(P, I, b, lane, &lc);
-        I.Ks = ws_Ks; I.Mt = nullptr; I.Pb = nullptr; I.ipm = nullptr;
+        I.Ks = ws_Ks; I.Mt = nullptr; I.Pb = nullptr; I.ipm = ws_ipm;
         I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr; I.ckpt = 0;
         I.BA = nullptr; I.bvec = nullptr;
         I.i0 = seg0; I.N = nst; I.NT = N;
@@ -3344,39 +3345,6 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
 #pragma unroll
         for (int r = 0; r < 3; r++) { x0v[r] = x0[rg + 4 * r]; xiv[r] = I.x[rg + 4 * r]; }
     }
-    // ---- 1. local factor sweep with the condensing accumulators
-    BwdState S;
-    PitAcc& acc = S.acc;
-    wave_fence();
-    if (last) bwd_init<true, 3>(I, S);
-    else { S.P = z4; S.pv = z4; S.ok = true; }
-#pragma unroll
-    for (int r = 0; r < 3; r++) acc.Psi[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
-    acc.Psi[3] = 0.0;
-    acc.G = z4;
-    bwd_chunk<true, 3, false, true, false, Inst, true>(I, S);
-    wave_fence();
-    bool good = S.ok && !S.illc;
-    const unsigned long long t_fac = P.dbg ? __builtin_readcyclecounter() : 0;
-    // vectors travel row-replicated (lane (rg, cl): elements rg, rg + 4, rg + 8)
-    d4 p0;   // p of the segment start: column 0 of S.pv -> every column
-#pragma unroll
-    for (int r = 0; r < 3; r++) p0[r] = dpp_f64<0x150>(S.pv[r]);
-    p0[3] = 0.0;
-    d4 cbar;   // row 12 of G (lanes rg == 0) -> row-replicated
-    {
-        lds_f64* t = (rg == 0 && cl < NX) ? tr_w + cl : tr_w + 16;
-        *t = acc.G[3];
-        cbar = d4{tr_w[rg], tr_w[rg + 4], tr_w[rg + 8], 0.0};
-    }
-    d4 G = acc.G;
-    G[3] = 0.0;
-    const d4 Psi = acc.Psi;
-    d4 idt;
-#pragma unroll
-    for (int r = 0; r < 3; r++) idt[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
-    idt[3] = 0.0;
-    const d4 Phi = tn<3>(Psi, idt, z4);   // the transpose
     // the iterate rows and the reference of the segment, for the bound check and the full step behind the forward sweeps: requested here, ahead
     // of the relay (lsub <= 20 stages -> 2 / 4 elements per lane)
     const int nu = nseg * 4, nxr = (last ? nseg + 1 : nseg) * NX;   // the last segment also commits the terminal node
@@ -3401,165 +3369,215 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
             yr[t] = yy[(size_t)i * NY + cc];
         }
     }
-    // ---- 2a. coarse relay, last boundary to first: wave j + 1 publishes the cost-to-go at its start, wave j takes it to its own start
-    d4 W = z4, vv = z4, pcn = z4, Pcn = z4;   // this segment's W, c - G pc, and the (Pc, pc) it was built with (the forward relay needs them)
-    auto publish = [&](const d4& Pt, const d4& pt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            lds_f64* t = cl < NX ? mailP + (rg + 4 * r) * NX + cl : tr_w + 16;   // (the wave's parking slot)
-            *t = Pt[r];
+    // One pass = local factor sweeps, relay, feed-forward correction, forward sweeps (steps 1 - 3 of the header).  Twice at most: the
+    // equality-constrained system (step0), and -- when its answer leaves the box -- ONE active-set try with the violated inputs pinned
+    // (Gamma = POL_BIG and a right-hand side that lands them on their bounds: qp_body's first try, same arithmetic).
+    bool good = true;
+    d4 lam = z4;   // the costate at this segment's end boundary (the adjoint sweep of the segment enters with it)
+    auto solve_pass = [&](const bool step0) __attribute__((always_inline)) {
+        // ---- 1. local factor sweep with the condensing accumulators
+        BwdState S;
+        PitAcc& acc = S.acc;
+        wave_fence();
+        if (last) bwd_init<true, 3>(I, S);
+        else { S.P = z4; S.pv = z4; S.ok = true; }
+    #pragma unroll
+        for (int r = 0; r < 3; r++) acc.Psi[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
+        acc.Psi[3] = 0.0;
+        acc.G = z4;
+        if (step0) bwd_chunk<true, 3, false, true, false, Inst, true>(I, S);
+        else bwd_chunk<true, 3, false, false, false, Inst, true>(I, S);   // (the try: Gamma and its right-hand side from the interior-point arrays)
+        wave_fence();
+        good = good && S.ok && !S.illc;
+        const unsigned long long t_fac = P.dbg ? __builtin_readcyclecounter() : 0;
+        // vectors travel row-replicated (lane (rg, cl): elements rg, rg + 4, rg + 8)
+        d4 p0;   // p of the segment start: column 0 of S.pv -> every column
+    #pragma unroll
+        for (int r = 0; r < 3; r++) p0[r] = dpp_f64<0x150>(S.pv[r]);
+        p0[3] = 0.0;
+        d4 cbar;   // row 12 of G (lanes rg == 0) -> row-replicated
+        {
+            lds_f64* t = (rg == 0 && cl < NX) ? tr_w + cl : tr_w + 16;
+            *t = acc.G[3];
+            cbar = d4{tr_w[rg], tr_w[rg + 4], tr_w[rg + 8], 0.0};
         }
-        store_vec12_lds(mailp, pt, rg, cl);
-    };
-    d4 Pst = S.P, pst = p0;   // the exact cost-to-go at this segment's start once the relay has passed (the last segment: already)
-    Pst[3] = 0.0;
-    for (int j = 3; j >= 1; j--) {
-        if (wv == j) publish(Pst, pst);
-        __syncthreads();
-        if (wv == j - 1) {
-            d4 Pc;
-#pragma unroll
-            for (int r = 0; r < 3; r++) Pc[r] = cl < NX ? (double)mailP[(rg + 4 * r) * NX + cl] : 0.0;
-            Pc[3] = 0.0;
-            Pcn = Pc;
-            pcn = d4{mailp[rg], mailp[rg + 4], mailp[rg + 8], 0.0};
-            d4 Pi = sweep12(Pc, rg, cl, good);
-#pragma unroll
-            for (int r = 0; r < 3; r++) Pi[r] += G[r];
-            W = sweep12(Pi, rg, cl, good);
-            const d4 Gp = tn<3>(G, pcn, z4);                    // G pc (G symmetric)
-#pragma unroll
-            for (int r = 0; r < 3; r++) vv[r] = cbar[r] - Gp[r];
-            d4 Pe, Ce;                                          // [Phi | v] and [0 | pc]: the vectors ride in column 12
-#pragma unroll
-            for (int r = 0; r < 3; r++) { Pe[r] = (cl == NX) ? vv[r] : Phi[r]; Ce[r] = (cl == NX) ? pcn[r] : 0.0; }
-            Pe[3] = 0.0; Ce[3] = 0.0;
-            d4 in = tn<3>(W, Pe, Ce);                           // [W Phi | W v + pc]
-            in[3] = 0.0;
-            const d4 out = tn<3>(Phi, in, z4);                  // Psi [W Phi | W v + pc]
-#pragma unroll
+        d4 G = acc.G;
+        G[3] = 0.0;
+        const d4 Psi = acc.Psi;
+        d4 idt;
+    #pragma unroll
+        for (int r = 0; r < 3; r++) idt[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
+        idt[3] = 0.0;
+        const d4 Phi = tn<3>(Psi, idt, z4);   // the transpose
+        // ---- 2a. coarse relay, last boundary to first: wave j + 1 publishes the cost-to-go at its start, wave j takes it to its own start
+        d4 W = z4, vv = z4, pcn = z4, Pcn = z4;   // this segment's W, c - G pc, and the (Pc, pc) it was built with (the forward relay needs them)
+        auto publish = [&](const d4& Pt, const d4& pt) __attribute__((always_inline)) {
+    #pragma unroll
             for (int r = 0; r < 3; r++) {
-                Pst[r] = S.P[r] + ((cl < NX) ? out[r] : 0.0);
-                pst[r] = p0[r] + dpp_f64<0x15C>(out[r]);        // row_newbcast:12
+                lds_f64* t = cl < NX ? mailP + (rg + 4 * r) * NX + cl : tr_w + 16;   // (the wave's parking slot)
+                *t = Pt[r];
+            }
+            store_vec12_lds(mailp, pt, rg, cl);
+        };
+        d4 Pst = S.P, pst = p0;   // the exact cost-to-go at this segment's start once the relay has passed (the last segment: already)
+        Pst[3] = 0.0;
+        for (int j = 3; j >= 1; j--) {
+            if (wv == j) publish(Pst, pst);
+            __syncthreads();
+            if (wv == j - 1) {
+                d4 Pc;
+    #pragma unroll
+                for (int r = 0; r < 3; r++) Pc[r] = cl < NX ? (double)mailP[(rg + 4 * r) * NX + cl] : 0.0;
+                Pc[3] = 0.0;
+                Pcn = Pc;
+                pcn = d4{mailp[rg], mailp[rg + 4], mailp[rg + 8], 0.0};
+                d4 Pi = sweep12(Pc, rg, cl, good);
+    #pragma unroll
+                for (int r = 0; r < 3; r++) Pi[r] += G[r];
+                W = sweep12(Pi, rg, cl, good);
+                const d4 Gp = tn<3>(G, pcn, z4);                    // G pc (G symmetric)
+    #pragma unroll
+                for (int r = 0; r < 3; r++) vv[r] = cbar[r] - Gp[r];
+                d4 Pe, Ce;                                          // [Phi | v] and [0 | pc]: the vectors ride in column 12
+    #pragma unroll
+                for (int r = 0; r < 3; r++) { Pe[r] = (cl == NX) ? vv[r] : Phi[r]; Ce[r] = (cl == NX) ? pcn[r] : 0.0; }
+                Pe[3] = 0.0; Ce[3] = 0.0;
+                d4 in = tn<3>(W, Pe, Ce);                           // [W Phi | W v + pc]
+                in[3] = 0.0;
+                const d4 out = tn<3>(Phi, in, z4);                  // Psi [W Phi | W v + pc]
+    #pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    Pst[r] = S.P[r] + ((cl < NX) ? out[r] : 0.0);
+                    pst[r] = p0[r] + dpp_f64<0x15C>(out[r]);        // row_newbcast:12
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned long long t_cb = P.dbg ? __builtin_readcyclecounter() : 0;
+        // ---- 2b. first boundary to last: boundary states and the costates at the segment ends
+        d4 xh = z4;
+        lam = z4;
+        if (wv == 0) {
+    #pragma unroll
+            for (int r = 0; r < 3; r++) xh[r] = x0v[r] - xiv[r];
+        }
+        for (int j = 0; j < 3; j++) {
+            if (wv == j) {
+                const d4 y1 = tn<3>(Psi, xh, z4);                   // Phi x
+                d4 y2;
+    #pragma unroll
+                for (int r = 0; r < 3; r++) y2[r] = y1[r] + vv[r];
+                y2[3] = 0.0;
+                lam = tn<3>(W, y2, pcn);                            // W (Phi x + c - G pc) + pc
+                lam[3] = 0.0;
+                const d4 gl = tn<3>(G, lam, z4);
+                d4 xn;
+    #pragma unroll
+                for (int r = 0; r < 3; r++) xn[r] = y1[r] + cbar[r] - gl[r];
+                xn[3] = 0.0;
+                store_vec12_lds(mailx, xn, rg, cl);
+                // What the two explicit inverses behind W are worth on THIS problem: the costate at the boundary must be the gradient of the
+                // cost-to-go there, lam = Pc x' + pc -- exactly so for the exact W, and off by (I + Pc G) times the error of lam otherwise.  An
+                // iterate on its way out of the physical regime (cond(Pc) 1e8 and more) fails this; its step is left to the resident kernel's
+                // sequential sweep, which needs no such inverse (tests/test_gpu_parity.py, the nominal-model fuzz, found such instances).
+                const d4 l2 = tn<3>(Pcn, xn, pcn);
+                double mis = 0.0, sc = 0.0;
+    #pragma unroll
+                for (int r = 0; r < 3; r++) { mis = fmax(mis, fabs(l2[r] - lam[r])); sc = fmax(sc, fabs(lam[r])); }
+                mis = wave_max(mis); sc = wave_max(sc);
+                if (!(mis <= 1e-9 * sc + 1e-300)) good = false;
+            }
+            __syncthreads();
+            if (wv == j + 1) xh = d4{mailx[rg], mailx[rg + 4], mailx[rg + 8], 0.0};
+            __syncthreads();
+        }
+        if (step0) PIT_STAMP(2);
+        if (step0 && P.dbg && threadIdx.x == 0) P.dbg[(size_t)b * 8 + 7] = ((t_fac - P.dbg[(size_t)b * 8 + 1]) & 0xFFFFF) | (((t_cb - t_fac) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - t_cb) & 0xFFFFF) << 40);
+        // ---- 3. the costate's share of the feed-forward terms, then the forward sweep of the segment
+        if (!last) {
+            store_vec12_lds(tr_w, lam, rg, cl);
+            const double lc_ = tr_w[cl < NX ? cl : 0];
+            const double lcl = cl < NX ? lc_ : 0.0;
+            // (a rolled loop over batches of four stages, the next batch requested before the current one is used: fully unrolled, the 20 stages
+            // cost the kernel 18 more SGPR spills than its one lane-spill register holds, and the rest went to scratch)
+            const double* kb = I.Ks + (size_t)s0 * 64 + lane;
+            const int nlast = nseg - 1;
+            double mz[4], mn[4];
+    #pragma unroll
+            for (int t = 0; t < 4; t++) mz[t] = kb[(t < nlast ? t : nlast) * 64];
+    #pragma clang loop unroll(disable)
+            for (int i0 = 0; i0 < nseg; i0 += 4) {
+    #pragma unroll
+                for (int t = 0; t < 4; t++) { const int i = i0 + 4 + t; mn[t] = kb[(i < nlast ? i : nlast) * 64]; }
+    #pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int i = i0 + t < nlast ? i0 + t : nlast;       // (past the end: the last stage again, same value written twice)
+                    double v = mz[t] * lcl;                              // (M Z')[rg][cl] lam[cl]
+                    v += dpp_f64<0xB1>(v);
+                    v += dpp_f64<0x4E>(v);
+                    v += dpp_f64<0x141>(v);
+                    v += dpp_f64<0x140>(v);                              // the row's sum in every lane
+                    lds_f64* kp = (cl == 0 && i0 + t < nseg) ? I.lds_kff + i * 4 + rg : tr_w + 16;
+                    const double k0 = I.lds_kff[i * 4 + rg];
+                    *kp = k0 - v;
+                }
+    #pragma unroll
+                for (int t = 0; t < 4; t++) mz[t] = mn[t];
             }
         }
-        __syncthreads();
-    }
-    const unsigned long long t_cb = P.dbg ? __builtin_readcyclecounter() : 0;
-    // ---- 2b. first boundary to last: boundary states and the costates at the segment ends
-    d4 xh = z4, lam = z4;
-    if (wv == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) xh[r] = x0v[r] - xiv[r];
-    }
-    for (int j = 0; j < 3; j++) {
-        if (wv == j) {
-            const d4 y1 = tn<3>(Psi, xh, z4);                   // Phi x
-            d4 y2;
-#pragma unroll
-            for (int r = 0; r < 3; r++) y2[r] = y1[r] + vv[r];
-            y2[3] = 0.0;
-            lam = tn<3>(W, y2, pcn);                            // W (Phi x + c - G pc) + pc
-            lam[3] = 0.0;
-            const d4 gl = tn<3>(G, lam, z4);
-            d4 xn;
-#pragma unroll
-            for (int r = 0; r < 3; r++) xn[r] = y1[r] + cbar[r] - gl[r];
-            xn[3] = 0.0;
-            store_vec12_lds(mailx, xn, rg, cl);
-            // What the two explicit inverses behind W are worth on THIS problem: the costate at the boundary must be the gradient of the
-            // cost-to-go there, lam = Pc x' + pc -- exactly so for the exact W, and off by (I + Pc G) times the error of lam otherwise.  An
-            // iterate on its way out of the physical regime (cond(Pc) 1e8 and more) fails this; its step is left to the resident kernel's
-            // sequential sweep, which needs no such inverse (tests/test_gpu_parity.py, the nominal-model fuzz, found such instances).
-            const d4 l2 = tn<3>(Pcn, xn, pcn);
-            double mis = 0.0, sc = 0.0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) { mis = fmax(mis, fabs(l2[r] - lam[r])); sc = fmax(sc, fabs(lam[r])); }
-            mis = wave_max(mis); sc = wave_max(sc);
-            if (!(mis <= 1e-9 * sc + 1e-300)) good = false;
+        wave_fence();
+        {
+            d4 xx = xh;
+            fwd_chunk<3>(I, xx, wv == 0 ? nullptr : tr_w);
         }
-        __syncthreads();
-        if (wv == j + 1) xh = d4{mailx[rg], mailx[rg + 4], mailx[rg + 8], 0.0};
-        __syncthreads();
-    }
-    PIT_STAMP(2);
-    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)b * 8 + 7] = ((t_fac - P.dbg[(size_t)b * 8 + 1]) & 0xFFFFF) | (((t_cb - t_fac) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - t_cb) & 0xFFFFF) << 40);
-    // ---- 3. the costate's share of the feed-forward terms, then the forward sweep of the segment
-    if (!last) {
-        store_vec12_lds(tr_w, lam, rg, cl);
-        const double lc_ = tr_w[cl < NX ? cl : 0];
-        const double lcl = cl < NX ? lc_ : 0.0;
-        // (a rolled loop over batches of four stages, the next batch requested before the current one is used: fully unrolled, the 20 stages
-        // cost the kernel 18 more SGPR spills than its one lane-spill register holds, and the rest went to scratch)
-        const double* kb = I.Ks + (size_t)s0 * 64 + lane;
-        const int nlast = nseg - 1;
-        double mz[4], mn[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) mz[t] = kb[(t < nlast ? t : nlast) * 64];
-#pragma clang loop unroll(disable)
-        for (int i0 = 0; i0 < nseg; i0 += 4) {
-#pragma unroll
-            for (int t = 0; t < 4; t++) { const int i = i0 + 4 + t; mn[t] = kb[(i < nlast ? i : nlast) * 64]; }
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int i = i0 + t < nlast ? i0 + t : nlast;       // (past the end: the last stage again, same value written twice)
-                double v = mz[t] * lcl;                              // (M Z')[rg][cl] lam[cl]
-                v += dpp_f64<0xB1>(v);
-                v += dpp_f64<0x4E>(v);
-                v += dpp_f64<0x141>(v);
-                v += dpp_f64<0x140>(v);                              // the row's sum in every lane
-                lds_f64* kp = (cl == 0 && i0 + t < nseg) ? I.lds_kff + i * 4 + rg : tr_w + 16;
-                const double k0 = I.lds_kff[i * 4 + rg];
-                *kp = k0 - v;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; t++) mz[t] = mn[t];
-        }
-    }
-    wave_fence();
-    {
-        d4 xx = xh;
-        fwd_chunk<3>(I, xx, wv == 0 ? nullptr : tr_w);
-    }
-    wave_fence();
-    // ---- 4. checks, full step and adjoint sweep, every wave on its own segment
+        wave_fence();
+    };
+    solve_pass(true);
+    // ---- 4. checks, (one active-set try,) full step and adjoint sweep, every wave on its own segment
     // (everything the record and the full step address is derived from an opaque copy of the instance index HERE: formed from `b` itself the
     // base addresses are loop invariants of the whole kernel, computed up front and spilled -- and the build then reserves scratch)
     int bq = b;
     asm volatile("s_mov_b32 %0, %0" : "+s"(bq));
-    const lds_f64* vh = I.lds_vhat;    // this segment's candidate inputs [nseg][4] and state steps (row 0 = the boundary it starts from)
+    lds_f64* vh = I.lds_vhat;          // this segment's candidate inputs [nseg][4] and state steps (row 0 = the boundary it starts from)
     const lds_f64* dxs = I.lds_dxb;
     double* x_it = P.x + ((size_t)bq * (N + 1) + s0) * NX;
     double* u_it = P.u + ((size_t)bq * N + s0) * NU;
     double* pi_it = P.pi + ((size_t)bq * N + s0) * NX;
     double* lam_it = P.lam + ((size_t)bq * N + s0) * 8;
-    bool bad = false, infeas = false;
-    {   // NaN among what the forward sweep produced; inputs inside their bounds
-        const double lbm = P.cst[32 + (lane & 3)], ubm = P.cst[36 + (lane & 3)];
+    const int mI = lane & 3;           // input index of this lane's elements j = lane + 64 t of the segment
+    const double lbI = P.cst[32 + mI], ubI = P.cst[36 + mI], rdI = P.Ts * P.cst[12 + mI];
+    auto seg_nan = [&]() __attribute__((always_inline)) {   // NaN among what the forward sweep of the segment produced
+        bool bad = false;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int j = lane + 64 * t;
-            const double vj = vh[j < nu ? j : 0];
-            bad = bad | !(vj == vj);
-            infeas = infeas | ((j < nu) & !(vj >= lbm - uo[t] && vj <= ubm - uo[t]));
-        }
+        for (int t = 0; t < 2; t++) { const double vj = vh[lane + 64 * t < nu ? lane + 64 * t : 0]; bad = bad | !(vj == vj); }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int j = lane + 64 * t + NX;                       // rows 1 .. nseg: the state steps this segment's sweep wrote
             const double e = dxs[j < (nseg + 1) * NX ? j : NX];
             bad = bad | !(e == e);
         }
+        return __ballot(bad) != 0ull;
+    };
+    bool infeas = false;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int j = lane + 64 * t;
+        const double vj = vh[j < nu ? j : 0];
+        infeas = infeas | ((j < nu) & !(vj >= lbI - uo[t] && vj <= ubI - uo[t]));
     }
-    const bool seg_ok = good && __ballot(bad) == 0ull && __ballot(infeas) == 0ull;
-    if (lane == 0) flag_s[4 + wv] = seg_ok ? 1.0 : 0.0;
+    {
+        const bool sn = seg_nan(), sf = __ballot(infeas) == 0ull;
+        if (lane == 0) { flag_s[4 + wv] = (good && !sn) ? 1.0 : 0.0; flag_s[8 + wv] = sf ? 1.0 : 0.0; }
+    }
     __syncthreads();
     PIT_STAMP(3);
-    bool all_good = true;
+    bool all_good = true, all_feas = true;
     double kkt_lin = 0.0;
     bool nan_lin = false;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         all_good = all_good && (flag_s[4 + w] == 1.0);
+        all_feas = all_feas && (flag_s[8 + w] == 1.0);
         const double v = flag_s[w];
         nan_lin = nan_lin | !(v == v);
         kkt_lin = fmax(kkt_lin, v);
@@ -3571,12 +3589,103 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     if (kkt != kkt) nanp2 = true;
     kkt = wave_max(fmax(kkt_lin, (kkt != kkt) ? 0.0 : kkt));
     const bool kkt_nan = __ballot(nanp2) != 0ull;
-    const bool accept = all_good && !kkt_nan && P.early_exit;    // (the same decision in every wave)
-    if (!accept) {
+    if (!all_good || kkt_nan) {       // (the same decision in every wave, here and below)
         if (threadIdx.x == 0) P.pit_done[bq] = 0;
         return;
     }
-    __syncthreads();   // (flag_s is reused for the cost partials)
+    // the adjoint sweep of the segment.  The multiplier of its last interval is the costate at its end boundary, which the relay has computed
+    // (lam; the last segment: the terminal gradient, which the sweep forms itself): the sweep enters with A'pi := lam - (Qd dx_e + q_e).
+    // Multipliers -> the head of the segment's K^T area, input gradient -> its feed-forward area (adj_chunk).
+    auto seg_adjoint = [&]() __attribute__((always_inline)) {
+        d4 atpi = z4;
+        if (!last) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int row = rg + 4 * r;
+                atpi[r] = lam[r] - (P.Ts * I.Wr[r] * (double)dxs[nseg * NX + row] + (double)I.lds_q[nseg * NX + row]);
+            }
+        }
+        wave_fence();
+        adj_chunk<true, 3>(I, atpi, nullptr, nullptr, nullptr);
+        wave_fence();
+    };
+    const bool early = all_feas && P.early_exit;
+    double gel[2] = {0.0, 0.0};        // the accepted try's input gradient of this lane's elements (bound multipliers)
+    if (!early) {
+        // ---- 5. ONE active-set try (qp_body's first try, element for element): the inputs of the Newton point that violate their bounds are
+        // pinned there (Gamma = POL_BIG and the right-hand side that lands them on the bound), the system is solved by a second pass, pinned
+        // inputs are snapped onto their bounds, and the point is THE minimiser if no free input leaves the box and no pinned input's multiplier
+        // has the wrong sign.  Then it is committed with one Newton system in its record; if not (15 % of the QPs that run the loop on the
+        // mixed batch), nothing has been touched and the resident kernel behind this one does the step.
+        if (!P.pit_try) {
+            if (threadIdx.x == 0) P.pit_done[bq] = 0;
+            return;
+        }
+        double act[2];
+        {
+            double* GAM = I.ipm + (size_t)IPM_GAM * I.nv + (size_t)s0 * 4;
+            double* RT = I.ipm + (size_t)IPM_RT * I.nv + (size_t)s0 * 4;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int j = lane + 64 * t;
+                const double vj = vh[j < nu ? j : 0], uj = uo[t];
+                const double ac = vj < lbI - uj ? -1.0 : (vj > ubI - uj ? 1.0 : 0.0);
+                act[t] = ac;
+                const double gm = ac != 0.0 ? POL_BIG : 0.0;
+                const double rr = rdI * (uj - ur[t]);
+                if (j < nu) { GAM[j] = gm; RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj); }
+            }
+        }
+        __syncthreads();   // (every wave is done with the hand-over buffers and flags of the first pass)
+        solve_pass(false);
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {   // pinned inputs exactly onto their bounds; free inputs that leave the box are marked (+-2: to be pinned)
+            const int j = lane + 64 * t;
+            const double uj = uo[t], lb = lbI - uj, ub = ubI - uj;
+            double vj = vh[j < nu ? j : 0];
+            bad = bad | ((j < nu) & !(vj == vj));
+            if (act[t] != 0.0) vj = act[t] < 0.0 ? lb : ub;
+            else act[t] = vj < lb ? -2.0 : (vj > ub ? 2.0 : 0.0);
+            lds_f64* o = j < nu ? vh + j : tr_w + 16;
+            *o = vj;
+        }
+        const bool seg_bad = __ballot(bad) != 0ull || seg_nan() || !good;
+        seg_adjoint();
+        double gmx = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t;
+            gel[t] = I.lds_kff[j < nu ? j : 0];
+            if (j < nu) gmx = fmax(gmx, fabs(gel[t]));
+        }
+        gmx = wave_max(gmx);
+        if (lane == 0) { flag_s[12 + wv] = seg_bad ? __builtin_nan("") : gmx; }
+        __syncthreads();
+        bool any_bad = false;
+        gmx = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const double v = flag_s[12 + w]; any_bad = any_bad | !(v == v); gmx = fmax(gmx, v); }
+        double cnt = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t;
+            if (j < nu) {
+                const double g = gel[t], ac = act[t];
+                const double tolg = POL_TOL_G * rdI + POL_TOL_GREL * gmx;
+                if (ac == 2.0 || ac == -2.0) cnt += 1.0;                                                   // would be pinned by a repair
+                else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) cnt += 1.0;                   // would be released
+            }
+        }
+        cnt = wave_sum(cnt);
+        if (lane == 0) flag_s[16 + wv] = cnt;
+        __syncthreads();
+        const double nchg = (flag_s[16] + flag_s[17]) + (flag_s[18] + flag_s[19]);
+        if (any_bad || nchg != 0.0) {
+            if (threadIdx.x == 0) P.pit_done[bq] = 0;
+            return;
+        }
+    }
     PIT_STAMP(4);
     // full step of the segment and its share of the objective at the new iterate
     double cost = 0.0, u0v = 0.0;
@@ -3585,13 +3694,14 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         const int j = lane + 64 * t;
         if (j < nu) {
             const int i = j >> 2, m = j & 3;
-            lam_it[(size_t)i * 8 + m] = 0.0;          // no active bound: the bound multipliers are zero
-            lam_it[(size_t)i * 8 + 4 + m] = 0.0;
+            const double gg = early ? 0.0 : gel[t];   // no active bound: the bound multipliers are zero
+            lam_it[(size_t)i * 8 + m] = gg > 0 ? gg : 0.0;
+            lam_it[(size_t)i * 8 + 4 + m] = gg < 0 ? -gg : 0.0;
             const double un = uo[t] + vh[j];
             u_it[j] = un;
             if (wv == 0 && j < 4) { P.res[bq].u0[j] = un; u0v = un; }
             const double e = un - ur[t];
-            cost += 0.5 * (P.Ts * P.cst[12 + m]) * e * e;
+            cost += 0.5 * rdI * e * e;
         }
     }
 #pragma unroll
@@ -3607,27 +3717,15 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     }
     {
         const double cw = wave_sum(cost);
-        if (lane == 0) flag_s[4 + wv] = cw;
+        if (lane == 0) flag_s[20 + wv] = cw;
     }
     __syncthreads();
     if (wv == 0) {   // the record: as soon as the four shares of the objective are in
-        const double ctot = ((flag_s[4] + flag_s[5]) + (flag_s[6] + flag_s[7]));
-        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt);
+        const double ctot = ((flag_s[20] + flag_s[21]) + (flag_s[22] + flag_s[23]));
+        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt, early ? 0 : 1);
         PIT_STAMP(5);
     }
-    // adjoint sweep of the segment.  The multiplier of its last interval is the costate at its end boundary, which the relay has computed
-    // (lam; the last segment: the terminal gradient, which the sweep forms itself): the sweep enters with A'pi := lam - (Qd dx_e + q_e)
-    d4 atpi = z4;
-    if (!last) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const int row = rg + 4 * r;
-            atpi[r] = lam[r] - (P.Ts * I.Wr[r] * (double)dxs[nseg * NX + row] + (double)I.lds_q[nseg * NX + row]);
-        }
-    }
-    wave_fence();
-    adj_chunk<true, 3>(I, atpi, nullptr, nullptr, nullptr);
-    wave_fence();
+    if (early) seg_adjoint();   // (an accepted try has run it already: its multipliers are the ones to keep)
     win_flush_small(pi_it, (const double*)I.lds_kt, nseg * NX, lane);
     if (threadIdx.x == 0) P.pit_done[bq] = 1;
     if (wv == 0) PIT_STAMP(6);

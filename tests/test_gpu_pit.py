@@ -72,7 +72,7 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
     op = oracle.opts(N, Ts)
     x, u, pi, lam = oracle.init_iterate(op, B)
     pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
-    prev, n_done, n_loop = None, 0, 0
+    prev, n_done, n_loop, n_try = None, 0, 0, 0
     for k in range(6):
         yref = np.ascontiguousarray(circ[k:k + N + 1])
         s.set_yref(yref); s.solve()
@@ -81,13 +81,17 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
         prev = ro
         _compare(r, it, ro, x, u, pi, lam, (N, B, far, mode, k))
         early = (ro["status"] == 0) & (ro["qp_iter"] == 0)
-        assert not np.any(done.astype(bool) & ~early), "an instance with active bounds must be left to the resident kernel"
+        one = (ro["status"] == 0) & (ro["qp_iter"] <= 1)          # no active bound, or a first active-set guess that is right
+        assert not np.any(done.astype(bool) & ~one), "more than one Newton system: the resident kernel's"
         if mode == "2":
-            assert np.array_equal(done.astype(bool), early), (k, done, early)     # every early exit is found
-        n_done += int(done.sum()); n_loop += int((~early).sum())
+            assert np.all(done.astype(bool)[early]), (k, done, early)                 # every early exit is found
+            assert done[one].sum() >= 0.8 * one.sum() - 1                            # ... and (nearly) every one-try answer
+        n_done += int(done.sum()); n_loop += int((~early).sum()); n_try += int((done.astype(bool) & ~early).sum())
     assert n_done > 0
     if far:
         assert n_loop > 0
+        if mode == "2" and B >= 12:
+            assert n_try > 0      # answers with active bounds completed by the parallel-in-time try
     s.close()
 
 
@@ -203,9 +207,9 @@ def test_long_closed_loop_with_reference_jumps_switches_between_the_two_kernels(
         err = np.abs(ra["u0"] - rb["u0"]).max() / max(1.0, np.abs(rb["u0"]).max())
         worst = max(worst, err)
         assert err < 1e-8, (k, err, done)
-        assert bool(done[0]) <= (ra["qp_iter"][0] == 0)
+        assert bool(done[0]) <= (ra["qp_iter"][0] <= 1)
         n_pit += int(done[0]); n_res += int(not done[0]); n_loop += int(ra["qp_iter"][0] > 0)
         a.plant_step(1.0 / N)
     print(f"[pit soak] {T} ticks: {n_pit} by the parallel-in-time kernel, {n_res} by the resident kernel ({n_loop} with active bounds), worst relative |du0| {worst:.1e}")
-    assert n_pit > T // 3 and n_loop > 30 and n_res >= n_loop
+    assert n_pit > T // 3 and n_loop > 30
     a.close(); b.close()
