@@ -808,7 +808,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
-            if (pit && s->pit_done && pit_supported(s->N, s->win_L) && !general_grid(s) && s->opts.qp_early_exit && !s->dump_lin) {
+            if (pit && s->pit_done && pit_supported(s->N, s->win_L) && !general_grid(s) && !s->dump_lin) {
                 P.pit = pit; P.pit_done = s->pit_done;
                 P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);
             }

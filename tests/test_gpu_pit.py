@@ -95,6 +95,32 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
     s.close()
 
 
+def test_forced_loop_option_goes_through_the_parallel_try(ba, oracle, golden_traj):
+    """qp_early_exit = 0: every instance runs at least one Newton system of the QP loop -- an empty or a correct first guess of the active
+    set is one try, which the kernel makes itself"""
+    os.environ["BROV_PIT"] = "2"
+    N, B = 40, 10
+    Ts = 1.0 / N
+    x0, circ = _inputs(golden_traj, B, seed=91, far=0.4)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, qp_early_exit=0)); s.set_x0(x0); s.set_params(P_NOMINAL)
+    op = oracle.opts(N, Ts, qp_early_exit=0)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
+    prev, n_done = None, 0
+    for k in range(5):
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        s.set_yref(yref); s.solve()
+        r, it, done = s.results(), s.get_iterate(), s.pit_last()
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        prev = ro
+        _compare(r, it, ro, x, u, pi, lam, ("forced", k))
+        assert np.all(ro["qp_iter"][ro["status"] == 0] >= 1)
+        assert not np.any(done.astype(bool) & (ro["qp_iter"] > 1))
+        n_done += int(done.sum())
+    assert n_done >= 3 * B
+    s.close()
+
+
 def test_off_is_the_resident_kernel_alone_and_on_agrees_with_it(ba, golden_traj):
     """BROV_PIT=0: the kernel is not launched (no instance reported); with it the records agree to rounding (different summation order
     inside the factorisation: 1e-11 on the inputs), bit for bit where the kernel did not complete the instance"""
