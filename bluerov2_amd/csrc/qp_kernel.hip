@@ -3617,7 +3617,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         // inputs are snapped onto their bounds, and the point is THE minimiser if no free input leaves the box and no pinned input's multiplier
         // has the wrong sign.  Then it is committed with one Newton system in its record; if not (15 % of the QPs that run the loop on the
         // mixed batch), nothing has been touched and the resident kernel behind this one does the step.
-        if (!P.pit_try) {
+        if (!P.pit_try || P.qp_iter_max < 1) {   // (no Newton system allowed: the resident kernel reports the iteration limit)
             if (threadIdx.x == 0) P.pit_done[bq] = 0;
             return;
         }
