@@ -3257,7 +3257,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     if (b >= P.B) return;
     {   // worth trying?  The previous step of this instance was an early exit (its record says so; a fresh solver: zeros = yes)
         const brov_result* prev = P.res + b;
-        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter <= (P.pit_try ? 1 : 0));
+        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter <= (P.pit_try ? 2 : 0));
         if (!try_it) { if (threadIdx.x == 0) P.pit_done[b] = 0; return; }
     }
     double* ba_s = smem;
@@ -3611,77 +3611,96 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     };
     const bool early = all_feas && P.early_exit;
     double gel[2] = {0.0, 0.0};        // the accepted try's input gradient of this lane's elements (bound multipliers)
+    int tries = 0;                     // Newton systems of the QP loop this kernel has solved for the answer it commits
     if (!early) {
         // ---- 5. ONE active-set try (qp_body's first try, element for element): the inputs of the Newton point that violate their bounds are
         // pinned there (Gamma = POL_BIG and the right-hand side that lands them on the bound), the system is solved by a second pass, pinned
         // inputs are snapped onto their bounds, and the point is THE minimiser if no free input leaves the box and no pinned input's multiplier
         // has the wrong sign.  Then it is committed with one Newton system in its record; if not (15 % of the QPs that run the loop on the
         // mixed batch), nothing has been touched and the resident kernel behind this one does the step.
-        if (!P.pit_try || P.qp_iter_max < 1) {   // (no Newton system allowed: the resident kernel reports the iteration limit)
+        if (!P.pit_try || P.qp_iter_max < 1) {   // (no try of its own / no Newton system allowed: the resident kernel's)
             if (threadIdx.x == 0) P.pit_done[bq] = 0;
             return;
         }
+        // first guess: the inputs of the Newton point that violate their bounds
         double act[2];
-        {
-            double* GAM = I.ipm + (size_t)IPM_GAM * I.nv + (size_t)s0 * 4;
-            double* RT = I.ipm + (size_t)IPM_RT * I.nv + (size_t)s0 * 4;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t;
+            const double vj = vh[j < nu ? j : 0];
+            act[t] = vj < lbI - uo[t] ? -1.0 : (vj > ubI - uo[t] ? 1.0 : 0.0);
+        }
+        // ... and up to kPitTries - 1 repairs of it, qp_body's first ROUND of tries as far as it goes without an interior-point iteration: a
+        // try that asks for more than POL_NCHG repairs ends the round there too
+        constexpr int kPitTries = 3;
+        bool accepted = false;
+#pragma clang loop unroll(disable)
+        for (int tk = 0; tk < kPitTries; tk++) {
+            if (tk + 1 > P.qp_iter_max) break;
+            {
+                double* GAM = I.ipm + (size_t)IPM_GAM * I.nv + (size_t)s0 * 4;
+                double* RT = I.ipm + (size_t)IPM_RT * I.nv + (size_t)s0 * 4;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int j = lane + 64 * t;
+                    const double uj = uo[t], ac = act[t];
+                    const double gm = ac != 0.0 ? POL_BIG : 0.0;
+                    const double rr = rdI * (uj - ur[t]);
+                    if (j < nu) { GAM[j] = gm; RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj); }
+                }
+            }
+            __syncthreads();   // (every wave is done with the hand-over buffers and flags of the pass before)
+            solve_pass(false);
+            bool bad = false;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {   // pinned inputs exactly onto their bounds; free inputs that leave the box are marked (+-2: to be pinned)
+                const int j = lane + 64 * t;
+                const double uj = uo[t], lb = lbI - uj, ub = ubI - uj;
+                double vj = vh[j < nu ? j : 0];
+                bad = bad | ((j < nu) & !(vj == vj));
+                if (act[t] != 0.0) vj = act[t] < 0.0 ? lb : ub;
+                else act[t] = vj < lb ? -2.0 : (vj > ub ? 2.0 : 0.0);
+                lds_f64* o = j < nu ? vh + j : tr_w + 16;
+                *o = vj;
+            }
+            const bool seg_bad = __ballot(bad) != 0ull || seg_nan() || !good;
+            seg_adjoint();
+            double gmx = 0.0;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const int j = lane + 64 * t;
-                const double vj = vh[j < nu ? j : 0], uj = uo[t];
-                const double ac = vj < lbI - uj ? -1.0 : (vj > ubI - uj ? 1.0 : 0.0);
-                act[t] = ac;
-                const double gm = ac != 0.0 ? POL_BIG : 0.0;
-                const double rr = rdI * (uj - ur[t]);
-                if (j < nu) { GAM[j] = gm; RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj); }
+                gel[t] = I.lds_kff[j < nu ? j : 0];
+                if (j < nu) gmx = fmax(gmx, fabs(gel[t]));
             }
-        }
-        __syncthreads();   // (every wave is done with the hand-over buffers and flags of the first pass)
-        solve_pass(false);
-        bool bad = false;
+            gmx = wave_max(gmx);
+            if (lane == 0) { flag_s[12 + wv] = seg_bad ? __builtin_nan("") : gmx; }
+            __syncthreads();
+            bool any_bad = false;
+            gmx = 0.0;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {   // pinned inputs exactly onto their bounds; free inputs that leave the box are marked (+-2: to be pinned)
-            const int j = lane + 64 * t;
-            const double uj = uo[t], lb = lbI - uj, ub = ubI - uj;
-            double vj = vh[j < nu ? j : 0];
-            bad = bad | ((j < nu) & !(vj == vj));
-            if (act[t] != 0.0) vj = act[t] < 0.0 ? lb : ub;
-            else act[t] = vj < lb ? -2.0 : (vj > ub ? 2.0 : 0.0);
-            lds_f64* o = j < nu ? vh + j : tr_w + 16;
-            *o = vj;
-        }
-        const bool seg_bad = __ballot(bad) != 0ull || seg_nan() || !good;
-        seg_adjoint();
-        double gmx = 0.0;
+            for (int w = 0; w < 4; w++) { const double v = flag_s[12 + w]; any_bad = any_bad | !(v == v); gmx = fmax(gmx, v); }
+            double cnt = 0.0;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int j = lane + 64 * t;
-            gel[t] = I.lds_kff[j < nu ? j : 0];
-            if (j < nu) gmx = fmax(gmx, fabs(gel[t]));
-        }
-        gmx = wave_max(gmx);
-        if (lane == 0) { flag_s[12 + wv] = seg_bad ? __builtin_nan("") : gmx; }
-        __syncthreads();
-        bool any_bad = false;
-        gmx = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { const double v = flag_s[12 + w]; any_bad = any_bad | !(v == v); gmx = fmax(gmx, v); }
-        double cnt = 0.0;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int j = lane + 64 * t;
-            if (j < nu) {
-                const double g = gel[t], ac = act[t];
-                const double tolg = POL_TOL_G * rdI + POL_TOL_GREL * gmx;
-                if (ac == 2.0 || ac == -2.0) cnt += 1.0;                                                   // would be pinned by a repair
-                else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) cnt += 1.0;                   // would be released
+            for (int t = 0; t < 2; t++) {
+                const int j = lane + 64 * t;
+                if (j < nu) {
+                    const double g = gel[t];
+                    double ac = act[t];
+                    const double tolg = POL_TOL_G * rdI + POL_TOL_GREL * gmx;
+                    if (ac == 2.0 || ac == -2.0) { ac *= 0.5; cnt += 1.0; }                                          // newly pinned
+                    else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) { ac = 0.0; cnt += 1.0; }          // released
+                    act[t] = ac;
+                }
             }
+            cnt = wave_sum(cnt);
+            if (lane == 0) flag_s[16 + wv] = cnt;
+            __syncthreads();
+            const double nchg = (flag_s[16] + flag_s[17]) + (flag_s[18] + flag_s[19]);
+            if (any_bad) break;
+            if (nchg == 0.0) { accepted = true; tries = tk + 1; break; }
+            if (nchg > (double)POL_NCHG) break;   // (the round ends: an interior-point iteration is next -- the resident kernel's)
         }
-        cnt = wave_sum(cnt);
-        if (lane == 0) flag_s[16 + wv] = cnt;
-        __syncthreads();
-        const double nchg = (flag_s[16] + flag_s[17]) + (flag_s[18] + flag_s[19]);
-        if (any_bad || nchg != 0.0) {
+        if (!accepted) {
             if (threadIdx.x == 0) P.pit_done[bq] = 0;
             return;
         }
@@ -3722,7 +3741,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     __syncthreads();
     if (wv == 0) {   // the record: as soon as the four shares of the objective are in
         const double ctot = ((flag_s[20] + flag_s[21]) + (flag_s[22] + flag_s[23]));
-        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt, early ? 0 : 1);
+        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt, early ? 0 : tries);
         PIT_STAMP(5);
     }
     if (early) seg_adjoint();   // (an accepted try has run it already: its multipliers are the ones to keep)

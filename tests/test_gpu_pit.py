@@ -82,7 +82,9 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
         _compare(r, it, ro, x, u, pi, lam, (N, B, far, mode, k))
         early = (ro["status"] == 0) & (ro["qp_iter"] == 0)
         one = (ro["status"] == 0) & (ro["qp_iter"] <= 1)          # no active bound, or a first active-set guess that is right
-        assert not np.any(done.astype(bool) & ~one), "more than one Newton system: the resident kernel's"
+        few = (ro["status"] == 0) & (ro["qp_iter"] <= 3)          # ... or one that two repairs make right (the kernel's round of tries)
+        assert not np.any(done.astype(bool) & ~few), "more than three Newton systems: the resident kernel's"
+        assert np.array_equal(r["qp_iter"][done.astype(bool)], ro["qp_iter"][done.astype(bool)])   # the same number of systems as the oracle's schedule
         if mode == "2":
             assert np.all(done.astype(bool)[early]), (k, done, early)                 # every early exit is found
             assert done[one].sum() >= 0.8 * one.sum() - 1                            # ... and (nearly) every one-try answer
@@ -115,7 +117,7 @@ def test_forced_loop_option_goes_through_the_parallel_try(ba, oracle, golden_tra
         prev = ro
         _compare(r, it, ro, x, u, pi, lam, ("forced", k))
         assert np.all(ro["qp_iter"][ro["status"] == 0] >= 1)
-        assert not np.any(done.astype(bool) & (ro["qp_iter"] > 1))
+        assert not np.any(done.astype(bool) & (ro["qp_iter"] > 3))
         n_done += int(done.sum())
     assert n_done >= 3 * B
     s.close()
@@ -233,7 +235,7 @@ def test_long_closed_loop_with_reference_jumps_switches_between_the_two_kernels(
         err = np.abs(ra["u0"] - rb["u0"]).max() / max(1.0, np.abs(rb["u0"]).max())
         worst = max(worst, err)
         assert err < 1e-8, (k, err, done)
-        assert bool(done[0]) <= (ra["qp_iter"][0] <= 1)
+        assert bool(done[0]) <= (ra["qp_iter"][0] <= 3)
         n_pit += int(done[0]); n_res += int(not done[0]); n_loop += int(ra["qp_iter"][0] > 0)
         a.plant_step(1.0 / N)
     print(f"[pit soak] {T} ticks: {n_pit} by the parallel-in-time kernel, {n_res} by the resident kernel ({n_loop} with active bounds), worst relative |du0| {worst:.1e}")
