@@ -3882,6 +3882,33 @@ __global__ void tile_tn_kernel(const double* xt, const double* y, const double* 
 }
 }  // namespace brov
 
+// ---- test hook: the 12 x 12 SPD inverse of the parallel-in-time kernel's relay (tests/test_gpu_pit.py checks it against numpy) ----
+namespace brov {
+__global__ void sweep12_kernel(const double* a, double* out, int* okf) {   // a, out: row-major [12][12]
+    const int lane = threadIdx.x, rg = lane >> 4, cl = lane & 15;
+    d4 S;
+#pragma unroll
+    for (int r = 0; r < 3; r++) S[r] = cl < 12 ? a[(rg + 4 * r) * 12 + cl] : 0.0;
+    S[3] = 0.0;
+    bool ok = true;
+    const d4 R = sweep12(S, rg, cl, ok);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (cl < 12) out[(rg + 4 * r) * 12 + cl] = R[r];
+    if (lane == 0) *okf = ok ? 1 : 0;
+}
+}  // namespace brov
+extern "C" int brov_selftest_sweep12(const double* a, double* out, int* ok) {
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, (2 * 144 + 1) * sizeof(double)) != hipSuccess) return BROV_ERR_NO_DEVICE;
+    hipMemcpy(d, a, 144 * sizeof(double), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(brov::sweep12_kernel, dim3(1), dim3(64), 0, 0, d, d + 144, (int*)(d + 288));
+    hipError_t e = hipMemcpy(out, d + 144, 144 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ok, d + 288, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? BROV_OK : BROV_ERR_HIP;
+}
+
 extern "C" int brov_selftest_tile_tn(const double* xt, const double* y, const double* c, double* out, int k4) {
     double* d = nullptr;
     if (hipMalloc((void**)&d, 4 * 256 * sizeof(double)) != hipSuccess) return BROV_ERR_NO_DEVICE;

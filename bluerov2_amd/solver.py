@@ -91,6 +91,7 @@ def _load():
         "brov_get_linearisation_host": [vp, dp, dp], "brov_select_best_host": [vp, ip, vp],
         "brov_get_thrusts_host": [vp, dp], "brov_last_solve_seconds": [vp, dp, dp], "brov_enable_timing": [vp, C.c_int],
         "brov_selftest_tile_tn": [dp, dp, dp, dp, C.c_int],
+        "brov_selftest_sweep12": [dp, dp, C.POINTER(C.c_int)],
         "brov_plant_set_params_host": [vp, dp], "brov_plant_step": [vp, C.c_double, C.c_int, vp], "brov_get_x0_host": [vp, dp],
         "brov_closed_loop": [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_int32)],
         "brov_traj_set_host": [vp, dp, C.c_int], "brov_traj_rows": [vp], "brov_set_yref_from_traj": [vp, C.c_int, C.c_int, vp],
@@ -460,6 +461,19 @@ class BatchSolver:
 
     def x0_device_ptr(self):
         return int(self._L.brov_x0_device(self._h))
+
+
+def selftest_sweep12(a):
+    """inverse of an SPD 12 x 12 matrix by the parallel-in-time kernel's block sweeps: (inverse, all pivot blocks positive definite)"""
+    L = _load()
+    a = _arr(a, (12, 12))
+    out, ok = np.empty((12, 12)), C.c_int(0)
+    rc = L.brov_selftest_sweep12(_dp(a), _dp(out), C.byref(ok))
+    if rc == -2:
+        raise NoDeviceError("no HIP device")
+    if rc != 0:
+        raise RuntimeError(f"selftest failed {rc}")
+    return out, bool(ok.value)
 
 
 def selftest_tile_tn(xt, y, c, k4):

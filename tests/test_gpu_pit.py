@@ -33,6 +33,24 @@ def _restore_env():
         os.environ["BROV_PIT"] = old
 
 
+def test_sweep12_inverts_spd_matrices(ba):
+    """the relay's 12 x 12 inverse (three symmetric block sweeps with the factor sweep's 4 x 4 pivot algebra) against numpy, over
+    condition numbers 1 .. 1e8; an indefinite matrix is flagged"""
+    from bluerov2_amd.solver import selftest_sweep12
+    rng = np.random.default_rng(12)
+    for cond in (1.0, 1e2, 1e4, 1e6, 1e8):
+        q, _ = np.linalg.qr(rng.normal(size=(12, 12)))
+        a = (q * np.geomspace(1.0, cond, 12)) @ q.T
+        a = 0.5 * (a + a.T)
+        inv, ok = selftest_sweep12(a)
+        assert ok
+        err = np.abs(inv @ a - np.eye(12)).max()
+        assert err < 1e-13 * cond * 30, (cond, err)
+        assert np.abs(inv - np.linalg.inv(a)).max() <= 1e-12 * cond * np.abs(np.linalg.inv(a)).max()
+    a = np.diag([1.0] * 5 + [-1.0] + [1.0] * 6)
+    assert not selftest_sweep12(a)[1]
+
+
 def _inputs(golden_traj, B, seed, far=0.0):
     rng = np.random.default_rng(seed)
     circ = golden_traj["circle"]
