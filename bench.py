@@ -389,7 +389,7 @@ def pmc_traffic(tag, kernel):
     return None, None
 
 
-def live_pmc_traffic(args, kernel, timeout=150):
+def live_pmc_traffic(args, kernel, timeout=60):
     """HBM bytes per launch of `kernel`, measured NOW: two child runs of this command's headline leg under rocprofv3 --pmc -- FETCH_SIZE and
     WRITE_SIZE, each in its own pass with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- and counts x unit,
     the units (bytes per count on gfx950 for this project's access pattern) from the committed calibration (profiles/r*_pmc_summary.json
