@@ -49,6 +49,8 @@ def main(tag, rnd):
     pe = os.path.join(ROOT, "gpurun_out", "parity_excused.json")
     if os.path.exists(pe):
         d = json.load(open(pe))
+        if "u0_abs" not in d.get("by_rule", {}) or "bvls_abs_1e-8" not in d.get("by_rule", {}):
+            print("WARNING: gpurun_out/parity_excused.json is not from a full `pytest tests -m gpu` run (rules:", sorted(d.get("by_rule", {})), ")")
         d["entries_with_excused"] = [{k: v for k, v in e.items() if k != "disagreements" or v} for e in d.get("entries_with_excused", [])][:40]
         d["note"] = ("summary of gpurun_out/parity_excused.json: per rule, the number of rule calls, instances checked and instances excused in ONE run of "
                      "`pytest tests -m gpu`; entries_with_excused lists the calls that excused anything (first 40)")

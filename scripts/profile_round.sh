@@ -6,6 +6,9 @@ TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# the whole GPU suite first: its session hook writes gpurun_out/parity_excused.json, which collect_profiles.py commits (a partial run of the
+# suite before this script would otherwise be what gets recorded)
+( cd $R && timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -rfE > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log )
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 for c in 3 4 5; do python $R/bench.py --config $c --no-cpu-baseline > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; done
