@@ -613,6 +613,24 @@ def configs_block(ba, args, device):
         s.close()
     out["config5_shard_sweep"] = dict(workload="BASELINE.json configs[4], one of 8 shards: 4096 instances per horizon, N in {10,20,40,80}, Ts = 1/N, "
                                                "x0 as config 2 (seed 4), shared circle window", legs=sweep)
+
+    # ---- a small batch at the reference's shipped horizon (N = 80, Ts = 0.0125): 64 instances, one per CU -- the resident mode of the windowed
+    # kernel with the parallel-in-time kernel ahead of it, early exits and with a quarter of the instances saturated
+    small = {}
+    for name, sat in (("tracking", 0.0), ("quarter_saturated", 0.25)):
+        B, N = 64, 80
+        x0, circ = synthetic_inputs(B, seed=6)
+        if sat:
+            x0 = saturate(x0, sat, seed=7)
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N), device=device)
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
+        s.init_iterate_default()
+        dt = timed(lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()))
+        r = s.results()
+        small[name] = dict(solves_per_s=B / dt, ms_per_step=dt * 1e3, status_nonzero=int((r["status"] != 0).sum()),
+                           ipm_instance_fraction=float((r["qp_iter"] > 0).mean()), completed_parallel_in_time=int(s.pit_last().sum()))
+        s.close()
+    out["small_batch_N80_B64"] = dict(workload="64 instances at N = 80, Ts = 0.0125 (one per CU: resident mode), shared circle window", **small)
     return out
 
 
