@@ -1149,6 +1149,19 @@ def main(argv=None):
                                                                note="the mixed batch with its instances in random order")
             out["mixed_batch_25pct_saturated_shuffled"].update(per_tick_kernel_ms(s4, tick4))
             s4.close()
+            # the same batch under a real-time iteration limit (qp_solver_iter_max = 10 instead of the reference's 50, acados_solver_bluerov2.c:
+            # 668-669): the ticks on which ONE instance grinds through 13..47 Newton systems -- iterates already far beyond the physical
+            # regime -- end with status MAXITER for that instance instead.  Information, not `value`: the default options are the reference's.
+            s5, tick5, _ = wl["make"](N, Ts, 1, sat=0.25)
+            s5.set_options(ba.SolverOptions(N, Ts, qp_early_exit=1, kernel_path=args.path, qp_iter_max=10))
+            dt5, _, _ = run(s5, tick5, K, W, False, False)
+            r5 = s5.results()
+            out["mixed_batch_25pct_saturated_iter_max_10"] = dict(value=B * K / dt5, unit="solves/s", ms_per_step=dt5 / K * 1e3,
+                                                                  max_qp_iter_last_tick=int(r5["qp_iter"].max()),
+                                                                  status_histogram=np.bincount(r5["status"], minlength=5).tolist(),
+                                                                  note="the mixed batch with qp_iter_max = 10 (the reference ships 50)")
+            out["mixed_batch_25pct_saturated_iter_max_10"].update(per_tick_kernel_ms(s5, tick5))
+            s5.close()
         if extra:
             out["batch1_tick"] = batch1_tick(ba)
             out["host_boundary"] = host_boundary(ba, B)
