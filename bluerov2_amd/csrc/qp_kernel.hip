@@ -3222,6 +3222,9 @@ __device__ __forceinline__ d4 sweep12(d4 S, int rg, int cl, bool& ok) {
     }
     return d4{-S[0], -S[1], -S[2], 0.0};
 }
+// (A copy of the record-writing part of qp_body's emit_record, deliberately: with ONE shared device function both call sites compile, pass every
+// test -- and the windowed kernel runs 2 % slower (10.69 against 10.89 M solves/s at N = 40, 5.52 against 5.65 M at N = 80, three alternating
+// repetitions on one box, scripts/gpu_r4_ao.sh): the register allocation of its tail shifts.  Keep the two in step by hand.)
 // the result record of an early exit (what qp_body's emit_record writes): device copy, thrust allocation epilogue
 // (bluerov2_dob.cpp:390-395), and -- brov_tick_host -- the host mailbox
 __device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int lane, double cost_lane, double u0_lane, double kkt, int qp_iter) {
