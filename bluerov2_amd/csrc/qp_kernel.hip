@@ -1650,7 +1650,9 @@ __device__ __forceinline__ void sched_zero_next(const DevParams& P, int lane) { 
 // LDS = 0 streaming kernels, 1 / 2 fused kernels (whole horizon resident; element arrays in LDS / registers: EL), 3 windowed
 // kernel (sweeps on the resident window through the sw_* wrappers, element loops on the flat HBM arrays like LDS = 0; the
 // step-0 factorisation has already run, fused with the linearisation: pre_ok)
-template <int LDS, class IT = Inst>
+// DF (fused kernel of the mailbox ticks, rti_fused_kernel_mail): an early exit sends its record BEFORE the adjoint sweep, as the resident windowed
+// kernel does -- nothing in the record depends on the multipliers that sweep computes for the iterate
+template <int LDS, class IT = Inst, bool DF = false>
 __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double lin_part, bool lin_nan, Win* W = nullptr,
                                         bool pre_ok = true, bool pre_illc = false) {
     constexpr bool EL = (LDS == 1 || LDS == 2);
@@ -2292,7 +2294,19 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             }
         }
         // fused kernels, accepted active-set point: the try's own adjoint sweep has left multipliers and input gradient in LDS
-        if (!(EL && polished)) sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
+        auto copy_pi = [&]() __attribute__((always_inline)) {
+            // N * 12 <= 276 elements: five per lane, read back to back, then stored (a guarded copy loop waits for LDS once per element)
+            double pv5[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) pv5[t] = I.lds_kt[lane + 64 * t < N * 12 ? lane + 64 * t : 0];
+#pragma unroll
+            for (int t = 0; t < 5; t++) asm volatile("" : "+v"(pv5[t]));
+#pragma unroll
+            for (int t = 0; t < 5; t++)
+                if (lane + 64 * t < N * 12) pi_it[lane + 64 * t] = pv5[t];
+        };
+        const bool late = DF && EL && early && P.mail != nullptr;   // (constant false outside the mailbox kernel)
+        if (!(EL && polished) && !late) sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
         DBG_STAMP(5);
         bool nanv = false;
         // fused kernels: the lane's elements of the accepted inputs and state steps (all of them: nv <= 128, nxe <= 320) are read
@@ -2352,15 +2366,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             }
             wrote_u0 = true;
             if constexpr (EL) {  // multipliers staged in LDS by adjoint<>: [N][12] at the head of the K^T array
-                // N * 12 <= 276 elements: five per lane, read back to back, then stored (a guarded copy loop waits for LDS once per element)
-                double pv5[5];
-#pragma unroll
-                for (int t = 0; t < 5; t++) pv5[t] = I.lds_kt[lane + 64 * t < N * 12 ? lane + 64 * t : 0];
-#pragma unroll
-                for (int t = 0; t < 5; t++) asm volatile("" : "+v"(pv5[t]));
-#pragma unroll
-                for (int t = 0; t < 5; t++)
-                    if (lane + 64 * t < N * 12) pi_it[lane + 64 * t] = pv5[t];
+                if (!late) copy_pi();
             }
             for (int j0 = lane; j0 < nxe; j0 += 64 * UX) {
                 double xo[UX], dj[UX], yr[UX];
@@ -2386,6 +2392,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
                         cost += 0.5 * sw * e * e;
                     }
                 }
+            }
+        }
+        if constexpr (DF && EL) {
+            if (late && status == BROV_STATUS_SUCCESS) {   // record first, then the multipliers of the iterate
+                emit_record(cost, u0v, wrote_u0);
+                sw_adjoint<true, LDS>(I, W, vfin, DVA, pi_it);
+                copy_pi();
+            } else if (late) {                             // (a NaN among the inputs: nothing was updated; the sweep the early path skipped is not needed)
             }
         }
         }   // LDS < 3
@@ -2821,7 +2835,7 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel_grid(DevParams P) { lin
 // are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
 // (interior-point) instance does not pin the LDS of three finished ones.
 constexpr int kFusedMaxN = 23;
-template <int W, bool GRID = false>
+template <int W, bool GRID = false, bool DF = false>
 __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
@@ -2889,7 +2903,7 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
         for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
         I.kt_str = cl < 4 ? kKtStage : 0;
     }
-    qp_body<W>(P, I, b, part, nanp);
+    qp_body<W, std::conditional_t<GRID, InstGrid, Inst>, DF>(P, I, b, part, nanp);
 }
 // One wave per SIMD (up to 512 VGPRs): the variant for horizons whose LDS slice admits only four blocks per CU anyway.
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fused_body<1>(P); }
@@ -2898,6 +2912,8 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fus
 __global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body<2>(P); }
 // General grid (per-stage time steps / a separate stage-0 weight), every N <= 23: one wave per SIMD
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_grid(DevParams P) { rti_fused_body<1, true>(P); }
+// brov_tick_host at small batches (host mailbox): the record of an early exit goes out ahead of the adjoint sweep (qp_body<.., DF>)
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel_mail(DevParams P) { rti_fused_body<1, false, true>(P); }
 
 // function attributes are per device (a process may hold solvers on several GPUs): one flag per (launcher, device)
 static bool first_launch_on_device(int which) {
@@ -3863,6 +3879,14 @@ void launch_fused(const DevParams& P, hipStream_t st) {
     // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
     static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;
     const bool w2 = fused_two_wave(lds);
+    if (P.mail && P.mail_early && !P.tsv && !w2) {   // mailbox tick (<= 64 instances): the variant that delivers first
+        static bool attr_set[64] = {};
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) { attr_set[dev_] = true; (void)hipFuncSetAttribute((const void*)rti_fused_kernel_mail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        hipLaunchKernelGGL(rti_fused_kernel_mail, dim3(P.B), dim3(64), lds + pad, st, P);
+        return;
+    }
     if (P.tsv) hipLaunchKernelGGL(rti_fused_kernel_grid, dim3(P.B), dim3(64), lds + pad, st, P);
     else if (w2) hipLaunchKernelGGL(rti_fused_kernel_w2, dim3(P.B), dim3(64), lds + pad, st, P);
     else hipLaunchKernelGGL(rti_fused_kernel, dim3(P.B), dim3(64), lds + pad, st, P);
