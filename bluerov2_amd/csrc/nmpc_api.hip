@@ -789,14 +789,8 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     // LDS-resident kernels (one launch): whole horizon for N <= 23, windowed above.  rti_phase 1 / 2 (preparation and feedback as
     // separate calls) need the linearisation in HBM between the calls: streaming kernels.
     // a general grid (per-stage time steps / separate stage-0 weight) runs on the LDS-resident kernels too (round 4: rti_fused_kernel_grid,
-    // rti_window_kernel_grid) -- except in the windowed kernel's resident mode (batches of at most one instance per CU at N > 23), which
-    // has no grid instantiation: those solvers use the streaming kernels, as every grid did up to round 3
-    const bool grid_resident = general_grid(s) && !(fused_supported(s->N) && !s->force_windowed) && s->ws != nullptr && windowed_is_resident(s->win_L);
-    if (grid_resident && path == BROV_PATH_FUSED) {
-        g_err = "brov_solve: per-stage time steps / a stage-0 weight at this batch and horizon need the streaming kernels (BROV_PATH_AUTO or BROV_PATH_STREAMING)";
-        return BROV_ERR_ARG;
-    }
-    const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING && !grid_resident;
+    // rti_window_kernel_grid, rti_window_kernel_res_grid); the parallel-in-time kernel has no grid instantiation (the resident one runs alone)
+    const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING;
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
     const bool windowed = lds_path && !fused && s->ws != nullptr;
     s->pit_ran = false;
@@ -983,7 +977,7 @@ extern "C" int brov_lds_kernel_info(const brov_solver* s, int32_t info[4]) {
     HIPCHK(hipSetDevice(s->device));
     const bool fused = fused_supported(s->N) && !s->force_windowed;
     // streaming kernels (asked for, or forced by a general grid, or no windowed workspace): stage blocks in HBM, nothing to report
-    if (s->opts.kernel_path == BROV_PATH_STREAMING || (!fused && !s->ws) || (general_grid(s) && !fused && windowed_is_resident(s->win_L))) { info[0] = info[1] = info[2] = info[3] = 0; return BROV_OK; }
+    if (s->opts.kernel_path == BROV_PATH_STREAMING || (!fused && !s->ws)) { info[0] = info[1] = info[2] = info[3] = 0; return BROV_OK; }
     lds_kernel_info(s->N, s->win_L, !fused, info);
     return BROV_OK;
 }

@@ -1416,14 +1416,14 @@ __device__ __forceinline__ void win_adjoint_commit(const DevParams& P, IT& I, Wi
                     const double un = u_it[i0 * 4 + j] + vh[j];
                     u_it[i0 * 4 + j] = un;
                     const double e = un - I.yref[(size_t)(i0 + i) * 16 + 12 + m];
-                    cost += 0.5 * P.Ts * cst[12 + m] * e * e;
+                    cost += 0.5 * (IT::kGrid ? I.wst[(size_t)(i0 + i) * 16 + 12 + m] : P.Ts * cst[12 + m]) * e * e;
                 }
                 for (int j = lane + 256; j < nxr; j += 64) {
                     const int i = j / 12, cc = j - i * 12;
                     const double xn = x_it[i0 * 12 + j] + dx[j];
                     x_it[i0 * 12 + j] = xn;
                     const double e = xn - I.yref[(size_t)(i0 + i) * 16 + cc];
-                    cost += 0.5 * ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc]) * e * e;
+                    cost += 0.5 * (IT::kGrid ? I.wst[(size_t)(i0 + i) * 16 + cc] : ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc])) * e * e;
                 }
             }
         };
@@ -2949,7 +2949,6 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // large-batch kernel carries none of its code.
 template <bool RES, bool GRID = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
-    static_assert(!(RES && GRID), "the resident mode has no general-grid instantiation (such solvers run on the streaming kernels)");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;       // (RES: four waves per block, see below)
@@ -2976,8 +2975,8 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             double part = 0.0;
             bool nanp = false;
             __syncthreads();   // wave 0's barrier ahead of the linearisation
-            lin_phase<true>(P, b, j0, nj, lane0, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s + (size_t)j0 * kRecInterval,
-                            q_s + (size_t)j0 * NX, r_s + (size_t)j0 * NU, part, nanp, false);
+            lin_phase<true, GRID>(P, b, j0, nj, lane0, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s + (size_t)j0 * kRecInterval,
+                                  q_s + (size_t)j0 * NX, r_s + (size_t)j0 * NU, part, nanp, false);
             ((lds_f64*)kt_s)[(size_t)j0 * kRecInterval + lane0] = nanp ? __builtin_nan("") : part;
             __syncthreads();   // ... and the one behind it
             return;
@@ -3079,7 +3078,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             if (RES && trip == 0) {
                 // first instance of the block: this wave takes the first quarter of the horizon, waves 1..3 the others
                 const int lsub = (n + 3) >> 2;
-                lin_phase<true>(P, b, 0, lsub, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+                lin_phase<true, GRID>(P, b, 0, lsub, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
                 __syncthreads();
                 for (int wv = 1; wv < 4; wv++) {
                     const double v = ((const lds_f64*)kt_s)[(size_t)wv * lsub * kRecInterval + lane];
@@ -3095,8 +3094,8 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                 const int nsub = (n + kWinMaxStages - 1) / kWinMaxStages, lsub = (n + nsub - 1) / nsub;
                 for (int j0 = 0; j0 < n; j0 += lsub) {
                     const int nj = n - j0 < lsub ? n - j0 : lsub;
-                    lin_phase<true>(P, b, i0 + j0, nj, lane, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s, q_s + (size_t)j0 * NX,
-                                    r_s + (size_t)j0 * NU, part, nanp, false);
+                    lin_phase<true, GRID>(P, b, i0 + j0, nj, lane, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s, q_s + (size_t)j0 * NX,
+                                          r_s + (size_t)j0 * NU, part, nanp, false);
                     __syncthreads();
                 }
             }
@@ -3157,6 +3156,7 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_wi
 // the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_grid(DevParams P) { rti_window_body<false, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
+__global__ __launch_bounds__(256, 1) void rti_window_kernel_res_grid(DevParams P) { rti_window_body<true, true>(P); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Parallel-in-time step-0 solve (round 4): rti_pit_kernel, for the batches the resident mode serves (at most one instance per CU, the
@@ -3809,6 +3809,7 @@ int windowed_blocks(int N, int B, int L) {
         (void)hipFuncSetAttribute((const void*)rti_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     int dev = 0, cus = 256, per_cu = 4;
     (void)hipGetDevice(&dev);
@@ -3831,7 +3832,8 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
             if (first_launch_on_device(3)) (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(rti_pit_kernel, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
         }
-        hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+        if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+        else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
     }
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
@@ -3875,15 +3877,12 @@ void launch_fused(const DevParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_mail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
     static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;
     const bool w2 = fused_two_wave(lds);
     if (P.mail && P.mail_early && !P.tsv && !w2) {   // mailbox tick (<= 64 instances): the variant that delivers first
-        static bool attr_set[64] = {};
-        int dev_ = 0;
-        (void)hipGetDevice(&dev_);
-        if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) { attr_set[dev_] = true; (void)hipFuncSetAttribute((const void*)rti_fused_kernel_mail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         hipLaunchKernelGGL(rti_fused_kernel_mail, dim3(P.B), dim3(64), lds + pad, st, P);
         return;
     }

@@ -34,11 +34,11 @@ def _inputs(golden_traj, B, seed):
 
 
 # (N, growth factor of the geometric grid, separate W_0, batch, kernel path asked for, kernel path that must run): round 4 runs general grids on
-# the LDS-resident kernels -- fused for N <= 23, windowed above for batches beyond one instance per CU; the windowed kernel's resident mode
-# (small batches at N > 23) and BROV_PATH_STREAMING keep the streaming pair
+# the LDS-resident kernels -- fused for N <= 23, windowed above (small batches at N > 23: its resident mode, rti_window_kernel_res_grid);
+# BROV_PATH_STREAMING keeps the streaming pair
 GRID_CASES = [(20, 1.08, True, 48, 0, 2), (7, 1.3, True, 48, 0, 2), (13, 1.1, False, 300, 2, 2), (23, 1.05, True, 64, 0, 2),
               (40, 1.04, False, 320, 0, 3), (80, 1.01, True, 320, 2, 3), (57, 1.02, True, 300, 0, 3),
-              (40, 1.04, False, 48, 0, 1), (80, 1.01, True, 48, 0, 1), (20, 1.08, True, 48, 1, 1)]
+              (40, 1.04, False, 48, 0, 3), (80, 1.01, True, 48, 0, 3), (80, 1.01, True, 3, 2, 3), (40, 1.04, False, 48, 1, 1), (20, 1.08, True, 48, 1, 1)]
 
 
 @pytest.mark.parametrize("N,grow,with_w0,B,path,ran", GRID_CASES)
@@ -132,14 +132,15 @@ def test_feature_gating(ba, golden_traj):
     assert s.last_kernel_path() == 2 and s.lds_kernel_info()["kind"] == "fused"
     s.set_time_steps(None); s.solve()          # back to the uniform grid
     assert s.last_kernel_path() == 2
-    # ... except where the windowed kernel runs in its resident mode (at most one instance per CU at N > 23), which has no grid
-    # instantiation: refused under BROV_PATH_FUSED, not silently ignored (BROV_PATH_AUTO takes the streaming kernels there)
+    # ... and so does the windowed kernel's resident mode (at most one instance per CU at N > 23: rti_window_kernel_res_grid); the parallel-in-time
+    # kernel has no grid instantiation and stays out of such a solve
     s2 = ba.BatchSolver(B, ba.SolverOptions(40, 0.025, kernel_path=ba.PATH_FUSED))
     s2.set_time_steps(0.02 * 1.03 ** np.arange(40))
     s2.set_x0(x0); s2.set_params(ba.P_NOMINAL); s2.set_yref(circ[:41])
-    with pytest.raises(RuntimeError):
-        s2.solve()
-    assert s2.lds_kernel_info()["kind"] == "streaming"
+    s2.solve()
+    assert s2.last_kernel_path() == 3 and s2.lds_kernel_info()["kind"] == "windowed, resident" and not s2.pit_last().any()
+    s2.set_time_steps(None); s2.solve()
+    assert s2.last_kernel_path() == 3 and s2.pit_last().any()
     s2.close()
     with pytest.raises(RuntimeError):
         s.set_time_steps(np.array([0.05] * (N - 1) + [-0.01]))
