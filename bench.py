@@ -616,21 +616,25 @@ def configs_block(ba, args, device):
 
     # ---- a small batch at the reference's shipped horizon (N = 80, Ts = 0.0125): 64 instances, one per CU -- the resident mode of the windowed
     # kernel with the parallel-in-time kernel ahead of it, early exits and with a quarter of the instances saturated
-    small = {}
-    for name, sat in (("tracking", 0.0), ("quarter_saturated", 0.25)):
-        B, N = 64, 80
-        x0, circ = synthetic_inputs(B, seed=6)
-        if sat:
-            x0 = saturate(x0, sat, seed=7)
-        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N), device=device)
-        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
-        s.init_iterate_default()
-        dt = timed(lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()))
-        r = s.results()
-        small[name] = dict(solves_per_s=B / dt, ms_per_step=dt * 1e3, status_nonzero=int((r["status"] != 0).sum()),
-                           ipm_instance_fraction=float((r["qp_iter"] > 0).mean()), completed_parallel_in_time=int(s.pit_last().sum()))
-        s.close()
-    out["small_batch_N80_B64"] = dict(workload="64 instances at N = 80, Ts = 0.0125 (one per CU: resident mode), shared circle window", **small)
+    for B, key, what in ((64, "small_batch_N80_B64", "64 instances at N = 80, Ts = 0.0125 (one per CU: resident mode), shared circle window"),
+                         (512, "mid_batch_N80_B512", "512 instances at N = 80, Ts = 0.0125 (two per CU: resident mode, the parallel-in-time kernel one block "
+                                                     "per instance), shared circle window")):
+        small = {}
+        for name, sat in (("tracking", 0.0), ("quarter_saturated", 0.25)):
+            N = 80
+            x0, circ = synthetic_inputs(B, seed=6)
+            if sat:
+                x0 = saturate(x0, sat, seed=7)
+            s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N), device=device)
+            s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
+            s.init_iterate_default()
+            dt = timed(lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()))
+            r = s.results()
+            small[name] = dict(solves_per_s=B / dt, ms_per_step=dt * 1e3, status_nonzero=int((r["status"] != 0).sum()),
+                               ipm_instance_fraction=float((r["qp_iter"] > 0).mean()), completed_parallel_in_time=int(s.pit_last().sum()),
+                               kernel_kind=s.lds_kernel_info()["kind"])
+            s.close()
+        out[key] = dict(workload=what, **small)
     return out
 
 

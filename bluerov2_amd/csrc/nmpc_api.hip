@@ -71,6 +71,7 @@ struct brov_solver {
     int32_t* counter = nullptr;
     unsigned win_tick = 0;           // windowed launches so far: which of the two hand-out counters the next one uses
     int win_blocks = 0, win_L = 0;
+    int alt_blocks = 0, alt_L = 0;   // parallel-in-time rounds (pit_rounds_stages): the resident configuration a solve may use instead
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
     // general grid (streaming kernels): per-stage time steps and / or a separate stage-0 weight
@@ -253,7 +254,13 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few) {
         s->win_L = windowed_stage_count(opts->N, B);
         s->win_blocks = windowed_blocks(opts->N, B, s->win_L);
-        AL(ws, (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L));
+        size_t ws_doubles = (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L);
+        if (!windowed_is_resident(s->win_L) && (s->alt_L = pit_rounds_stages(opts->N, B)) != 0) {   // one workspace per instance for rti_pit_kernel's blocks
+            s->alt_blocks = windowed_blocks(opts->N, B, s->alt_L);
+            const size_t alt = (size_t)B * windowed_ws_doubles(opts->N, s->alt_L);
+            ws_doubles = alt > ws_doubles ? alt : ws_doubles;
+        }
+        AL(ws, ws_doubles);
     }
 #undef AL
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
@@ -802,7 +809,13 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
-            if (pit && s->pit_done && pit_supported(s->N, s->win_L) && !general_grid(s) && !s->dump_lin) {
+            const bool pit_can = pit && s->pit_done && !general_grid(s) && !s->dump_lin;
+            P.pit_blocks = P.win_blocks;
+            if (pit_can && s->alt_L) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
+                P.win_L = s->alt_L; P.win_blocks = s->alt_blocks; P.ws_stride = (int64_t)windowed_ws_doubles(s->N, s->alt_L);
+                P.pit_blocks = (int32_t)s->B;
+            }
+            if (pit_can && pit_supported(s->N, P.win_L)) {
                 P.pit = pit; P.pit_done = s->pit_done;
                 P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);
             }

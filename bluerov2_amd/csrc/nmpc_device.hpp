@@ -22,6 +22,7 @@ struct DevParams {
     int32_t qp_iter_max, early_exit;
     int32_t pit;             // parallel-in-time step-0 solve ahead of the resident windowed kernel: 0 off, 1 instances whose previous step was an early exit, 2 every instance (tests)
     int32_t pit_try;         // ... and, when the step-0 answer leaves the box, ONE active-set try parallel in time as well (default 1; BROV_PIT_TRY=0: A/B)
+    int32_t pit_blocks;      // blocks of rti_pit_kernel = tickets it serves (win_blocks; B where every instance has a workspace of its own: pit_rounds_stages)
     int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
     int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)
@@ -88,10 +89,11 @@ bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
 void launch_windowed(const DevParams& P, hipStream_t st);
 void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]);   // LDS bytes per block, blocks per CU, threads, kernel kind
 bool pit_supported(int N, int win_L);       // rti_pit_kernel ahead of the resident kernel
-bool windowed_is_resident(int win_L);      // one window = the whole horizon (small batches): no general-grid instantiation
+bool windowed_is_resident(int win_L);      // one window = the whole horizon (small batches)
 int windowed_stage_count(int N, int B);   // stages per window (= N for batches of at most one instance per CU: resident mode)
 int windowed_blocks(int N, int B, int L); // persistent blocks that will be launched on the current device
 size_t windowed_ws_doubles(int N, int L); // per-block workspace
+int pit_rounds_stages(int N, int B);          // batches of up to two instances per CU: resident stage count for parallel-in-time rounds, or 0
 void launch_window(const double* traj, int rows, const int* lines, int line0, int B, int N, int ncols, double* out, hipStream_t st);
 void launch_plant(double* x0, const brov_result* res, const double* pplant, const double* prp, int rp_stride, int B, double dt, int substeps,
                   double* xlog, double* ulog, hipStream_t st);   // prp: roll / pitch disturbance moments, instance b at prp + b * rp_stride (or nullptr)

@@ -3007,21 +3007,20 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         int b = 0;
         if (RES && trip == 0) {
             b = (int)blockIdx.x;   // the helper waves work on this ticket
-            if constexpr (RES) {
-                if (P.pit_done) {
-                    const int bm = __builtin_amdgcn_readfirstlane(sched_map(P, b));
-                    if (P.pit_done[bm]) {   // done by rti_pit_kernel: nothing to do but to keep the work-ordering tables consistent
-                        sched_note(P, bm, -1);
-                        continue;
-                    }
-                }
-            }
         } else {
             if (lane == 0) b = atomicAdd(P.counter, 1) + (RES ? (int)gridDim.x : 0);
             b = __builtin_amdgcn_readfirstlane(b);
         }
         if (b >= P.B) break;
+        const int ticket = b;
         b = __builtin_amdgcn_readfirstlane(sched_map(P, b));   // expensive instances first
+        if constexpr (RES) {
+            // (tickets beyond rti_pit_kernel's grid were not its to serve: their flags are stale)
+            if (P.pit_done && ticket < P.pit_blocks && P.pit_done[b]) {   // done by rti_pit_kernel: nothing to do but to keep the work-ordering tables consistent
+                sched_note(P, b, -1);
+                continue;
+            }
+        }
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
         // lin_phase (which needs the whole architectural register file)
         const LaneCst lc = load_lane_cst(P.cst, lane);
@@ -3823,6 +3822,21 @@ int windowed_blocks(int N, int B, int L) {
     if (const char* e = getenv("BROV_DEV_WIN_BLOCKS")) { const long long v = atoll(e); if (v >= 1 && v < fit) fit = v; }
     return (int)(B < fit ? B : fit);
 }
+// Batches between one and two instances per CU at 48 <= N <= 80: as long as the parallel-in-time kernel can serve a solve (uniform grid,
+// BROV_PIT != 0) it runs ONE BLOCK PER INSTANCE -- a CU's second block follows its first -- with the resident kernel behind it for what
+// it leaves, instead of the windowed kernel: 512 instances at N = 80 take 0.154 ms against 0.192 ms (N = 60: 0.135 / ~0.153; N = 40:
+// 0.120 / 0.114 -- hence the lower limit; scripts/dev/mid_batch_rate.py).  What the parallel kernel leaves (instances with many active
+// bounds) is then served two per block by one wave: a batch with a quarter of its instances saturated loses 20 % against the windowed
+// kernel (BROV_PIT_ROUNDS=0 keeps the windowed kernel).  Decided per solve: the solver is created for the windowed kernel and with a
+// workspace that serves either.  Returns the resident stage count (= N) or 0.
+constexpr int kPitRounds = 2, kPitRoundsMinN = 48;
+int pit_rounds_stages(int N, int B) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool off = (getenv("BROV_PIT_ROUNDS") && atoi(getenv("BROV_PIT_ROUNDS")) == 0) || (getenv("BROV_DEV_NO_RESIDENT") && atoi(getenv("BROV_DEV_NO_RESIDENT")) != 0);
+    return (!off && B > cus && B <= kPitRounds * cus && N >= kPitRoundsMinN && pit_supported(N, N)) ? N : 0;
+}
 bool pit_supported(int N, int win_L) {
     return windowed_resident(win_L) && win_L == N && N >= 24 && N <= 80 && windowed_lds_bytes(win_L) + kPitExtraDoubles * sizeof(double) <= 160 * 1024;
 }
@@ -3830,7 +3844,8 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
     if (windowed_resident(P.win_L)) {
         if (P.pit && P.pit_done) {   // parallel-in-time step-0 solve first; the resident kernel skips what it completed
             if (first_launch_on_device(3)) (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL(rti_pit_kernel, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+            // (pit_blocks = B where every instance has a workspace of its own: beyond one instance per CU the blocks queue for the CUs)
+            hipLaunchKernelGGL(rti_pit_kernel, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
         }
         if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);

@@ -115,6 +115,44 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
     s.close()
 
 
+@pytest.mark.parametrize("N,B,far", [(80, 300, 0.1), (48, 512, 0.0), (64, 257, 0.25)])
+def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_instance(ba, oracle, golden_traj, N, B, far):
+    """256 < B <= 512 at 48 <= N <= 80: the solver is the windowed kernel's (20-stage windows), but as long as a solve can be served
+    parallel in time (uniform grid, BROV_PIT != 0) it runs in the resident configuration -- rti_pit_kernel with ONE BLOCK PER INSTANCE,
+    the resident kernel (one block per CU, further instances from its counter) behind it for what is left.  Every tick against the
+    oracle; the mode may change from one solve to the next (BROV_PIT=0: the windowed kernel; back again)."""
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count >= B:
+        pytest.skip("needs a batch beyond one instance per CU")
+    Ts = 1.0 / N
+    x0, circ = _inputs(golden_traj, B, seed=900 + N, far=far)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    assert 0 < s.window_stages() <= 20                     # created for the windowed kernel
+    s.set_x0(x0); s.set_params(P_NOMINAL)
+    op = oracle.opts(N, Ts)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
+    prev = None
+    for k, mode in enumerate(["1", "1", "1", "0", "1", "2"]):
+        os.environ["BROV_PIT"] = mode
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        s.set_yref(yref); s.solve()
+        assert s.last_kernel_path() == 3
+        r, it, done = s.results(), s.get_iterate(), s.pit_last().astype(bool)
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        _compare(r, it, ro, x, u, pi, lam, (N, B, far, mode, k))
+        early = (ro["status"] == 0) & (ro["qp_iter"] == 0)
+        if mode == "0":
+            assert not done.any()
+        else:
+            was_early = np.ones(B, dtype=bool) if prev is None else (prev["status"] == 0) & (prev["qp_iter"] <= 2)
+            tried = was_early if mode == "1" else np.ones(B, dtype=bool)
+            assert np.all(done[early & tried]) and not np.any(done & ~tried)
+            assert np.array_equal(r["qp_iter"][done], ro["qp_iter"][done])
+        prev = ro
+    s.close()
+
+
 def test_forced_loop_option_goes_through_the_parallel_try(ba, oracle, golden_traj):
     """qp_early_exit = 0: every instance runs at least one Newton system of the QP loop -- an empty or a correct first guess of the active
     set is one try, which the kernel makes itself"""

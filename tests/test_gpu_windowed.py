@@ -121,9 +121,11 @@ def test_several_instances_per_block_at_small_batches(ba, oracle, N, B, blocks):
     s.close()
 
 
-@pytest.mark.parametrize("N,B,blocks", [(24, 40, None), (40, 200, None), (57, 96, 32), (80, 64, 21), (80, 256, None), (81, 16, None)])
+@pytest.mark.parametrize("N,B,blocks", [(24, 40, None), (40, 200, None), (57, 96, 32), (80, 64, 21), (80, 256, None), (81, 16, None),
+                                        (80, 400, None), (48, 512, None), (40, 512, None), (80, 300, 100)])
 def test_resident_mode_small_batches(ba, oracle, N, B, blocks):
-    """Batches of at most one instance per CU (the ROS node's batch of one, small Monte-Carlo sets): the whole horizon in ONE window of
+    """Batches of at most one instance per CU (the ROS node's batch of one, small Monte-Carlo sets; two per CU where the parallel-in-time
+    kernel serves the horizon: one block per instance there, the resident kernel behind it for what it leaves): the whole horizon in ONE window of
     up to 160 KB, one block per CU -- no parking, no window fetches; the linearisation in sub-chunks of <= 23 intervals.  Against the
     oracle like every other mode, also with several instances per block."""
     s, *_ = _run_against_oracle(ba, oracle, N, B, ticks=3, blocks=blocks)
