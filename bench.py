@@ -48,6 +48,7 @@ PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 CAND_TOTAL, CAND_SHARDS = 65536, 8   # BASELINE config 4
 KERNEL_NAMES = {2: "rti_fused_kernel", 3: "rti_window_kernel"}
+PIT_KERNELS = "rti_pit_kernel + rti_window_kernel_res"   # batches of at most two instances per CU at 24 <= N <= 80
 
 
 def circle_trajectory(rows):
@@ -475,7 +476,10 @@ def configs_block(ba, args, device):
         path = s.last_kernel_path()
         fl = qp_flops(r["qp_iter"], N) + s.B * N * F_LIN
         kt = ks[1] if path in KERNEL_NAMES else ks.sum()
-        return dict(solves_per_s=s.B / dt, ms_per_step=dt * 1e3, kernel_ms=kt * 1e3, kernel=KERNEL_NAMES.get(path, "lin_wave_kernel + qp_kernel"),
+        kname = KERNEL_NAMES.get(path, "lin_wave_kernel + qp_kernel")
+        if path == 3 and 2 * int(s.pit_last().sum()) > s.B:   # small batches at 24 <= N <= 80: most steps completed by the parallel-in-time kernel
+            kname = PIT_KERNELS
+        return dict(solves_per_s=s.B / dt, ms_per_step=dt * 1e3, kernel_ms=kt * 1e3, kernel=kname,
                     status_nonzero=int((r["status"] != 0).sum()), mean_qp_iter=float(r["qp_iter"].mean()),
                     ipm_instance_fraction=float((r["qp_iter"] > 0).mean()),
                     roofline_frac=fl / kt / 1e12 / PEAK_FP64_MFMA_TFLOPS, achieved_tflops=fl / kt / 1e12,
@@ -1003,7 +1007,7 @@ def main(argv=None):
             info["gather_ms"], info["select_ms"] = info2.get("gather_ms"), info2.get("select_ms")   # per-step event pairs exist in this pass only
             res2 = s.results()
             legs.append(dict(N=N, Ts=Ts, dt=dt, ksec=ksec, n_bad=n_bad, info=info, qp_iter=res2["qp_iter"].copy(), path=s.last_kernel_path(),
-                             lds=s.lds_kernel_info(), shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
+                             lds=s.lds_kernel_info(), pit=int(s.pit_last().sum()), shared=shared, device_bytes=s.device_bytes, status_hist=np.bincount(res2["status"], minlength=5).tolist()))
             last = (s, gathered, best)
             if (N, Ts) != wl["horizons"][-1]:
                 s.close()
@@ -1026,6 +1030,8 @@ def main(argv=None):
             ksec = lg["ksec"]
             if lg["path"] in KERNEL_NAMES:  # one kernel does both phases
                 dom, dom_fl, dom_t = KERNEL_NAMES[lg["path"]], qp_fl + lin_fl, ksec[1]
+                if lg["path"] == 3 and 2 * lg["pit"] > B:
+                    dom = PIT_KERNELS
                 kernel_ms = {dom: ksec[1] * 1e3}
             else:
                 dom = "qp_kernel" if ksec[1] >= ksec[0] else "lin_wave_kernel"

@@ -21,7 +21,7 @@ def main(tag, rnd):
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for sub, name in (("stats", "kernel_stats"), ("stats_cfg5", "cfg5_kernel_stats"), ("stats_ekf", "ekf_kernel_stats"),
-                      ("stats_res", "resident_kernel_stats")):
+                      ("stats_res", "resident_kernel_stats"), ("stats_mid", "mid_batch_kernel_stats")):
         f = os.path.join(src, sub, "stats_kernel_stats.csv")
         if os.path.exists(f):
             shutil.copy(f, os.path.join(dst, f"{rnd}_{name}.csv"))

@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg5 -o stats -- python $R/bench.py --config 5 --no-cpu-baseline > $OUT/bench_cfg5_stats.json 2> $OUT/bench_cfg5_stats.err
 # small batches at the shipped horizon: the resident windowed kernel (one window = the whole horizon, four waves per block)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_res -o stats -- python $R/bench.py --config 5 --horizon 80 --batch 64 --no-cpu-baseline > $OUT/bench_N80_B64_resident.json 2> $OUT/bench_N80_B64_resident.err
+# between one and two instances per CU at the shipped horizon: the parallel-in-time kernel with one block per instance
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_mid -o stats -- python $R/bench.py --config 5 --horizon 80 --batch 512 --no-cpu-baseline > $OUT/bench_N80_B512_rounds.json 2> $OUT/bench_N80_B512_rounds.err
 # counters in their own runs, --kernel-trace only (no --stats / sys-trace together with --pmc on this pool)
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg2_N20
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80 --config 5 --horizon 80
