@@ -796,7 +796,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     // LDS-resident kernels (one launch): whole horizon for N <= 23, windowed above.  rti_phase 1 / 2 (preparation and feedback as
     // separate calls) need the linearisation in HBM between the calls: streaming kernels.
     // a general grid (per-stage time steps / separate stage-0 weight) runs on the LDS-resident kernels too (round 4: rti_fused_kernel_grid,
-    // rti_window_kernel_grid, rti_window_kernel_res_grid); the parallel-in-time kernel has no grid instantiation (the resident one runs alone)
+    // rti_window_kernel_grid, rti_window_kernel_res_grid, rti_pit_kernel_grid)
     const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING;
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
     const bool windowed = lds_path && !fused && s->ws != nullptr;
@@ -809,7 +809,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
-            const bool pit_can = pit && s->pit_done && !general_grid(s) && !s->dump_lin;
+            const bool pit_can = pit && s->pit_done && !s->dump_lin;
             P.pit_blocks = P.win_blocks;
             if (pit_can && s->alt_L) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
                 P.win_L = s->alt_L; P.win_blocks = s->alt_blocks; P.ws_stride = (int64_t)windowed_ws_doubles(s->N, s->alt_L);

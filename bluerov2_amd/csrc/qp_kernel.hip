@@ -3266,7 +3266,9 @@ __device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int l
     }
 }
 
-__global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
+template <bool GRID>
+__device__ __forceinline__ void rti_pit_body(const DevParams& P) {
+    using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -3305,7 +3307,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     bool nanp = false;
     const LaneCst lc = load_lane_cst(P.cst, lane);
     __syncthreads();
-    lin_phase<true>(P, b, s0, nseg, lane, ba_s + (size_t)s0 * kBaStage, bv_s + (size_t)s0 * NX, kt_s + (size_t)s0 * kRecInterval, q_s + (size_t)s0 * NX,
+    lin_phase<true, GRID>(P, b, s0, nseg, lane, ba_s + (size_t)s0 * kBaStage, bv_s + (size_t)s0 * NX, kt_s + (size_t)s0 * kRecInterval, q_s + (size_t)s0 * NX,
                     r_s + (size_t)s0 * NU, part, nanp, false);
     {
         const double pw = wave_max(part);
@@ -3322,7 +3324,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     double* ws_dxb = ws_vhat + (size_t)N * 4;
     double* ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
     double* ws_ipm = ws_Ks + (size_t)N * (64 + 64 + NX);   // (behind Ks | Mt | Pb) Gamma and the right-hand side of the try
-    auto setup = [&](Inst& I, int seg0, int nst, lds_f64* tr) __attribute__((always_inline)) {
+    auto setup = [&](InstT& I, int seg0, int nst, lds_f64* tr) __attribute__((always_inline)) {
         setup_inst(P, I, b, lane, &lc);
         I.Ks = ws_Ks; I.Mt = nullptr; I.Pb = nullptr; I.ipm = ws_ipm;
         I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = nullptr; I.ckpt = 0;
@@ -3352,7 +3354,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
         I.kt_str = cl < 4 ? kKtStage : 0;
     };
-    Inst I;
+    InstT I;
     setup(I, s0, nseg, tr_w);
     const int rg = I.rg, cl = I.cl;
     const d4 z4 = {0, 0, 0, 0};
@@ -3403,8 +3405,8 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
         for (int r = 0; r < 3; r++) acc.Psi[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
         acc.Psi[3] = 0.0;
         acc.G = z4;
-        if (step0) bwd_chunk<true, 3, false, true, false, Inst, true>(I, S);
-        else bwd_chunk<true, 3, false, false, false, Inst, true>(I, S);   // (the try: Gamma and its right-hand side from the interior-point arrays)
+        if (step0) bwd_chunk<true, 3, false, true, false, InstT, true>(I, S);
+        else bwd_chunk<true, 3, false, false, false, InstT, true>(I, S);   // (the try: Gamma and its right-hand side from the interior-point arrays)
         wave_fence();
         good = good && S.ok && !S.illc;
         const unsigned long long t_fac = P.dbg ? __builtin_readcyclecounter() : 0;
@@ -3563,7 +3565,13 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     double* pi_it = P.pi + ((size_t)bq * N + s0) * NX;
     double* lam_it = P.lam + ((size_t)bq * N + s0) * 8;
     const int mI = lane & 3;           // input index of this lane's elements j = lane + 64 t of the segment
-    const double lbI = P.cst[32 + mI], ubI = P.cst[36 + mI], rdI = P.Ts * P.cst[12 + mI];
+    const double lbI = P.cst[32 + mI], ubI = P.cst[36 + mI];
+    double rd[2];                      // the elements' own Hessian entries (general grid: the scaled input weight of the element's stage)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int j = lane + 64 * t, jj = j < nu ? j : 0;
+        rd[t] = GRID ? P.wst[(size_t)(s0 + (jj >> 2)) * 16 + 12 + mI] : P.Ts * P.cst[12 + mI];
+    }
     auto seg_nan = [&]() __attribute__((always_inline)) {   // NaN among what the forward sweep of the segment produced
         bool bad = false;
 #pragma unroll
@@ -3620,7 +3628,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 const int row = rg + 4 * r;
-                atpi[r] = lam[r] - (P.Ts * I.Wr[r] * (double)dxs[nseg * NX + row] + (double)I.lds_q[nseg * NX + row]);
+                atpi[r] = lam[r] - ((GRID ? P.wst[(size_t)(s0 + nseg) * 16 + row] : P.Ts * I.Wr[r]) * (double)dxs[nseg * NX + row] + (double)I.lds_q[nseg * NX + row]);
             }
         }
         wave_fence();
@@ -3663,7 +3671,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
                     const int j = lane + 64 * t;
                     const double uj = uo[t], ac = act[t];
                     const double gm = ac != 0.0 ? POL_BIG : 0.0;
-                    const double rr = rdI * (uj - ur[t]);
+                    const double rr = rd[t] * (uj - ur[t]);
                     if (j < nu) { GAM[j] = gm; RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj); }
                 }
             }
@@ -3704,7 +3712,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
                 if (j < nu) {
                     const double g = gel[t];
                     double ac = act[t];
-                    const double tolg = POL_TOL_G * rdI + POL_TOL_GREL * gmx;
+                    const double tolg = POL_TOL_G * rd[t] + POL_TOL_GREL * gmx;
                     if (ac == 2.0 || ac == -2.0) { ac *= 0.5; cnt += 1.0; }                                          // newly pinned
                     else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) { ac = 0.0; cnt += 1.0; }          // released
                     act[t] = ac;
@@ -3738,7 +3746,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
             u_it[j] = un;
             if (wv == 0 && j < 4) { P.res[bq].u0[j] = un; u0v = un; }
             const double e = un - ur[t];
-            cost += 0.5 * rdI * e * e;
+            cost += 0.5 * rd[t] * e * e;
         }
     }
 #pragma unroll
@@ -3749,7 +3757,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
             const double xn = xo[t] + dxs[j];
             x_it[j] = xn;
             const double e = xn - yr[t];
-            cost += 0.5 * ((s0 + i == N) ? P.cst[16 + cc] : P.Ts * P.cst[cc]) * e * e;
+            cost += 0.5 * (GRID ? P.wst[(size_t)(s0 + i) * 16 + cc] : ((s0 + i == N) ? P.cst[16 + cc] : P.Ts * P.cst[cc])) * e * e;
         }
     }
     {
@@ -3768,6 +3776,9 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) {
     if (wv == 0) PIT_STAMP(6);
 #undef PIT_STAMP
 }
+__global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) { rti_pit_body<false>(P); }
+// the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
+__global__ __launch_bounds__(256, 1) void rti_pit_kernel_grid(DevParams P) { rti_pit_body<true>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
@@ -3822,7 +3833,7 @@ int windowed_blocks(int N, int B, int L) {
     if (const char* e = getenv("BROV_DEV_WIN_BLOCKS")) { const long long v = atoll(e); if (v >= 1 && v < fit) fit = v; }
     return (int)(B < fit ? B : fit);
 }
-// Batches between one and two instances per CU at 48 <= N <= 80: as long as the parallel-in-time kernel can serve a solve (uniform grid,
+// Batches between one and two instances per CU at 48 <= N <= 80: as long as the parallel-in-time kernel can serve a solve (no dumped linearisation,
 // BROV_PIT != 0) it runs ONE BLOCK PER INSTANCE -- a CU's second block follows its first -- with the resident kernel behind it for what
 // it leaves, instead of the windowed kernel: 512 instances at N = 80 take 0.154 ms against 0.192 ms (N = 60: 0.135 / ~0.153; N = 40:
 // 0.120 / 0.114 -- hence the lower limit; scripts/dev/mid_batch_rate.py).  What the parallel kernel leaves (instances with many active
@@ -3843,9 +3854,13 @@ bool pit_supported(int N, int win_L) {
 void launch_windowed(const DevParams& P, hipStream_t st) {
     if (windowed_resident(P.win_L)) {
         if (P.pit && P.pit_done) {   // parallel-in-time step-0 solve first; the resident kernel skips what it completed
-            if (first_launch_on_device(3)) (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (first_launch_on_device(3)) {
+                (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)rti_pit_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
             // (pit_blocks = B where every instance has a workspace of its own: beyond one instance per CU the blocks queue for the CUs)
-            hipLaunchKernelGGL(rti_pit_kernel, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+            if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+            else hipLaunchKernelGGL(rti_pit_kernel, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
         }
         if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);

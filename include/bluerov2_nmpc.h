@@ -233,9 +233,8 @@ int brov_debug_dump_linearisation(brov_solver* s, int enable);
  * new_time_steps[i].  brov_set_time_steps does the same for the whole batch (ts[N]; NULL or a uniform vector = the uniform grid
  * with brov_opts::Ts).  Separate stage-0 weight: the generated solver carries W_0 next to W (.c:422-441, same numbers as
  * shipped); brov_set_stage0_weight(W0[16]) gives stage 0 its own (NULL or W itself = one stage weight).
- * Round 4: either feature runs on the LDS-resident kernels (grid instantiations of the fused kernel, of the windowed kernel and of
- * its resident mode) as well as on the streaming pair; only the parallel-in-time step-0 kernel of small batches has none (such a
- * solve runs on the resident kernel alone). */
+ * Round 4: either feature runs on the LDS-resident kernels (grid instantiations of the fused kernel, of the windowed kernel, of its
+ * resident mode and of the parallel-in-time step-0 kernel of small batches) as well as on the streaming pair. */
 int brov_set_time_steps(brov_solver* s, const double* ts /*[N] or NULL*/);
 int brov_set_stage0_weight(brov_solver* s, const double* W0 /*[16] or NULL*/);
 int brov_general_grid(const brov_solver* s);   /* 1 while either feature is in force */

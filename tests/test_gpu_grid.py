@@ -56,11 +56,12 @@ def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_
     op = oracle.opts(N, float(ts[0]), ts_vec=ts, W0=W0, **kw)
     x, u, pi, lam = oracle.init_iterate(op, B)
     pf = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16)))
-    prev, n_qp = None, 0
+    prev, n_qp, n_pit = None, 0, 0
     for k in range(3):
         yref = circ[k:k + N + 1]
         s.set_yref(yref); s.solve()
         assert s.last_kernel_path() == ran
+        n_pit += int(s.pit_last().sum())
         res = s.results(); gx, gu, gpi, glam = s.get_iterate()
         _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
         kk = ro["kkt"]
@@ -75,6 +76,8 @@ def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_
         x, u, pi, lam = gx.copy(), gu.copy(), gpi.copy(), glam.copy()
         prev = res.copy()
     assert n_qp > 0
+    if ran == 3 and B <= 256 and 24 <= N <= 80:   # small batches: the parallel-in-time kernel's grid instantiation takes part
+        assert n_pit > 0
     s.close()
 
 
@@ -132,13 +135,13 @@ def test_feature_gating(ba, golden_traj):
     assert s.last_kernel_path() == 2 and s.lds_kernel_info()["kind"] == "fused"
     s.set_time_steps(None); s.solve()          # back to the uniform grid
     assert s.last_kernel_path() == 2
-    # ... and so does the windowed kernel's resident mode (at most one instance per CU at N > 23: rti_window_kernel_res_grid); the parallel-in-time
-    # kernel has no grid instantiation and stays out of such a solve
+    # ... and so do the windowed kernel's resident mode (at most one instance per CU at N > 23: rti_window_kernel_res_grid) and the
+    # parallel-in-time kernel in front of it (rti_pit_kernel_grid)
     s2 = ba.BatchSolver(B, ba.SolverOptions(40, 0.025, kernel_path=ba.PATH_FUSED))
     s2.set_time_steps(0.02 * 1.03 ** np.arange(40))
     s2.set_x0(x0); s2.set_params(ba.P_NOMINAL); s2.set_yref(circ[:41])
     s2.solve()
-    assert s2.last_kernel_path() == 3 and s2.lds_kernel_info()["kind"] == "windowed, resident" and not s2.pit_last().any()
+    assert s2.last_kernel_path() == 3 and s2.lds_kernel_info()["kind"] == "windowed, resident" and s2.pit_last().any()
     s2.set_time_steps(None); s2.solve()
     assert s2.last_kernel_path() == 3 and s2.pit_last().any()
     s2.close()

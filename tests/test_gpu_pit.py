@@ -118,7 +118,7 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
 @pytest.mark.parametrize("N,B,far", [(80, 300, 0.1), (48, 512, 0.0), (64, 257, 0.25)])
 def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_instance(ba, oracle, golden_traj, N, B, far):
     """256 < B <= 512 at 48 <= N <= 80: the solver is the windowed kernel's (20-stage windows), but as long as a solve can be served
-    parallel in time (uniform grid, BROV_PIT != 0) it runs in the resident configuration -- rti_pit_kernel with ONE BLOCK PER INSTANCE,
+    parallel in time (BROV_PIT != 0) it runs in the resident configuration -- rti_pit_kernel with ONE BLOCK PER INSTANCE,
     the resident kernel (one block per CU, further instances from its counter) behind it for what is left.  Every tick against the
     oracle; the mode may change from one solve to the next (BROV_PIT=0: the windowed kernel; back again)."""
     import torch
