@@ -138,7 +138,7 @@ def test_shipped_library_has_no_vector_code_ahead_of_an_exec_restore():
 def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
     """The checker against REAL compiler output.  (1) A committed excerpt of hipcc 7.2's own assembly of this repository's qp_kernel.hip
     (commit da0d7bb with -DBROV_SCHED_TICKET_LATE: the work-ordering ticket taken at the end of the wave, a harmless reordering) in which
-    the register allocator's AGPR copies sit ahead of an exec restore in rti_fused_kernel: the checker must find it.  (2) The product
+    the register allocator's AGPR copies sit ahead of an exec restore in rti_fused_kernel: the checker must find it.  With BROV_TEST_CANARY=1 also: (2) the product
     order compiled now: nothing.  (3) The canary order compiled now: reported, not asserted -- which statement order builds the defect
     moves with every change of the source (rti_window_kernel, then rti_fused_kernel, then -- with the parallel-in-time kernel in the
     file -- nowhere), which is the reason the link rule runs the checker on every build."""
@@ -147,6 +147,10 @@ def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
     hits = chk.scan(open(fixture).read().split("\n"))
     assert len(hits) == 1 and hits[0][0].endswith("rti_fused_kernelENS_9DevParamsE") and hits[0][2] == ".LBB3_47", hits
     assert all("v_accvgpr_write_b32" in ins for _, ins in hits[0][4])
+    # (2), (3): two more device compiles of qp_kernel.hip (~75 s each).  The product order is already checked on the linked library
+    # (Makefile link rule, test_shipped_library_has_no_vector_code_ahead_of_an_exec_restore); the live canary only prints.  On request:
+    if os.environ.get("BROV_TEST_CANARY", "0") == "0":
+        return
     src = os.path.join(ROOT, "bluerov2_amd", "csrc", "qp_kernel.hip")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
