@@ -89,6 +89,12 @@ struct brov_solver {
     // brov_tick_host, mailbox path: inputs passed with the tick are read by THIS launch straight from the pinned staging buffer (no copy
     // command ahead of the kernel); their device copies are refreshed behind the kernel.  Non-null only while that launch is built.
     const double *tick_x0 = nullptr, *tick_yref = nullptr, *tick_par = nullptr;
+    hipEvent_t ev_tick = nullptr;        // ticks with inputs read in place: the kernel's end (neither the host nor the next tick's kernel waits for the copies behind it)
+    hipStream_t copy_stream = nullptr;   // ... those copies (pinned staging buffer -> the device arrays every other entry point works on) run here, behind ev_tick
+    hipEvent_t ev_copy = nullptr;        // ... and end here
+    bool copies_pending = false;         // ev_copy recorded and not yet waited for by the host
+    int copy_mask = 0;                   // ... which device arrays those copies write: 1 x0, 2 shared window, 4 stage parameters
+    bool in_tick = false;                // brov_tick_host is calling brov_solve_phase (whose kernel reads the pinned inputs: no need to order it behind the copies)
     brov_result* mail = nullptr;     // host mailbox of the tick in flight (device-visible pinned memory), else nullptr
     int32_t* mail_flag = nullptr;
     bool pit_ran = false;            // the last solve launched rti_pit_kernel
@@ -293,6 +299,9 @@ extern "C" void brov_destroy(brov_solver* s) {
     if (s->traj) hipFree(s->traj);
     if (s->dbg) hipFree(s->dbg);
     if (s->pin) hipHostFree(s->pin);
+    if (s->copy_stream) { hipStreamSynchronize(s->copy_stream); hipStreamDestroy(s->copy_stream); }
+    if (s->ev_tick) hipEventDestroy(s->ev_tick);
+    if (s->ev_copy) hipEventDestroy(s->ev_copy);
     if (s->tick_stream) hipStreamDestroy(s->tick_stream);
     for (int k = 0; k < 3; k++)
         if (s->ev[k]) hipEventDestroy(s->ev[k]);
@@ -308,8 +317,16 @@ extern "C" size_t brov_device_bytes(const brov_solver* s) { return s ? s->bytes 
 // stream than the one last used would overlap that work and race on the iterate / work-ordering buffers / hand-out counters: the
 // host waits for the earlier stream first.  Same stream (every loop in bench.py, the closed loop, tick after tick): a pointer
 // comparison, no cost.
+// host-side wait for everything the solver has in flight: the last stream, and the input copies a tick left running on the copy stream
+static hipError_t sync_last(brov_solver* s) {
+    hipError_t e = hipStreamSynchronize(s->last_stream);
+    if (e == hipSuccess && s->copies_pending) { e = hipEventSynchronize(s->ev_copy); s->copies_pending = false; }
+    return e;
+}
 static int order_behind_last(brov_solver* s, hipStream_t st) {
     if (s->last_stream != st) HIPCHK(hipStreamSynchronize(s->last_stream));
+    // a tick's input copies (copy stream) write the device arrays this stream's next command may read or overwrite
+    if (s->copies_pending && !s->in_tick) HIPCHK(hipStreamWaitEvent(st, s->ev_copy, 0));
     return BROV_OK;
 }
 extern "C" int brov_order_stream(brov_solver* s, void* stream) {
@@ -324,7 +341,7 @@ static int copy_in(brov_solver* s, double* dst, const double* src, size_t n, boo
     if (host) {
         // a solve may still be running on the caller's (possibly non-blocking) stream: the blocking copy on the null stream does not
         // wait for such a stream by itself
-        HIPCHK(hipStreamSynchronize(s->last_stream));
+        HIPCHK(sync_last(s));
         HIPCHK(hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
     } else {
         if (int rc = order_behind_last(s, (hipStream_t)stream)) return rc;
@@ -366,7 +383,7 @@ static int set_par(brov_solver* s, const double* p, int per_stage, bool host, vo
     double* tmp = nullptr;
     if (!host) { if (int rc = order_behind_last(s, (hipStream_t)st)) return rc; }
     if (host) {
-        HIPCHK(hipStreamSynchronize(s->last_stream));
+        HIPCHK(sync_last(s));
         HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 16 * sizeof(double)));
         hipError_t e = hipMemcpy(tmp, p, (size_t)s->B * 16 * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { hipFree(tmp); g_err = hipGetErrorString(e); return BROV_ERR_HIP; }
@@ -387,7 +404,7 @@ extern "C" int brov_set_params_device(brov_solver* s, const double* p, int per_s
 extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, const double* p16) {
     if (!s || !p16 || inst < 0 || inst >= s->B || stage < 0 || stage > s->N) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     HIPCHK(hipMemcpy(s->par + ((size_t)inst * (s->N + 1) + stage) * 16, p16, 16 * sizeof(double), hipMemcpyHostToDevice));
     if (stage == 0) s->pplant_stale = true;
     return BROV_OK;
@@ -396,7 +413,7 @@ extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, co
 extern "C" int brov_set_time_steps(brov_solver* s, const double* ts) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     if (!ts) s->ts_host.clear();
     else {
         for (int i = 0; i < s->N; i++)
@@ -411,7 +428,7 @@ extern "C" int brov_set_time_steps(brov_solver* s, const double* ts) {
 extern "C" int brov_set_stage0_weight(brov_solver* s, const double* W0) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     s->has_W0 = false;
     if (W0) {
         bool same = true;
@@ -444,7 +461,7 @@ __global__ void split_p18_kernel(const double* __restrict__ p18, double* __restr
 extern "C" int brov_enable_dist6(brov_solver* s, int on) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     if (on && !s->par_rp) {
         const size_t n = (size_t)s->B * (s->N + 1) * 2;
         int rc = dalloc(s, &s->par_rp, n);
@@ -472,7 +489,7 @@ static int set_rp(brov_solver* s, const double* d, int per_stage, bool host, voi
     double* tmp = nullptr;
     if (!host) { if (int rc = order_behind_last(s, (hipStream_t)st)) return rc; }
     if (host) {
-        HIPCHK(hipStreamSynchronize(s->last_stream));
+        HIPCHK(sync_last(s));
         HIPCHK(hipMalloc((void**)&tmp, (size_t)s->B * 2 * sizeof(double)));
         hipError_t e = hipMemcpy(tmp, d, (size_t)s->B * 2 * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { hipFree(tmp); g_err = hipGetErrorString(e); return BROV_ERR_HIP; }
@@ -499,7 +516,7 @@ extern "C" int brov_set_params18_host(brov_solver* s, const double* p18, int per
     if (int rc = need_dist6(s, "brov_set_params18_host")) return rc;
     if (!p18) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     const size_t N1 = s->N + 1, rows = (size_t)s->B * N1, nsrc = (per_stage ? rows : (size_t)s->B) * 18;
     double* tmp = nullptr;
     HIPCHK(hipMalloc((void**)&tmp, nsrc * sizeof(double)));
@@ -517,7 +534,7 @@ extern "C" int brov_plant_set_rp_disturbance_host(brov_solver* s, const double* 
     if (int rc = need_dist6(s, "brov_plant_set_rp_disturbance_host")) return rc;
     if (!d) { s->prp_plant_set = false; return BROV_OK; }
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     HIPCHK(hipMemcpy(s->prp_plant, d, (size_t)s->B * 2 * sizeof(double), hipMemcpyHostToDevice));
     s->prp_plant_set = true;
     return BROV_OK;
@@ -526,7 +543,7 @@ extern "C" int brov_plant_set_rp_disturbance_host(brov_solver* s, const double* 
 extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, const double* y, int ny) {
     if (!s || !y || inst < 0 || inst >= s->B || stage < 0 || stage > s->N || ny < 1 || ny > 16) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     if (s->yref_shared) {  // materialise the shared window per instance first
         for (int b = 0; b < s->B; b++)
             HIPCHK(hipMemcpy(s->yref + (size_t)b * (s->N + 1) * 16, shared_window(s), (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
@@ -540,7 +557,7 @@ extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, con
 extern "C" int brov_traj_set_host(brov_solver* s, const double* traj, int rows) {
     if (!s || !traj || rows < 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     if (s->yref_view) {   // the window in force is a view into the table that is about to go: keep a copy
         HIPCHK(hipMemcpy(s->yref_sh, s->yref_view, (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
         s->yref_view = nullptr;
@@ -570,7 +587,7 @@ extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void
 extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t* lines, int ncols) {
     if (!s || !s->traj || !lines || (ncols != 12 && ncols != 16)) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     HIPCHK(hipMemcpy(s->lines, lines, (size_t)s->B * sizeof(int), hipMemcpyHostToDevice));
     launch_window(s->traj, s->traj_rows, s->lines, 0, s->B, s->N, ncols, s->yref, nullptr);
     s->yref_shared = false;
@@ -581,7 +598,7 @@ extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t*
 extern "C" int brov_set_candidate_params_host(brov_solver* s, int kind, const double* p0, const double* p1, const double* phase) {
     if (!s || !p0 || !p1 || !phase || kind < 0 || kind > 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     const size_t nb = (size_t)s->B * sizeof(double);
     HIPCHK(hipMemcpy(s->scratch3, p0, nb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(s->scratch3 + s->B, p1, nb, hipMemcpyHostToDevice));
@@ -718,7 +735,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
 extern "C" int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));   // a solve on a non-blocking stream may still be writing the iterate
+    HIPCHK(sync_last(s));   // a solve on a non-blocking stream may still be writing the iterate
     const size_t B = s->B, N = s->N;
     if (x) HIPCHK(hipMemcpy(s->x, x, B * (N + 1) * 12 * sizeof(double), hipMemcpyHostToDevice));
     if (u) HIPCHK(hipMemcpy(s->u, u, B * N * 4 * sizeof(double), hipMemcpyHostToDevice));
@@ -729,7 +746,7 @@ extern "C" int brov_set_iterate_host(brov_solver* s, const double* x, const doub
 extern "C" int brov_get_iterate_host(brov_solver* s, double* x, double* u, double* pi, double* lam) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     const size_t B = s->B, N = s->N;
     if (x) HIPCHK(hipMemcpy(x, s->x, B * (N + 1) * 12 * sizeof(double), hipMemcpyDeviceToHost));
     if (u) HIPCHK(hipMemcpy(u, s->u, B * N * 4 * sizeof(double), hipMemcpyDeviceToHost));
@@ -740,7 +757,7 @@ extern "C" int brov_get_iterate_host(brov_solver* s, double* x, double* u, doubl
 extern "C" int brov_reset(brov_solver* s) {  // acados_solver_bluerov2.c:797-830: everything to zero
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     const size_t B = s->B, N = s->N;
     HIPCHK(hipMemset(s->x, 0, B * (N + 1) * 12 * sizeof(double)));
     HIPCHK(hipMemset(s->u, 0, B * N * 4 * sizeof(double)));
@@ -877,7 +894,7 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     if (!s->tick_stream) HIPCHK(hipStreamCreateWithFlags(&s->tick_stream, hipStreamNonBlocking));
     if (int rc = tick_pin(s)) return rc;
     hipStream_t st = s->tick_stream;
-    if (s->last_stream != st) HIPCHK(hipStreamSynchronize(s->last_stream));   // an earlier solve on the caller's stream
+    if (s->last_stream != st) HIPCHK(sync_last(s));   // an earlier solve on the caller's stream
     double* px = s->pin; double* py = px + n_x0; double* pp = py + n_y; double* pr = pp + n_p;
     volatile int32_t* pf = (volatile int32_t*)(pr + n_r);
     if (x0 && x0 != px) std::memcpy(px, x0, n_x0 * sizeof(double));   // (equal: the caller wrote into the staging buffer, brov_tick_buffers)
@@ -891,38 +908,66 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     // memory: 21 KB over PCIe inside the linearisation's staging loads) instead of waiting for a copy command ahead of it; the device
     // copies every other entry point works on are refreshed by the same copies, enqueued BEHIND the launch (BROV_TICK_ZEROCOPY=0: ahead).
     const bool mailbox = rti_phase != 1 && B <= kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0);
-    const bool zerocopy = mailbox && rti_phase == 0 && !(getenv("BROV_TICK_ZEROCOPY") && atoi(getenv("BROV_TICK_ZEROCOPY")) == 0);
-    auto upload = [&]() -> int {
+    // Larger batches whose records the kernel writes into the pinned buffer itself (bulk, below): the same for x0 and a shared window (96 bytes
+    // per instance over PCIe inside the linearisation's staging loads) -- not for per-stage parameters passed with the tick (2.7 KB per instance
+    // at N = 20: those go through the copy engine ahead of the launch, and the other inputs with them).
+    const bool bulk = !mailbox && rti_phase != 1 && B > kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0) &&
+                      !(getenv("BROV_TICK_BULK") && atoi(getenv("BROV_TICK_BULK")) == 0);
+    const bool zerocopy = (mailbox || (bulk && !par_stage)) && rti_phase == 0 && !(getenv("BROV_TICK_ZEROCOPY") && atoi(getenv("BROV_TICK_ZEROCOPY")) == 0);
+    auto upload = [&](hipStream_t cs) -> int {
         if (x0 && yref_shared && par_stage) {   // device side: one allocation in the same order (brov_create)
-            HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, cs));
         } else {
-            if (x0) HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, st));
-            if (yref_shared) HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, st));
-            if (par_stage) HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, st));
+            if (x0) HIPCHK(hipMemcpyAsync(s->x0, px, n_x0 * sizeof(double), hipMemcpyHostToDevice, cs));
+            if (yref_shared) HIPCHK(hipMemcpyAsync(s->yref_sh, py, n_y * sizeof(double), hipMemcpyHostToDevice, cs));
+            if (par_stage) HIPCHK(hipMemcpyAsync(s->par, pp, n_p * sizeof(double), hipMemcpyHostToDevice, cs));
         }
         return BROV_OK;
     };
-    if (!zerocopy) { if (int rc = upload()) return rc; }
-    else { s->tick_x0 = x0 ? px : nullptr; s->tick_yref = yref_shared ? py : nullptr; s->tick_par = par_stage ? pp : nullptr; }
+    if (!zerocopy) {
+        if (s->copies_pending) HIPCHK(hipStreamWaitEvent(st, s->ev_copy, 0));   // (an earlier tick's copies into the same device arrays)
+        if (int rc = upload(st)) return rc;
+    } else {
+        s->tick_x0 = x0 ? px : nullptr; s->tick_yref = yref_shared ? py : nullptr; s->tick_par = par_stage ? pp : nullptr;
+        if (!s->copy_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_tick, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_copy, hipEventDisableTiming));
+        }
+    }
     // Results.  Small batches (the ROS node's batch of one): the kernel writes every record into the pinned buffer itself and then the
     // instance's sequence word; the host polls those words -- no copy command, no stream synchronisation on the way back.  The stream
     // is queried now and then: a launch that ended without delivering (a device fault) falls back to the synchronous path's error.
     // Larger batches: the kernel still writes the records into the pinned buffer itself (no copy command behind it), without the
     // per-instance sequence words -- the host waits for the stream once.
-    const bool bulk = !mailbox && rti_phase != 1 && B > kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0) &&
-                      !(getenv("BROV_TICK_BULK") && atoi(getenv("BROV_TICK_BULK")) == 0);
     if (mailbox) {
         s->mail_seq = s->mail_seq == 0x7fffffff ? 1 : s->mail_seq + 1;
         s->mail = (brov_result*)pr; s->mail_flag = (int32_t*)pf;
     } else if (bulk) {
         s->mail = (brov_result*)pr; s->mail_flag = nullptr;
     }
+    // (inputs NOT passed with this tick are read from their device arrays: if the copies an earlier tick left running write one of those, the
+    // kernel is ordered behind them after all -- a loop that passes the same inputs every tick never is)
+    const int passed = (x0 ? 1 : 0) | (yref_shared ? 2 : 0) | (par_stage ? 4 : 0);
+    const bool behind_copies = s->copies_pending && (s->copy_mask & ~passed) != 0;
+    s->in_tick = zerocopy && !behind_copies;
     const int rc = brov_solve_phase(s, st, rti_phase);
+    s->in_tick = false;
     const int32_t seq = s->mail_seq;
     s->mail = nullptr; s->mail_flag = nullptr;
     s->tick_x0 = s->tick_yref = s->tick_par = nullptr;
     if (rc) return rc;
-    if (zerocopy) { if (int rc2 = upload()) return rc2; }   // the device copies, behind the kernel that has read the pinned ones
+    if (zerocopy) {
+        // the device copies every other entry point works on: refreshed BEHIND the kernel that has read the pinned ones, on the copy stream --
+        // neither the host (which waits for the kernel's end / the mailbox) nor the next tick's kernel waits for them; whatever else touches
+        // those arrays is ordered behind ev_copy (order_behind_last, sync_last)
+        HIPCHK(hipEventRecord(s->ev_tick, st));
+        HIPCHK(hipStreamWaitEvent(s->copy_stream, s->ev_tick, 0));
+        if (int rc2 = upload(s->copy_stream)) return rc2;
+        HIPCHK(hipEventRecord(s->ev_copy, s->copy_stream));
+        s->copy_mask = (s->copies_pending && !behind_copies) ? (s->copy_mask | passed) : passed;   // (arrays written by copies no kernel on st is ordered behind yet)
+        s->copies_pending = true;
+    }
     if (mailbox) {
         size_t done = 0;
         for (unsigned long spin = 1; done < B; spin++) {
@@ -941,7 +986,8 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         std::atomic_thread_fence(std::memory_order_acquire);
     } else {
         if (!bulk) HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if (zerocopy) HIPCHK(hipEventSynchronize(s->ev_tick));
+        else HIPCHK(hipStreamSynchronize(st));
     }
     if (res && res != (brov_result*)pr) std::memcpy(res, pr, B * sizeof(brov_result));
     return BROV_OK;
@@ -957,7 +1003,7 @@ extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
         return BROV_ERR_ARG;
     }
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     s->opts = *o;
     return upload_cst(s);
 }
@@ -980,7 +1026,7 @@ extern "C" int brov_last_kernel_path(const brov_solver* s) {
 extern "C" int brov_pit_last(brov_solver* s, int32_t* done) {
     if (!s || !done) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     if (!s->pit_ran) { std::memset(done, 0, (size_t)s->B * sizeof(int32_t)); return BROV_OK; }
     HIPCHK(hipMemcpy(done, s->pit_done, (size_t)s->B * sizeof(int32_t), hipMemcpyDeviceToHost));
     return BROV_OK;
@@ -1004,7 +1050,7 @@ extern "C" int brov_debug_dump_linearisation(brov_solver* s, int enable) {
 extern "C" int brov_debug_phase_stamps(brov_solver* s, int enable, unsigned long long* out_host) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     // [B][8] phase stamps followed by [B][8] interior-point phase totals (the latter only filled by a -DBROV_DBG_IPM build)
     if (enable && !s->dbg) { HIPCHK(hipMalloc((void**)&s->dbg, (size_t)s->B * 128)); HIPCHK(hipMemset(s->dbg, 0, (size_t)s->B * 128)); }
     if (out_host && s->dbg) HIPCHK(hipMemcpy(out_host, s->dbg, (size_t)s->B * (enable == 2 ? 128 : 64), hipMemcpyDeviceToHost));
@@ -1026,14 +1072,14 @@ extern "C" int brov_last_solve_seconds(brov_solver* s, double* total, double* k2
 extern "C" int brov_get_results_host(brov_solver* s, brov_result* res) {
     if (!s || !res) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     HIPCHK(hipMemcpy(res, s->res, (size_t)s->B * sizeof(brov_result), hipMemcpyDeviceToHost));
     return BROV_OK;
 }
 extern "C" int brov_get_u0_host(brov_solver* s, double* u0) {
     if (!s || !u0) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     HIPCHK(hipMemcpy2D(u0, 4 * sizeof(double), s->res, sizeof(brov_result), 4 * sizeof(double), s->B, hipMemcpyDeviceToHost));
     return BROV_OK;
 }
@@ -1047,7 +1093,7 @@ extern "C" double* brov_u_device(brov_solver* s) { return s ? s->u : nullptr; }
 extern "C" int brov_get_linearisation_host(brov_solver* s, double* AB, double* b) {
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     if (AB) HIPCHK(hipMemcpy(AB, s->BA, (size_t)s->B * s->N * 192 * sizeof(double), hipMemcpyDeviceToHost));
     if (b) HIPCHK(hipMemcpy(b, s->bvec, (size_t)s->B * s->N * 12 * sizeof(double), hipMemcpyDeviceToHost));
     return BROV_OK;
@@ -1083,7 +1129,7 @@ extern "C" int brov_select_best_host(brov_solver* s, int* best_index, brov_resul
     HIPCHK(hipSetDevice(s->device));
     hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(256), 0, s->last_stream, s->res, s->B, s->best);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     int idx = -1;
     HIPCHK(hipMemcpy(&idx, s->best, sizeof(int), hipMemcpyDeviceToHost));
     *best_index = idx;
@@ -1094,7 +1140,7 @@ extern "C" int brov_select_best_host(brov_solver* s, int* best_index, brov_resul
 extern "C" int brov_get_thrusts_host(brov_solver* s, double* t6) {
     if (!s || !t6) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipStreamSynchronize(s->last_stream));
+    HIPCHK(sync_last(s));
     HIPCHK(hipMemcpy2D(t6, 6 * sizeof(double), (const char*)s->res + offsetof(brov_result, thrust), sizeof(brov_result), 6 * sizeof(double),
                        s->B, hipMemcpyDeviceToHost));
     return BROV_OK;

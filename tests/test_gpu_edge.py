@@ -368,7 +368,7 @@ def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mai
     a.close(); b.close(); c.close()
 
 
-@pytest.mark.parametrize("N,B", [(80, 4), (20, 8), (40, 64)])
+@pytest.mark.parametrize("N,B", [(80, 4), (20, 8), (40, 64), (20, 300)])
 def test_tick_followed_by_calls_on_another_stream_is_ordered(ba, golden_traj, N, B):
     """brov_tick_host runs on the solver's own non-blocking stream and, for small batches, returns as soon as the
     records are in the mailbox -- while the tail of its kernel (the last adjoint sweep, the multipliers) may still be running.  A
