@@ -295,11 +295,15 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
 extern "C" void brov_destroy(brov_solver* s) {
     if (!s) return;
     hipSetDevice(s->device);
+    // nothing of this solver may still be in flight when its memory goes: the tail of a tick's kernel, the input copies behind it
+    if (s->tick_stream) hipStreamSynchronize(s->tick_stream);
+    if (s->copy_stream) hipStreamSynchronize(s->copy_stream);
+    // (a caller's own stream is the caller's to drain -- it may not exist any more; hipFree below waits for the device in any case)
     for (void* p : s->allocs) hipFree(p);
     if (s->traj) hipFree(s->traj);
     if (s->dbg) hipFree(s->dbg);
     if (s->pin) hipHostFree(s->pin);
-    if (s->copy_stream) { hipStreamSynchronize(s->copy_stream); hipStreamDestroy(s->copy_stream); }
+    if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->ev_tick) hipEventDestroy(s->ev_tick);
     if (s->ev_copy) hipEventDestroy(s->ev_copy);
     if (s->tick_stream) hipStreamDestroy(s->tick_stream);
