@@ -368,6 +368,41 @@ def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mai
     a.close(); b.close(); c.close()
 
 
+@pytest.mark.parametrize("N,B", [(20, 1), (80, 2), (20, 70), (20, 300)])
+def test_ticks_with_changing_subsets_of_inputs_equal_setters_plus_solve(ba, golden_traj, N, B):
+    """The device copies of a tick's inputs are refreshed BEHIND its kernel, on a stream of their own, and the next tick's kernel does not
+    wait for them -- unless it reads one of those device arrays because the tick does not bring that input itself.  120 ticks with a
+    random subset of (x0, window, parameters) passed each time, interleaved now and then with a getter and with a plain solve on the
+    null stream: bit for bit the records and iterates of a second solver driven through setters + brov_solve."""
+    rng = np.random.default_rng(7 * N + B)
+    x0, circ = _inputs(golden_traj, B, seed=44, big=1.5)
+    win = np.concatenate([circ, np.repeat(circ[-1:], 400, axis=0)])
+    p = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16))).copy()
+    a = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); b = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
+    a.set_x0(x0); a.set_yref(win[:N + 1]); a.set_params(p)
+    b.tick(x0=x0, yref=win[:N + 1], params=p); a.solve()
+    for k in range(1, 120):
+        px, py, pp = rng.random() < 0.7, rng.random() < 0.7, rng.random() < 0.2
+        xk = x0 + 0.01 * rng.normal(size=x0.shape) if px else None
+        yk = win[k:k + N + 1] if py else None
+        if pp:
+            p[:, :, 0] = rng.uniform(-5, 5)
+        if px: a.set_x0(xk)
+        if py: a.set_yref(yk)
+        if pp: a.set_params(p)
+        a.solve(); ra = a.results()
+        rb = b.tick(x0=xk, yref=yk, params=p if pp else None)
+        assert ra.tobytes() == rb.tobytes(), k
+        if k % 17 == 0:                                   # a getter / a plain solve on another stream in between
+            assert np.array_equal(a.get_x0(), b.get_x0())
+            a.solve(); b.solve()
+            assert a.results().tobytes() == b.results().tobytes(), k
+        if k % 29 == 0:
+            for ia, ib in zip(a.get_iterate(), b.get_iterate()):
+                assert np.array_equal(ia, ib)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("N,B", [(80, 4), (20, 8), (40, 64), (20, 300)])
 def test_tick_followed_by_calls_on_another_stream_is_ordered(ba, golden_traj, N, B):
     """brov_tick_host runs on the solver's own non-blocking stream and, for small batches, returns as soon as the
