@@ -17,6 +17,7 @@
 using namespace brov;
 
 #define kTickMailboxMaxBatch 64          /* brov_tick_host: up to this many instances deliver their records through the host mailbox */
+#define kPitRoundsPause 8                  /* solves on the windowed kernel after the parallel-in-time rounds left an instance behind */
 #define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N > 81: up to this many instances run on the streaming kernels */
 
 static thread_local std::string g_err;
@@ -72,6 +73,8 @@ struct brov_solver {
     unsigned win_tick = 0;           // windowed launches so far: which of the two hand-out counters the next one uses
     int win_blocks = 0, win_L = 0;
     int alt_blocks = 0, alt_L = 0;   // parallel-in-time rounds (pit_rounds_stages): the resident configuration a solve may use instead
+    int32_t* pit_left_host = nullptr;   // ... pinned word: instances the parallel-in-time kernel left to the resident kernel in the last such solve
+    int rounds_pause = 0;            // ... solves still to run on the windowed kernel before the rounds are tried again
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
     // general grid (streaming kernels): per-stage time steps and / or a separate stage-0 weight
@@ -263,6 +266,8 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
         size_t ws_doubles = (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L);
         if (!windowed_is_resident(s->win_L) && (s->alt_L = pit_rounds_stages(opts->N, B)) != 0) {   // one workspace per instance for rti_pit_kernel's blocks
             s->alt_blocks = windowed_blocks(opts->N, B, s->alt_L);
+            if (hipHostMalloc((void**)&s->pit_left_host, 64, hipHostMallocDefault) != hipSuccess) { s->pit_left_host = nullptr; rc = BROV_ERR_HIP; }
+            else *s->pit_left_host = 0;
             const size_t alt = (size_t)B * windowed_ws_doubles(opts->N, s->alt_L);
             ws_doubles = alt > ws_doubles ? alt : ws_doubles;
         }
@@ -303,6 +308,7 @@ extern "C" void brov_destroy(brov_solver* s) {
     if (s->traj) hipFree(s->traj);
     if (s->dbg) hipFree(s->dbg);
     if (s->pin) hipHostFree(s->pin);
+    if (s->pit_left_host) hipHostFree(s->pit_left_host);
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->ev_tick) hipEventDestroy(s->ev_tick);
     if (s->ev_copy) hipEventDestroy(s->ev_copy);
@@ -832,9 +838,25 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
             const bool pit_can = pit && s->pit_done && !s->dump_lin;
             P.pit_blocks = P.win_blocks;
-            if (pit_can && s->alt_L) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
+            bool rounds = pit_can && s->alt_L != 0;
+            if (rounds && !(getenv("BROV_PIT_ROUNDS_ADAPT") && atoi(getenv("BROV_PIT_ROUNDS_ADAPT")) == 0)) {
+                // What the parallel kernel leaves (instances that need an interior-point iteration or a fourth try) STARTS only when its rounds
+                // are over, from scratch, on the resident kernel: one such instance makes the solve longer than the windowed kernel's, where
+                // it would have started at once (a quarter of the batch saturated, one to three instances left: 0.465 against 0.375 ms).  The
+                // resident kernel reports the number into a pinned word; when the last report (a solve or two old: nobody waits for it) is not
+                // zero -- such instances stay for many ticks --, the next kPitRoundsPause solves run on the windowed kernel, then the
+                // rounds are tried again.
+                if (s->rounds_pause > 0) {
+                    rounds = false;
+                    if (--s->rounds_pause == 0) __atomic_store_n(s->pit_left_host, 0, __ATOMIC_RELAXED);   // (the retry starts from a clean slate: the reports
+                } else if (__atomic_load_n(s->pit_left_host, __ATOMIC_RELAXED) > 0) {   //  of the solves before the pause have landed)
+                    s->rounds_pause = kPitRoundsPause - 1; rounds = false;
+                }
+            }
+            if (rounds) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
                 P.win_L = s->alt_L; P.win_blocks = s->alt_blocks; P.ws_stride = (int64_t)windowed_ws_doubles(s->N, s->alt_L);
                 P.pit_blocks = (int32_t)s->B;
+                P.pit_left_host = s->pit_left_host;
             }
             if (pit_can && pit_supported(s->N, P.win_L)) {
                 P.pit = pit; P.pit_done = s->pit_done;

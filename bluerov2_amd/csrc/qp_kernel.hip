@@ -2986,6 +2986,16 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     if (blockIdx.x == 0) {
         sched_zero_next(P, lane0);
         if (lane0 == 0) *P.counter_next = 0;   // the next launch's hand-out counter (this launch uses the other one)
+        if constexpr (RES) {
+            // batches between one and two instances per CU (pit_rounds_stages): how many instances the parallel-in-time kernel has left to
+            // this one -- into a pinned host word the host reads, a solve or two later, when it chooses the mode of a solve
+            if (P.pit_left_host && P.pit_done) {
+                int done = 0;
+                for (int j = lane0; j < P.B; j += 64) done += P.pit_done[j] != 0;
+                done = (int)wave_sum((double)done);
+                if (lane0 == 0) __hip_atomic_store(P.pit_left_host, P.B - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
     Win W;
@@ -3837,8 +3847,8 @@ int windowed_blocks(int N, int B, int L) {
 // BROV_PIT != 0) it runs ONE BLOCK PER INSTANCE -- a CU's second block follows its first -- with the resident kernel behind it for what
 // it leaves, instead of the windowed kernel: 512 instances at N = 80 take 0.154 ms against 0.192 ms (N = 60: 0.135 / ~0.153; N = 40:
 // 0.120 / 0.114 -- hence the lower limit; scripts/dev/mid_batch_rate.py).  What the parallel kernel leaves (instances with many active
-// bounds) is then served two per block by one wave: a batch with a quarter of its instances saturated loses 20 % against the windowed
-// kernel (BROV_PIT_ROUNDS=0 keeps the windowed kernel).  Decided per solve: the solver is created for the windowed kernel and with a
+// bounds) starts only then, on one wave: a batch with a quarter of its instances saturated would lose 20 % against the windowed kernel --
+// the host follows the number of instances left (nmpc_api.hip, kPitRoundsPause; BROV_PIT_ROUNDS=0 keeps the windowed kernel altogether).  Decided per solve: the solver is created for the windowed kernel and with a
 // workspace that serves either.  Returns the resident stage count (= N) or 0.
 constexpr int kPitRounds = 2, kPitRoundsMinN = 48;
 int pit_rounds_stages(int N, int B) {

@@ -25,12 +25,13 @@ def ba():
 
 @pytest.fixture(autouse=True)
 def _restore_env():
-    old = os.environ.get("BROV_PIT")
+    old = {k: os.environ.get(k) for k in ("BROV_PIT", "BROV_PIT_ROUNDS_ADAPT")}
     yield
-    if old is None:
-        os.environ.pop("BROV_PIT", None)
-    else:
-        os.environ["BROV_PIT"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def test_sweep12_inverts_spd_matrices(ba):
@@ -133,6 +134,7 @@ def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_inst
     x, u, pi, lam = oracle.init_iterate(op, B)
     pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
     prev = None
+    os.environ["BROV_PIT_ROUNDS_ADAPT"] = "0"          # (the mode is this test's to choose; the adaptive choice: next test)
     for k, mode in enumerate(["1", "1", "1", "0", "1", "2"]):
         os.environ["BROV_PIT"] = mode
         yref = np.ascontiguousarray(circ[k:k + N + 1])
@@ -150,6 +152,45 @@ def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_inst
             assert np.all(done[early & tried]) and not np.any(done & ~tried)
             assert np.array_equal(r["qp_iter"][done], ro["qp_iter"][done])
         prev = ro
+    s.close()
+
+
+@pytest.mark.parametrize("far", [0.0, 0.3])
+def test_mode_of_such_batches_follows_what_the_parallel_kernel_leaves_behind(ba, oracle, golden_traj, far):
+    """What rti_pit_kernel leaves is served by one wave per instance behind it: when the resident kernel reports (pinned host word, read a
+    solve or two later) that an instance was left (it starts only when the rounds are over), the next eight solves run on the windowed kernel, then the rounds
+    are tried again.  A tracking batch stays in the rounds; one with 30 % of its instances far off alternates; every tick agrees with the
+    oracle in either mode."""
+    import torch
+    N, B = 80, 400
+    if torch.cuda.get_device_properties(0).multi_processor_count >= B:
+        pytest.skip("needs a batch beyond one instance per CU")
+    Ts = 1.0 / N
+    x0, circ = _inputs(golden_traj, B, seed=77, far=far)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    s.set_x0(x0); s.set_params(P_NOMINAL)
+    op = oracle.opts(N, Ts)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
+    prev, modes = None, []
+    for k in range(26):
+        yref = np.ascontiguousarray(circ[k % 8:k % 8 + N + 1])
+        s.set_yref(yref); s.solve()
+        r, it, done = s.results(), s.get_iterate(), s.pit_last().astype(bool)
+        modes.append(bool(done.any()))
+        if k < 6 or k % 5 == 0:                                    # (the oracle takes its time at this size)
+            _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+            _compare(r, it, ro, x, u, pi, lam, (far, k))
+            prev = ro
+        else:                                                      # keep the oracle's iterate in step with the solver's
+            x, u, pi, lam = (a.copy() for a in it)
+            prev = r.copy()
+    if far == 0.0:
+        assert all(modes), modes
+    else:
+        assert modes[0] and not all(modes), modes
+        i = modes.index(False)
+        assert not any(modes[i:i + 8]) and any(modes[i + 8:i + 10]), modes    # eight solves on the windowed kernel once a report is not zero, then a retry
     s.close()
 
 
