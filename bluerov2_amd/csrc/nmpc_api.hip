@@ -17,7 +17,7 @@
 using namespace brov;
 
 #define kTickMailboxMaxBatch 64          /* brov_tick_host: up to this many instances deliver their records through the host mailbox */
-#define kPitRoundsPause 8                  /* solves on the windowed kernel after the parallel-in-time rounds left an instance behind */
+#define kPitPause 8                        /* solves without the parallel-in-time kernel after it left some (not all) instances of a batch behind */
 #define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N > 81: up to this many instances run on the streaming kernels */
 
 static thread_local std::string g_err;
@@ -73,8 +73,10 @@ struct brov_solver {
     unsigned win_tick = 0;           // windowed launches so far: which of the two hand-out counters the next one uses
     int win_blocks = 0, win_L = 0;
     int alt_blocks = 0, alt_L = 0;   // parallel-in-time rounds (pit_rounds_stages): the resident configuration a solve may use instead
-    int32_t* pit_left_host = nullptr;   // ... pinned word: instances the parallel-in-time kernel left to the resident kernel in the last such solve
-    int rounds_pause = 0;            // ... solves still to run on the windowed kernel before the rounds are tried again
+    unsigned long long* pit_left_host = nullptr;   // pinned word: (sequence number << 32 | instances the parallel-in-time kernel left to the resident kernel) of the last solve it ran in
+    int32_t pit_seq = 0, pit_ignore_upto = 0, pit_probe_seq = 0;   // solves with that kernel issued so far / reports up to here are old news / the probe whose report is awaited
+    bool pit_want_probe = false;
+    int pit_pause = 0;               // ... solves still to run without the parallel-in-time kernel before it is tried again
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
     // general grid (streaming kernels): per-stage time steps and / or a separate stage-0 weight
@@ -266,12 +268,14 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
         size_t ws_doubles = (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L);
         if (!windowed_is_resident(s->win_L) && (s->alt_L = pit_rounds_stages(opts->N, B)) != 0) {   // one workspace per instance for rti_pit_kernel's blocks
             s->alt_blocks = windowed_blocks(opts->N, B, s->alt_L);
-            if (hipHostMalloc((void**)&s->pit_left_host, 64, hipHostMallocDefault) != hipSuccess) { s->pit_left_host = nullptr; rc = BROV_ERR_HIP; }
-            else *s->pit_left_host = 0;
             const size_t alt = (size_t)B * windowed_ws_doubles(opts->N, s->alt_L);
             ws_doubles = alt > ws_doubles ? alt : ws_doubles;
         }
         AL(ws, ws_doubles);
+        if (B > 1 && (s->alt_L || windowed_is_resident(s->win_L))) {   // the parallel-in-time kernel may serve this solver: its report word
+            if (hipHostMalloc((void**)&s->pit_left_host, 64, hipHostMallocDefault) != hipSuccess) { s->pit_left_host = nullptr; rc = BROV_ERR_HIP; }
+            else *s->pit_left_host = 0;
+        }
     }
 #undef AL
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
@@ -838,29 +842,48 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
             const bool pit_can = pit && s->pit_done && !s->dump_lin;
             P.pit_blocks = P.win_blocks;
-            bool rounds = pit_can && s->alt_L != 0;
-            if (rounds && !(getenv("BROV_PIT_ROUNDS_ADAPT") && atoi(getenv("BROV_PIT_ROUNDS_ADAPT")) == 0)) {
-                // What the parallel kernel leaves (instances that need an interior-point iteration or a fourth try) STARTS only when its rounds
-                // are over, from scratch, on the resident kernel: one such instance makes the solve longer than the windowed kernel's, where
-                // it would have started at once (a quarter of the batch saturated, one to three instances left: 0.465 against 0.375 ms).  The
-                // resident kernel reports the number into a pinned word; when the last report (a solve or two old: nobody waits for it) is not
-                // zero -- such instances stay for many ticks --, the next kPitRoundsPause solves run on the windowed kernel, then the
-                // rounds are tried again.
-                if (s->rounds_pause > 0) {
-                    rounds = false;
-                    if (--s->rounds_pause == 0) __atomic_store_n(s->pit_left_host, 0, __ATOMIC_RELAXED);   // (the retry starts from a clean slate: the reports
-                } else if (__atomic_load_n(s->pit_left_host, __ATOMIC_RELAXED) > 0) {   //  of the solves before the pause have landed)
-                    s->rounds_pause = kPitRoundsPause - 1; rounds = false;
+            // The parallel kernel runs AHEAD of the resident one: what it leaves (instances that need an interior-point iteration or a fourth
+            // try, and those its hint does not even let it try) STARTS only when it is over.  Alone, such an instance costs nothing extra (its
+            // block of the parallel kernel ends at once); next to instances the parallel kernel does complete it makes the solve LONGER than
+            // without that kernel -- 64 instances at N = 80 with a quarter saturated: the launch waits ~0.06 ms longer for its last three;
+            // 512 instances, two per CU: 0.465 against 0.375 ms on the windowed kernel.  The resident kernel therefore reports how many
+            // instances were left to it into a pinned host word, and when the last report (a solve or two old: nobody waits for it) says
+            // "some, not all" -- such instances stay for many ticks -- the next kPitPause solves go without the parallel kernel (resident
+            // kernel alone / windowed kernel), then it is tried again.  A batch of one never pauses.  BROV_PIT_ADAPT=0: never.
+            bool pit_now = pit_can && (s->alt_L != 0 || pit_supported(s->N, P.win_L));
+            bool probe = false;
+            if (pit_now && pit != 2 && s->pit_left_host && !(getenv("BROV_PIT_ADAPT") && atoi(getenv("BROV_PIT_ADAPT")) == 0)) {
+                // (the host may be many solves ahead of the device: reports carry the sequence number of their solve.  A report that
+                // starts a pause makes everything issued up to then old news; after the pause ONE solve probes, and until ITS report is
+                // in the solves go without the parallel kernel)
+                const unsigned long long rep = __atomic_load_n(s->pit_left_host, __ATOMIC_RELAXED);
+                const int32_t rs = (int32_t)(rep >> 32), left = (int32_t)(rep & 0xffffffffu);
+                const bool some = left > 0 && left < (int32_t)s->B;
+                if (s->pit_pause > 0) {
+                    pit_now = false;
+                    if (--s->pit_pause == 0) s->pit_want_probe = true;
+                } else if (s->pit_probe_seq) {
+                    if (rs == s->pit_probe_seq) {
+                        s->pit_probe_seq = 0;
+                        if (some) { s->pit_pause = kPitPause - 1; s->pit_ignore_upto = s->pit_seq; pit_now = false; }
+                    } else pit_now = false;
+                } else if (s->pit_want_probe) {
+                    s->pit_want_probe = false; probe = true;
+                } else if (some && rs > s->pit_ignore_upto) {
+                    s->pit_pause = kPitPause - 1; s->pit_ignore_upto = s->pit_seq; pit_now = false;
                 }
             }
-            if (rounds) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
+            if (pit_now && s->alt_L) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
                 P.win_L = s->alt_L; P.win_blocks = s->alt_blocks; P.ws_stride = (int64_t)windowed_ws_doubles(s->N, s->alt_L);
                 P.pit_blocks = (int32_t)s->B;
-                P.pit_left_host = s->pit_left_host;
             }
-            if (pit_can && pit_supported(s->N, P.win_L)) {
+            if (pit_now && pit_supported(s->N, P.win_L)) {
                 P.pit = pit; P.pit_done = s->pit_done;
                 P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);
+                P.pit_left_host = s->pit_left_host;
+                P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
+                if (s->pit_seq == 1) s->pit_ignore_upto = 0;   // (wrapped)
+                if (probe) s->pit_probe_seq = s->pit_seq;
             }
             s->pit_ran = P.pit != 0;
             launch_windowed(P, st); s->win_tick++;   // persistent blocks; the two hand-out counters alternate

@@ -23,7 +23,8 @@ struct DevParams {
     int32_t pit;             // parallel-in-time step-0 solve ahead of the resident windowed kernel: 0 off, 1 instances whose previous step was an early exit, 2 every instance (tests)
     int32_t pit_try;         // ... and, when the step-0 answer leaves the box, ONE active-set try parallel in time as well (default 1; BROV_PIT_TRY=0: A/B)
     int32_t pit_blocks;      // blocks of rti_pit_kernel = tickets it serves (win_blocks; B where every instance has a workspace of its own: pit_rounds_stages)
-    int32_t* pit_left_host;  // pinned host word (or nullptr): the resident kernel reports how many instances rti_pit_kernel left to it (pit_rounds_stages: the host's choice of mode)
+    unsigned long long* pit_left_host;   // pinned host word (or nullptr): the resident kernel reports (pit_seq << 32 | instances rti_pit_kernel left to it) -- the host's choice of mode
+    int32_t pit_seq;         // ... sequence number of this solve among those the parallel-in-time kernel ran in
     int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
     int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)

@@ -2993,7 +2993,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                 int done = 0;
                 for (int j = lane0; j < P.B; j += 64) done += P.pit_done[j] != 0;
                 done = (int)wave_sum((double)done);
-                if (lane0 == 0) __hip_atomic_store(P.pit_left_host, P.B - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane0 == 0) __hip_atomic_store(P.pit_left_host, ((unsigned long long)(unsigned)P.pit_seq << 32) | (unsigned)(P.B - done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -3848,7 +3848,7 @@ int windowed_blocks(int N, int B, int L) {
 // it leaves, instead of the windowed kernel: 512 instances at N = 80 take 0.154 ms against 0.192 ms (N = 60: 0.135 / ~0.153; N = 40:
 // 0.120 / 0.114 -- hence the lower limit; scripts/dev/mid_batch_rate.py).  What the parallel kernel leaves (instances with many active
 // bounds) starts only then, on one wave: a batch with a quarter of its instances saturated would lose 20 % against the windowed kernel --
-// the host follows the number of instances left (nmpc_api.hip, kPitRoundsPause; BROV_PIT_ROUNDS=0 keeps the windowed kernel altogether).  Decided per solve: the solver is created for the windowed kernel and with a
+// the host follows the number of instances left (nmpc_api.hip, kPitPause; BROV_PIT_ROUNDS=0 keeps the windowed kernel altogether).  Decided per solve: the solver is created for the windowed kernel and with a
 // workspace that serves either.  Returns the resident stage count (= N) or 0.
 constexpr int kPitRounds = 2, kPitRoundsMinN = 48;
 int pit_rounds_stages(int N, int B) {

@@ -25,7 +25,8 @@ def ba():
 
 @pytest.fixture(autouse=True)
 def _restore_env():
-    old = {k: os.environ.get(k) for k in ("BROV_PIT", "BROV_PIT_ROUNDS_ADAPT")}
+    old = {k: os.environ.get(k) for k in ("BROV_PIT", "BROV_PIT_ADAPT")}
+    os.environ["BROV_PIT_ADAPT"] = "0"      # (which kernel completes what is these tests' subject; the host's adaptive choice has its own test)
     yield
     for k, v in old.items():
         if v is None:
@@ -134,7 +135,6 @@ def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_inst
     x, u, pi, lam = oracle.init_iterate(op, B)
     pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
     prev = None
-    os.environ["BROV_PIT_ROUNDS_ADAPT"] = "0"          # (the mode is this test's to choose; the adaptive choice: next test)
     for k, mode in enumerate(["1", "1", "1", "0", "1", "2"]):
         os.environ["BROV_PIT"] = mode
         yref = np.ascontiguousarray(circ[k:k + N + 1])
@@ -155,16 +155,17 @@ def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_inst
     s.close()
 
 
-@pytest.mark.parametrize("far", [0.0, 0.3])
-def test_mode_of_such_batches_follows_what_the_parallel_kernel_leaves_behind(ba, oracle, golden_traj, far):
-    """What rti_pit_kernel leaves is served by one wave per instance behind it: when the resident kernel reports (pinned host word, read a
-    solve or two later) that an instance was left (it starts only when the rounds are over), the next eight solves run on the windowed kernel, then the rounds
-    are tried again.  A tracking batch stays in the rounds; one with 30 % of its instances far off alternates; every tick agrees with the
-    oracle in either mode."""
+@pytest.mark.parametrize("B,far", [(400, 0.0), (400, 0.3), (48, 0.0), (48, 0.3)])
+def test_the_host_pauses_the_parallel_kernel_while_it_leaves_instances_behind(ba, oracle, golden_traj, B, far):
+    """What rti_pit_kernel leaves starts only when that kernel is over: when the resident kernel reports (pinned host word, read a solve or
+    two later) that some -- not all -- instances were left, the next eight solves run without the parallel kernel (windowed kernel for
+    batches of two per CU, the resident kernel alone below), then it is tried again.  A tracking batch never pauses; one with 30 % of its
+    instances far off alternates; every tick agrees with the oracle in either mode."""
     import torch
-    N, B = 80, 400
-    if torch.cuda.get_device_properties(0).multi_processor_count >= B:
+    if B > 256 and torch.cuda.get_device_properties(0).multi_processor_count >= B:
         pytest.skip("needs a batch beyond one instance per CU")
+    os.environ["BROV_PIT_ADAPT"] = "1"
+    N = 80
     Ts = 1.0 / N
     x0, circ = _inputs(golden_traj, B, seed=77, far=far)
     s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
