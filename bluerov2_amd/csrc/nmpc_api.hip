@@ -848,10 +848,11 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // without that kernel -- 64 instances at N = 80 with a quarter saturated: the launch waits ~0.06 ms longer for its last three;
             // 512 instances, two per CU: 0.465 against 0.375 ms on the windowed kernel.  The resident kernel therefore reports how many
             // instances were left to it into a pinned host word, and when the last report (a solve or two old: nobody waits for it) says
-            // "some, not all" -- such instances stay for many ticks -- the next kPitPause solves go without the parallel kernel (resident
-            // kernel alone / windowed kernel), then it is tried again.  A batch of one never pauses.  BROV_PIT_ADAPT=0: never.
+            // "some, not all" -- such instances stay for many ticks -- the solves go without the parallel kernel: the resident kernel alone
+            // (which keeps reporting: the parallel kernel is back as soon as nothing would be left) or, for batches of two per CU, the
+            // windowed kernel for kPitPause solves, then one probe.  A batch of one never pauses.  BROV_PIT_ADAPT=0: never.
             bool pit_now = pit_can && (s->alt_L != 0 || pit_supported(s->N, P.win_L));
-            bool probe = false;
+            bool probe = false, resident_report = false;
             if (pit_now && pit != 2 && s->pit_left_host && !(getenv("BROV_PIT_ADAPT") && atoi(getenv("BROV_PIT_ADAPT")) == 0)) {
                 // (the host may be many solves ahead of the device: reports carry the sequence number of their solve.  A report that
                 // starts a pause makes everything issued up to then old news; after the pause ONE solve probes, and until ITS report is
@@ -859,7 +860,13 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
                 const unsigned long long rep = __atomic_load_n(s->pit_left_host, __ATOMIC_RELAXED);
                 const int32_t rs = (int32_t)(rep >> 32), left = (int32_t)(rep & 0xffffffffu);
                 const bool some = left > 0 && left < (int32_t)s->B;
-                if (s->pit_pause > 0) {
+                if (!s->alt_L) {
+                    // at most one instance per CU: without the parallel kernel the solve is the resident kernel's as well, which then reports what
+                    // that kernel WOULD leave (its hint, from the records of the solve before) -- no pause to count, no probe: the parallel
+                    // kernel runs whenever the latest report says "none" or "all"
+                    pit_now = !some;
+                    resident_report = true;
+                } else if (s->pit_pause > 0) {
                     pit_now = false;
                     if (--s->pit_pause == 0) s->pit_want_probe = true;
                 } else if (s->pit_probe_seq) {
@@ -884,6 +891,10 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
                 P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
                 if (s->pit_seq == 1) s->pit_ignore_upto = 0;   // (wrapped)
                 if (probe) s->pit_probe_seq = s->pit_seq;
+            }
+            if (resident_report && !P.pit) {   // (the resident kernel alone: its estimate goes into the same word)
+                P.pit_left_host = s->pit_left_host;
+                P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
             }
             s->pit_ran = P.pit != 0;
             launch_windowed(P, st); s->win_tick++;   // persistent blocks; the two hand-out counters alternate
