@@ -76,6 +76,7 @@ struct brov_solver {
     unsigned long long* pit_left_host = nullptr;   // pinned word: (sequence number << 32 | instances the parallel-in-time kernel left to the resident kernel) of the last solve it ran in
     int32_t pit_seq = 0, pit_ignore_upto = 0, pit_probe_seq = 0;   // solves with that kernel issued so far / reports up to here are old news / the probe whose report is awaited
     bool pit_want_probe = false;
+    int prep_path = 0;               // the last rti_phase-1 call: 1 streaming pair (linearisation in HBM), 2 resident split (factorised LDS image parked)
     int pit_pause = 0;               // ... solves still to run without the parallel-in-time kernel before it is tried again
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
@@ -828,7 +829,15 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     // separate calls) need the linearisation in HBM between the calls: streaming kernels.
     // a general grid (per-stage time steps / separate stage-0 weight) runs on the LDS-resident kernels too (round 4: rti_fused_kernel_grid,
     // rti_window_kernel_grid, rti_window_kernel_res_grid, rti_pit_kernel_grid)
-    const bool lds_path = rti_phase == 0 && path != BROV_PATH_STREAMING;
+    // rti_phase 1 / 2 in the windowed kernel's resident mode (at most one instance per CU at 24 <= N <= 81, uniform grid): the split
+    // launches of rti_window_kernel_res_split -- preparation parks the factorised LDS image per instance, feedback runs from the forward
+    // sweep on.  A feedback call follows the path its preparation took (prep_path); BROV_SPLIT_RESIDENT=0: the streaming pair as before.
+    const bool split_res_ok = path != BROV_PATH_STREAMING && !(fused_supported(s->N) && !s->force_windowed) && s->ws != nullptr &&
+                              windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !general_grid(s) && !s->dump_lin &&
+                              !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0);
+    const bool split_res = (rti_phase == 1 && split_res_ok) || (rti_phase == 2 && split_res_ok && s->prep_path == 2);
+    if (rti_phase == 1) s->prep_path = split_res ? 2 : 1;
+    const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING;
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
     const bool windowed = lds_path && !fused && s->ws != nullptr;
     s->pit_ran = false;
@@ -840,7 +849,8 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
-            const bool pit_can = pit && s->pit_done && !s->dump_lin;
+            const bool pit_can = pit && s->pit_done && !s->dump_lin && rti_phase == 0;
+            P.rti_split = rti_phase;
             P.pit_blocks = P.win_blocks;
             // The parallel kernel runs AHEAD of the resident one: what it leaves (instances that need an interior-point iteration or a fourth
             // try, and those its hint does not even let it try) STARTS only when it is over.  Alone, such an instance costs nothing extra (its
@@ -973,7 +983,8 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     // at N = 20: those go through the copy engine ahead of the launch, and the other inputs with them).
     const bool bulk = !mailbox && rti_phase != 1 && B > kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0) &&
                       !(getenv("BROV_TICK_BULK") && atoi(getenv("BROV_TICK_BULK")) == 0);
-    const bool zerocopy = (mailbox || (bulk && !par_stage)) && rti_phase == 0 && !(getenv("BROV_TICK_ZEROCOPY") && atoi(getenv("BROV_TICK_ZEROCOPY")) == 0);
+    // (a feedback call, rti_phase 2, too: its kernel reads the new measurement where the host has just put it)
+    const bool zerocopy = (mailbox || (bulk && !par_stage)) && rti_phase != 1 && !(getenv("BROV_TICK_ZEROCOPY") && atoi(getenv("BROV_TICK_ZEROCOPY")) == 0);
     auto upload = [&](hipStream_t cs) -> int {
         if (x0 && yref_shared && par_stage) {   // device side: one allocation in the same order (brov_create)
             HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, cs));

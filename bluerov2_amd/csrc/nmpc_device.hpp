@@ -27,6 +27,7 @@ struct DevParams {
     int32_t pit_seq;         // ... sequence number of this solve among those the parallel-in-time kernel ran in
     int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
     int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
+    int32_t rti_split;       // resident windowed kernel, rti_phase 1 / 2 as separate launches: 1 = preparation (linearise + step-0 factor sweep, LDS image parked per instance), 2 = feedback (image fetched, everything that depends on x0); 0 = one launch
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)
     double Ts, tol_mu, tol_stat;
     double W[16], We[12], lbu[4], ubu[4];

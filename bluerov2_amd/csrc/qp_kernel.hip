@@ -2947,8 +2947,14 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
 // one instance per CU.  Nothing is parked and no window is fetched.  A separate instantiation (rti_window_kernel_res), so that the
 // large-batch kernel carries none of its code.
-template <bool RES, bool GRID = false>
+// SPLIT (resident mode only): acados' rti_phase 1 / 2 as two launches (DevParams::rti_split).  The whole backward sweep -- P, p, gains,
+// feed-forward terms -- is independent of the measured state (x0 enters with dx_0 = x0 - x_0 in the forward roll-out only), so the
+// PREPARATION launch linearises, factorises and parks the LDS image in the instance's workspace, and the FEEDBACK launch fetches it and runs
+// qp_body from the forward sweep on: what is left between the arrival of a measurement and u0 is the forward sweep, the bound check, the
+// step and the record.  A separate instantiation (rti_window_kernel_res_split).
+template <bool RES, bool GRID = false, bool SPLIT = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
+    static_assert(!SPLIT || (RES && !GRID), "the split launches exist for the resident mode on the uniform grid");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;       // (RES: four waves per block, see below)
@@ -2968,6 +2974,17 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         // without communication), hand their KKT partials over through the (then dead) stage-record area and end.  The sweeps are
         // serial recursions: wave 0 runs them alone, as it runs everything of any further instance of the block.
         if (threadIdx.x >= 64) {
+            if constexpr (SPLIT) {
+                if (P.rti_split == 2) {   // feedback: nothing to linearise -- the helper waves fetch their quarters of the parked image and end
+                    const int wvf = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                    const int bf = __builtin_amdgcn_readfirstlane(sched_map(P, (int)blockIdx.x));
+                    const int nd = win_img_doubles(Lc), q = ((nd / 4 + 127) / 128) * 128, o = wvf * q;
+                    if (o < nd) win_fetch(P.ws + (size_t)bf * P.ws_stride + o, smem + o, nd - o < q ? nd - o : q, lane0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    return;
+                }
+            }
             const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
             const int b = __builtin_amdgcn_readfirstlane(sched_map(P, (int)blockIdx.x));
             if (P.pit_done && P.pit_done[b]) return;   // rti_pit_kernel has completed this instance's step (wave 0 takes the same decision)
@@ -3037,6 +3054,12 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         // everything per-lane the sweeps need is (re)built AFTER each linearisation call, so that nothing of it is live across
         // lin_phase (which needs the whole architectural register file)
         const LaneCst lc = load_lane_cst(P.cst, lane);
+        if constexpr (SPLIT) {   // the parked image belongs to the INSTANCE (the two launches need not give it the same block)
+            ws = P.ws + (size_t)b * P.ws_stride;
+            W.img = ws;
+            ws_vhat = ws + (size_t)nc * win_img_doubles(Lc); ws_dxb = ws_vhat + (size_t)N * 4; ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
+            ws_Mt = ws_Ks + (size_t)N * 64; ws_Pb = ws_Mt + (size_t)N * 64; ws_ipm = ws_Pb + (size_t)N * NX; ws_ck = ws_ipm + (size_t)IPM_NARR * 4 * N;
+        }
         auto setup = [&](InstT& I) __attribute__((always_inline)) {
             setup_inst(P, I, b, lane, &lc);
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
@@ -3075,7 +3098,8 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         BwdState S;
         W.cur = -1;
         unsigned long long t_lin = 0, t_bwd = 0, t_fl = 0;   // developer instrumentation (P.dbg): pass-1 split, slot 7
-        for (int c = nc - 1; c >= 0; c--) {
+        const bool feedback = SPLIT && P.rti_split == 2;
+        for (int c = feedback ? -1 : nc - 1; c >= 0; c--) {
             const int i0 = c * Lc, n = (N - i0 < Lc) ? N - i0 : Lc;
             const unsigned long long t0 = P.dbg ? __builtin_readcyclecounter() : 0;
             // cost gradient of the stage after the window (row n of the window's q array; the adjoint sweep reads it): requested
@@ -3147,6 +3171,29 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             if (P.dbg) { const unsigned long long t3 = __builtin_readcyclecounter(); t_lin += t1 - t0; t_bwd += t2 - t1; t_fl += t3 - t2; }
         }
         if (P.dbg && lane == 0) P.dbg[(size_t)b * 8 + 7] = (t_lin & 0xFFFFF) | ((t_bwd & 0xFFFFF) << 20) | ((t_fl & 0xFFFFF) << 40);
+        if constexpr (SPLIT) {
+            double* hdr = ws_ck + 384 + 504;   // (behind the resident mode's copy of the feed-forward terms: 4 N <= 320 of its 512 doubles)
+            if (P.rti_split == 1) {
+                // preparation ends here: the slice as it stands -- [A B] | b | q | r | K^T | kff -- into the instance's workspace, with the KKT
+                // partial of the linearisation and the verdicts of the factor sweep
+                const double pw = wave_max(part);
+                const bool nn = __ballot(nanp) != 0ull;
+                win_flush(W.img, smem, win_img_doubles(Lc), lane);
+                if (lane == 0) { hdr[0] = nn ? __builtin_nan("") : pw; hdr[1] = S.ok ? 1.0 : 0.0; hdr[2] = S.illc ? 1.0 : 0.0; }
+                __syncthreads();
+                continue;
+            }
+            // feedback starts here
+            const double h0 = hdr[0], h1 = hdr[1], h2 = hdr[2];
+            {   // this wave's quarter of the image (the helper waves fetch the others, see above)
+                const int nd = win_img_doubles(Lc), q = ((nd / 4 + 127) / 128) * 128;
+                win_fetch(W.img, smem, nd < q ? nd : q, lane);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            nanp = !(h0 == h0); part = nanp ? 0.0 : h0;
+            S.ok = h1 != 0.0; S.illc = h2 != 0.0;
+        }
         InstT I;
         setup(I);
         W.cur = -1;
@@ -3169,6 +3216,8 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_wi
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_grid(DevParams P) { rti_window_body<false, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res_grid(DevParams P) { rti_window_body<true, true>(P); }
+// rti_phase 1 / 2 as separate launches in the resident mode (see SPLIT above)
+__global__ __launch_bounds__(256, 1) void rti_window_kernel_res_split(DevParams P) { rti_window_body<true, false, true>(P); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Parallel-in-time step-0 solve (round 4): rti_pit_kernel, for the batches the resident mode serves (at most one instance per CU, the
@@ -3833,6 +3882,7 @@ int windowed_blocks(int N, int B, int L) {
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     int dev = 0, cus = 256, per_cu = 4;
     (void)hipGetDevice(&dev);
@@ -3875,7 +3925,8 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
             if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
             else hipLaunchKernelGGL(rti_pit_kernel, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
         }
-        if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+        if (P.rti_split) hipLaunchKernelGGL(rti_window_kernel_res_split, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+        else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
     }
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+timeout 900 python -m pytest tests/test_gpu_edge.py tests/test_gpu_shim.py -m gpu -q --timeout 600 -x -rfE 2>&1 | grep -v "^$" | tail -15
+timeout 300 python scripts/dev/split_tick_latency.py 80
+timeout 300 python scripts/dev/split_tick_latency.py 40

@@ -247,6 +247,56 @@ def test_rti_phase_split_equals_full_step(ba, golden_traj):
         s.close()
 
 
+@pytest.mark.parametrize("N,B,big", [(80, 1, 0.0), (80, 6, 2.5), (40, 3, 2.5), (57, 2, 0.0)])
+def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, golden_traj, N, B, big):
+    """At most one instance per CU at N > 23: rti_phase 1 / 2 run as the two launches of rti_window_kernel_res_split -- the preparation
+    linearises, runs the step-0 factor sweep (independent of the measured state) and parks the LDS image, the feedback fetches it and
+    runs from the forward sweep on.  Same code on the same data as the one-launch resident kernel: bit-identical records and iterates
+    (BROV_PIT=0 on the reference side: the parallel-in-time kernel sums in another order), tick after tick, also through the tick call,
+    also for instances that run the QP loop (checkpoint of the partial refactorisation parked with the image)."""
+    import ctypes as C
+    x0, circ = _inputs(golden_traj, B, seed=61, big=big)
+    win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])
+    old = os.environ.get("BROV_PIT")
+    os.environ["BROV_PIT"] = "0"
+    try:
+        full = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); split = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); tk = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
+        for s in (full, split, tk):
+            s.set_params(ba.P_NOMINAL); s.set_x0(x0)
+        n_loop = 0
+        for k in range(5):
+            xk = x0 + 0.02 * k
+            full.set_yref(win[k:k + N + 1]); full.set_x0(xk); full.solve()
+            split.set_yref(win[k:k + N + 1])
+            assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0          # preparation with the OLD measurement ...
+            split.set_x0(xk)
+            assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0          # ... feedback with the new one
+            assert split.last_kernel_path() == 3
+            tk.tick(yref=win[k:k + N + 1], rti_phase=1)
+            rt = tk.tick(x0=xk, rti_phase=2)
+            rf = full.results()
+            assert rf.tobytes() == split.results().tobytes() == rt.tobytes(), k
+            for a, b_, c in zip(full.get_iterate(), split.get_iterate(), tk.get_iterate()):
+                assert np.array_equal(a, b_) and np.array_equal(a, c)
+            n_loop += int((rf["qp_iter"] > 0).sum())
+        if big:
+            assert n_loop > 0
+        # the streaming pair on request: the same step to rounding
+        os.environ["BROV_SPLIT_RESIDENT"] = "0"
+        st = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); st.set_params(ba.P_NOMINAL); st.set_x0(x0); st.set_yref(win[:N + 1])
+        ref = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); ref.set_params(ba.P_NOMINAL); ref.set_x0(x0); ref.set_yref(win[:N + 1]); ref.solve()
+        assert st._L.brov_solve_phase(st._h, C.c_void_p(0), 1) == 0 and st._L.brov_solve_phase(st._h, C.c_void_p(0), 2) == 0
+        assert st.last_kernel_path() == 1 and np.abs(st.results()["u0"] - ref.results()["u0"]).max() < 1e-7
+        for s in (full, split, tk, st, ref):
+            s.close()
+    finally:
+        os.environ.pop("BROV_SPLIT_RESIDENT", None)
+        if old is None:
+            os.environ.pop("BROV_PIT", None)
+        else:
+            os.environ["BROV_PIT"] = old
+
+
 def test_setters_reject_bad_shapes(ba):
     s = ba.BatchSolver(3, ba.SolverOptions(10))
     with pytest.raises(ValueError):
