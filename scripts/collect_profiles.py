@@ -55,7 +55,7 @@ def main(tag, rnd):
         d["note"] = ("summary of gpurun_out/parity_excused.json: per rule, the number of rule calls, instances checked and instances excused in ONE run of "
                      "`pytest tests -m gpu`; entries_with_excused lists the calls that excused anything (first 40)")
         json.dump(d, open(os.path.join(dst, f"{rnd}_parity_excused.json"), "w"), indent=1)
-    for txt in ("phase_stamps_N20.txt", "phase_stamps_N80.txt", "pit_stamps_N80.txt", "phase_stamps_N80_B1_sequential.txt", "shim_latency.txt"):
+    for txt in ("phase_stamps_N20.txt", "phase_stamps_N80.txt", "pit_stamps_N80.txt", "phase_stamps_N80_B1_sequential.txt", "shim_latency.txt", "split_tick_latency.txt"):
         if os.path.exists(os.path.join(src, txt)):
             shutil.copy(os.path.join(src, txt), os.path.join(dst, f"{rnd}_{txt}"))
     print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(rnd + "_")))
