@@ -131,13 +131,31 @@ def batch1_tick(ba, ticks=300, warm=30):
                 if rep >= 5:
                     w1.append((t1 - t0) * 1e6); it1.append(int(r1["qp_iter"][0]))
             one_try = dict(wall_us_median=float(np.median(w1)), newton_systems=int(np.median(it1)), solved_parallel_in_time=bool(s.pit_last()[0]))
+        split = None
+        if N == 80:
+            # acados' preparation / feedback split (rti_phase 1, then 2 with the new measurement): the preparation -- linearisation and the
+            # step-0 factor sweep, which does not depend on x0 -- runs between two measurements; what is timed is the FEEDBACK call
+            s.reset(); s.init_iterate_default()
+            wf, wp = [], []
+            for k in range(warm + 200):
+                y = np.ascontiguousarray(circ[k % 16:k % 16 + N + 1])
+                t0 = time.perf_counter(); s.tick(yref=y, params=p, rti_phase=1); t1 = time.perf_counter()
+                while time.perf_counter() - t1 < 100e-6:
+                    pass
+                t2 = time.perf_counter(); r2 = s.tick(x0=x0, rti_phase=2); t3 = time.perf_counter()
+                if k >= warm:
+                    wp.append((t1 - t0) * 1e6); wf.append((t3 - t2) * 1e6)
+            split = dict(feedback_wall_us_median=float(np.median(wf)), feedback_wall_us_p99=float(np.sort(wf)[int(0.99 * len(wf))]),
+                         preparation_wall_us_median=float(np.median(wp)), status=int(r2["status"][0]), kernel_path=int(s.last_kernel_path()))
         out[f"N{N}"] = dict(wall_us_median=res["back_to_back"]["wall_us_median"], wall_us_p99=res["back_to_back"]["wall_us_p99"],
                             idle_200us_between_ticks=res["idle_200us_between_ticks"], status=int(r["status"][0]), kernel_path=int(s.last_kernel_path()),
-                            step0_parallel_in_time=bool(n_pit == 2), **({"saturated_inputs_one_try": one_try} if one_try else {}))
+                            step0_parallel_in_time=bool(n_pit == 2), **({"saturated_inputs_one_try": one_try} if one_try else {}),
+                            **({"rti_phase_split": split} if split else {}))
         s.close()
     out["note"] = ("one instance through brov_tick_host (python ctypes caller): host -> device upload, RTI step, record back; "
                    "compare cpu_baseline_single_thread.  N80: the step-0 solve runs parallel in time on the block's four wavefronts "
-                   "(rti_pit_kernel, DESIGN.md 4.5; BROV_PIT=0: the sequential resident kernel alone, 132 / 119 us)")
+                   "(rti_pit_kernel, DESIGN.md 4.5; BROV_PIT=0: the sequential resident kernel alone, 124 / 115 us); rti_phase_split: the feedback half of "
+                   "a tick whose preparation ran between two measurements (rti_window_kernel_res_split)")
     return out
 
 
