@@ -836,6 +836,10 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
                               windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !general_grid(s) && !s->dump_lin &&
                               !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0);
     const bool split_res = (rti_phase == 1 && split_res_ok) || (rti_phase == 2 && split_res_ok && s->prep_path == 2);
+    if (rti_phase == 2 && s->prep_path == 2 && !split_res_ok) {   // (a grid / option / path change between the two calls)
+        g_err = "brov_solve: rti_phase 2 after a preparation on the resident kernel, which the solver's settings no longer allow: repeat rti_phase 1";
+        return BROV_ERR_ARG;
+    }
     if (rti_phase == 1) s->prep_path = split_res ? 2 : 1;
     const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING;
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;

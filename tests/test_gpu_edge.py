@@ -281,6 +281,13 @@ def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, g
             n_loop += int((rf["qp_iter"] > 0).sum())
         if big:
             assert n_loop > 0
+        # a feedback call whose preparation the solver's settings no longer allow is refused, not served from a stale image
+        split.set_yref(win[:N + 1])
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0
+        split.set_time_steps(1.0 / N * 1.01 ** np.arange(N))
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) != 0
+        split.set_time_steps(None)
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0 and split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0
         # the streaming pair on request: the same step to rounding
         os.environ["BROV_SPLIT_RESIDENT"] = "0"
         st = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); st.set_params(ba.P_NOMINAL); st.set_x0(x0); st.set_yref(win[:N + 1])
