@@ -76,7 +76,7 @@ struct brov_solver {
     unsigned long long* pit_left_host = nullptr;   // pinned word: (sequence number << 32 | instances the parallel-in-time kernel left to the resident kernel) of the last solve it ran in
     int32_t pit_seq = 0, pit_ignore_upto = 0, pit_probe_seq = 0;   // solves with that kernel issued so far / reports up to here are old news / the probe whose report is awaited
     bool pit_want_probe = false;
-    int prep_path = 0;               // the last rti_phase-1 call: 1 streaming pair (linearisation in HBM), 2 resident split (factorised LDS image parked)
+    int prep_path = 0;               // the last rti_phase-1 call: 1 streaming pair (linearisation in HBM), 2 resident split (factorised LDS image parked), 3 the latter, invalidated by a setter
     int pit_pause = 0;               // ... solves still to run without the parallel-in-time kernel before it is tried again
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
@@ -190,6 +190,7 @@ static int upload_cst(brov_solver* s) {
 }
 
 extern "C" int brov_init_iterate_default(brov_solver* s) {
+    if (s && s->prep_path == 2) s->prep_path = 3;   // a parked preparation (rti_phase 1, resident kernel) does not survive this call
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     const int B = s->B, N = s->N;
@@ -426,6 +427,7 @@ extern "C" int brov_set_param_stage_host(brov_solver* s, int inst, int stage, co
 }
 // ---- boundary corners of the reference API: non-uniform grids and a separate stage-0 weight ------------------------------------
 extern "C" int brov_set_time_steps(brov_solver* s, const double* ts) {
+    if (s && s->prep_path == 2) s->prep_path = 3;   // a parked preparation (rti_phase 1, resident kernel) does not survive this call
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(sync_last(s));
@@ -441,6 +443,7 @@ extern "C" int brov_set_time_steps(brov_solver* s, const double* ts) {
     return upload_cst(s);
 }
 extern "C" int brov_set_stage0_weight(brov_solver* s, const double* W0) {
+    if (s && s->prep_path == 2) s->prep_path = 3;   // a parked preparation (rti_phase 1, resident kernel) does not survive this call
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(sync_last(s));
@@ -748,6 +751,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
 }
 
 extern "C" int brov_set_iterate_host(brov_solver* s, const double* x, const double* u, const double* pi, const double* lam) {
+    if (s && s->prep_path == 2) s->prep_path = 3;   // a parked preparation (rti_phase 1, resident kernel) does not survive this call
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(sync_last(s));   // a solve on a non-blocking stream may still be writing the iterate
@@ -770,6 +774,7 @@ extern "C" int brov_get_iterate_host(brov_solver* s, double* x, double* u, doubl
     return BROV_OK;
 }
 extern "C" int brov_reset(brov_solver* s) {  // acados_solver_bluerov2.c:797-830: everything to zero
+    if (s && s->prep_path == 2) s->prep_path = 3;   // a parked preparation (rti_phase 1, resident kernel) does not survive this call
     if (!s) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(sync_last(s));
@@ -829,14 +834,14 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     // separate calls) need the linearisation in HBM between the calls: streaming kernels.
     // a general grid (per-stage time steps / separate stage-0 weight) runs on the LDS-resident kernels too (round 4: rti_fused_kernel_grid,
     // rti_window_kernel_grid, rti_window_kernel_res_grid, rti_pit_kernel_grid)
-    // rti_phase 1 / 2 in the windowed kernel's resident mode (at most one instance per CU at 24 <= N <= 81, uniform grid): the split
+    // rti_phase 1 / 2 in the windowed kernel's resident mode (at most one instance per CU at 24 <= N <= 81): the split
     // launches of rti_window_kernel_res_split -- preparation parks the factorised LDS image per instance, feedback runs from the forward
     // sweep on.  A feedback call follows the path its preparation took (prep_path); BROV_SPLIT_RESIDENT=0: the streaming pair as before.
     const bool split_res_ok = path != BROV_PATH_STREAMING && !(fused_supported(s->N) && !s->force_windowed) && s->ws != nullptr &&
-                              windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !general_grid(s) && !s->dump_lin &&
+                              windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !s->dump_lin &&
                               !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0);
     const bool split_res = (rti_phase == 1 && split_res_ok) || (rti_phase == 2 && split_res_ok && s->prep_path == 2);
-    if (rti_phase == 2 && s->prep_path == 2 && !split_res_ok) {   // (a grid / option / path change between the two calls)
+    if (rti_phase == 2 && (s->prep_path == 3 || (s->prep_path == 2 && !split_res_ok))) {   // (a grid / option / iterate / path change between the two calls)
         g_err = "brov_solve: rti_phase 2 after a preparation on the resident kernel, which the solver's settings no longer allow: repeat rti_phase 1";
         return BROV_ERR_ARG;
     }
@@ -1069,6 +1074,7 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
 }
 
 extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
+    if (s && s->prep_path == 2) s->prep_path = 3;   // a parked preparation (rti_phase 1, resident kernel) does not survive this call
     if (!s || !o || o->N != s->N) { g_err = "brov_set_opts: bad argument (N is fixed at create)"; return BROV_ERR_ARG; }
     if (const char* why = opts_problem(o)) { g_err = std::string("brov_set_opts: ") + why; return BROV_ERR_ARG; }
     if (o->kernel_path == BROV_PATH_FUSED && !fused_supported(o->N) && !s->ws) {

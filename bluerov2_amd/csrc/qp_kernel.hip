@@ -2951,10 +2951,10 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // feed-forward terms -- is independent of the measured state (x0 enters with dx_0 = x0 - x_0 in the forward roll-out only), so the
 // PREPARATION launch linearises, factorises and parks the LDS image in the instance's workspace, and the FEEDBACK launch fetches it and runs
 // qp_body from the forward sweep on: what is left between the arrival of a measurement and u0 is the forward sweep, the bound check, the
-// step and the record.  A separate instantiation (rti_window_kernel_res_split).
+// step and the record.  Separate instantiations (rti_window_kernel_res_split, _split_grid).
 template <bool RES, bool GRID = false, bool SPLIT = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
-    static_assert(!SPLIT || (RES && !GRID), "the split launches exist for the resident mode on the uniform grid");
+    static_assert(!SPLIT || RES, "the split launches exist for the resident mode");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;       // (RES: four waves per block, see below)
@@ -3218,6 +3218,7 @@ __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { r
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res_grid(DevParams P) { rti_window_body<true, true>(P); }
 // rti_phase 1 / 2 as separate launches in the resident mode (see SPLIT above)
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res_split(DevParams P) { rti_window_body<true, false, true>(P); }
+__global__ __launch_bounds__(256, 1) void rti_window_kernel_res_split_grid(DevParams P) { rti_window_body<true, true, true>(P); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Parallel-in-time step-0 solve (round 4): rti_pit_kernel, for the batches the resident mode serves (at most one instance per CU, the
@@ -3883,6 +3884,7 @@ int windowed_blocks(int N, int B, int L) {
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     int dev = 0, cus = 256, per_cu = 4;
     (void)hipGetDevice(&dev);
@@ -3925,7 +3927,8 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
             if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
             else hipLaunchKernelGGL(rti_pit_kernel, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
         }
-        if (P.rti_split) hipLaunchKernelGGL(rti_window_kernel_res_split, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+        if (P.rti_split && P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_split_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+        else if (P.rti_split) hipLaunchKernelGGL(rti_window_kernel_res_split, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
     }

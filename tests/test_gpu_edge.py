@@ -247,12 +247,12 @@ def test_rti_phase_split_equals_full_step(ba, golden_traj):
         s.close()
 
 
-@pytest.mark.parametrize("N,B,big", [(80, 1, 0.0), (80, 6, 2.5), (40, 3, 2.5), (57, 2, 0.0)])
-def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, golden_traj, N, B, big):
+@pytest.mark.parametrize("N,B,big,grid", [(80, 1, 0.0, False), (80, 6, 2.5, False), (40, 3, 2.5, False), (57, 2, 0.0, False), (80, 3, 2.5, True)])
+def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, golden_traj, N, B, big, grid):
     """At most one instance per CU at N > 23: rti_phase 1 / 2 run as the two launches of rti_window_kernel_res_split -- the preparation
     linearises, runs the step-0 factor sweep (independent of the measured state) and parks the LDS image, the feedback fetches it and
     runs from the forward sweep on.  Same code on the same data as the one-launch resident kernel: bit-identical records and iterates
-    (BROV_PIT=0 on the reference side: the parallel-in-time kernel sums in another order), tick after tick, also through the tick call,
+    (BROV_PIT=0 on the reference side: the parallel-in-time kernel sums in another order), tick after tick, also through the tick call, on a general grid,
     also for instances that run the QP loop (checkpoint of the partial refactorisation parked with the image)."""
     import ctypes as C
     x0, circ = _inputs(golden_traj, B, seed=61, big=big)
@@ -263,6 +263,8 @@ def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, g
         full = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); split = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); tk = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
         for s in (full, split, tk):
             s.set_params(ba.P_NOMINAL); s.set_x0(x0)
+            if grid:   # (a geometric grid: rti_window_kernel_res_split_grid against rti_window_kernel_res_grid)
+                s.set_time_steps(1.0 / N * 1.01 ** np.arange(N))
         n_loop = 0
         for k in range(5):
             xk = x0 + 0.02 * k
@@ -284,9 +286,8 @@ def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, g
         # a feedback call whose preparation the solver's settings no longer allow is refused, not served from a stale image
         split.set_yref(win[:N + 1])
         assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0
-        split.set_time_steps(1.0 / N * 1.01 ** np.arange(N))
+        split.set_time_steps(1.0 / N * 1.02 ** np.arange(N))
         assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) != 0
-        split.set_time_steps(None)
         assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0 and split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0
         # the streaming pair on request: the same step to rounding
         os.environ["BROV_SPLIT_RESIDENT"] = "0"
