@@ -2937,11 +2937,15 @@ constexpr int kWinMaxStages = 20;
 constexpr int kLinMaxIntervals = 23;   // lin_phase: 64 / n >= 2 lanes per interval
 __host__ __device__ inline int win_chunks(int N) { return (N + kWinMaxStages - 1) / kWinMaxStages; }
 __host__ __device__ inline int win_len(int N) { const int nc = win_chunks(N); return (N + nc - 1) / nc; }
+// resident split launches: what the preparation parks per quarter of the horizon for a feedback that rolls out the four quarters at once --
+// the quarter's closed-loop transition (Psi = Phi', 256), its affine term (row 12 of G as the lanes hold it, 64), and the cost-to-go (P, p) at
+// the quarter's END (192 + 192)
+constexpr int kSegPark = 704;
 __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
     return (size_t)((N + L - 1) / L) * win_img_doubles(L)                  // parked window images
            + (size_t)N * 4 + (size_t)(N + 1) * NX                          // vhat, dx (flat over the horizon)
            + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N         // Ks Mt Pb | interior-point vectors
-           + 384 + 512;                                                    // (P, p) entering window 0 (resident mode: stage ckpt): checkpoint of the partial
+           + 384 + 512 + 4 * kSegPark;                                     // (P, p) entering window 0 (resident mode: stage ckpt): checkpoint of the partial
                                                                            // refactorisation; resident mode: + the step-0 feed-forward terms (4 N <= 512)
 }
 // RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
@@ -2978,6 +2982,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                 if (P.rti_split == 2) {   // feedback: nothing to linearise -- the helper waves fetch their quarters of the parked image and end
                     const int wvf = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
                     const int bf = __builtin_amdgcn_readfirstlane(sched_map(P, (int)blockIdx.x));
+                    if (P.pit_done && P.pit_done[bf]) return;   // (rti_pit_kernel_fb has completed this instance's step)
                     const int nd = win_img_doubles(Lc), q = ((nd / 4 + 127) / 128) * 128, o = wvf * q;
                     if (o < nd) win_fetch(P.ws + (size_t)bf * P.ws_stride + o, smem + o, nd - o < q ? nd - o : q, lane0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3143,7 +3148,34 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             setup(I);
             win_select(I, W, c);
             if (c == nc - 1) bwd_init<true, 3>(I, S);
-            if constexpr (RES) {
+            if constexpr (SPLIT) {
+                // preparation of a split tick: the same sweep in FOUR parts (the quarters the linearisation was made in; the stage checkpoint is
+                // the first quarter's end) with the condensing accumulators of the parallel-in-time kernel -- here, with the exact cost-to-go
+                // carried from quarter to quarter, they yield each quarter's exact closed-loop transition (Psi, c) --, parked with the
+                // cost-to-go at the quarter's end for a feedback launch that rolls out the four quarters at once (rti_pit_kernel_fb)
+                const int lsub = (n + 3) >> 2, rg = I.rg, cl = I.cl;
+                double* par = ws_ck + 896;
+#pragma clang loop unroll(disable)
+                for (int j = 3; j >= 0; j--) {
+                    const int lo = j * lsub, hi = lo + lsub < n ? lo + lsub : n;
+                    if (lo >= n) continue;
+                    double* pj = par + (size_t)j * kSegPark;
+#pragma unroll
+                    for (int r = 0; r < 3; r++) { pj[320 + r * 64 + lane] = S.P[r]; pj[512 + r * 64 + lane] = S.pv[r]; }
+                    if (hi == I.ckpt) {
+#pragma unroll
+                        for (int r = 0; r < 3; r++) { ws_ck[r * 64 + lane] = S.P[r]; ws_ck[192 + r * 64 + lane] = S.pv[r]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; r++) S.acc.Psi[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
+                    S.acc.Psi[3] = 0.0;
+                    S.acc.G = d4{0, 0, 0, 0};
+                    bwd_chunk<true, 3, false, true, false, InstT, true>(I, S, hi, lo);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) pj[r * 64 + lane] = S.acc.Psi[r];
+                    pj[256 + lane] = S.acc.G[3];
+                }
+            } else if constexpr (RES) {
                 // resident mode: one window, so the checkpoint of the partial refactorisation is a STAGE (as in the fused kernels): the
                 // sweep in two parts out of one copy of the stage loop, (P, p) entering stage ckpt - 1 stored between them
 #pragma clang loop unroll(disable)
@@ -3329,8 +3361,14 @@ __device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int l
     }
 }
 
-template <bool GRID>
+// FB: the FEEDBACK half of a split tick (rti_phase 2 behind a preparation by rti_window_kernel_res_split, which has parked the factorised LDS
+// image and, per quarter of the horizon, the exact closed-loop transition (Psi, c) and the cost-to-go at the quarter's end).  Nothing is
+// linearised or factorised for the step-0 answer: the four waves fetch the image, the relay forms the three boundary states and costates from
+// the parked quantities (W = Pc, G = 0: x' = Phi x + c, lam = Pc x' + pc), and the quarters are rolled out at once.  The tries -- answers
+// that leave the box -- run the kernel's ordinary passes on the fetched image.
+template <bool GRID, bool FB = false>
 __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
+    static_assert(!(FB && GRID), "the feedback instantiation is uniform-grid");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;
@@ -3370,8 +3408,21 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     bool nanp = false;
     const LaneCst lc = load_lane_cst(P.cst, lane);
     __syncthreads();
+    const double* wsb = P.ws + (size_t)(FB ? b : (int)blockIdx.x) * P.ws_stride;   // (a split tick parks by INSTANCE)
+    const double* ck_b = wsb + (size_t)1 * win_img_doubles(Lc) + (size_t)N * 4 + (size_t)(N + 1) * NX + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N;
+    bool pre_bad = false;
+    if constexpr (FB) {
+        const int nd = win_img_doubles(Lc), q = ((nd / 4 + 127) / 128) * 128, o = wv * q;
+        if (o < nd) win_fetch(wsb + o, smem + o, nd - o < q ? nd - o : q, lane);
+        const double h0 = ck_b[384 + 504], h1 = ck_b[384 + 505], h2 = ck_b[384 + 506];   // KKT partial of the linearisation, verdicts of the factor sweep
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        nanp = !(h0 == h0);
+        part = (wv == 0 && !nanp) ? h0 : 0.0;
+        pre_bad = !(h1 != 0.0) || (h2 != 0.0);
+    } else {
     lin_phase<true, GRID>(P, b, s0, nseg, lane, ba_s + (size_t)s0 * kBaStage, bv_s + (size_t)s0 * NX, kt_s + (size_t)s0 * kRecInterval, q_s + (size_t)s0 * NX,
                     r_s + (size_t)s0 * NU, part, nanp, false);
+    }
     {
         const double pw = wave_max(part);
         const bool nw = __ballot(nanp) != 0ull;
@@ -3382,7 +3433,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     // ---- this wave's view of its segment
     // (the block's workspace as the resident kernel lays it out: one parked image -- unused here --, candidate inputs, state steps, and the
     // gain | M tiles of the in-loop sweeps, where this kernel keeps its M Z' tiles; nothing else of it is touched)
-    double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
+    double* ws = P.ws + (size_t)(FB ? b : (int)blockIdx.x) * P.ws_stride;
     double* ws_vhat = ws + (size_t)1 * win_img_doubles(Lc);
     double* ws_dxb = ws_vhat + (size_t)N * 4;
     double* ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
@@ -3455,7 +3506,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     // One pass = local factor sweeps, relay, feed-forward correction, forward sweeps (steps 1 - 3 of the header).  Twice at most: the
     // equality-constrained system (step0), and -- when its answer leaves the box -- ONE active-set try with the violated inputs pinned
     // (Gamma = POL_BIG and a right-hand side that lands them on their bounds: qp_body's first try, same arithmetic).
-    bool good = true;
+    bool good = !pre_bad;
     d4 lam = z4;   // the costate at this segment's end boundary (the adjoint sweep of the segment enters with it)
     auto solve_pass = [&](const bool step0) __attribute__((always_inline)) {
         // ---- 1. local factor sweep with the condensing accumulators
@@ -3468,7 +3519,14 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
         for (int r = 0; r < 3; r++) acc.Psi[r] = (rg + 4 * r == cl) ? 1.0 : 0.0;
         acc.Psi[3] = 0.0;
         acc.G = z4;
-        if (step0) bwd_chunk<true, 3, false, true, false, InstT, true>(I, S);
+        const bool parked = FB && step0;   // (uniform over the block)
+        const double* pj = ck_b + 896 + (size_t)wv * kSegPark;   // what the preparation parked for this quarter
+        if (parked) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc.Psi[r] = pj[r * 64 + lane];
+            acc.G = d4{0.0, 0.0, 0.0, pj[256 + lane]};
+            S.P = z4; S.pv = z4; S.ok = true;
+        } else if (step0) bwd_chunk<true, 3, false, true, false, InstT, true>(I, S);
         else bwd_chunk<true, 3, false, false, false, InstT, true>(I, S);   // (the try: Gamma and its right-hand side from the interior-point arrays)
         wave_fence();
         good = good && S.ok && !S.illc;
@@ -3504,6 +3562,18 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
         };
         d4 Pst = S.P, pst = p0;   // the exact cost-to-go at this segment's start once the relay has passed (the last segment: already)
         Pst[3] = 0.0;
+        if (parked) {   // the cost-to-go at this quarter's end is exact and parked: W = Pc, G = 0 (x' = Phi x + c, lam = Pc x' + pc)
+            if (!last) {
+                d4 pq;
+#pragma unroll
+                for (int r = 0; r < 3; r++) { Pcn[r] = cl < NX ? pj[320 + r * 64 + lane] : 0.0; pq[r] = dpp_f64<0x150>(pj[512 + r * 64 + lane]); }
+                Pcn[3] = 0.0; pq[3] = 0.0;
+                store_vec12_lds(tr_w, pq, rg, cl);
+                pcn = d4{tr_w[rg], tr_w[rg + 4], tr_w[rg + 8], 0.0};
+                W = Pcn;
+                vv = cbar;
+            }
+        } else
         for (int j = 3; j >= 1; j--) {
             if (wv == j) publish(Pst, pst);
             __syncthreads();
@@ -3577,7 +3647,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
         if (step0) PIT_STAMP(2);
         if (step0 && P.dbg && threadIdx.x == 0) P.dbg[(size_t)b * 8 + 7] = ((t_fac - P.dbg[(size_t)b * 8 + 1]) & 0xFFFFF) | (((t_cb - t_fac) & 0xFFFFF) << 20) | (((__builtin_readcyclecounter() - t_cb) & 0xFFFFF) << 40);
         // ---- 3. the costate's share of the feed-forward terms, then the forward sweep of the segment
-        if (!last) {
+        if (!last && !parked) {   // (the parked feed-forward terms are exact: nothing to add)
             store_vec12_lds(tr_w, lam, rg, cl);
             const double lc_ = tr_w[cl < NX ? cl : 0];
             const double lcl = cl < NX ? lc_ : 0.0;
@@ -3839,6 +3909,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     if (wv == 0) PIT_STAMP(6);
 #undef PIT_STAMP
 }
+__global__ __launch_bounds__(256, 1) void rti_pit_kernel_fb(DevParams P) { rti_pit_body<false, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) { rti_pit_body<false>(P); }
 // the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
 __global__ __launch_bounds__(256, 1) void rti_pit_kernel_grid(DevParams P) { rti_pit_body<true>(P); }
@@ -3918,11 +3989,14 @@ bool pit_supported(int N, int win_L) {
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
     if (windowed_resident(P.win_L)) {
-        if (P.pit && P.pit_done) {   // parallel-in-time step-0 solve first; the resident kernel skips what it completed
-            if (first_launch_on_device(3)) {
-                (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)rti_pit_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            }
+        if (P.pit && P.pit_done && first_launch_on_device(3)) {
+            (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)rti_pit_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)rti_pit_kernel_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (P.pit && P.pit_done && P.rti_split == 2) {   // feedback of a split tick: the quarters rolled out at once from what the preparation parked
+            hipLaunchKernelGGL(rti_pit_kernel_fb, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+        } else if (P.pit && P.pit_done) {   // parallel-in-time step-0 solve first; the resident kernel skips what it completed
             // (pit_blocks = B where every instance has a workspace of its own: beyond one instance per CU the blocks queue for the CUs)
             if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
             else hipLaunchKernelGGL(rti_pit_kernel, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);

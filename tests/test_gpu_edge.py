@@ -305,6 +305,48 @@ def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, g
             os.environ["BROV_PIT"] = old
 
 
+@pytest.mark.parametrize("N,B,big", [(80, 1, 0.0), (80, 5, 2.0), (40, 4, 2.0), (57, 3, 0.0)])
+def test_feedback_half_rolled_out_in_quarters_agrees_with_the_one_call_tick(ba, oracle, golden_traj, N, B, big):
+    """The feedback launch of a split tick with the parallel-in-time kernel's feedback instantiation in front (rti_pit_kernel_fb: boundary
+    states from the closed-loop transitions the preparation parked, the four quarters rolled out at once; answers that leave the box get
+    that kernel's tries on the fetched image, the rest the sequential feedback launch behind it): every tick against the oracle like
+    every other mode, and the instances it completes are reported (brov_pit_last)."""
+    import ctypes as C
+    from conftest import status_agreement, u0_abs_ok
+    Ts = 1.0 / N
+    x0, circ = _inputs(golden_traj, B, seed=71, big=big)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    s.set_params(ba.P_NOMINAL); s.set_x0(x0)
+    op = oracle.opts(N, Ts)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16)))
+    prev, n_done = None, 0
+    for k in range(6):
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        xk = x0 + 0.01 * k
+        s.set_yref(yref)
+        assert s._L.brov_solve_phase(s._h, C.c_void_p(0), 1) == 0
+        s.set_x0(xk)
+        assert s._L.brov_solve_phase(s._h, C.c_void_p(0), 2) == 0
+        r, it, done = s.results(), s.get_iterate(), s.pit_last().astype(bool)
+        _, ro = oracle.rti_step_batch(op, xk, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        prev = ro
+        live = status_agreement(r["status"], ro["status"], ro["kkt"])
+        kk = np.maximum(1.0, np.nan_to_num(ro["kkt"], nan=1.0, posinf=1e300))
+        for name, a, b_ in (("x", it[0], x), ("u", it[1], u), ("pi", it[2], pi)):
+            err = np.abs(a - b_).reshape(B, -1).max(axis=1)
+            scale = kk * (max(1.0, np.abs(b_).max()) if name == "pi" else 1.0)
+            assert np.all((err <= 1e-7 * scale) | ~live), (k, name, err)
+        u0_abs_ok(r["u0"], ro["u0"], r["status"], ro["status"], ro["kkt"], ("split", N, k))
+        early = (ro["status"] == 0) & (ro["qp_iter"] == 0)
+        was_ok = np.ones(B, dtype=bool) if k == 0 else (prev_r["status"] == 0) & (prev_r["qp_iter"] <= 2)
+        assert np.all(done[early & was_ok]), (k, done, early)        # every early exit the hint lets it try is the parallel kernel's
+        assert np.array_equal(r["qp_iter"][done], ro["qp_iter"][done])
+        prev_r = r.copy(); n_done += int(done.sum())
+    assert n_done > 0
+    s.close()
+
+
 def test_setters_reject_bad_shapes(ba):
     s = ba.BatchSolver(3, ba.SolverOptions(10))
     with pytest.raises(ValueError):
