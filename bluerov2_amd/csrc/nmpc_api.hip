@@ -72,6 +72,7 @@ struct brov_solver {
     int32_t* counter = nullptr;
     unsigned win_tick = 0;           // windowed launches so far: which of the two hand-out counters the next one uses
     int win_blocks = 0, win_L = 0;
+    double* ws_split = nullptr;      // fused-kernel horizons, at most one instance per CU: per-instance workspace of the resident kernel's split launches (rti_phase 1 / 2)
     int alt_blocks = 0, alt_L = 0;   // parallel-in-time rounds (pit_rounds_stages): the resident configuration a solve may use instead
     unsigned long long* pit_left_host = nullptr;   // pinned word: (sequence number << 32 | instances the parallel-in-time kernel left to the resident kernel) of the last solve it ran in
     int32_t pit_seq = 0, pit_ignore_upto = 0, pit_probe_seq = 0;   // solves with that kernel issued so far / reports up to here are old news / the probe whose report is awaited
@@ -277,6 +278,17 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
         if (B > 1 && (s->alt_L || windowed_is_resident(s->win_L))) {   // the parallel-in-time kernel may serve this solver: its report word
             if (hipHostMalloc((void**)&s->pit_left_host, 64, hipHostMallocDefault) != hipSuccess) { s->pit_left_host = nullptr; rc = BROV_ERR_HIP; }
             else *s->pit_left_host = 0;
+        }
+    }
+    // rti_phase 1 / 2 at a horizon the fused kernels serve: the resident kernel's split launches need a workspace per instance
+    if (fused_supported(opts->N) && !s->force_windowed && opts->kernel_path != BROV_PATH_STREAMING && split_resident_horizon(opts->N) &&
+        !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0)) {
+        int dev_ = 0, cus_ = 256;
+        (void)hipGetDevice(&dev_);
+        (void)hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_);
+        if (B <= cus_) {
+            (void)windowed_blocks(opts->N, B, opts->N);   // (sets the kernels' LDS attribute on first use)
+            AL(ws_split, (size_t)B * windowed_ws_doubles(opts->N, opts->N));
         }
     }
 #undef AL
@@ -837,9 +849,11 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     // rti_phase 1 / 2 in the windowed kernel's resident mode (at most one instance per CU at 24 <= N <= 81): the split
     // launches of rti_window_kernel_res_split -- preparation parks the factorised LDS image per instance, feedback runs from the forward
     // sweep on.  A feedback call follows the path its preparation took (prep_path); BROV_SPLIT_RESIDENT=0: the streaming pair as before.
-    const bool split_res_ok = path != BROV_PATH_STREAMING && !(fused_supported(s->N) && !s->force_windowed) && s->ws != nullptr &&
-                              windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !s->dump_lin &&
-                              !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0);
+    const bool fused_h = fused_supported(s->N) && !s->force_windowed;
+    const bool split_env = !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0);
+    const bool split_fused_h = fused_h && s->ws_split != nullptr && path != BROV_PATH_STREAMING && !s->dump_lin && split_env;   // (N <= 23: see brov_create)
+    const bool split_res_ok = split_fused_h || (path != BROV_PATH_STREAMING && !fused_h && s->ws != nullptr &&
+                              windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !s->dump_lin && split_env);
     const bool split_res = (rti_phase == 1 && split_res_ok) || (rti_phase == 2 && split_res_ok && s->prep_path == 2);
     if (rti_phase == 2 && (s->prep_path == 3 || (s->prep_path == 2 && !split_res_ok))) {   // (a grid / option / iterate / path change between the two calls)
         g_err = "brov_solve: rti_phase 2 after a preparation on the resident kernel, which the solver's settings no longer allow: repeat rti_phase 1";
@@ -847,8 +861,11 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     }
     if (rti_phase == 1) s->prep_path = split_res ? 2 : 1;
     const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING;
-    const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed;
-    const bool windowed = lds_path && !fused && s->ws != nullptr;
+    const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed && !(split_res && split_fused_h);
+    const bool windowed = lds_path && !fused && (s->ws != nullptr || (split_res && split_fused_h));
+    if (split_res && split_fused_h) {   // the resident configuration of a fused-kernel horizon: one window = the horizon, one block per instance
+        P.ws = s->ws_split; P.ws_stride = (int64_t)windowed_ws_doubles(s->N, s->N); P.win_L = s->N; P.win_blocks = (int32_t)s->B;
+    }
     s->pit_ran = false;
     if (s->timing) hipEventRecord(s->ev[0], st);
     if (fused || windowed) {

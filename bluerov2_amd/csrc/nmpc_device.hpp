@@ -96,6 +96,7 @@ bool windowed_is_resident(int win_L);      // one window = the whole horizon (sm
 int windowed_stage_count(int N, int B);   // stages per window (= N for batches of at most one instance per CU: resident mode)
 int windowed_blocks(int N, int B, int L); // persistent blocks that will be launched on the current device
 size_t windowed_ws_doubles(int N, int L); // per-block workspace
+bool split_resident_horizon(int N);           // rti_phase 1 / 2 on the resident kernel's split launches at a fused-kernel horizon
 int pit_rounds_stages(int N, int B);          // batches of up to two instances per CU: resident stage count for parallel-in-time rounds, or 0
 void launch_window(const double* traj, int rows, const int* lines, int line0, int B, int N, int ncols, double* out, hipStream_t st);
 void launch_plant(double* x0, const brov_result* res, const double* pplant, const double* prp, int rp_stride, int B, double dt, int substeps,

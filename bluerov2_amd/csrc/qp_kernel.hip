@@ -3988,7 +3988,7 @@ bool pit_supported(int N, int win_L) {
     return windowed_resident(win_L) && win_L == N && N >= 24 && N <= 80 && windowed_lds_bytes(win_L) + kPitExtraDoubles * sizeof(double) <= 160 * 1024;
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
-    if (windowed_resident(P.win_L)) {
+    if (windowed_resident(P.win_L) || P.rti_split) {   // (the split launches are the resident mode's at every horizon)
         if (P.pit && P.pit_done && first_launch_on_device(3)) {
             (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)rti_pit_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -4010,6 +4010,9 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }
 bool windowed_is_resident(int win_L) { return windowed_resident(win_L); }
+// the split launches (rti_phase 1 / 2) of the resident kernel at a horizon the FUSED kernels serve in one call (N <= 23): the four quarters the
+// block's waves linearise must all hold a stage
+bool split_resident_horizon(int N) { return N >= 4 && 3 * ((N + 3) >> 2) < N && windowed_lds_bytes(N) <= 160 * 1024; }
 
 
 static size_t fused_lds_bytes(int N) { return ((size_t)N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(N + 1) * NX + 2 + 17) * sizeof(double); }

@@ -347,6 +347,54 @@ def test_feedback_half_rolled_out_in_quarters_agrees_with_the_one_call_tick(ba, 
     s.close()
 
 
+@pytest.mark.parametrize("N,B,big", [(20, 1, 0.0), (20, 6, 2.5), (10, 3, 2.5), (23, 2, 0.0), (14, 1, 0.0)])
+def test_rti_phase_split_at_a_fused_kernel_horizon(ba, oracle, golden_traj, N, B, big):
+    """N <= 23 (one call: the fused kernels), at most one instance per CU: rti_phase 1 / 2 run on the resident kernel's split launches too
+    (one window = the horizon; a per-instance workspace allocated at create) -- the preparation factorises, the feedback is forward sweep +
+    step.  Every tick against the oracle and against the one-call fused tick; also through the tick call."""
+    import ctypes as C
+    from conftest import status_agreement, u0_abs_ok
+    Ts = 1.0 / N
+    x0, circ = _inputs(golden_traj, B, seed=81, big=big)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts)); one = ba.BatchSolver(B, ba.SolverOptions(N, Ts)); tk = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+    for q in (s, one, tk):
+        q.set_params(ba.P_NOMINAL); q.set_x0(x0)
+    op = oracle.opts(N, Ts)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16)))
+    prev, n_loop = None, 0
+    for k in range(5):
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        xk = x0 + 0.01 * k
+        s.set_yref(yref)
+        assert s._L.brov_solve_phase(s._h, C.c_void_p(0), 1) == 0
+        s.set_x0(xk)
+        assert s._L.brov_solve_phase(s._h, C.c_void_p(0), 2) == 0
+        assert s.last_kernel_path() == 3
+        one.set_yref(yref); one.set_x0(xk); one.solve()
+        assert one.last_kernel_path() == 2
+        tk.tick(yref=yref, rti_phase=1); rt = tk.tick(x0=xk, rti_phase=2)
+        r, it = s.results(), s.get_iterate()
+        assert rt.tobytes() == r.tobytes()
+        _, ro = oracle.rti_step_batch(op, xk, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        prev = ro
+        live = status_agreement(r["status"], ro["status"], ro["kkt"])
+        kk = np.maximum(1.0, np.nan_to_num(ro["kkt"], nan=1.0, posinf=1e300))
+        for name, a, b_ in (("x", it[0], x), ("u", it[1], u), ("pi", it[2], pi)):
+            err = np.abs(a - b_).reshape(B, -1).max(axis=1)
+            scale = kk * (max(1.0, np.abs(b_).max()) if name == "pi" else 1.0)
+            assert np.all((err <= 1e-7 * scale) | ~live), (k, name, err)
+        u0_abs_ok(r["u0"], ro["u0"], r["status"], ro["status"], ro["kkt"], ("split fused horizon", N, k))
+        r1 = one.results()
+        ok = live & (r1["status"] == 0) & (r["status"] == 0)
+        assert np.all(np.abs(r1["u0"][ok] - r["u0"][ok]).max(axis=1) <= 1e-9 * kk[ok]) and np.array_equal(r1["qp_iter"][ok], r["qp_iter"][ok])
+        n_loop += int((r["qp_iter"] > 0).sum())
+    if big:
+        assert n_loop > 0
+    for q in (s, one, tk):
+        q.close()
+
+
 def test_setters_reject_bad_shapes(ba):
     s = ba.BatchSolver(3, ba.SolverOptions(10))
     with pytest.raises(ValueError):
