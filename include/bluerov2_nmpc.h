@@ -183,7 +183,7 @@ int brov_solve(brov_solver* s, void* stream);
  * (linearise at the current iterate), 2 = feedback only (QP + step with the current x0; needs a prior phase 1).  Batches of at most one
  * instance per CU at N <= 81: the preparation also runs the step-0 factor sweep -- it does not depend on x0 -- and
  * parks the factorised LDS image; the feedback is forward sweep + bound check + step + record (a batch of one at N = 80 through
- * brov_tick_host: 31 us from the measurement to u0, against 70 us for rti_phase 0); a call that changes the iterate, the grid or the options
+ * brov_tick_host: 33 us from the measurement to u0, against 71 us for rti_phase 0); a call that changes the iterate, the grid or the options
  * between the two makes the feedback fail (BROV_ERR_ARG: repeat the preparation).  Elsewhere: linearisation / QP on the streaming pair. */
 int brov_solve_phase(brov_solver* s, void* stream, int rti_phase);
 int brov_synchronize(brov_solver* s, void* stream);
