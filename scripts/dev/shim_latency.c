@@ -13,6 +13,8 @@ static int cmp(const void* a, const void* b) { double d = *(const double*)a - *(
 
 int main(int argc, char** argv) {
     const double gap_us = argc > 1 ? atof(argv[1]) : 0.0;   /* idle time between ticks (a control loop does not run back to back) */
+    const int split = argc > 2 && atoi(argv[2]) != 0;       /* 1: acados' preparation / feedback split -- rti_phase 1 with the references and parameters
+                                                              * of the tick, the idle time, then the measurement and rti_phase 2; timed: the feedback half */
     bluerov2_solver_capsule* c = bluerov2_acados_create_capsule();
     if (bluerov2_acados_create(c)) return 1;
     static double yref[BLUEROV2_N + 1][BLUEROV2_NY], par[BLUEROV2_N + 1][BLUEROV2_NP];
@@ -29,12 +31,30 @@ int main(int argc, char** argv) {
             for (int j = 0; j < 16; j++) par[i][j] = pn[j];
         }
         struct timespec a, b;
+        int st;
+        if (split) {
+            int ph = 1;
+            ocp_nlp_solver_opts_set(c->nlp_config, c->nlp_opts, "rti_phase", &ph);
+            for (int i = 0; i <= BLUEROV2_N; i++) bluerov2_acados_update_params(c, i, par[i], BLUEROV2_NP);
+            for (int i = 0; i <= BLUEROV2_N; i++) ocp_nlp_cost_model_set(c->nlp_config, c->nlp_dims, c->nlp_in, i, "yref", yref[i]);
+            if (bluerov2_acados_solve(c)) return 2;
+            struct timespec g0, g1;
+            clock_gettime(CLOCK_MONOTONIC, &g0);
+            do clock_gettime(CLOCK_MONOTONIC, &g1); while ((g1.tv_sec - g0.tv_sec) * 1e6 + (g1.tv_nsec - g0.tv_nsec) * 1e-3 < (gap_us > 0 ? gap_us : 100.0));
+            ph = 2;
+            clock_gettime(CLOCK_MONOTONIC, &a);                      /* the measurement arrives */
+            ocp_nlp_solver_opts_set(c->nlp_config, c->nlp_opts, "rti_phase", &ph);
+            ocp_nlp_constraints_model_set(c->nlp_config, c->nlp_dims, c->nlp_in, 0, "lbx", x0);
+            ocp_nlp_constraints_model_set(c->nlp_config, c->nlp_dims, c->nlp_in, 0, "ubx", x0);
+            st = bluerov2_acados_solve(c);
+        } else {
         clock_gettime(CLOCK_MONOTONIC, &a);
         ocp_nlp_constraints_model_set(c->nlp_config, c->nlp_dims, c->nlp_in, 0, "lbx", x0);
         ocp_nlp_constraints_model_set(c->nlp_config, c->nlp_dims, c->nlp_in, 0, "ubx", x0);
         for (int i = 0; i <= BLUEROV2_N; i++) bluerov2_acados_update_params(c, i, par[i], BLUEROV2_NP);
         for (int i = 0; i <= BLUEROV2_N; i++) ocp_nlp_cost_model_set(c->nlp_config, c->nlp_dims, c->nlp_in, i, "yref", yref[i]);
-        int st = bluerov2_acados_solve(c);
+        st = bluerov2_acados_solve(c);
+        }
         double u0[4], kkt = c->nlp_out->inf_norm_res, tt = 0;
         ocp_nlp_get(c->nlp_config, c->nlp_solver, "time_tot", &tt);
         ocp_nlp_out_get(c->nlp_config, c->nlp_dims, c->nlp_out, 0, "u", u0);
@@ -43,7 +63,7 @@ int main(int argc, char** argv) {
         tot[k] = tt * 1e6;
         if (st != 0 && k > 5) { printf("tick %d status %d kkt %g\n", k, st, kkt); }
         x0[0] = yref[1][0]; x0[1] = yref[1][1]; x0[5] = yref[1][5];   /* a perfect plant: the state follows the reference */
-        if (gap_us > 0) {
+        if (gap_us > 0 && !split) {
             struct timespec g0, g1;
             clock_gettime(CLOCK_MONOTONIC, &g0);
             do clock_gettime(CLOCK_MONOTONIC, &g1); while ((g1.tv_sec - g0.tv_sec) * 1e6 + (g1.tv_nsec - g0.tv_nsec) * 1e-3 < gap_us);
@@ -51,6 +71,7 @@ int main(int argc, char** argv) {
     }
     qsort(wall + 20, T - 20, sizeof(double), cmp);
     qsort(tot + 20, T - 20, sizeof(double), cmp);
+    if (split) printf("shim SPLIT tick at N = %d, batch 1 (rti_phase 1, %.0f us, measurement, rti_phase 2): FEEDBACK half, measurement -> u0: ", BLUEROV2_N, gap_us > 0 ? gap_us : 100.0);
     printf("shim tick at N = %d, batch 1, %.0f us idle between ticks: wall median %.1f us, p99 %.1f us;  time_tot median %.1f us\n", BLUEROV2_N, gap_us, wall[20 + (T - 20) / 2],
            wall[20 + (T - 20) * 99 / 100], tot[20 + (T - 20) / 2]);
     double tl = 0, tq = 0;

@@ -41,7 +41,7 @@ python $R/scripts/dev/pit_stamps.py 80 > $OUT/pit_stamps_N80.txt 2>/dev/null
 ( python $R/scripts/dev/split_tick_latency.py 80; python $R/scripts/dev/split_tick_latency.py 40; python $R/scripts/dev/split_tick_latency.py 20; echo "== BROV_SPLIT_PARALLEL=0 (sequential feedback alone)"; BROV_SPLIT_PARALLEL=0 python $R/scripts/dev/split_tick_latency.py 80 | head -1; BROV_SPLIT_PARALLEL=0 python $R/scripts/dev/split_tick_latency.py 40 | head -1 ) > $OUT/split_tick_latency.txt 2>/dev/null
 BROV_PIT=0 python $R/scripts/dev/phase_stamps.py 1 80 1 0 2>/dev/null | head -9 > $OUT/phase_stamps_N80_B1_sequential.txt
 gcc -O2 -I$R/include/acados_shim -o /tmp/shim_latency $R/scripts/dev/shim_latency.c -L$R/bluerov2_amd/lib -lacados_ocp_solver_bluerov2 -lacados -Wl,-rpath,$R/bluerov2_amd/lib -lm
-( for pit in 1 0; do echo "== acados-shaped drop-in, C caller (scripts/dev/shim_latency.c), BROV_PIT=$pit"; BROV_PIT=$pit /tmp/shim_latency 300 2>&1 | grep "shim tick"; BROV_PIT=$pit /tmp/shim_latency 0 2>&1 | grep "shim tick"; done ) > $OUT/shim_latency.txt
+( for pit in 1 0; do echo "== acados-shaped drop-in, C caller (scripts/dev/shim_latency.c), BROV_PIT=$pit"; BROV_PIT=$pit /tmp/shim_latency 300 2>&1 | grep "shim tick"; BROV_PIT=$pit /tmp/shim_latency 0 2>&1 | grep "shim tick"; done; echo "== the same caller with acados' preparation / feedback split (rti_phase 1 between two measurements, then 2)"; /tmp/shim_latency 300 1 2>&1 | grep "shim"; BROV_SPLIT_PARALLEL=0 /tmp/shim_latency 300 1 2>&1 | grep "shim" | sed 's/^/BROV_SPLIT_PARALLEL=0: /' ) > $OUT/shim_latency.txt
 python $R/scripts/bench_ekf.py > $OUT/bench_ekf.json 2> $OUT/bench_ekf.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ekf -o stats -- python $R/scripts/bench_ekf.py --no-cpu-baseline > /dev/null 2> $OUT/stats_ekf.err
 python $R/scripts/bench_batch_sweep.py > $OUT/batch_sweep.log 2>&1
