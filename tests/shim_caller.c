@@ -43,14 +43,26 @@ int main(int argc, char** argv) {
 
     for (int tick = 0; tick < nticks; tick++) {
         if (fread(yref, sizeof(double), (BLUEROV2_N + 1) * BLUEROV2_NY, f) != (size_t)(BLUEROV2_N + 1) * BLUEROV2_NY) return 2;
-        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", x0);
-        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", x0);
+        const int split = argc >= 3 && argv[2][0] == 'S';   /* acados' preparation / feedback split (main_bluerov2.c:217 sets the option) */
+        if (!split) {
+            ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", x0);
+            ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", x0);
+        }
         for (int i = 0; i < BLUEROV2_N + 1; i++) {
             for (int j = 0; j < BLUEROV2_NP; j++) acados_param[i][j] = p[j];
             bluerov2_acados_update_params(mpc_capsule, i, acados_param[i], BLUEROV2_NP);
         }
         for (unsigned int i = 0; i <= BLUEROV2_N; i++)
             ocp_nlp_cost_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, i, "yref", yref[i]);
+        if (split) {   /* preparation with references and parameters; the measurement arrives; feedback */
+            int ph = 1;
+            ocp_nlp_solver_opts_set(mpc_capsule->nlp_config, mpc_capsule->nlp_opts, "rti_phase", &ph);
+            if (bluerov2_acados_solve(mpc_capsule) != 0) { printf("preparation failed\n"); return 1; }
+            ph = 2;
+            ocp_nlp_solver_opts_set(mpc_capsule->nlp_config, mpc_capsule->nlp_opts, "rti_phase", &ph);
+            ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", x0);
+            ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", x0);
+        }
         int acados_status = bluerov2_acados_solve(mpc_capsule);
         double kkt_res = (double)mpc_capsule->nlp_out->inf_norm_res, cpu_time = 0.0, u0[BLUEROV2_NU], x1[BLUEROV2_NX];
         ocp_nlp_get(mpc_capsule->nlp_config, mpc_capsule->nlp_solver, "time_tot", &cpu_time);

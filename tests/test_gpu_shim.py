@@ -14,7 +14,11 @@ INC = os.path.join(ROOT, "include", "acados_shim")
 LIBDIR = os.path.join(ROOT, "bluerov2_amd", "lib")
 
 
-def test_control_tick_call_sequence_matches_known_answers(tmp_path, golden_rti, oracle):
+@pytest.mark.parametrize("mode", ["one call", "split"])
+def test_control_tick_call_sequence_matches_known_answers(tmp_path, golden_rti, oracle, mode):
+    """mode "split": the same ticks with acados' preparation / feedback split set through ocp_nlp_solver_opts_set("rti_phase") -- two
+    bluerov2_acados_solve calls per tick, the measurement handed over between them (resident split launches, the feedback half rolled
+    out in quarters): the same known answers"""
     g, name = golden_rti, "circle_N80"
     exe = tmp_path / "shim_caller"
     subprocess.check_call(["gcc", "-O2", f"-I{INC}", "-o", str(exe), os.path.join(ROOT, "tests", "shim_caller.c"),
@@ -23,7 +27,7 @@ def test_control_tick_call_sequence_matches_known_answers(tmp_path, golden_rti, 
     blob = np.concatenate([g[f"{name}/x0_meas"], g[f"{name}/p"][0], [float(nt)]] + [g[f"{name}/yref{k}"].ravel() for k in range(nt)])
     inp = tmp_path / "in.bin"
     inp.write_bytes(blob.astype(np.float64).tobytes())
-    r = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([str(exe), str(inp)] + (["S"] if mode == "split" else []), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     ticks = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("TICK")]
     assert len(ticks) == nt
