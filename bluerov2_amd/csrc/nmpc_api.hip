@@ -877,9 +877,9 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
             const bool pit_can = pit && s->pit_done && !s->dump_lin && rti_phase == 0;
             P.rti_split = rti_phase;
-            // the feedback half of a split tick: the parallel-in-time kernel's feedback instantiation first (uniform grid), rolling out the
+            // the feedback half of a split tick: the parallel-in-time kernel's feedback instantiation first, rolling out the
             // four quarters at once from what the preparation parked; the resident feedback launch behind it for what it leaves
-            if (rti_phase == 2 && pit && s->pit_done && !general_grid(s) && pit_supported(s->N, P.win_L) &&
+            if (rti_phase == 2 && pit && s->pit_done && pit_supported(s->N, P.win_L) &&
                 !(getenv("BROV_SPLIT_PARALLEL") && atoi(getenv("BROV_SPLIT_PARALLEL")) == 0)) {
                 P.pit = pit; P.pit_done = s->pit_done; P.pit_blocks = P.win_blocks;
                 P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);

@@ -3368,7 +3368,6 @@ __device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int l
 // that leave the box -- run the kernel's ordinary passes on the fetched image.
 template <bool GRID, bool FB = false>
 __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
-    static_assert(!(FB && GRID), "the feedback instantiation is uniform-grid");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;
@@ -3910,6 +3909,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
 #undef PIT_STAMP
 }
 __global__ __launch_bounds__(256, 1) void rti_pit_kernel_fb(DevParams P) { rti_pit_body<false, true>(P); }
+__global__ __launch_bounds__(256, 1) void rti_pit_kernel_fb_grid(DevParams P) { rti_pit_body<true, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_pit_kernel(DevParams P) { rti_pit_body<false>(P); }
 // the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
 __global__ __launch_bounds__(256, 1) void rti_pit_kernel_grid(DevParams P) { rti_pit_body<true>(P); }
@@ -3993,9 +3993,11 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)rti_pit_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)rti_pit_kernel_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)rti_pit_kernel_fb_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         if (P.pit && P.pit_done && P.rti_split == 2) {   // feedback of a split tick: the quarters rolled out at once from what the preparation parked
-            hipLaunchKernelGGL(rti_pit_kernel_fb, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+            if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_fb_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
+            else hipLaunchKernelGGL(rti_pit_kernel_fb, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
         } else if (P.pit && P.pit_done) {   // parallel-in-time step-0 solve first; the resident kernel skips what it completed
             // (pit_blocks = B where every instance has a workspace of its own: beyond one instance per CU the blocks queue for the CUs)
             if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);

@@ -305,8 +305,8 @@ def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, g
             os.environ["BROV_PIT"] = old
 
 
-@pytest.mark.parametrize("N,B,big", [(80, 1, 0.0), (80, 5, 2.0), (40, 4, 2.0), (57, 3, 0.0)])
-def test_feedback_half_rolled_out_in_quarters_agrees_with_the_one_call_tick(ba, oracle, golden_traj, N, B, big):
+@pytest.mark.parametrize("N,B,big,grid", [(80, 1, 0.0, False), (80, 5, 2.0, False), (40, 4, 2.0, False), (57, 3, 0.0, False), (80, 4, 2.0, True)])
+def test_feedback_half_rolled_out_in_quarters_agrees_with_the_one_call_tick(ba, oracle, golden_traj, N, B, big, grid):
     """The feedback launch of a split tick with the parallel-in-time kernel's feedback instantiation in front (rti_pit_kernel_fb: boundary
     states from the closed-loop transitions the preparation parked, the four quarters rolled out at once; answers that leave the box get
     that kernel's tries on the fetched image, the rest the sequential feedback launch behind it): every tick against the oracle like
@@ -317,7 +317,10 @@ def test_feedback_half_rolled_out_in_quarters_agrees_with_the_one_call_tick(ba, 
     x0, circ = _inputs(golden_traj, B, seed=71, big=big)
     s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
     s.set_params(ba.P_NOMINAL); s.set_x0(x0)
-    op = oracle.opts(N, Ts)
+    ts = Ts * 1.01 ** np.arange(N) if grid else None      # (a geometric grid: rti_pit_kernel_fb_grid)
+    if grid:
+        s.set_time_steps(ts)
+    op = oracle.opts(N, Ts, ts_vec=ts) if grid else oracle.opts(N, Ts)
     x, u, pi, lam = oracle.init_iterate(op, B)
     pf = np.ascontiguousarray(np.broadcast_to(ba.P_NOMINAL, (B, N + 1, 16)))
     prev, n_done = None, 0

@@ -28,7 +28,7 @@ def _report(src):
 def test_solver_kernels_use_no_scratch_and_keep_their_occupancy():
     rep = _report("qp_kernel.hip")
     want = {"rti_fused_kernel": 1, "rti_fused_kernel_w2": 2, "rti_fused_kernel_grid": 1, "rti_window_kernel": 1, "rti_window_kernel_grid": 1,
-            "rti_window_kernel_res": 1, "rti_window_kernel_res_grid": 1, "rti_window_kernel_res_split": 1, "rti_window_kernel_res_split_grid": 1, "rti_pit_kernel": 1, "rti_pit_kernel_grid": 1, "rti_pit_kernel_fb": 1, "rti_fused_kernel_mail": 1, "qp_kernel": 2, "lin_wave_kernel": 1, "lin_wave_kernel_grid": 1}
+            "rti_window_kernel_res": 1, "rti_window_kernel_res_grid": 1, "rti_window_kernel_res_split": 1, "rti_window_kernel_res_split_grid": 1, "rti_pit_kernel": 1, "rti_pit_kernel_grid": 1, "rti_pit_kernel_fb": 1, "rti_pit_kernel_fb_grid": 1, "rti_fused_kernel_mail": 1, "qp_kernel": 2, "lin_wave_kernel": 1, "lin_wave_kernel_grid": 1}
     seen = {}
     for mangled, r in rep.items():
         for short in want:
