@@ -132,7 +132,7 @@ def batch1_tick(ba, ticks=300, warm=30):
                     w1.append((t1 - t0) * 1e6); it1.append(int(r1["qp_iter"][0]))
             one_try = dict(wall_us_median=float(np.median(w1)), newton_systems=int(np.median(it1)), solved_parallel_in_time=bool(s.pit_last()[0]))
         split = None
-        if N == 80:
+        if N in (20, 80):
             # acados' preparation / feedback split (rti_phase 1, then 2 with the new measurement): the preparation -- linearisation and the
             # step-0 factor sweep, which does not depend on x0 -- runs between two measurements; what is timed is the FEEDBACK call
             s.reset(); s.init_iterate_default()
