@@ -96,6 +96,7 @@ struct brov_solver {
     // brov_tick_host, mailbox path: inputs passed with the tick are read by THIS launch straight from the pinned staging buffer (no copy
     // command ahead of the kernel); their device copies are refreshed behind the kernel.  Non-null only while that launch is built.
     const double *tick_x0 = nullptr, *tick_yref = nullptr, *tick_par = nullptr;
+    hipEvent_t ev_up = nullptr;          // a preparation tick (rti_phase 1): its uploads have left the pinned staging buffer
     hipEvent_t ev_tick = nullptr;        // ticks with inputs read in place: the kernel's end (neither the host nor the next tick's kernel waits for the copies behind it)
     hipStream_t copy_stream = nullptr;   // ... those copies (pinned staging buffer -> the device arrays every other entry point works on) run here, behind ev_tick
     hipEvent_t ev_copy = nullptr;        // ... and end here
@@ -329,6 +330,7 @@ extern "C" void brov_destroy(brov_solver* s) {
     if (s->pit_left_host) hipHostFree(s->pit_left_host);
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->ev_tick) hipEventDestroy(s->ev_tick);
+    if (s->ev_up) hipEventDestroy(s->ev_up);
     if (s->ev_copy) hipEventDestroy(s->ev_copy);
     if (s->tick_stream) hipStreamDestroy(s->tick_stream);
     for (int k = 0; k < 3; k++)
@@ -1031,6 +1033,10 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     if (!zerocopy) {
         if (s->copies_pending) HIPCHK(hipStreamWaitEvent(st, s->ev_copy, 0));   // (an earlier tick's copies into the same device arrays)
         if (int rc = upload(st)) return rc;
+        if (rti_phase == 1) {   // a preparation delivers nothing: the call returns when the staging buffer is free again (below), not when the kernel ends
+            if (!s->ev_up) HIPCHK(hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(s->ev_up, st));
+        }
     } else {
         s->tick_x0 = x0 ? px : nullptr; s->tick_yref = yref_shared ? py : nullptr; s->tick_par = par_stage ? pp : nullptr;
         if (!s->copy_stream) {
@@ -1088,6 +1094,9 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+    } else if (rti_phase == 1) {
+        HIPCHK(hipEventSynchronize(s->ev_up));   // the inputs have left the pinned buffer; the preparation itself runs on (stream-ordered ahead of
+        return BROV_OK;                          // whatever follows; no record: `res` is left alone)
     } else {
         if (!bulk) HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
         if (zerocopy) HIPCHK(hipEventSynchronize(s->ev_tick));

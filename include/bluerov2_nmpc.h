@@ -200,7 +200,8 @@ int brov_order_stream(brov_solver* s, void* stream);
  * by a sequence word the host polls (BROV_TICK_MAILBOX=0 in the environment: copy + stream synchronisation, as for larger
  * batches).  A tick that passes all three inputs uploads them with one copy.  This is what the acados-shaped drop-in makes of one
  * bluerov2_acados_solve (bluerov2_dob.cpp:306-388: lbx / ubx, (N+1) x update_params, (N+1) x yref, solve, u0 / status / kkt).
- * HOST pointers. */
+ * rti_phase 1 (a preparation) delivers no records: the call returns as soon as the inputs have left the pinned buffer, `res` is left alone,
+ * and the preparation runs on, stream-ordered ahead of whatever follows.  HOST pointers. */
 int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
                    brov_result* res /*[B] or NULL*/);
 /* The staging buffers brov_tick_host copies its arguments into / its records out of: device-visible pinned host memory, valid until
