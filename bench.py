@@ -140,7 +140,7 @@ def batch1_tick(ba, ticks=300, warm=30):
             for k in range(warm + 200):
                 y = np.ascontiguousarray(circ[k % 16:k % 16 + N + 1])
                 t0 = time.perf_counter(); s.tick(yref=y, params=p, rti_phase=1); t1 = time.perf_counter()
-                while time.perf_counter() - t1 < 100e-6:
+                while time.perf_counter() - t1 < 250e-6:   # (the preparation call returns ahead of its kernel: ~0.1 ms of GPU time)
                     pass
                 t2 = time.perf_counter(); r2 = s.tick(x0=x0, rti_phase=2); t3 = time.perf_counter()
                 if k >= warm:
