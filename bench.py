@@ -903,6 +903,12 @@ def main(argv=None):
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
+    # BROV_BENCH_BACKEND=gloo: development route -- the ranks share the visible GPUs round-robin (two ranks on the ONE GPU of a test
+    # box: real solvers, real records, real device-side selection, the collective through the host), since RCCL refuses two ranks on a GPU
+    backend = os.environ.get("BROV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+        os.environ["LOCAL_RANK"] = str(local_rank)   # workload() places its solver by it
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
@@ -910,7 +916,10 @@ def main(argv=None):
     if world > 1 or args.force_gather:
         # RCCL writes its debug/warn lines to stdout; keep them away from the one JSON line this script must print
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bluerov2_amd as ba
     from bluerov2_amd import distributed as D
@@ -937,7 +946,7 @@ def main(argv=None):
             gev = []   # (before gather, after gather, after select) events, one triple per timed step of the pass that times kernels
             if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
                 with torch.cuda.stream(side):
-                    dist.all_gather_into_tensor(gathered[0], stage[0])
+                    D.all_gather_into(gathered[0], stage[0])
                 torch.cuda.synchronize()
             s.init_iterate_default()
             s.enable_timing(False)
@@ -966,7 +975,7 @@ def main(argv=None):
                         if not direct:
                             stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
                         if te: te[0].record(main)
-                        dist.all_gather_into_tensor(gathered[j], res_view if direct else stage[j])
+                        D.all_gather_into(gathered[j], res_view if direct else stage[j])
                         if te: te[1].record(main)
                         if select:
                             best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
@@ -979,7 +988,7 @@ def main(argv=None):
                     side.wait_event(ready[j])
                     with torch.cuda.stream(side):
                         if te: te[0].record(side)
-                        dist.all_gather_into_tensor(gathered[j], stage[j])
+                        D.all_gather_into(gathered[j], stage[j])
                         if te: te[1].record(side)
                         if select:
                             best = D.select_best_device(gathered[j])
@@ -1011,7 +1020,7 @@ def main(argv=None):
             if world > 1:
                 tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
                 every = torch.empty(world, dtype=torch.float64, device="cuda")
-                dist.all_gather_into_tensor(every, tt)
+                D.all_gather_into(every, tt)
                 info["per_rank_ms"] = [float(v) / max(steps, 1) * 1e3 for v in every.cpu()]
                 dt = float(every.max().item())
             return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best, info)
@@ -1041,7 +1050,7 @@ def main(argv=None):
         if dist.is_initialized():
             rk = torch.tensor([rank], dtype=torch.int64, device=dev)
             allr = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allr, rk)
+            D.all_gather_into(allr, rk)
             ranks_seen = sorted(int(v) for v in allr.cpu())
 
         if rank == 0:
@@ -1095,6 +1104,8 @@ def main(argv=None):
                            "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
                                            "records per step, enqueued behind the solve on its stream") if world > 1 else "single GPU"},
                 "ranks_seen": ranks_seen,
+                **({} if backend == "nccl" or not dist.is_initialized() else
+                   {"collective_backend": backend + " (development route: ranks share GPUs, collective through the host -- NOT a scaling measurement)"}),
                 "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
                 "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),
                 "kernel_ms": kernel_ms, "device_bytes": lg["device_bytes"],

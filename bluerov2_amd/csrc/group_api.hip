@@ -13,17 +13,35 @@
 // bluerov2_amd/distributed.py (one process PER GPU on torch.distributed) stays as the second route.
 //
 // RCCL is resolved at run time (dlopen of librccl.so.1, the copy PyTorch may already have mapped): a process that never creates a
-// group never loads it, and libbluerov2_nmpc.so has no link-time dependency on it.
+// group never loads it, and libbluerov2_nmpc.so has neither a link-time nor a build-time dependency on it (the few RCCL types this
+// file needs are declared below, with the values of rccl.h 2.x).
+//
+// Second collective, BROV_COLLECTIVE_COPY (brov_group_create_ex / brov_group_create_rank_ex): the all-gather as device-to-device copies
+// between the ranks' buffers -- every rank publishes its contribution behind an event on its own stream, every rank pulls the others'
+// into its own `gathered` / `pairs` array on its own stream.  No RCCL involved, devices may repeat: W ranks on ONE GPU run exactly the
+// bookkeeping of W GPUs (shard bounds by global rank, padded staging, rank-major gathered layout, packed pairs, select over W x slots,
+// mailbox), which is how the 1-GPU test box executes this file with W > 1 (tests/test_gpu_group_loopback.py).  The ranks of a copy
+// group must live in one process (they meet in a process-wide table keyed by the 128-byte id).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
+
+// ---- what this file uses of rccl.h (resolved by dlsym; values as in RCCL 2.x) ----
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclDouble = 8 } ncclDataType_t;
 
 #include "../../include/bluerov2_nmpc.h"
 
@@ -53,13 +71,47 @@ Rccl& rccl() {
         r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
     }
-    if (!r.handle) { r.why = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+    if (!r.handle) {
+        const char* e = dlerror();   // once: the call clears the message
+        r.why = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "?");
+        return r;
+    }
 #define SYM(field, name) r.field = (decltype(r.field))dlsym(r.handle, name); if (!r.field) { r.why = std::string("RCCL symbol missing: ") + name; r.handle = nullptr; return r; }
     SYM(CommInitAll, "ncclCommInitAll") SYM(CommInitRank, "ncclCommInitRank") SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetVersion, "ncclGetVersion") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     return r;
 }
+
+// ---- BROV_COLLECTIVE_COPY: where the ranks of one group meet (one table entry per 128-byte id; the brov_group objects that hold the
+// ranks share it).  A rank publishes what it contributes (pointer + an event recorded on its stream behind the data) and counts the
+// gathers it has entered / finished pulling; the other ranks wait for those counters on the host and for the events on their streams.
+struct CopyPeer {
+    bool present = false;
+    int dev = -1;
+    const brov_result* src_rec = nullptr;   // contribution to a BROV_GATHER_RECORDS gather: [Bmax] records (the solver's own array, or the padded staging copy)
+    const double* src_pair = nullptr;       // ... to a BROV_GATHER_PACKED gather: (cost, global index)
+    hipEvent_t ready = nullptr;             // recorded on the rank's stream behind its contribution
+    hipEvent_t pulled = nullptr;            // ... behind its copies out of the other ranks' buffers
+    long entered = 0, done = 0;             // gathers this rank has entered / has issued all pulls of
+    int mode = -1;
+};
+struct CopyComm {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<CopyPeer> peer;             // by GLOBAL rank
+    int joined = 0;
+};
+std::mutex g_copy_m;
+std::map<std::string, std::shared_ptr<CopyComm>> g_copy;
+std::atomic<int> kCopyWaitSeconds{60};       // a rank that does not show up within this time is reported, not waited for forever
+
+// the calling thread's current device is the caller's business: every entry point that switches devices puts it back
+struct DeviceKeeper {
+    int d = -1;
+    DeviceKeeper() { if (hipGetDevice(&d) != hipSuccess) { d = -1; (void)hipGetLastError(); } }
+    ~DeviceKeeper() { if (d >= 0) (void)hipSetDevice(d); }
+};
 
 }  // namespace
 
@@ -87,6 +139,10 @@ struct brov_group {
     int32_t mail_seq = 0;
     std::vector<hipEvent_t> ev;           // 4 per device: solve start / end = gather start / gather end / select end
     int last_mode = -1;
+    int collective = BROV_COLLECTIVE_RCCL;
+    std::shared_ptr<CopyComm> cc;         // BROV_COLLECTIVE_COPY: the meeting point of the group's ranks
+    std::string cc_key;
+    long round = 0;                       // gathers entered by this process's ranks
     bool timing = true;
     bool ev_sel = false;                  // the select-end event of the current step has been recorded
     bool ev_solve = false, ev_gather = false;   // ... the solve's pair, the gather's end
@@ -222,9 +278,31 @@ int brov_group_rccl_version(int* version) {
 
 void brov_group_destroy(brov_group* g) {
     if (!g) return;
-    for (int d = 0; d < g->n; d++) {
+    DeviceKeeper keep;
+    for (int d = 0; d < g->n; d++) {   // everything this process's ranks have enqueued is over before anything is taken apart
         if (d < (int)g->dev.size()) hipSetDevice(g->dev[d]);
         if (d < (int)g->st.size() && g->st[d]) hipStreamSynchronize(g->st[d]);
+    }
+    if (g->cc) {   // leave the copy collective's table (the other ranks must have finished the gathers they share with this one)
+        {
+            std::lock_guard<std::mutex> lk(g->cc->m);
+            for (int d = 0; d < g->n; d++) {
+                const int q = g->r0 + d;
+                if (q >= (int)g->cc->peer.size() || !g->cc->peer[q].present || g->cc->peer[q].src_pair != (d < (int)g->pair.size() ? g->pair[d] : nullptr)) continue;
+                CopyPeer& me = g->cc->peer[q];
+                if (me.ready) hipEventDestroy(me.ready);
+                if (me.pulled) hipEventDestroy(me.pulled);
+                me = CopyPeer();
+                g->cc->joined--;
+            }
+        }
+        std::lock_guard<std::mutex> lk(g_copy_m);
+        auto it = g_copy.find(g->cc_key);
+        if (it != g_copy.end() && it->second == g->cc && g->cc->joined <= 0) g_copy.erase(it);
+        g->cc.reset();
+    }
+    for (int d = 0; d < g->n; d++) {
+        if (d < (int)g->dev.size()) hipSetDevice(g->dev[d]);
         if (d < (int)g->comm.size() && g->comm[d] && rccl().handle) rccl().CommDestroy(g->comm[d]);
         if (d < (int)g->sol.size()) brov_destroy(g->sol[d]);
         if (d < (int)g->stage.size() && g->stage[d]) hipFree(g->stage[d]);
@@ -247,18 +325,21 @@ void brov_group_destroy(brov_group* g) {
 
 // common part of the two creators: local devices dev[0..n), global ranks r0 .. r0 + n - 1 of W, instances per global rank in cnt[W]
 static int group_build(brov_group** out, const int* devices, int n, int W, int r0, const std::vector<int>& cnt, const brov_opts* opts,
-                       const ncclUniqueId* id) {
+                       const ncclUniqueId* id, int collective) {
+    if (collective != BROV_COLLECTIVE_RCCL && collective != BROV_COLLECTIVE_COPY) { g_gerr = "brov_group_create: unknown collective"; return BROV_ERR_ARG; }
+    const bool copy = collective == BROV_COLLECTIVE_COPY;
+    DeviceKeeper keep;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_gerr = "brov_group_create: no usable HIP device (this library has no CPU fallback)"; return BROV_ERR_NO_DEVICE; }
     for (int d = 0; d < n; d++) {
         if (devices[d] < 0 || devices[d] >= ndev) { g_gerr = "brov_group_create: device ordinal out of range"; return BROV_ERR_NO_DEVICE; }
-        for (int e = 0; e < d; e++)
-            if (devices[e] == devices[d]) { g_gerr = "brov_group_create: a device may appear once (one RCCL rank per GPU)"; return BROV_ERR_ARG; }
+        for (int e = 0; e < d && !copy; e++)
+            if (devices[e] == devices[d]) { g_gerr = "brov_group_create: a device may appear once (one RCCL rank per GPU; BROV_COLLECTIVE_COPY lifts this)"; return BROV_ERR_ARG; }
     }
-    Rccl& R = rccl();
-    if (!R.handle) { g_gerr = "brov_group_create: " + R.why; return BROV_ERR_HIP; }
+    Rccl* Rp = copy ? nullptr : &rccl();
+    if (Rp && !Rp->handle) { g_gerr = "brov_group_create: " + Rp->why; return BROV_ERR_HIP; }
     brov_group* g = new brov_group();
-    g->n = n; g->W = W; g->r0 = r0;
+    g->n = n; g->W = W; g->r0 = r0; g->collective = collective;
     g->dev.assign(devices, devices + n);
     g->cnt = cnt; g->lo.assign(W, 0);
     g->even = true;
@@ -299,23 +380,54 @@ static int group_build(brov_group** out, const int* devices, int n, int W, int r
         if (!ok) { g_gerr = "brov_group_create: allocation of the gather buffers failed"; return fail(BROV_ERR_ALLOC); }
         g->pairs[d] = g->pair[d] + 2;
     }
-    ncclResult_t nr;
-    if (id) {   // one process per GPU: this process is rank r0 of W
-        if (hipSetDevice(g->dev[0]) != hipSuccess) { g_gerr = "brov_group_create_rank: hipSetDevice failed"; return fail(BROV_ERR_HIP); }
-        nr = R.CommInitRank(&g->comm[0], W, *id, r0);
+    if (copy) {   // join the table entry of this group's id (the one-process form has an id of its own)
+        g->cc_key = id ? std::string(id->internal, sizeof(id->internal)) : "one-process group " + std::to_string((unsigned long long)(uintptr_t)g);
+        {
+            std::lock_guard<std::mutex> lk(g_copy_m);
+            std::shared_ptr<CopyComm>& sp = g_copy[g->cc_key];
+            if (!sp) { sp = std::make_shared<CopyComm>(); sp->peer.resize(W); }
+            g->cc = sp;
+        }
+        std::unique_lock<std::mutex> lk(g->cc->m);
+        if ((int)g->cc->peer.size() != W) { lk.unlock(); g_gerr = "brov_group_create_rank: the ranks of this id disagree about the world size"; return fail(BROV_ERR_ARG); }
+        for (int d = 0; d < n; d++)
+            if (g->cc->peer[r0 + d].present) { lk.unlock(); g_gerr = "brov_group_create_rank: rank " + std::to_string(r0 + d) + " of this id exists already"; return fail(BROV_ERR_ARG); }
+        for (int d = 0; d < n; d++) {
+            CopyPeer& me = g->cc->peer[r0 + d];
+            me.dev = g->dev[d];
+            me.src_rec = g->even ? brov_results_device(g->sol[d]) : g->stage[d];
+            me.src_pair = g->pair[d];
+            bool ok = hipSetDevice(g->dev[d]) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&me.ready, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&me.pulled, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { lk.unlock(); g_gerr = "brov_group_create: events of the copy collective"; return fail(BROV_ERR_HIP); }
+            me.present = true;
+            g->cc->joined++;
+        }
+        g->cc->cv.notify_all();
     } else {
-        nr = R.CommInitAll(g->comm.data(), n, g->dev.data());
+        Rccl& R = *Rp;
+        ncclResult_t nr;
+        if (id) {   // one process per GPU: this process is rank r0 of W
+            if (hipSetDevice(g->dev[0]) != hipSuccess) { g_gerr = "brov_group_create_rank: hipSetDevice failed"; return fail(BROV_ERR_HIP); }
+            nr = R.CommInitRank(&g->comm[0], W, *id, r0);
+        } else {
+            nr = R.CommInitAll(g->comm.data(), n, g->dev.data());
+        }
+        if (nr != ncclSuccess) { g_gerr = std::string("brov_group_create: RCCL communicator set-up: ") + R.GetErrorString(nr); return fail(BROV_ERR_HIP); }
     }
-    if (nr != ncclSuccess) { g_gerr = std::string("brov_group_create: RCCL communicator set-up: ") + R.GetErrorString(nr); return fail(BROV_ERR_HIP); }
     *out = g;
     return BROV_OK;
 }
 
-int brov_group_create(brov_group** out, const int* devices, int n, int total, const brov_opts* opts) {
+int brov_group_create_ex(brov_group** out, const int* devices, int n, int total, const brov_opts* opts, int collective) {
     if (!out || !devices || !opts || n < 1 || n > 64 || total < n) { g_gerr = "brov_group_create: bad argument (1 <= n <= 64 devices, at least one instance each)"; return BROV_ERR_ARG; }
     std::vector<int> cnt(n);
     for (int d = 0; d < n; d++) cnt[d] = total / n + (d < total % n ? 1 : 0);
-    return group_build(out, devices, n, n, 0, cnt, opts, nullptr);
+    return group_build(out, devices, n, n, 0, cnt, opts, nullptr, collective);
+}
+int brov_group_create(brov_group** out, const int* devices, int n, int total, const brov_opts* opts) {
+    return brov_group_create_ex(out, devices, n, total, opts, BROV_COLLECTIVE_RCCL);
 }
 
 // ---- one process per GPU: the same group, each process holding ONE rank of it ----------------------------------------------------
@@ -328,15 +440,20 @@ int brov_group_unique_id(char id[128]) {
     std::memcpy(id, &u, 128);
     return BROV_OK;
 }
-int brov_group_create_rank(brov_group** out, int device, int rank, int world, const char id[128], const int* counts, const brov_opts* opts) {
+int brov_group_create_rank_ex(brov_group** out, int device, int rank, int world, const char id[128], const int* counts, const brov_opts* opts, int collective) {
     if (!out || !id || !counts || !opts || world < 1 || rank < 0 || rank >= world) { g_gerr = "brov_group_create_rank: bad argument"; return BROV_ERR_ARG; }
     std::vector<int> cnt(counts, counts + world);
     for (int r = 0; r < world; r++)
         if (cnt[r] < 1) { g_gerr = "brov_group_create_rank: every rank needs at least one instance"; return BROV_ERR_ARG; }
     ncclUniqueId u;
     std::memcpy(&u, id, 128);
-    return group_build(out, &device, 1, world, rank, cnt, opts, &u);
+    return group_build(out, &device, 1, world, rank, cnt, opts, &u, collective);
 }
+int brov_group_create_rank(brov_group** out, int device, int rank, int world, const char id[128], const int* counts, const brov_opts* opts) {
+    return brov_group_create_rank_ex(out, device, rank, world, id, counts, opts, BROV_COLLECTIVE_RCCL);
+}
+int brov_group_collective(const brov_group* g) { return g ? g->collective : -1; }
+int brov_group_set_copy_wait_seconds(int seconds) { if (seconds < 1) return BROV_ERR_ARG; kCopyWaitSeconds = seconds; return BROV_OK; }
 
 int brov_group_size(const brov_group* g) { return g ? g->n : 0; }          /* devices of this process */
 int brov_group_world(const brov_group* g) { return g ? g->W : 0; }         /* ranks of the whole group */
@@ -354,12 +471,14 @@ int brov_group_shard(const brov_group* g, int rank, int* lo, int* hi) {
 // ---- whole-batch setters: global HOST arrays, sliced per shard -------------------------------------------------------------
 int brov_group_set_x0_host(brov_group* g, const double* x0) {
     if (!g || !x0) return BROV_ERR_ARG;
+    DeviceKeeper keep;
     for (int d = 0; d < g->n; d++)
         if (int rc = brov_set_x0_host(g->sol[d], x0 + (size_t)g->lo[g->r0 + d] * 12)) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
 }
 int brov_group_set_params_host(brov_group* g, const double* p, int per_stage) {
     if (!g || !p) return BROV_ERR_ARG;
+    DeviceKeeper keep;
     const size_t row = per_stage ? (size_t)(brov_horizon(g->sol[0]) + 1) * 16 : 16;
     for (int d = 0; d < g->n; d++)
         if (int rc = brov_set_params_host(g->sol[d], p + (size_t)g->lo[g->r0 + d] * row, per_stage)) { g_gerr = brov_last_error(); return rc; }
@@ -367,6 +486,7 @@ int brov_group_set_params_host(brov_group* g, const double* p, int per_stage) {
 }
 int brov_group_set_yref_host(brov_group* g, const double* yref, int shared) {
     if (!g || !yref) return BROV_ERR_ARG;
+    DeviceKeeper keep;
     const size_t row = (size_t)(brov_horizon(g->sol[0]) + 1) * 16;
     for (int d = 0; d < g->n; d++)
         if (int rc = brov_set_yref_host(g->sol[d], shared ? yref : yref + (size_t)g->lo[g->r0 + d] * row, shared)) { g_gerr = brov_last_error(); return rc; }
@@ -374,12 +494,14 @@ int brov_group_set_yref_host(brov_group* g, const double* yref, int shared) {
 }
 int brov_group_set_candidate_params_host(brov_group* g, int kind, const double* p0, const double* p1, const double* phase) {
     if (!g || !p0 || !p1 || !phase) return BROV_ERR_ARG;
+    DeviceKeeper keep;
     for (int d = 0; d < g->n; d++)
         if (int rc = brov_set_candidate_params_host(g->sol[d], kind, p0 + g->lo[g->r0 + d], p1 + g->lo[g->r0 + d], phase + g->lo[g->r0 + d])) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
 }
 int brov_group_set_yref_candidates(brov_group* g, double t0, double dt) {   // one window kernel per device, on the device's stream
     if (!g) return BROV_ERR_ARG;
+    DeviceKeeper keep;
     for (int d = 0; d < g->n; d++)
         if (int rc = brov_set_yref_candidates(g->sol[d], t0, dt, g->st[d])) { g_gerr = brov_last_error(); return rc; }
     return BROV_OK;
@@ -387,8 +509,77 @@ int brov_group_set_yref_candidates(brov_group* g, double t0, double dt) {   // o
 
 int brov_group_enable_timing(brov_group* g, int on) { if (!g) return BROV_ERR_ARG; g->timing = on != 0; return BROV_OK; }
 
+// BROV_COLLECTIVE_COPY: before a rank rewrites what it contributed to the last gather (its records: the next solve; its staging copy /
+// its pair: the next gather), every rank has pulled it -- waited for on the host until the pulls are enqueued, on the streams until
+// they have run.  (RCCL needs nothing of the kind: its all-gather ends on all streams together.)
+static int copy_fence(brov_group* g) {
+    if (!g->cc || g->round == 0) return BROV_OK;
+    CopyComm& c = *g->cc;
+    {
+        std::unique_lock<std::mutex> lk(c.m);
+        int missing = -1;
+        const bool ok = c.cv.wait_for(lk, std::chrono::seconds(kCopyWaitSeconds.load()), [&] {
+            for (int r = 0; r < g->W; r++)
+                if (!c.peer[r].present || c.peer[r].done < g->round) { missing = r; return false; }
+            return true;
+        });
+        if (!ok) { g_gerr = "copy collective: rank " + std::to_string(missing) + " has not finished gather " + std::to_string(g->round); return BROV_ERR_HIP; }
+    }
+    for (int d = 0; d < g->n; d++) {
+        GHIP(hipSetDevice(g->dev[d]));
+        for (int r = 0; r < g->W; r++)
+            if (r != g->r0 + d) GHIP(hipStreamWaitEvent(g->st[d], c.peer[r].pulled, 0));
+    }
+    return BROV_OK;
+}
+
+// the all-gather as copies (see the head of the file): publish, meet, pull
+static int copy_gather(brov_group* g, int mode) {
+    CopyComm& c = *g->cc;
+    const size_t rec = sizeof(brov_result);
+    const long round = ++g->round;
+    for (int d = 0; d < g->n; d++) {
+        GHIP(hipSetDevice(g->dev[d]));
+        GHIP(hipEventRecord(c.peer[g->r0 + d].ready, g->st[d]));
+    }
+    {
+        std::unique_lock<std::mutex> lk(c.m);
+        for (int d = 0; d < g->n; d++) { c.peer[g->r0 + d].entered = round; c.peer[g->r0 + d].mode = mode; }
+        c.cv.notify_all();
+        // every rank has entered this gather: what a collective waits for on the device is waited for on the host here
+        int missing = -1;
+        const bool ok = c.cv.wait_for(lk, std::chrono::seconds(kCopyWaitSeconds.load()), [&] {
+            for (int r = 0; r < g->W; r++)
+                if (!c.peer[r].present || c.peer[r].entered < round) { missing = r; return false; }
+            return true;
+        });
+        if (!ok) { g_gerr = "copy collective: rank " + std::to_string(missing) + " did not enter gather " + std::to_string(round); return BROV_ERR_HIP; }
+        for (int r = 0; r < g->W; r++)
+            if (c.peer[r].entered == round && c.peer[r].mode != mode) { g_gerr = "copy collective: the ranks disagree about the gather mode"; return BROV_ERR_ARG; }
+    }
+    for (int d = 0; d < g->n; d++) {
+        GHIP(hipSetDevice(g->dev[d]));
+        for (int r = 0; r < g->W; r++) {
+            if (r != g->r0 + d) GHIP(hipStreamWaitEvent(g->st[d], c.peer[r].ready, 0));
+            if (mode == BROV_GATHER_RECORDS)
+                GHIP(hipMemcpyAsync(g->gathered[d] + (size_t)r * g->Bmax, c.peer[r].src_rec, (size_t)g->Bmax * rec, hipMemcpyDefault, g->st[d]));
+            else
+                GHIP(hipMemcpyAsync(g->pairs[d] + 2 * r, c.peer[r].src_pair, 2 * sizeof(double), hipMemcpyDefault, g->st[d]));
+        }
+        GHIP(hipEventRecord(c.peer[g->r0 + d].pulled, g->st[d]));
+    }
+    {
+        std::lock_guard<std::mutex> lk(c.m);
+        for (int d = 0; d < g->n; d++) c.peer[g->r0 + d].done = round;
+        c.cv.notify_all();
+    }
+    return BROV_OK;
+}
+
 int brov_group_solve(brov_group* g) {
     if (!g) return BROV_ERR_ARG;
+    DeviceKeeper keep;
+    if (int rc = copy_fence(g)) return rc;
     for (int d = 0; d < g->n; d++) {
         GHIP(hipSetDevice(g->dev[d]));
         if (g->timing) GHIP(hipEventRecord(g->ev[4 * d + 0], g->st[d]));
@@ -402,8 +593,9 @@ int brov_group_solve(brov_group* g) {
 
 int brov_group_gather(brov_group* g, int mode) {
     if (!g || (mode != BROV_GATHER_RECORDS && mode != BROV_GATHER_PACKED)) return BROV_ERR_ARG;
-    Rccl& R = rccl();
+    DeviceKeeper keep;
     const size_t rec = sizeof(brov_result);
+    if (int rc = copy_fence(g)) return rc;
     // what each device contributes, produced on its own stream behind the solve
     for (int d = 0; d < g->n; d++) {
         GHIP(hipSetDevice(g->dev[d]));
@@ -415,18 +607,23 @@ int brov_group_gather(brov_group* g, int mode) {
             GHIP(hipGetLastError());
         }
     }
-    GNCCL(R.GroupStart());
-    for (int d = 0; d < g->n; d++) {
-        ncclResult_t r;
-        if (mode == BROV_GATHER_RECORDS) {
-            const void* src = g->even ? (const void*)brov_results_device(g->sol[d]) : (const void*)g->stage[d];
-            r = R.AllGather(src, g->gathered[d], (size_t)g->Bmax * rec, ncclUint8, g->comm[d], g->st[d]);
-        } else {
-            r = R.AllGather(g->pair[d], g->pairs[d], 2, ncclDouble, g->comm[d], g->st[d]);
+    if (g->cc) {
+        if (int rc = copy_gather(g, mode)) return rc;
+    } else {
+        Rccl& R = rccl();
+        GNCCL(R.GroupStart());
+        for (int d = 0; d < g->n; d++) {
+            ncclResult_t r;
+            if (mode == BROV_GATHER_RECORDS) {
+                const void* src = g->even ? (const void*)brov_results_device(g->sol[d]) : (const void*)g->stage[d];
+                r = R.AllGather(src, g->gathered[d], (size_t)g->Bmax * rec, ncclUint8, g->comm[d], g->st[d]);
+            } else {
+                r = R.AllGather(g->pair[d], g->pairs[d], 2, ncclDouble, g->comm[d], g->st[d]);
+            }
+            if (r != ncclSuccess) { R.GroupEnd(); g_gerr = std::string("ncclAllGather: ") + R.GetErrorString(r); return BROV_ERR_HIP; }
         }
-        if (r != ncclSuccess) { R.GroupEnd(); g_gerr = std::string("ncclAllGather: ") + R.GetErrorString(r); return BROV_ERR_HIP; }
+        GNCCL(R.GroupEnd());
     }
-    GNCCL(R.GroupEnd());
     if (g->timing)
         for (int d = 0; d < g->n; d++) { GHIP(hipSetDevice(g->dev[d])); GHIP(hipEventRecord(g->ev[4 * d + 2], g->st[d])); }
     g->ev_gather = g->timing && g->ev_solve;
@@ -436,6 +633,7 @@ int brov_group_gather(brov_group* g, int mode) {
 
 int brov_group_synchronize(brov_group* g) {
     if (!g) return BROV_ERR_ARG;
+    DeviceKeeper keep;
     for (int d = 0; d < g->n; d++) { GHIP(hipSetDevice(g->dev[d])); GHIP(hipStreamSynchronize(g->st[d])); }
     return BROV_OK;
 }
@@ -469,6 +667,7 @@ static int mail_wait(brov_group* g, int32_t seq) {
 int brov_group_select_best(brov_group* g, int* best_index, brov_result* best) {
     if (!g || !best_index) return BROV_ERR_ARG;
     if (g->last_mode < 0) { g_gerr = "brov_group_select_best: call brov_group_gather first"; return BROV_ERR_ARG; }
+    DeviceKeeper keep;
     *best_index = -1;
     if (g->last_mode == BROV_GATHER_RECORDS) {
         // every device holds all records: device 0 selects (any would do).  The kernel delivers the winning slot and its record into
@@ -519,6 +718,7 @@ int brov_group_get_results_host(brov_group* g, brov_result* res) {
     if (!g || !res) return BROV_ERR_ARG;
     if (g->last_mode != BROV_GATHER_RECORDS) { g_gerr = "brov_group_get_results_host: needs a BROV_GATHER_RECORDS gather"; return BROV_ERR_ARG; }
     if (int rc = brov_group_synchronize(g)) return rc;
+    DeviceKeeper keep;
     GHIP(hipSetDevice(g->dev[0]));
     for (int r = 0; r < g->W; r++)   // strip the padding slots of uneven shards
         GHIP(hipMemcpy(res + g->lo[r], g->gathered[0] + (size_t)r * g->Bmax, (size_t)g->cnt[r] * sizeof(brov_result), hipMemcpyDeviceToHost));
@@ -530,6 +730,7 @@ int brov_group_slots_per_rank(const brov_group* g) { return g ? g->Bmax : 0; }
 int brov_group_last_seconds(brov_group* g, double* solve, double* gather, double* select) {
     if (!g || !g->timing || !g->ev_solve) { g_gerr = "brov_group_last_seconds: no timed solve yet (timing must be on before brov_group_solve)"; return BROV_ERR_ARG; }
     double ts = 0, tg = 0, tsel = 0;
+    DeviceKeeper keep;
     for (int d = 0; d < g->n; d++) {
         GHIP(hipSetDevice(g->dev[d]));
         float a = 0, b = 0;

@@ -108,7 +108,40 @@ struct brov_solver {
     bool pit_ran = false;            // the last solve launched rti_pit_kernel
     int32_t* pit_done = nullptr;     // [B]: written by rti_pit_kernel (parallel-in-time step-0 solve), read by the resident kernel launched behind it
     int32_t mail_seq = 0;
+    DevKnobs k;                      // development knobs (BROV_* environment), read once in brov_create: no getenv on the path of a solve
 };
+
+// The solver's development knobs: A/B switches and test hooks, all of them BROV_* environment variables.  Read ONCE per solver (brov_create;
+// brov_dev_reload_knobs re-reads them for tests that flip a switch between two solves of one solver) -- a linear scan of the environment
+// per variable has no place inside a 29 us feedback call (round 4 did up to 16 of them per solve).
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static DevKnobs read_knobs() {
+    DevKnobs k;
+    k.robust_pivot = env_int("BROV_ROBUST_PIVOT", 1);            // 0 off, 1 on demand (default), 2 every instance
+    k.partial_refactor = env_int("BROV_PARTIAL_REFACTOR", 1) != 0;
+    k.mail_early = env_int("BROV_DEV_NO_EARLY_RECORD", 0) == 0;
+    k.split_resident = env_int("BROV_SPLIT_RESIDENT", 1) != 0;
+    k.pit = env_int("BROV_PIT", 1);                               // 0 off, 1 product rule, 2 every instance is tried
+    k.split_parallel = env_int("BROV_SPLIT_PARALLEL", 1) != 0;
+    k.pit_try = env_int("BROV_PIT_TRY", 1) != 0;
+    k.pit_adapt = env_int("BROV_PIT_ADAPT", 1) != 0;
+    k.tick_mailbox = env_int("BROV_TICK_MAILBOX", 1) != 0;
+    k.tick_bulk = env_int("BROV_TICK_BULK", 1) != 0;
+    k.tick_zerocopy = env_int("BROV_TICK_ZEROCOPY", 1) != 0;
+    k.sched = env_int("BROV_SCHED", 1) != 0;
+    k.force_windowed = env_int("BROV_DEV_FORCE_WINDOWED", 0) != 0;
+    k.fused_waves = env_int("BROV_DEV_FUSED_WAVES", 0);           // 1 / 2: force a variant of the fused kernel (default by LDS size)
+    k.lds_pad = env_int("BROV_DEV_LDS_PAD", 0);
+    return k;
+}
+extern "C" int brov_dev_reload_knobs(brov_solver* s) {
+    if (!s) return BROV_ERR_ARG;
+    const bool fw = s->force_windowed;
+    s->k = read_knobs();
+    s->k.force_windowed = fw;        // (the workspaces were allocated for the create-time choice)
+    s->sched_on = s->k.sched != 0;
+    return BROV_OK;
+}
 
 extern "C" void brov_default_opts(brov_opts* o, int N, double Ts) {
     // /root/reference/bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.c:422-481 (W), :559-566 (bounds), :668
@@ -259,7 +292,8 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     AL(pit_done, Bz);   // rti_pit_kernel's per-instance verdict
     AL(sched, 3 * (size_t)sched_buffer_ints_host(B));
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
-    s->force_windowed = getenv("BROV_DEV_FORCE_WINDOWED") && atoi(getenv("BROV_DEV_FORCE_WINDOWED")) != 0;
+    s->k = read_knobs();
+    s->force_windowed = s->k.force_windowed != 0;
     // BROV_PATH_AUTO at long horizons and a handful of instances (the ROS node's batch of one): when the whole horizon fits one
     // window (N <= 81: resident mode, no parking and no window fetches) the windowed kernel has the shorter latency (N = 80, B = 1:
     // 128 vs 172 us); beyond that the streaming pair, which spreads the linearisation over several wavefronts, is as fast and
@@ -283,7 +317,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     }
     // rti_phase 1 / 2 at a horizon the fused kernels serve: the resident kernel's split launches need a workspace per instance
     if (fused_supported(opts->N) && !s->force_windowed && opts->kernel_path != BROV_PATH_STREAMING && split_resident_horizon(opts->N) &&
-        !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0)) {
+        s->k.split_resident) {
         int dev_ = 0, cus_ = 256;
         (void)hipGetDevice(&dev_);
         (void)hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_);
@@ -302,7 +336,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     hipMemset(s->sched, 0, 3 * (size_t)sched_buffer_ints_host(B) * sizeof(int32_t));
     hipMemset(s->counter, 0, 64 * sizeof(int32_t));
     // development knob: BROV_SCHED=0 hands the instances out in index order (A/B of the work ordering)
-    s->sched_on = !(getenv("BROV_SCHED") && atoi(getenv("BROV_SCHED")) == 0);
+    s->sched_on = s->k.sched != 0;
     {
         std::vector<double> h0(Bz * 12, 0.0);
         for (size_t k = 0; k < Bz; k++) h0[k * 12 + 2] = -20.0;
@@ -808,8 +842,8 @@ static DevParams make_params(const brov_solver* s) {
     P.B = s->B; P.N = s->N;
     P.qp_iter_max = s->opts.qp_iter_max; P.early_exit = s->opts.qp_early_exit;
     P.on_failure = s->opts.on_failure; P.dump_lin = s->dump_lin ? 1 : 0;
-    P.robust_pivot = getenv("BROV_ROBUST_PIVOT") ? atoi(getenv("BROV_ROBUST_PIVOT")) : 1;   // development knob: 0 off, 1 on demand (default), 2 every instance
-    P.partial_refactor = !(getenv("BROV_PARTIAL_REFACTOR") && atoi(getenv("BROV_PARTIAL_REFACTOR")) == 0);   // development knob (A/B, tests)
+    P.robust_pivot = s->k.robust_pivot;            // development knob: 0 off, 1 on demand (default), 2 every instance
+    P.partial_refactor = s->k.partial_refactor;    // development knob (A/B, tests)
     P.Ts = s->opts.Ts; P.tol_mu = s->opts.qp_tol_mu; P.tol_stat = s->opts.qp_tol_stat;
     for (int j = 0; j < 16; j++) P.W[j] = s->opts.W[j];
     for (int j = 0; j < 12; j++) P.We[j] = s->opts.We[j];
@@ -829,7 +863,7 @@ static DevParams make_params(const brov_solver* s) {
     P.Ks = s->Ks; P.Kt = s->Kt; P.Mt = s->Mt; P.Pb = s->Pb; P.kff = s->kff; P.vhat = s->vhat; P.ipm = s->ipm;
     P.dxb = s->dxb; P.cst = s->cst; P.res = s->res;
     P.mail = s->mail; P.mail_flag = s->mail_flag; P.mail_seq = s->mail_seq;
-    P.mail_early = !(getenv("BROV_DEV_NO_EARLY_RECORD") && atoi(getenv("BROV_DEV_NO_EARLY_RECORD")) != 0);   // development knob (A/B)
+    P.mail_early = s->k.mail_early;   // development knob (A/B)
     P.ws = s->ws; P.ws_stride = s->win_L ? (int64_t)windowed_ws_doubles(s->N, s->win_L) : 0; P.counter = s->counter + 32 * (s->win_tick & 1u);
     P.counter_next = s->counter + 32 * ((s->win_tick + 1u) & 1u);
     P.win_L = s->win_L; P.win_blocks = s->win_blocks;
@@ -852,11 +886,15 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     // launches of rti_window_kernel_res_split -- preparation parks the factorised LDS image per instance, feedback runs from the forward
     // sweep on.  A feedback call follows the path its preparation took (prep_path); BROV_SPLIT_RESIDENT=0: the streaming pair as before.
     const bool fused_h = fused_supported(s->N) && !s->force_windowed;
-    const bool split_env = !(getenv("BROV_SPLIT_RESIDENT") && atoi(getenv("BROV_SPLIT_RESIDENT")) == 0);
+    const bool split_env = s->k.split_resident != 0;
     const bool split_fused_h = fused_h && s->ws_split != nullptr && path != BROV_PATH_STREAMING && !s->dump_lin && split_env;   // (N <= 23: see brov_create)
     const bool split_res_ok = split_fused_h || (path != BROV_PATH_STREAMING && !fused_h && s->ws != nullptr &&
                               windowed_is_resident(s->win_L) && s->win_blocks == (int)s->B && !s->dump_lin && split_env);
     const bool split_res = (rti_phase == 1 && split_res_ok) || (rti_phase == 2 && split_res_ok && s->prep_path == 2);
+    if (rti_phase == 2 && s->prep_path == 0) {   // no preparation, or one that a later step (rti_phase 0, an earlier feedback) has used up: the iterate it linearised is gone
+        g_err = "brov_solve: rti_phase 2 needs a preparation (rti_phase 1) of the CURRENT iterate: none since the last step";
+        return BROV_ERR_ARG;
+    }
     if (rti_phase == 2 && (s->prep_path == 3 || (s->prep_path == 2 && !split_res_ok))) {   // (a grid / option / iterate / path change between the two calls)
         g_err = "brov_solve: rti_phase 2 after a preparation on the resident kernel, which the solver's settings no longer allow: repeat rti_phase 1";
         return BROV_ERR_ARG;
@@ -872,19 +910,18 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     if (s->timing) hipEventRecord(s->ev[0], st);
     if (fused || windowed) {
         if (s->timing) hipEventRecord(s->ev[1], st);
-        if (fused) launch_fused(P, st);
+        if (fused) launch_fused(P, st, s->k);
         else {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)
-            const int pit = getenv("BROV_PIT") ? atoi(getenv("BROV_PIT")) : 1;
+            const int pit = s->k.pit;
             const bool pit_can = pit && s->pit_done && !s->dump_lin && rti_phase == 0;
             P.rti_split = rti_phase;
             // the feedback half of a split tick: the parallel-in-time kernel's feedback instantiation first, rolling out the
             // four quarters at once from what the preparation parked; the resident feedback launch behind it for what it leaves
-            if (rti_phase == 2 && pit && s->pit_done && pit_supported(s->N, P.win_L) &&
-                !(getenv("BROV_SPLIT_PARALLEL") && atoi(getenv("BROV_SPLIT_PARALLEL")) == 0)) {
+            if (rti_phase == 2 && pit && s->pit_done && pit_supported(s->N, P.win_L) && s->k.split_parallel) {
                 P.pit = pit; P.pit_done = s->pit_done; P.pit_blocks = P.win_blocks;
-                P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);
+                P.pit_try = s->k.pit_try;
             }
             P.pit_blocks = P.win_blocks;
             // The parallel kernel runs AHEAD of the resident one: what it leaves (instances that need an interior-point iteration or a fourth
@@ -898,7 +935,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // windowed kernel for kPitPause solves, then one probe.  A batch of one never pauses.  BROV_PIT_ADAPT=0: never.
             bool pit_now = pit_can && (s->alt_L != 0 || pit_supported(s->N, P.win_L));
             bool probe = false, resident_report = false;
-            if (pit_now && pit != 2 && s->pit_left_host && !(getenv("BROV_PIT_ADAPT") && atoi(getenv("BROV_PIT_ADAPT")) == 0)) {
+            if (pit_now && pit != 2 && s->pit_left_host && s->k.pit_adapt) {
                 // (the host may be many solves ahead of the device: reports carry the sequence number of their solve.  A report that
                 // starts a pause makes everything issued up to then old news; after the pause ONE solve probes, and until ITS report is
                 // in the solves go without the parallel kernel)
@@ -931,7 +968,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             }
             if (pit_now && pit_supported(s->N, P.win_L)) {
                 P.pit = pit; P.pit_done = s->pit_done;
-                P.pit_try = !(getenv("BROV_PIT_TRY") && atoi(getenv("BROV_PIT_TRY")) == 0);
+                P.pit_try = s->k.pit_try;
                 P.pit_left_host = s->pit_left_host;
                 P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
                 if (s->pit_seq == 1) s->pit_ignore_upto = 0;   // (wrapped)
@@ -951,6 +988,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     }
     if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
     if (rti_phase != 1) s->sched_tick++;   // a QP kernel ran: it wrote the next ordering
+    if (rti_phase != 1) s->prep_path = 0;  // ... and the iterate moved (and the per-block workspace was rewritten): whatever preparation there was is used up
     s->last_fused = fused;
     s->last_windowed = windowed;
     s->last_stream = st;
@@ -1002,6 +1040,15 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     if (s->last_stream != st) HIPCHK(sync_last(s));   // an earlier solve on the caller's stream
     double* px = s->pin; double* py = px + n_x0; double* pp = py + n_y; double* pr = pp + n_p;
     volatile int32_t* pf = (volatile int32_t*)(pr + n_r);
+    // The refresh copies a zero-copy tick leaves running behind its kernel (pinned staging buffer -> device arrays, copy_stream) still READ the
+    // staging regions they were enqueued for: before the host rewrites one of those regions the copies must be over (round-4 advisor: a
+    // torn or already-next-tick x0 in the device array).  They are 21 KB behind a kernel that has long ended: the query almost always says so.
+    const int passed_now = (x0 ? 1 : 0) | (yref_shared ? 2 : 0) | (par_stage ? 4 : 0);
+    if (s->copies_pending && (s->copy_mask & passed_now) && hipEventQuery(s->ev_copy) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipEventSynchronize(s->ev_copy));
+    }
+    const bool in_place = (x0 && x0 == px) || (yref_shared && yref_shared == py) || (par_stage && par_stage == pp);
     if (x0 && x0 != px) std::memcpy(px, x0, n_x0 * sizeof(double));   // (equal: the caller wrote into the staging buffer, brov_tick_buffers)
     if (yref_shared) {
         if (yref_shared != py) std::memcpy(py, yref_shared, n_y * sizeof(double));
@@ -1012,14 +1059,13 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     // Small batches with the mailbox: the kernel reads the inputs of this tick where the host has just put them (pinned, device-visible
     // memory: 21 KB over PCIe inside the linearisation's staging loads) instead of waiting for a copy command ahead of it; the device
     // copies every other entry point works on are refreshed by the same copies, enqueued BEHIND the launch (BROV_TICK_ZEROCOPY=0: ahead).
-    const bool mailbox = rti_phase != 1 && B <= kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0);
+    const bool mailbox = rti_phase != 1 && B <= kTickMailboxMaxBatch && s->k.tick_mailbox;
     // Larger batches whose records the kernel writes into the pinned buffer itself (bulk, below): the same for x0 and a shared window (96 bytes
     // per instance over PCIe inside the linearisation's staging loads) -- not for per-stage parameters passed with the tick (2.7 KB per instance
     // at N = 20: those go through the copy engine ahead of the launch, and the other inputs with them).
-    const bool bulk = !mailbox && rti_phase != 1 && B > kTickMailboxMaxBatch && !(getenv("BROV_TICK_MAILBOX") && atoi(getenv("BROV_TICK_MAILBOX")) == 0) &&
-                      !(getenv("BROV_TICK_BULK") && atoi(getenv("BROV_TICK_BULK")) == 0);
+    const bool bulk = !mailbox && rti_phase != 1 && B > kTickMailboxMaxBatch && s->k.tick_mailbox && s->k.tick_bulk;
     // (a feedback call, rti_phase 2, too: its kernel reads the new measurement where the host has just put it)
-    const bool zerocopy = (mailbox || (bulk && !par_stage)) && rti_phase != 1 && !(getenv("BROV_TICK_ZEROCOPY") && atoi(getenv("BROV_TICK_ZEROCOPY")) == 0);
+    const bool zerocopy = (mailbox || (bulk && !par_stage)) && rti_phase != 1 && s->k.tick_zerocopy;
     auto upload = [&](hipStream_t cs) -> int {
         if (x0 && yref_shared && par_stage) {   // device side: one allocation in the same order (brov_create)
             HIPCHK(hipMemcpyAsync(s->x0, px, (n_x0 + n_y + n_p) * sizeof(double), hipMemcpyHostToDevice, cs));
@@ -1103,6 +1149,9 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         else HIPCHK(hipStreamSynchronize(st));
     }
     if (res && res != (brov_result*)pr) std::memcpy(res, pr, B * sizeof(brov_result));
+    // a caller that builds its inputs IN the staging buffers (brov_tick_buffers) is free to write the next tick's as soon as this call is back:
+    // the refresh copies out of them are over by then
+    if (zerocopy && in_place) HIPCHK(hipEventSynchronize(s->ev_copy));
     return BROV_OK;
 }
 
@@ -1151,7 +1200,7 @@ extern "C" int brov_lds_kernel_info(const brov_solver* s, int32_t info[4]) {
     const bool fused = fused_supported(s->N) && !s->force_windowed;
     // streaming kernels (asked for, or forced by a general grid, or no windowed workspace): stage blocks in HBM, nothing to report
     if (s->opts.kernel_path == BROV_PATH_STREAMING || (!fused && !s->ws)) { info[0] = info[1] = info[2] = info[3] = 0; return BROV_OK; }
-    lds_kernel_info(s->N, s->win_L, !fused, info);
+    lds_kernel_info(s->N, s->win_L, !fused, info, s->k);
     return BROV_OK;
 }
 extern "C" int brov_window_stages(const brov_solver* s) { return s ? (s->ws ? s->win_L : 0) : BROV_ERR_ARG; }

@@ -81,16 +81,22 @@ struct DevParams {
     unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
+// development knobs (BROV_* environment variables), read once per solver by the host API (nmpc_api.hip, read_knobs)
+struct DevKnobs {
+    int robust_pivot = 1, partial_refactor = 1, mail_early = 1, split_resident = 1, pit = 1, split_parallel = 1, pit_try = 1, pit_adapt = 1;
+    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0;
+};
+
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_ACT, IPM_NARR };
 
 int sched_buffer_ints_host(int B);   // int32 per work-ordering buffer (three of them)
 void launch_linearise(const DevParams& P, hipStream_t st);
 void launch_qp(const DevParams& P, hipStream_t st);
-void launch_fused(const DevParams& P, hipStream_t st);  // linearise + QP in one kernel, stage blocks in LDS
+void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k);  // linearise + QP in one kernel, stage blocks in LDS
 bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
 // windowed LDS-resident kernel for longer horizons: persistent blocks (one wavefront each) that take instances from a counter
 void launch_windowed(const DevParams& P, hipStream_t st);
-void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]);   // LDS bytes per block, blocks per CU, threads, kernel kind
+void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4], const DevKnobs& k);   // LDS bytes per block, blocks per CU, threads, kernel kind
 bool pit_supported(int N, int win_L);       // rti_pit_kernel ahead of the resident kernel
 bool windowed_is_resident(int win_L);      // one window = the whole horizon (small batches)
 int windowed_stage_count(int N, int B);   // stages per window (= N for batches of at most one instance per CU: resident mode)

@@ -4018,14 +4018,13 @@ bool split_resident_horizon(int N) { return N >= 4 && 3 * ((N + 3) >> 2) < N && 
 
 
 static size_t fused_lds_bytes(int N) { return ((size_t)N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(N + 1) * NX + 2 + 17) * sizeof(double); }
-static bool fused_two_wave(size_t lds) {
-    const int force = getenv("BROV_DEV_FUSED_WAVES") ? atoi(getenv("BROV_DEV_FUSED_WAVES")) : 0;
+static bool fused_two_wave(size_t lds, int force) {   // force: DevKnobs::fused_waves (development knob)
     return force ? force == 2 : 6 * lds <= 160 * 1024;   // N <= 13
 }
 // what the LDS-resident kernel of this horizon asks of a CU: info = {dynamic LDS bytes per block, blocks the occupancy query grants
 // per CU, threads per block, 1 fused / 2 fused two-wave / 3 windowed / 4 windowed resident}.  For bench.py's horizon sweep (the
 // "LDS-occupancy crossover" of BASELINE configs[4]): which horizon still fits four instances into a CU's 160 KB.
-void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]) {
+void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4], const DevKnobs& k) {
     const void* fn;
     size_t lds;
     int threads = 64, kind;
@@ -4038,7 +4037,7 @@ void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     } else {
         lds = fused_lds_bytes(N);
-        const bool w2 = fused_two_wave(lds);
+        const bool w2 = fused_two_wave(lds, k.fused_waves);
         fn = w2 ? (const void*)rti_fused_kernel_w2 : (const void*)rti_fused_kernel;
         kind = w2 ? 2 : 1;
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -4047,7 +4046,7 @@ void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4]) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
     info[0] = (int32_t)lds; info[1] = per_cu; info[2] = threads; info[3] = kind;
 }
-void launch_fused(const DevParams& P, hipStream_t st) {
+void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k) {
     const size_t lds = fused_lds_bytes(P.N);
     if (first_launch_on_device(1)) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -4056,8 +4055,8 @@ void launch_fused(const DevParams& P, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)rti_fused_kernel_mail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
-    static const size_t pad = getenv("BROV_DEV_LDS_PAD") ? (size_t)atol(getenv("BROV_DEV_LDS_PAD")) : 0;
-    const bool w2 = fused_two_wave(lds);
+    const size_t pad = (size_t)k.lds_pad;
+    const bool w2 = fused_two_wave(lds, k.fused_waves);
     if (P.mail && P.mail_early && !P.tsv && !w2) {   // mailbox tick (<= 64 instances): the variant that delivers first
         hipLaunchKernelGGL(rti_fused_kernel_mail, dim3(P.B), dim3(64), lds + pad, st, P);
         return;

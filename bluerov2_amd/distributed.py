@@ -31,13 +31,25 @@ def records_tensor_from_solver(solver):
     return torch.as_tensor(DevicePointerView(solver.results_device_ptr(), RECORD_BYTES * solver.B), device=f"cuda:{solver.device}")
 
 
+def all_gather_into(out, inp, group=None):
+    """dist.all_gather_into_tensor for device tensors under either backend.  "nccl" (= RCCL): the collective itself.  Any other backend
+    (gloo: the development route that puts SEVERAL ranks on ONE GPU, which RCCL refuses -- BROV_BENCH_BACKEND=gloo in bench.py) moves
+    device tensors through the host; the ranks' solvers, records and device-side selections stay what they are under RCCL."""
+    if dist.get_backend(group) == "nccl" or not inp.is_cuda:
+        dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
+        return
+    host = torch.empty(out.numel(), dtype=out.dtype)
+    dist.all_gather_into_tensor(host, inp.contiguous().cpu(), group=group)
+    out.copy_(host.view(out.shape))
+
+
 def gather_records(local_bytes, group=None):
     """all-gather of equally sized uint8 record buffers -> [world * n] uint8 tensor on the same device"""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_bytes.clone()
     out = torch.empty(world * local_bytes.numel(), dtype=torch.uint8, device=local_bytes.device)
-    dist.all_gather_into_tensor(out, local_bytes.contiguous(), group=group)
+    all_gather_into(out, local_bytes, group=group)
     return out
 
 
@@ -88,7 +100,7 @@ def select_best_packed(local_bytes, index_offset, group=None):
     if world == 1:
         return idx + int(index_offset), cost, torch.zeros((), dtype=torch.int64, device=pair.device)
     allp = torch.empty(2 * world, dtype=torch.float64, device=pair.device)
-    dist.all_gather_into_tensor(allp, pair.contiguous(), group=group)
+    all_gather_into(allp, pair, group=group)
     allp = allp.view(world, 2)
     # lexicographic (cost, index): ranks hold disjoint, ascending index ranges, so the first minimal cost is the lowest index
     owner = torch.argmin(allp[:, 0])

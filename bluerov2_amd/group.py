@@ -9,6 +9,7 @@ import numpy as np
 from .solver import BatchSolver, NoDeviceError, RESULT_DTYPE, SolverOptions, _arr, _dp, _load
 
 GATHER_RECORDS, GATHER_PACKED = 0, 1
+COLLECTIVE_RCCL, COLLECTIVE_COPY = 0, 1
 _bound = False
 
 
@@ -19,6 +20,10 @@ def _lib():
         vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
         L.brov_group_last_error.restype = C.c_char_p
         L.brov_group_create.argtypes = [C.POINTER(vp), ip, C.c_int, C.c_int, vp]
+        L.brov_group_create_ex.argtypes = [C.POINTER(vp), ip, C.c_int, C.c_int, vp, C.c_int]
+        L.brov_group_create_ex.restype = C.c_int
+        L.brov_group_create_rank_ex.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_char_p, ip, vp, C.c_int]
+        L.brov_group_create_rank_ex.restype = C.c_int
         L.brov_group_destroy.argtypes = [vp]
         L.brov_group_destroy.restype = None
         L.brov_group_solver.argtypes = [vp, C.c_int]
@@ -31,7 +36,7 @@ def _lib():
         L.brov_group_unique_id.restype = C.c_int
         L.brov_group_create_rank.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_char_p, ip, vp]
         L.brov_group_create_rank.restype = C.c_int
-        for name, args in {"brov_group_world": [vp], "brov_group_first_rank": [vp], "brov_group_rccl_version": [ip], "brov_group_size": [vp], "brov_group_total": [vp], "brov_group_shard": [vp, C.c_int, ip, ip],
+        for name, args in {"brov_group_set_copy_wait_seconds": [C.c_int], "brov_group_collective": [vp], "brov_group_world": [vp], "brov_group_first_rank": [vp], "brov_group_rccl_version": [ip], "brov_group_size": [vp], "brov_group_total": [vp], "brov_group_shard": [vp, C.c_int, ip, ip],
                            "brov_group_set_x0_host": [vp, dp], "brov_group_set_params_host": [vp, dp, C.c_int],
                            "brov_group_set_yref_host": [vp, dp, C.c_int], "brov_group_set_candidate_params_host": [vp, C.c_int, dp, dp, dp],
                            "brov_group_set_yref_candidates": [vp, C.c_double, C.c_double], "brov_group_solve": [vp], "brov_group_gather": [vp, C.c_int],
@@ -80,21 +85,25 @@ class SolverGroup:
     """devices + total: ONE process holds every device of the group.  rank= / world= / uid= / counts= (with devices = [this process's
     device]): one process per GPU, this process holds rank `rank` of `world` (uid: unique_id() of rank 0, handed to every rank by the
     launcher).  The whole-batch setters take GLOBAL arrays in both forms (every process uses the slice of its own shard);
-    `shards[0]` is the local shard's solver for everything else."""
+    `shards[0]` is the local shard's solver for everything else.  collective="copy" (BROV_COLLECTIVE_COPY): the all-gather as
+    device-to-device copies instead of RCCL -- `devices` may then repeat a GPU (several ranks on one device: the 1-GPU test route),
+    and the ranks of a rank= group must live in one process, one thread each."""
 
-    def __init__(self, devices, total=None, opts=None, rank=None, world=None, uid=None, counts=None):
+    def __init__(self, devices, total=None, opts=None, rank=None, world=None, uid=None, counts=None, collective="rccl"):
         L = _lib()
         self.opts = opts if opts is not None else SolverOptions()
         self.devices = [int(d) for d in devices]
         self.N = int(self.opts.N)
         h = C.c_void_p()
+        coll = {"rccl": COLLECTIVE_RCCL, "copy": COLLECTIVE_COPY}[collective]
+        self.collective = collective
         if rank is None:
             self.total = int(total)
             arr = (C.c_int * len(self.devices))(*self.devices)
-            rc = L.brov_group_create(C.byref(h), arr, len(self.devices), self.total, C.byref(self.opts._o))
+            rc = L.brov_group_create_ex(C.byref(h), arr, len(self.devices), self.total, C.byref(self.opts._o), coll)
         else:
             cnt = (C.c_int * int(world))(*[int(c) for c in counts])
-            rc = L.brov_group_create_rank(C.byref(h), self.devices[0], int(rank), int(world), C.c_char_p(bytes(uid)), cnt, C.byref(self.opts._o))
+            rc = L.brov_group_create_rank_ex(C.byref(h), self.devices[0], int(rank), int(world), C.c_char_p(bytes(uid)), cnt, C.byref(self.opts._o), coll)
             self.total = int(sum(counts))
         if rc == -2:
             raise NoDeviceError(L.brov_group_last_error().decode() or "no HIP device")

@@ -197,7 +197,7 @@ int brov_order_stream(brov_solver* s, void* stream);
  * reference window shared by the batch [N+1][16], per-stage parameters [B][N+1][16]) are staged through a pinned buffer and copied
  * asynchronously on the solver's own stream, the step (rti_phase as brov_solve_phase) runs behind them, the result records come
  * back the same way -- for up to 64 instances without a copy: the kernel writes each record into the pinned buffer itself, followed
- * by a sequence word the host polls (BROV_TICK_MAILBOX=0 in the environment: copy + stream synchronisation, as for larger
+ * by a sequence word the host polls (BROV_TICK_MAILBOX=0 in the environment at brov_create: copy + stream synchronisation, as for larger
  * batches).  A tick that passes all three inputs uploads them with one copy.  This is what the acados-shaped drop-in makes of one
  * bluerov2_acados_solve (bluerov2_dob.cpp:306-388: lbx / ubx, (N+1) x update_params, (N+1) x yref, solve, u0 / status / kkt).
  * rti_phase 1 (a preparation) delivers no records: the call returns as soon as the inputs have left the pinned buffer, `res` is left alone,
@@ -208,11 +208,17 @@ int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, 
  * brov_destroy.  A caller that builds its inputs in them and reads its records from them -- pass exactly these pointers as x0 /
  * yref_shared / par_stage, and NULL as res -- saves the tick its host-side copies (0.8 MB per step at a batch of 4096).  The result
  * records are written there by the solve kernel itself (no copy command behind the launch; batches <= 64: with a sequence word per
- * instance that the host polls, larger ones: the host waits for the launch once; BROV_TICK_BULK=0: the copy command of round 3). */
+ * instance that the host polls, larger ones: the host waits for the launch once; BROV_TICK_BULK=0: the copy command of round 3).
+ * The input buffers may be rewritten as soon as brov_tick_host has returned (a tick that was handed these pointers waits for the copies it
+ * enqueued out of them; a tick that copies its arguments in waits, before it does, for what an earlier tick left reading them). */
 /* instrumentation: which instances of the last solve were completed by the parallel-in-time kernel */
 int brov_pit_last(brov_solver* s, int32_t* done /*[B]*/);
 int brov_tick_buffers(brov_solver* s, double** x0 /*[B][12]*/, double** yref_shared /*[N+1][16]*/, double** par_stage /*[B][N+1][16]*/,
                       const brov_result** res /*[B]*/);
+/* Development knobs.  The solver's A/B switches and test hooks are BROV_* environment variables (BROV_PIT, BROV_TICK_MAILBOX,
+ * BROV_PARTIAL_REFACTOR, ...: DESIGN.md section 4.6 lists them); a solver reads them ONCE, in brov_create -- no call on the path of a
+ * solve touches the environment.  brov_dev_reload_knobs reads them again (tests that flip a switch between two solves of one solver). */
+int brov_dev_reload_knobs(brov_solver* s);
 /* replace weights / bounds / Ts / QP options of an existing solver (N must not change) */
 int brov_set_opts(brov_solver* s, const brov_opts* opts);
 int brov_get_opts(const brov_solver* s, brov_opts* opts);
@@ -286,6 +292,18 @@ typedef struct brov_group brov_group;
 #define BROV_GATHER_RECORDS 0
 #define BROV_GATHER_PACKED 1
 int  brov_group_create(brov_group** out, const int* devices /*[n] distinct HIP ordinals*/, int n, int total_instances, const brov_opts* opts);
+/* Which collective carries the gather.  BROV_COLLECTIVE_RCCL (what brov_group_create / brov_group_create_rank use): ncclAllGather.
+ * BROV_COLLECTIVE_COPY: the all-gather as device-to-device copies -- every rank publishes its contribution behind an event on its own
+ * stream, every rank pulls the others' into its own gathered array on its own stream.  RCCL is not loaded, and `devices` may name a GPU
+ * more than once: W ranks on ONE GPU run the whole bookkeeping of W GPUs (shard bounds, padded staging, rank-major gathered layout, packed
+ * pairs, the select over W x slots) -- the development and test route on a 1-GPU box, and a fallback where RCCL is not installed.  The
+ * ranks of a copy group live in ONE process; brov_group_gather blocks the calling thread until every rank of the group has entered the
+ * same gather (ranks held by other brov_group objects: call from one thread per object, as RCCL asks of ncclCommInitRank ranks that share
+ * a process), and the id of brov_group_create_rank_ex may be any 128 bytes the ranks agree on.  The entry points put the calling thread's
+ * current HIP device back before they return. */
+#define BROV_COLLECTIVE_RCCL 0
+#define BROV_COLLECTIVE_COPY 1
+int  brov_group_create_ex(brov_group** out, const int* devices /*[n]*/, int n, int total_instances, const brov_opts* opts, int collective);
 /* The same group with ONE PROCESS PER GPU (the launcher's route, e.g. torchrun): every process creates its rank of the group on its own
  * device.  Rank 0 calls brov_group_unique_id and hands the 128 bytes to the other ranks by whatever means the launcher has (a file, MPI,
  * torch.distributed.broadcast); counts[world] = instances per rank.  All entry points below then act on the local shard, the gather
@@ -293,6 +311,10 @@ int  brov_group_create(brov_group** out, const int* devices /*[n] distinct HIP o
  * 104-byte records were gathered (with BROV_GATHER_PACKED and a remote winner: cost and status only). */
 int  brov_group_unique_id(char id[128]);
 int  brov_group_create_rank(brov_group** out, int device, int rank, int world, const char id[128], const int* counts /*[world]*/, const brov_opts* opts);
+int  brov_group_create_rank_ex(brov_group** out, int device, int rank, int world, const char id[128], const int* counts /*[world]*/, const brov_opts* opts,
+                               int collective);
+int  brov_group_collective(const brov_group* g);     /* BROV_COLLECTIVE_* */
+int  brov_group_set_copy_wait_seconds(int seconds);  /* BROV_COLLECTIVE_COPY: how long a gather waits for a rank that has not entered it (60) */
 void brov_group_destroy(brov_group* g);
 const char* brov_group_last_error(void);
 int  brov_group_rccl_version(int* version);          /* loads RCCL if need be; BROV_ERR_HIP when it cannot be loaded */

@@ -289,6 +289,13 @@ def test_rti_phase_split_in_the_resident_mode_is_the_full_step_bit_for_bit(ba, g
         split.set_time_steps(1.0 / N * 1.02 ** np.arange(N))
         assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) != 0
         assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0 and split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0
+        # ... nor one whose iterate a step in between has moved on (round-4 advisor: a full solve between the two rewrote the parked
+        # workspace and the feedback applied a step linearised at the older iterate), nor a second feedback on one preparation
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0
+        split.solve()
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == -1 and "rti_phase 1" in split._L.brov_last_error().decode()
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 1) == 0 and split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0
+        assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == -1
         # the streaming pair on request: the same step to rounding
         os.environ["BROV_SPLIT_RESIDENT"] = "0"
         st = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N)); st.set_params(ba.P_NOMINAL); st.set_x0(x0); st.set_yref(win[:N + 1])
@@ -490,6 +497,8 @@ def test_tick_host_is_setters_plus_solve_plus_results(ba, golden_traj, N, B, mai
     assert buf["x0"].shape == (B, 12) and buf["yref"].shape == (N + 1, 16) and buf["params"].shape == (B, N + 1, 16) and buf["results"].shape == (B,)
     if not mailbox:
         os.environ["BROV_TICK_MAILBOX"] = "0"
+        for s_ in (a, b, c):
+            s_.reload_knobs()          # (the knobs are read at create)
     try:
         for k in range(5):
             a.set_x0(x0); a.set_yref(win[k:k + N + 1])

@@ -44,6 +44,35 @@ def test_rccl_gather_and_select_single_rank_under_the_launcher():
     assert sb["selected_every_step_on_device"] and sb["index"] == sb["last_step_index_on_device"]
 
 
+def test_two_ranks_on_one_gpu_over_gloo_select_what_a_single_rank_selects():
+    """The per-process route with world size 2 on whatever GPUs the box has -- ONE here: RCCL refuses two ranks on a GPU, so the
+    collective goes through gloo (BROV_BENCH_BACKEND=gloo, bluerov2_amd.distributed.all_gather_into), while the launcher, the strong-
+    scaling shard bounds (uneven: 2049 candidates), the two solvers, their records, the padded gather layout and the device-side
+    arg-min of every step are what a 2-GPU RCCL run executes.  The selection must equal the single-rank run of the same total."""
+    import torch
+    assert torch.cuda.is_available()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BROV_BENCH_BACKEND"] = "gloo"
+    common = ["--config", "4", "--scaling", "strong", "--batch", "2049", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+
+    def run(gpus, extra):
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), *common, *extra], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+        lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+        assert pr.returncode == 0 and len(lines) == 1, (pr.returncode, pr.stdout[-2000:], pr.stderr[-3000:])
+        return json.loads(lines[0])
+    two = run(2, [])
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == [0, 1] and two["instances_per_rank"] == [1025, 1024] and two["total_instances"] == 2049
+    assert "gloo" in two["collective_backend"] and two["value"] > 0
+    one = run(1, ["--force-gather"])
+    assert one["instances_per_rank"] == [2049]
+    a, b = two["select_best"], one["select_best"]
+    assert a["selected_every_step_on_device"] and a["index"] == a["last_step_index_on_device"]
+    assert a["records_gathered"] == 2049 and a["record_slots_gathered"] == 2 * 1025
+    assert (a["index"], a["cost"], a["u0"], a["thrust"]) == (b["index"], b["cost"], b["u0"], b["thrust"])     # bit for bit
+
+
 def test_two_rank_rccl_run():
     """two GPUs visible: the real thing -- two processes, RCCL all-gather over xGMI, global arg-min"""
     import torch

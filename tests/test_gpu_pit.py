@@ -137,6 +137,7 @@ def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_inst
     prev = None
     for k, mode in enumerate(["1", "1", "1", "0", "1", "2"]):
         os.environ["BROV_PIT"] = mode
+        s.reload_knobs()                                   # (read at create; this test flips the switch between two solves)
         yref = np.ascontiguousarray(circ[k:k + N + 1])
         s.set_yref(yref); s.solve()
         assert s.last_kernel_path() == 3
