@@ -1,0 +1,85 @@
+// qp/fused.hpp -- rti_fused_body: one wavefront owns one instance from the linearisation to the updated iterate, the whole horizon in LDS (N <= 23).
+// Part of ONE translation unit: qp_kernel.hip includes these headers in layer order (tiles -> sweeps -> window -> sched -> qp_body ->
+// lin_phase -> fused -> windowed -> pit) and instantiates the kernels between them; see the file map at the head of qp_kernel.hip.
+#pragma once
+
+namespace brov {
+
+// fused path: ONE wavefront owns one OCP instance from linearisation to the updated iterate.  The wave first integrates
+// all N intervals at once (64/N lanes per interval, lin_device.hpp) and leaves [A_i B_i] and b_i in its LDS slice
+// (N <= kFusedMaxN: 4 waves x 40.5 KB per CU at N = 20), then runs the Riccati IPM on the LDS-resident stage blocks: they
+// are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
+// (interior-point) instance does not pin the LDS of three finished ones.
+constexpr int kFusedMaxN = 23;
+template <int W, bool GRID = false, bool DF = false>
+__device__ __forceinline__ void rti_fused_body(const DevParams& P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
+    const int lane = threadIdx.x;
+    const int N = P.N;
+    const bool listed = sched_listed(P, b);   // requested here, used after the linearisation
+    if (blockIdx.x == 0) sched_zero_next(P, lane);
+    DBG_STAMP(0);
+    // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
+    double* ba_s = smem;                          // [N][12][13]
+    double* bv_s = ba_s + (size_t)N * kBaStage;   // [N][12]
+    double* kt_s = bv_s + (size_t)N * NX;         // [N][12][4]
+    double* kff_s = kt_s + (size_t)N * kKtStage;  // [N][4]
+    double* vh_s = kff_s + (size_t)N * 4;         // [N][4]
+    double* dx_s = vh_s + (size_t)N * 4;          // [N+1][12]
+    double* q_s = dx_s + (size_t)(N + 1) * NX;    // [N+1][12] cost gradient w.r.t. x (row N = terminal)
+    double* r_s = q_s + (size_t)(N + 1) * NX;     // [N][4]    cost gradient w.r.t. u
+    double* const_s = r_s + (size_t)N * 4;        // {0.0, 1.0}: targets of structurally constant tile elements
+    if (lane == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
+    // ---- preparation: ERK4 + sensitivities of all N intervals at once (lin_phase below)
+    double part = 0.0;
+    bool nanp = false;
+    LaneCst lc;
+    if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
+    lin_phase<W == 1, GRID>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
+    __syncthreads();  // single wave: orders the LDS writes above against the reads below
+    if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
+    std::conditional_t<GRID, InstGrid, Inst> I;
+    setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr);
+    // partial refactorisation of the active-set tries (riccati_backward_tries): checkpoint stage = ceil(N / 4); off for horizons too
+    // short to gain from it and for instances the previous solve did not list as expensive
+#ifndef BROV_EXP_NO_SPLIT
+    I.ckpt = (N >= 8 && P.partial_refactor && listed) ? (N + 3) >> 2 : 0;
+#else
+    I.ckpt = 0; (void)listed;
+#endif
+    I.lds_ba = (const lds_f64*)ba_s;
+    I.lds_bv = (const lds_f64*)bv_s;
+    I.lds_kt = (lds_f64*)kt_s;
+    I.lds_q = (const lds_f64*)q_s;
+    I.lds_r = (const lds_f64*)r_s;
+    I.kff = kff_s;   // generic pointers into LDS (element loops): feed-forward terms, candidate inputs and state steps
+    I.vhat = vh_s;   // never leave the CU; the sweeps use the LDS-typed aliases below
+    I.dxb = dx_s;
+    I.lds_kff = (lds_f64*)kff_s;
+    I.lds_vhat = (lds_f64*)vh_s;
+    I.lds_dxb = (lds_f64*)dx_s;
+    I.lds_zero = (lds_f64*)const_s;
+    I.lds_tr = (lds_f64*)const_s + 2;
+    {
+        const int rg = I.rg, cl = I.cl;
+        const int zero = (int)(const_s - ba_s), one = zero + 1, kt0 = (int)(kt_s - ba_s);
+        // [A B] image: element (k = rg+4r, c = cl) lives at k*13 + c-3 for c >= 3; columns 0..2 are e_c
+        for (int r = 0; r < 3; r++) I.ba_off[r] = cl >= 3 ? (rg + 4 * r) * kBaStride + cl - 3 : ((r == 0 && rg == cl) ? one : zero);
+        I.ba_str = cl >= 3 ? kBaStage : 0;
+        // [A B]^T image: element (c = rg+4r, k = cl) = [A B](k, c); k >= 12 is padding, c < 3 is e_c
+        for (int r = 0; r < 4; r++) {
+            const int c = rg + 4 * r;
+            I.bat_off[r] = cl >= NX ? zero : (c >= 3 ? cl * kBaStride + c - 3 : (c == cl ? one : zero));
+        }
+        // lanes cl < 12 read real elements in registers 1..3; register 0 (c = rg) is real only for rg == 3, else e_c
+        I.bat_str = cl >= NX ? 0 : kBaStage;
+        I.bat_str0 = (cl < NX && rg == 3) ? kBaStage : 0;
+        // K^T compact [12][4]: element (c = rg+4r, m = cl < 4)
+        for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
+        I.kt_str = cl < 4 ? kKtStage : 0;
+    }
+    qp_body<W, std::conditional_t<GRID, InstGrid, Inst>, DF>(P, I, b, part, nanp);
+}
+
+}  // namespace brov
