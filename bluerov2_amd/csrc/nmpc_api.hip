@@ -108,6 +108,7 @@ struct brov_solver {
     bool pit_ran = false;            // the last solve launched rti_pit_kernel
     int32_t* pit_done = nullptr;     // [B]: written by rti_pit_kernel (parallel-in-time step-0 solve), read by the resident kernel launched behind it
     int32_t mail_seq = 0;
+    int fused_resident = 0;          // blocks of the fused kernel resident at once on this device (occupancy query x CUs), filled at create
     DevKnobs k;                      // development knobs (BROV_* environment), read once in brov_create: no getenv on the path of a solve
 };
 
@@ -117,7 +118,7 @@ struct brov_solver {
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static DevKnobs read_knobs() {
     DevKnobs k;
-    k.robust_pivot = env_int("BROV_ROBUST_PIVOT", 1);            // 0 off, 1 on demand (default), 2 every instance
+    k.robust_pivot = env_int("BROV_ROBUST_PIVOT", 1);            // 0 off, 1 on demand (default), 2 every instance, 3 on demand without the KKT <= 1e6 limit
     k.partial_refactor = env_int("BROV_PARTIAL_REFACTOR", 1) != 0;
     k.mail_early = env_int("BROV_DEV_NO_EARLY_RECORD", 0) == 0;
     k.split_resident = env_int("BROV_SPLIT_RESIDENT", 1) != 0;
@@ -132,6 +133,7 @@ static DevKnobs read_knobs() {
     k.force_windowed = env_int("BROV_DEV_FORCE_WINDOWED", 0) != 0;
     k.fused_waves = env_int("BROV_DEV_FUSED_WAVES", 0);           // 1 / 2: force a variant of the fused kernel (default by LDS size)
     k.lds_pad = env_int("BROV_DEV_LDS_PAD", 0);
+    k.prefetch = env_int("BROV_PREFETCH", 0);                     // fused kernels: L2 warm-up for the next block of the XCD (round-5 experiment)
     return k;
 }
 extern "C" int brov_dev_reload_knobs(brov_solver* s) {
@@ -346,6 +348,12 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     if (rc == BROV_OK) rc = brov_init_iterate_default(s);
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
     for (int k = 0; k < 3; k++) hipEventCreate(&s->ev[k]);
+    if (fused_supported(opts->N) && !s->force_windowed && opts->kernel_path != BROV_PATH_STREAMING) {
+        int32_t info[4] = {0, 0, 0, 0};
+        int cus = 0;
+        lds_kernel_info(opts->N, 0, false, info, s->k);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && info[1] > 0) s->fused_resident = info[1] * cus;
+    }
     *out = s;
     return BROV_OK;
 }
@@ -910,7 +918,10 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     if (s->timing) hipEventRecord(s->ev[0], st);
     if (fused || windowed) {
         if (s->timing) hipEventRecord(s->ev[1], st);
-        if (fused) launch_fused(P, st, s->k);
+        if (fused) {
+            if (s->k.prefetch && s->fused_resident > 0 && (s->fused_resident & 7) == 0 && (int)s->B > s->fused_resident) P.pf_stride = s->fused_resident;
+            launch_fused(P, st, s->k);
+        }
         else {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)

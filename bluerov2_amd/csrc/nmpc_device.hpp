@@ -78,13 +78,17 @@ struct DevParams {
     // instances whose QP had active bounds in the previous solve are handed out first in this one; nullptr = instances in index order
     int32_t* sched;
     int32_t sched_stride, sched_r, sched_w, sched_z;   // buffer read / written / zeroed by this launch
+    // fused kernels: blocks resident at once (occupancy x CUs).  Block t warms the L2 of its XCD for block t + pf_stride -- which the
+    // dispatcher places on the same XCD (round-robin over the 8 XCDs, pf_stride % 8 == 0) -- by touching that instance's input lines
+    // ahead of its own last sweep.  0 = off (batches that fit the chip at once, BROV_PREFETCH=0).
+    int32_t pf_stride;
     unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
 // development knobs (BROV_* environment variables), read once per solver by the host API (nmpc_api.hip, read_knobs)
 struct DevKnobs {
     int robust_pivot = 1, partial_refactor = 1, mail_early = 1, split_resident = 1, pit = 1, split_parallel = 1, pit_try = 1, pit_adapt = 1;
-    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0;
+    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0, prefetch = 0;
 };
 
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_ACT, IPM_NARR };

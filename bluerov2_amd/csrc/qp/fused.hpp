@@ -18,6 +18,9 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     const int lane = threadIdx.x;
     const int N = P.N;
     const bool listed = sched_listed(P, b);   // requested here, used after the linearisation
+    // the instance of the block that follows this one on its XCD (see DevParams::pf_stride): looked up here, under the staging loads
+    int b2 = -1;
+    if (P.pf_stride > 0 && (int)blockIdx.x + P.pf_stride < P.B) b2 = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x + P.pf_stride));
     if (blockIdx.x == 0) sched_zero_next(P, lane);
     DBG_STAMP(0);
     // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
@@ -79,7 +82,9 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
         for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
         I.kt_str = cl < 4 ? kKtStage : 0;
     }
+    I.pf_b = b2; I.pf_sink = 0.0;
     qp_body<W, std::conditional_t<GRID, InstGrid, Inst>, DF>(P, I, b, part, nanp);
+    asm volatile("" :: "v"(I.pf_sink));
 }
 
 }  // namespace brov

@@ -84,6 +84,8 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 struct Inst {
     int lane, rg, cl, N, nv;   // N = stages the sweeps run over (the whole horizon, or the resident window of it)
     int i0, NT;                // windowed kernel: global index of the window's first stage, total horizon (else 0, N)
+    int pf_b;                  // fused kernels: instance whose inputs this wave touches ahead of its last sweep (DevParams::pf_stride), or -1
+    double pf_sink;            // ... and what that load returns (consumed by nothing: an empty asm at the end of the kernel keeps it alive)
     int ckpt;                  // fused kernels: the step-0 factor sweep leaves (P, p) entering stage ckpt - 1 in HBM (partial refactorisation); 0 = off
     const double* x;     // [N+1][12] entering iterate
     const double* u;     // [N][4]
