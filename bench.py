@@ -1123,12 +1123,12 @@ def main(argv=None):
             roof_valu = None
             if world == 1 and len(legs) == 1 and not args.no_traffic and not args.no_extra and not profiled and not os.environ.get("BROV_BENCH_PMC_CHILD"):
                 cal = pmc_calibration()
-                counts, why = live_pmc(fwd_args(args), dom, (("FETCH_SIZE",), ("WRITE_SIZE",), SQ_PASS)) if cal else (None, "no committed counter calibration")
-                if counts is None:
+                pmc, why = live_pmc(fwd_args(args), dom, (("FETCH_SIZE",), ("WRITE_SIZE",), SQ_PASS)) if cal else (None, "no committed counter calibration")
+                if pmc is None:
                     why_not_live = why
                 else:
-                    traffic, traffic_src = traffic_from_counts(counts, cal)
-                    roof_valu = valu_roofline(counts, dom)
+                    traffic, traffic_src = traffic_from_counts(pmc, cal)
+                    roof_valu = valu_roofline(pmc, dom)
             for pj in (() if traffic is not None else ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json")):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", pj)))
@@ -1231,7 +1231,28 @@ def main(argv=None):
                                                       note="25 % of the instances start up to 4 m off the reference (inputs saturate at +-50): "
                                                            "14 % of the batch runs the QP loop (active-set tries, interior-point fallback)")
             out["mixed_batch_25pct_saturated"].update(per_tick_kernel_ms(s3, tick3))
+
+            def one_launch(sx):
+                """the same K steps as ONE launch (brov_solve_ticks, rti_fused_kernel_ticks: every instance goes on to its next step when its own is
+                done) -- same arithmetic, bit-identical records (tests/test_gpu_ticks.py), no launch boundary for a slow instance to hold"""
+                st_ = torch.cuda.current_stream().cuda_stream
+                sx.init_iterate_default()
+                for k in range(W):
+                    sx.set_yref_from_trajectory(k, 16, stream=st_); sx.solve(stream=st_)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                sx.set_yref_from_trajectory(W, 16, stream=st_); sx.solve_ticks(K, 1, stream=st_)
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - t0_
+                rr = sx.results()
+                return dict(value=B * K / dt_, unit="solves/s", ms_per_step=dt_ / K * 1e3, steps_in_the_launch=K, status_nonzero=int((rr["status"] != 0).sum()),
+                            note="brov_solve_ticks: the K timed steps as one launch; for workloads whose steps do not depend on each other through the host "
+                                 "(x0 held, window advancing one trajectory row per step, as in every leg of this line)")
+            out["mixed_batch_25pct_saturated"]["one_launch_of_all_steps"] = one_launch(s3)
             s3.close()
+            s6, _, _ = wl["make"](N, Ts, 1)
+            out["headline_steps_in_one_launch"] = one_launch(s6)
+            s6.close()
             # the same instances in a random order (the leg above has the saturated quarter FIRST, an artefact of the generator: the slow
             # instances then start in the first round anyway).  The kernels reorder the work themselves -- instances whose QP had active
             # bounds in the previous tick are handed out first (qp_kernel.hip, sched_map)

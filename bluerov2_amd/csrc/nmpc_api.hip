@@ -40,6 +40,7 @@ struct brov_solver {
     brov_opts opts{};
     bool yref_shared = false;
     const double* yref_view = nullptr;   // shared window = rows of the resident trajectory table, used in place (no copy)
+    int traj_line = -1, traj_ncols = 0;  // the shared window in force was built from this row of the table by brov_set_yref_from_traj (-1: by something else)
     // device buffers
     double *x0 = nullptr, *yref = nullptr, *yref_sh = nullptr, *par = nullptr;
     double *x = nullptr, *u = nullptr, *pi = nullptr, *lam = nullptr;
@@ -108,7 +109,6 @@ struct brov_solver {
     bool pit_ran = false;            // the last solve launched rti_pit_kernel
     int32_t* pit_done = nullptr;     // [B]: written by rti_pit_kernel (parallel-in-time step-0 solve), read by the resident kernel launched behind it
     int32_t mail_seq = 0;
-    int fused_resident = 0;          // blocks of the fused kernel resident at once on this device (occupancy query x CUs), filled at create
     DevKnobs k;                      // development knobs (BROV_* environment), read once in brov_create: no getenv on the path of a solve
 };
 
@@ -119,6 +119,7 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static DevKnobs read_knobs() {
     DevKnobs k;
     k.robust_pivot = env_int("BROV_ROBUST_PIVOT", 1);            // 0 off, 1 on demand (default), 2 every instance, 3 on demand without the KKT <= 1e6 limit
+    if (const char* v = getenv("BROV_ROBUST_KKT_MAX")) k.robust_kkt_max = atof(v);   // entering KKT up to which the robust form is taken on demand
     k.partial_refactor = env_int("BROV_PARTIAL_REFACTOR", 1) != 0;
     k.mail_early = env_int("BROV_DEV_NO_EARLY_RECORD", 0) == 0;
     k.split_resident = env_int("BROV_SPLIT_RESIDENT", 1) != 0;
@@ -133,7 +134,6 @@ static DevKnobs read_knobs() {
     k.force_windowed = env_int("BROV_DEV_FORCE_WINDOWED", 0) != 0;
     k.fused_waves = env_int("BROV_DEV_FUSED_WAVES", 0);           // 1 / 2: force a variant of the fused kernel (default by LDS size)
     k.lds_pad = env_int("BROV_DEV_LDS_PAD", 0);
-    k.prefetch = env_int("BROV_PREFETCH", 0);                     // fused kernels: L2 warm-up for the next block of the XCD (round-5 experiment)
     return k;
 }
 extern "C" int brov_dev_reload_knobs(brov_solver* s) {
@@ -348,12 +348,6 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     if (rc == BROV_OK) rc = brov_init_iterate_default(s);
     if (rc != BROV_OK) { brov_destroy(s); return rc; }
     for (int k = 0; k < 3; k++) hipEventCreate(&s->ev[k]);
-    if (fused_supported(opts->N) && !s->force_windowed && opts->kernel_path != BROV_PATH_STREAMING) {
-        int32_t info[4] = {0, 0, 0, 0};
-        int cus = 0;
-        lds_kernel_info(opts->N, 0, false, info, s->k);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && info[1] > 0) s->fused_resident = info[1] * cus;
-    }
     *out = s;
     return BROV_OK;
 }
@@ -429,7 +423,7 @@ static const double* shared_window(const brov_solver* s) { return s->yref_view ?
 
 static int set_yref(brov_solver* s, const double* y, int shared, bool host, void* st) {
     if (!s) return BROV_ERR_ARG;
-    s->yref_view = nullptr;
+    s->yref_view = nullptr; s->traj_line = -1;
     s->yref_shared = shared != 0;
     const size_t n = (size_t)(s->N + 1) * 16;
     return shared ? copy_in(s, s->yref_sh, y, n, host, st) : copy_in(s, s->yref, y, n * s->B, host, st);
@@ -622,7 +616,7 @@ extern "C" int brov_set_yref_stage_host(brov_solver* s, int inst, int stage, con
         for (int b = 0; b < s->B; b++)
             HIPCHK(hipMemcpy(s->yref + (size_t)b * (s->N + 1) * 16, shared_window(s), (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
         s->yref_shared = false;
-        s->yref_view = nullptr;
+        s->yref_view = nullptr; s->traj_line = -1;
     }
     HIPCHK(hipMemcpy(s->yref + ((size_t)inst * (s->N + 1) + stage) * 16, y, (size_t)ny * sizeof(double), hipMemcpyHostToDevice));
     return BROV_OK;
@@ -634,7 +628,7 @@ extern "C" int brov_traj_set_host(brov_solver* s, const double* traj, int rows) 
     HIPCHK(sync_last(s));
     if (s->yref_view) {   // the window in force is a view into the table that is about to go: keep a copy
         HIPCHK(hipMemcpy(s->yref_sh, s->yref_view, (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
-        s->yref_view = nullptr;
+        s->yref_view = nullptr; s->traj_line = -1;
     }
     if (s->traj) { hipFree(s->traj); s->traj = nullptr; }
     HIPCHK(hipMalloc((void**)&s->traj, (size_t)rows * 16 * sizeof(double)));
@@ -651,9 +645,10 @@ extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void
         // the window is N+1 consecutive whole rows of the resident table: use them where they lie (no kernel, no copy)
         s->yref_view = s->traj + (size_t)line * 16;
     } else {
-        s->yref_view = nullptr;
+        s->yref_view = nullptr; s->traj_line = -1;
         launch_window(s->traj, s->traj_rows, nullptr, line, 1, s->N, ncols, s->yref_sh, (hipStream_t)stream);
     }
+    s->traj_line = line; s->traj_ncols = ncols;
     s->yref_shared = true;
     HIPCHK(hipGetLastError());
     return BROV_OK;
@@ -665,7 +660,7 @@ extern "C" int brov_set_yref_from_traj_lines_host(brov_solver* s, const int32_t*
     HIPCHK(hipMemcpy(s->lines, lines, (size_t)s->B * sizeof(int), hipMemcpyHostToDevice));
     launch_window(s->traj, s->traj_rows, s->lines, 0, s->B, s->N, ncols, s->yref, nullptr);
     s->yref_shared = false;
-    s->yref_view = nullptr;
+    s->yref_view = nullptr; s->traj_line = -1;
     HIPCHK(hipGetLastError());
     return BROV_OK;
 }
@@ -688,7 +683,7 @@ extern "C" int brov_set_yref_candidates(brov_solver* s, double t0, double dt, vo
     launch_candidates(s->cand_kind, s->scratch3, s->scratch3 + s->B, s->scratch3 + 2 * (size_t)s->B, t0, dt, s->B, s->N, s->yref,
                       (hipStream_t)stream);
     s->yref_shared = false;
-    s->yref_view = nullptr;
+    s->yref_view = nullptr; s->traj_line = -1;
     HIPCHK(hipGetLastError());
     return BROV_OK;
 }
@@ -787,7 +782,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
         rc = BROV_ERR_HIP;
     }
     for (int k = 0; k < ticks && rc == BROV_OK; k++) {
-        s->yref_view = nullptr;
+        s->yref_view = nullptr; s->traj_line = -1;
         launch_window(s->traj, s->traj_rows, nullptr, line0 + k, 1, s->N, ncols, s->yref_sh, st);
         s->yref_shared = true;
         rc = brov_solve_phase(s, st, 0);
@@ -850,6 +845,7 @@ static DevParams make_params(const brov_solver* s) {
     P.B = s->B; P.N = s->N;
     P.qp_iter_max = s->opts.qp_iter_max; P.early_exit = s->opts.qp_early_exit;
     P.on_failure = s->opts.on_failure; P.dump_lin = s->dump_lin ? 1 : 0;
+    P.robust_kkt_max = s->k.robust_kkt_max;
     P.robust_pivot = s->k.robust_pivot;            // development knob: 0 off, 1 on demand (default), 2 every instance
     P.partial_refactor = s->k.partial_refactor;    // development knob (A/B, tests)
     P.Ts = s->opts.Ts; P.tol_mu = s->opts.qp_tol_mu; P.tol_stat = s->opts.qp_tol_stat;
@@ -918,10 +914,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     if (s->timing) hipEventRecord(s->ev[0], st);
     if (fused || windowed) {
         if (s->timing) hipEventRecord(s->ev[1], st);
-        if (fused) {
-            if (s->k.prefetch && s->fused_resident > 0 && (s->fused_resident & 7) == 0 && (int)s->B > s->fused_resident) P.pf_stride = s->fused_resident;
-            launch_fused(P, st, s->k);
-        }
+        if (fused) launch_fused(P, st, s->k);
         else {
             // batches the resident mode serves: the parallel-in-time step-0 solve goes first (rti_pit_kernel; BROV_PIT=0 off, 2: every
             // instance is tried, not only those whose previous step was an early exit)
@@ -987,6 +980,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             }
             if (resident_report && !P.pit) {   // (the resident kernel alone: its estimate goes into the same word)
                 P.pit_left_host = s->pit_left_host;
+                P.pit_try = s->k.pit_try;          // (... by the parallel kernel's own rule)
                 P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
             }
             s->pit_ran = P.pit != 0;
@@ -1007,6 +1001,48 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
     return BROV_OK;
 }
 extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phase(s, stream, 0); }
+
+// `ticks` RTI steps of every instance with ONE launch where the fused kernels serve the solver (N <= 23, uniform grid): rti_fused_kernel_ticks,
+// every instance going on to its next step as soon as its own is done.  Elsewhere (and when the moving window would leave the resident
+// table): the same steps as `ticks` launches.  Either way the result equals `ticks` x { brov_set_yref_from_traj(line + k row_stride); brov_solve }.
+extern "C" int brov_solve_ticks(brov_solver* s, void* stream, int ticks, int row_stride, int32_t* status_log) {
+    if (!s || ticks < 1 || row_stride < 0) { g_err = "brov_solve_ticks: bad argument"; return BROV_ERR_ARG; }
+    if (row_stride > 0 && !(s->yref_shared && s->traj && s->traj_line >= 0)) {
+        g_err = "brov_solve_ticks: a moving window (row_stride > 0) needs the window in force to come from brov_set_yref_from_traj";
+        return BROV_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int line0 = s->traj_line, ncols = s->traj_ncols;
+    const bool one_launch = fused_supported(s->N) && !s->force_windowed && s->opts.kernel_path != BROV_PATH_STREAMING && !general_grid(s) && !s->dump_lin &&
+                            (row_stride == 0 || (s->yref_view != nullptr && line0 + (ticks - 1) * row_stride + s->N <= s->traj_rows - 1));
+    if (!one_launch) {
+        for (int k = 0; k < ticks; k++) {
+            if (k > 0 && row_stride > 0)
+                if (int rc = brov_set_yref_from_traj(s, line0 + k * row_stride, ncols, stream)) return rc;
+            if (int rc = brov_solve_phase(s, stream, 0)) return rc;
+            if (status_log) hipLaunchKernelGGL(gather_status_kernel, dim3((unsigned)((s->B + 255) / 256)), dim3(256), 0, st, s->res, status_log + (size_t)k * s->B, (int)s->B);
+        }
+        HIPCHK(hipGetLastError());
+        return BROV_OK;
+    }
+    if (int rc = order_behind_last(s, st)) return rc;
+    DevParams P = make_params(s);
+    P.sched = nullptr;                 // a launch of many steps neither reads nor writes the work ordering: every instance follows its own history
+    P.ticks = ticks; P.tick_yref = (int64_t)row_stride * 16; P.tick_status = status_log;
+    s->pit_ran = false;
+    if (s->timing) { hipEventRecord(s->ev[0], st); hipEventRecord(s->ev[1], st); }
+    launch_fused_ticks(P, st, s->k);
+    if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
+    s->prep_path = 0;
+    s->last_fused = true; s->last_windowed = false; s->last_stream = st;
+    if (row_stride > 0) {              // the window in force is the last step's
+        s->traj_line = line0 + (ticks - 1) * row_stride;
+        s->yref_view = s->traj + (size_t)s->traj_line * 16;
+    }
+    HIPCHK(hipGetLastError());
+    return BROV_OK;
+}
 
 // One control tick with the fewest host round trips (what the acados-shaped drop-in calls per bluerov2_acados_solve): the inputs that
 // changed go through ONE pinned staging buffer and asynchronous copies on the solver's own stream, the step is enqueued behind them,
@@ -1063,7 +1099,7 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     if (x0 && x0 != px) std::memcpy(px, x0, n_x0 * sizeof(double));   // (equal: the caller wrote into the staging buffer, brov_tick_buffers)
     if (yref_shared) {
         if (yref_shared != py) std::memcpy(py, yref_shared, n_y * sizeof(double));
-        s->yref_view = nullptr;
+        s->yref_view = nullptr; s->traj_line = -1;
         s->yref_shared = true;
     }
     if (par_stage) { if (par_stage != pp) std::memcpy(pp, par_stage, n_p * sizeof(double)); s->pplant_stale = true; }
@@ -1259,7 +1295,7 @@ extern "C" int brov_get_u0_host(brov_solver* s, double* u0) {
 }
 extern "C" const brov_result* brov_results_device(const brov_solver* s) { return s ? s->res : nullptr; }
 extern "C" double* brov_x0_device(brov_solver* s) { return s ? s->x0 : nullptr; }
-extern "C" double* brov_yref_device(brov_solver* s) { if (!s) return nullptr; s->yref_shared = false; s->yref_view = nullptr; return s->yref; }
+extern "C" double* brov_yref_device(brov_solver* s) { if (!s) return nullptr; s->yref_shared = false; s->yref_view = nullptr; s->traj_line = -1; return s->yref; }
 extern "C" double* brov_params_device(brov_solver* s) { if (!s) return nullptr; s->pplant_stale = true; return s->par; }
 extern "C" double* brov_x_device(brov_solver* s) { return s ? s->x : nullptr; }
 extern "C" double* brov_u_device(brov_solver* s) { return s ? s->u : nullptr; }

@@ -26,6 +26,7 @@ struct DevParams {
     unsigned long long* pit_left_host;   // pinned host word (or nullptr): the resident kernel reports (pit_seq << 32 | instances rti_pit_kernel left to it) -- the host's choice of mode
     int32_t pit_seq;         // ... sequence number of this solve among those the parallel-in-time kernel ran in
     int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
+    double robust_kkt_max;   // robust pivot form on demand only while the entering KKT is at most this (1e6; BROV_ROBUST_KKT_MAX: development knob)
     int32_t partial_refactor, robust_pivot;   // robust_pivot: ill-conditioned instances refactorise in the Cholesky pivot form (default 1; BROV_ROBUST_PIVOT=0: A/B);   // active-set tries restart their factor sweep from the step-0 checkpoint where they may (default 1; BROV_PARTIAL_REFACTOR=0: A/B)
     int32_t rti_split;       // resident windowed kernel, rti_phase 1 / 2 as separate launches: 1 = preparation (linearise + step-0 factor sweep, LDS image parked per instance), 2 = feedback (image fetched, everything that depends on x0); 0 = one launch
     int32_t on_failure, dump_lin;   // BROV_ON_FAILURE_*; dump_lin != 0: LDS-resident kernels copy [A B | b] out to BA / bvec (tests)
@@ -78,17 +79,19 @@ struct DevParams {
     // instances whose QP had active bounds in the previous solve are handed out first in this one; nullptr = instances in index order
     int32_t* sched;
     int32_t sched_stride, sched_r, sched_w, sched_z;   // buffer read / written / zeroed by this launch
-    // fused kernels: blocks resident at once (occupancy x CUs).  Block t warms the L2 of its XCD for block t + pf_stride -- which the
-    // dispatcher places on the same XCD (round-robin over the 8 XCDs, pf_stride % 8 == 0) -- by touching that instance's input lines
-    // ahead of its own last sweep.  0 = off (batches that fit the chip at once, BROV_PREFETCH=0).
-    int32_t pf_stride;
+    // rti_fused_kernel_ticks (brov_solve_ticks): `ticks` RTI steps of an instance back to back inside one launch; the shared reference window
+    // moves on tick_yref doubles per step (row stride x 16 inside the resident trajectory table; 0: the window stays); optional status log
+    int32_t ticks;
+    int64_t tick_yref;
+    int32_t* tick_status;    // [ticks][B] or nullptr
     unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
 // development knobs (BROV_* environment variables), read once per solver by the host API (nmpc_api.hip, read_knobs)
 struct DevKnobs {
+    double robust_kkt_max = 1e6;
     int robust_pivot = 1, partial_refactor = 1, mail_early = 1, split_resident = 1, pit = 1, split_parallel = 1, pit_try = 1, pit_adapt = 1;
-    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0, prefetch = 0;
+    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0;
 };
 
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_ACT, IPM_NARR };
@@ -96,7 +99,8 @@ enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_
 int sched_buffer_ints_host(int B);   // int32 per work-ordering buffer (three of them)
 void launch_linearise(const DevParams& P, hipStream_t st);
 void launch_qp(const DevParams& P, hipStream_t st);
-void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k);  // linearise + QP in one kernel, stage blocks in LDS
+void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k);
+void launch_fused_ticks(const DevParams& P, hipStream_t st, const DevKnobs& k);   // P.ticks steps per instance in one launch (uniform grid, N <= 23)  // linearise + QP in one kernel, stage blocks in LDS
 bool fused_supported(int N);      // whole horizon fits the LDS slice (N <= 23)
 // windowed LDS-resident kernel for longer horizons: persistent blocks (one wavefront each) that take instances from a counter
 void launch_windowed(const DevParams& P, hipStream_t st);

@@ -11,18 +11,14 @@ namespace brov {
 // are read 3-4 times per Newton system and never touch HBM.  One 64-thread block per instance so that a long-running
 // (interior-point) instance does not pin the LDS of three finished ones.
 constexpr int kFusedMaxN = 23;
-template <int W, bool GRID = false, bool DF = false>
-__device__ __forceinline__ void rti_fused_body(const DevParams& P) {
+// MULTI (rti_fused_kernel_ticks, brov_solve_ticks): P.ticks RTI steps of the instance back to back -- linearise, QP, full step, again -- with the
+// reference window moving on P.tick_yref doubles per step.  The same code on the same data as P.ticks launches (bit-identical records and
+// iterates, tests/test_gpu_ticks.py); what changes is the scheduling: an instance goes on to its next step when ITS step is done, so a step
+// with a slow instance (13 .. 47 Newton systems on the mixed batch) no longer holds the whole batch at a launch boundary.
+template <int W, bool GRID, bool DF>
+__device__ __forceinline__ bool rti_fused_step(const DevParams& P, int b, int lane, bool listed, size_t yoff) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
-    const int lane = threadIdx.x;
     const int N = P.N;
-    const bool listed = sched_listed(P, b);   // requested here, used after the linearisation
-    // the instance of the block that follows this one on its XCD (see DevParams::pf_stride): looked up here, under the staging loads
-    int b2 = -1;
-    if (P.pf_stride > 0 && (int)blockIdx.x + P.pf_stride < P.B) b2 = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x + P.pf_stride));
-    if (blockIdx.x == 0) sched_zero_next(P, lane);
-    DBG_STAMP(0);
     // LDS slice of this wave: [A B] (13 non-trivial columns) | b | K^T compact | kff | vhat | dx
     double* ba_s = smem;                          // [N][12][13]
     double* bv_s = ba_s + (size_t)N * kBaStage;   // [N][12]
@@ -34,16 +30,16 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     double* r_s = q_s + (size_t)(N + 1) * NX;     // [N][4]    cost gradient w.r.t. u
     double* const_s = r_s + (size_t)N * 4;        // {0.0, 1.0}: targets of structurally constant tile elements
     if (lane == 0) { const_s[0] = 0.0; const_s[1] = 1.0; }
+    LaneCst lc;
+    if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
     // ---- preparation: ERK4 + sensitivities of all N intervals at once (lin_phase below)
     double part = 0.0;
     bool nanp = false;
-    LaneCst lc;
-    if constexpr (W == 1) lc = load_lane_cst(P.cst, lane);   // the two-wave variant has no registers to spare across lin_phase
-    lin_phase<W == 1, GRID>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true);
+    lin_phase<W == 1, GRID>(P, b, 0, N, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, true, yoff);
     __syncthreads();  // single wave: orders the LDS writes above against the reads below
     if (P.dump_lin) copy_out_linearisation(P, b, 0, N, lane, ba_s, bv_s);
     std::conditional_t<GRID, InstGrid, Inst> I;
-    setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr);
+    setup_inst(P, I, b, lane, W == 1 ? &lc : nullptr, yoff);
     // partial refactorisation of the active-set tries (riccati_backward_tries): checkpoint stage = ceil(N / 4); off for horizons too
     // short to gain from it and for instances the previous solve did not list as expensive
 #ifndef BROV_EXP_NO_SPLIT
@@ -82,9 +78,33 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
         for (int r = 0; r < 3; r++) I.kt_off[r] = cl < 4 ? kt0 + (rg + 4 * r) * 4 + cl : zero;
         I.kt_str = cl < 4 ? kKtStage : 0;
     }
-    I.pf_b = b2; I.pf_sink = 0.0;
     qp_body<W, std::conditional_t<GRID, InstGrid, Inst>, DF>(P, I, b, part, nanp);
-    asm volatile("" :: "v"(I.pf_sink));
+    return I.ran_loop;
+}
+template <int W, bool GRID = false, bool DF = false, bool MULTI = false>
+__device__ __forceinline__ void rti_fused_body(const DevParams& P) {
+    const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
+    const int lane = threadIdx.x;
+    bool listed = sched_listed(P, b);   // requested here, used after the linearisation
+    if (blockIdx.x == 0) sched_zero_next(P, lane);
+    DBG_STAMP(0);
+    if constexpr (!MULTI) {
+        (void)rti_fused_step<W, GRID, DF>(P, b, lane, listed, 0);
+    } else {
+#pragma clang loop unroll(disable)
+        for (int tk = 0; tk < P.ticks; tk++) {
+            // opaque copies per step: nothing derived from the instance or lane index is a loop invariant of the step loop (hoisted, the base
+            // addresses of every phase would be live across all of them -- the register file is full, the build forbids scratch)
+            int bq = b, lq = lane;
+            asm volatile("s_mov_b32 %0, %0" : "+s"(bq));
+            asm volatile("v_mov_b32 %0, %0" : "+v"(lq));
+            // the instance's own history replaces the work ordering's list (which such a launch neither reads nor writes)
+            listed = rti_fused_step<W, GRID, DF>(P, bq, lq, listed, (size_t)tk * (size_t)P.tick_yref);
+            if (P.tick_status && lq == 0) P.tick_status[(size_t)tk * P.B + bq] = P.res[bq].status;   // (lane 0 wrote the record itself)
+            __syncthreads();       // single wave: the step's stores (iterate, record) against the next step's loads
+            wave_fence();
+        }
+    }
 }
 
 }  // namespace brov

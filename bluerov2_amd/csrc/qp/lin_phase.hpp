@@ -32,7 +32,7 @@ __device__ __forceinline__ void stage_store(double* l, int nd, int lane, const d
 //   rec_s: scratch for the stage records, n*68 doubles.  part / nanp: this lane's share of the KKT max / NaN flag.
 template <bool TWO = true, bool GRID = false>
 __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int n, int lane, double* ba_s, double* bv_s,
-                                          double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp) {
+                                          double* rec_s, double* q_s, double* r_s, double& part, bool& nanp, bool stamp, size_t yoff = 0) {   // yoff: rti_fused_kernel_ticks, the window of the step in hand
 #ifdef BROV_DBG_LIN
     unsigned long long lin_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -65,7 +65,7 @@ __device__ __forceinline__ void lin_phase(const DevParams& P, int b, int i0, int
         dbl2 vx[3], vp[3], vy[3], vpi[3], vu[1];
         stage_issue(P.x + ((size_t)b * (N + 1) + i0) * NX, (n + 1) * NX, lane, vx);
         stage_issue(P.par + ((size_t)b * (N + 1) + i0) * NP, n * NP, lane, vp);
-        stage_issue(P.yref + (size_t)b * P.yref_stride + (size_t)i0 * NY, (n + 1) * NY, lane, vy);
+        stage_issue(P.yref + yoff + (size_t)b * P.yref_stride + (size_t)i0 * NY, (n + 1) * NY, lane, vy);
         stage_issue(P.pi + ((size_t)b * N + i0 - po) * NX, (n + po) * NX, lane, vpi);
         stage_issue(P.u + ((size_t)b * N + i0) * NU, n * NU, lane, vu);
         stage_store(sx, (n + 1) * NX, lane, vx);

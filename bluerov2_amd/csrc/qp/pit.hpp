@@ -130,7 +130,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     if (b >= P.B) return;
     {   // worth trying?  The previous step of this instance was an early exit (its record says so; a fresh solver: zeros = yes)
         const brov_result* prev = P.res + b;
-        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter <= (P.pit_try ? 2 : 0));
+        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter <= (P.pit_try ? PIT_TRIES : 0));
         if (!try_it) { if (threadIdx.x == 0) P.pit_done[b] = 0; return; }
     }
     double* ba_s = smem;
@@ -541,9 +541,9 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
             const double vj = vh[j < nu ? j : 0];
             act[t] = vj < lbI - uo[t] ? -1.0 : (vj > ubI - uo[t] ? 1.0 : 0.0);
         }
-        // ... and up to kPitTries - 1 repairs of it, qp_body's first ROUND of tries as far as it goes without an interior-point iteration: a
+        // ... and up to kPitTries - 1 repairs of it, qp_body's first ROUND of tries (POL_FIRST of them; three until round 5) -- as far as it goes without an interior-point iteration: a
         // try that asks for more than POL_NCHG repairs ends the round there too
-        constexpr int kPitTries = 3;
+        constexpr int kPitTries = PIT_TRIES;
         bool accepted = false;
 #pragma clang loop unroll(disable)
         for (int tk = 0; tk < kPitTries; tk++) {

@@ -5,22 +5,6 @@
 
 namespace brov {
 
-// L2 warm-up for the block that will run instance b2 on this XCD (DevParams::pf_stride): one 8-byte load per 128-byte line of what lin_phase
-// stages -- x [N+1][12], par [N][16], pi [N][12], u [N][4]: 56 lines at N = 20, one per lane.  The value is of no interest.
-__device__ __forceinline__ double prefetch_inputs(const DevParams& P, int b2, int lane) {
-    const int N = P.N;
-    const int nx = ((N + 1) * NX + 15) >> 4, np = (N * NP + 15) >> 4, npi = (N * NX + 15) >> 4, nu = (N * NU + 15) >> 4;   // lines of 16 doubles
-    double acc = 0.0;
-    for (int k = lane; k < nx + np + npi + nu; k += 64) {
-        const double* base = k < nx ? P.x + (size_t)b2 * (N + 1) * NX + (size_t)k * 16
-                           : k < nx + np ? P.par + (size_t)b2 * (N + 1) * NP + (size_t)(k - nx) * 16
-                           : k < nx + np + npi ? P.pi + (size_t)b2 * N * NX + (size_t)(k - nx - np) * 16
-                                               : P.u + (size_t)b2 * N * NU + (size_t)(k - nx - np - npi) * 16;
-        acc += __builtin_nontemporal_load(base);
-    }
-    return acc;
-}
-
 // everything after the linearisation: QP solve, multiplier recovery, full step, result record.  lin_part / lin_nan carry this
 // lane's share of the linearisation's KKT partials (max / NaN flag), reduced over the wave here.
 // developer instrumentation: s_memtime stamps of the phase boundaries (P.dbg == nullptr in normal operation)
@@ -163,7 +147,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
         // full-step SQP is ill-conditioned without end, and with pivots that never fail its interior-point loop grinds through all
         // qp_iter_max systems (measured: 50 instead of the 1..19 after which the fast form gives up or fails -- one such instance
         // made its whole launch 2.6 times as long).
-        robust_ok = kkt <= 1e6 || P.robust_pivot == 3;   // (3: development knob -- no limit: the oracle's behaviour, profiles/r5_status_direction.txt)
+        robust_ok = kkt <= P.robust_kkt_max || P.robust_pivot == 3;   // (3: development knob -- no limit: the oracle's behaviour, profiles/r5_status_direction.txt)
         if ((__ballot(illc0) != 0ull && P.robust_pivot && robust_ok) || P.robust_pivot == 2) {   // (2: development knob, every instance)
             robust = true;
             I.ckpt = 0;   // (no partial refactorisation: the checkpoint belongs to the fast sweep)
@@ -661,7 +645,6 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             sw_rollout<LDS>(I, W, d0, vfin);
         }
         DBG_STAMP(4);
-        if constexpr (EL) { if (I.pf_b >= 0) I.pf_sink = prefetch_inputs(P, I.pf_b, lane); }
         // fused path: the iterate and the reference of the commit loops below are requested before the adjoint sweep, which
         // hides their round trip (the single resident wave has nothing else to switch to)
         if constexpr (LDS >= 3) {
@@ -831,6 +814,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
     if (sched_p == -2) sched_p = sched_ticket(P, b);
 #endif
     sched_note(P, b, sched_p);
+    I.ran_loop = !early;   // (rti_fused_kernel_ticks: the instance's own hint for its next step; dead everywhere else)
     DBG_STAMP(6);
 }
 
@@ -854,14 +838,14 @@ __device__ __forceinline__ LaneCst load_lane_cst(const double* __restrict__ cst,
     c.Wuq = cst[12 + ((lane >> 2) & 3)];
     return c;
 }
-__device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane, const LaneCst* pre = nullptr) {
+__device__ __forceinline__ void setup_inst(const DevParams& P, Inst& I, int b, int lane, const LaneCst* pre = nullptr, size_t yoff = 0) {
     const int N = P.N, nv = 4 * N;
     const double* __restrict__ cst = P.cst;
     I.lane = lane; I.rg = lane >> 4; I.cl = lane & 15; I.N = N; I.nv = nv;
     I.i0 = 0; I.NT = N; I.ckpt = 0;
     I.x = P.x + (size_t)b * (N + 1) * 12;
     I.u = P.u + (size_t)b * N * 4;
-    I.yref = P.yref + (size_t)b * P.yref_stride;
+    I.yref = P.yref + yoff + (size_t)b * P.yref_stride;
     I.BA = P.BA + (size_t)b * N * 192;
     I.bvec = P.bvec + (size_t)b * N * 12;
     I.Ks = P.Ks + (size_t)b * N * 64;

@@ -74,6 +74,9 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 #define POL_BIG 1e30      /* Hessian entry that pins an input */
 #define POL_FIRST 5       /* tries before the first interior-point iteration (at most) */
 #define POL_LOOP 3        /* ... per round after an interior-point iteration (at most) */
+// the parallel-in-time kernel (qp/pit.hpp) runs qp_body's FIRST round of tries itself -- all POL_FIRST of them since round 5 (three before) -- and is
+// offered every instance whose previous step succeeded with at most that many Newton systems (more: an interior-point iteration was involved)
+#define PIT_TRIES POL_FIRST
 #define POL_NCHG 8        /* a round ends when a try repairs more than this many inputs, or more than the try before it */
 #define POL_MU_GATE 0.5   /* after a failed round the next one waits until the interior-point loop has cut mu by this factor ... */
 #define POL_ALPHA_GATE 0.9 /* ... and has just taken a (nearly) full step */
@@ -84,8 +87,7 @@ __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_S
 struct Inst {
     int lane, rg, cl, N, nv;   // N = stages the sweeps run over (the whole horizon, or the resident window of it)
     int i0, NT;                // windowed kernel: global index of the window's first stage, total horizon (else 0, N)
-    int pf_b;                  // fused kernels: instance whose inputs this wave touches ahead of its last sweep (DevParams::pf_stride), or -1
-    double pf_sink;            // ... and what that load returns (consumed by nothing: an empty asm at the end of the kernel keeps it alive)
+    bool ran_loop;             // set by qp_body: the step ran the QP loop (no early exit)
     int ckpt;                  // fused kernels: the step-0 factor sweep leaves (P, p) entering stage ckpt - 1 in HBM (partial refactorisation); 0 = off
     const double* x;     // [N+1][12] entering iterate
     const double* u;     // [N][4]

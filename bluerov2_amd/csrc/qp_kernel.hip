@@ -92,6 +92,11 @@ __global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_grid(DevParams P) { rti_fused_body<1, true>(P); }
 // brov_tick_host at small batches (host mailbox): the record of an early exit goes out ahead of the adjoint sweep (qp_body<.., DF>)
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_mail(DevParams P) { rti_fused_body<1, false, true>(P); }
+// brov_solve_ticks: P.ticks steps per instance in one launch (see MULTI in qp/fused.hpp)
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel_ticks(DevParams P) { rti_fused_body<1, false, false, true>(P); }
+// (N <= 13: the code of rti_fused_kernel_w2 -- qp_body<2> -- so that the steps are bit-identical to single launches; compiled for one wave per
+// SIMD, because the step loop's few live values no longer fit the 256 registers of the two-wave form without scratch)
+__global__ __launch_bounds__(64, 1) void rti_fused_kernel_ticks_w2(DevParams P) { rti_fused_body<2, false, false, true>(P); }
 
 // function attributes are per device (a process may hold solvers on several GPUs): one flag per (launcher, device)
 static bool first_launch_on_device(int which) {
@@ -257,6 +262,19 @@ void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4], const Dev
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
     info[0] = (int32_t)lds; info[1] = per_cu; info[2] = threads; info[3] = kind;
+}
+void launch_fused_ticks(const DevParams& P, hipStream_t st, const DevKnobs& k) {
+    const size_t lds = fused_lds_bytes(P.N);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_ticks_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[dev] = true;
+    }
+    // the variant a single step of this solver runs (two waves per SIMD for short horizons): the steps are then the same code on the same data
+    if (fused_two_wave(lds, k.fused_waves)) hipLaunchKernelGGL(rti_fused_kernel_ticks_w2, dim3(P.B), dim3(64), lds + (size_t)k.lds_pad, st, P);
+    else hipLaunchKernelGGL(rti_fused_kernel_ticks, dim3(P.B), dim3(64), lds + (size_t)k.lds_pad, st, P);
 }
 void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k) {
     const size_t lds = fused_lds_bytes(P.N);

@@ -186,6 +186,16 @@ int brov_solve(brov_solver* s, void* stream);
  * brov_tick_host: 33 us from the measurement to u0, against 71 us for rti_phase 0); a call that changes the iterate, the grid or the options
  * between the two makes the feedback fail (BROV_ERR_ARG: repeat the preparation).  Elsewhere: linearisation / QP on the streaming pair. */
 int brov_solve_phase(brov_solver* s, void* stream, int rti_phase);
+/* `ticks` consecutive RTI steps of every instance, the measured state held, the shared reference window moving on `row_stride` rows of the
+ * resident trajectory table per step (0: the window in force stays -- several SQP iterations on one problem, e.g. candidates iterated to
+ * convergence; > 0 needs the window to come from brov_set_yref_from_traj).  Result: exactly that of
+ *     for k in 0 .. ticks-1: brov_set_yref_from_traj(s, line + k * row_stride, ncols, stream); brov_solve(s, stream)
+ * (records of the last step; status_log, DEVICE [ticks][B] or NULL, keeps every step's status) -- but where the fused kernels serve the
+ * solver (N <= 23, uniform grid) it is ONE launch in which every instance goes on to its next step as soon as its own is done
+ * (rti_fused_kernel_ticks): a step with a slow instance -- 13 .. 47 Newton systems on a diverging one -- no longer holds the whole batch at a
+ * launch boundary, and there are no launch gaps.  For workloads whose steps do not depend on each other through the host (parameter sweeps,
+ * candidate libraries, Monte-Carlo draws at a fixed measurement); a control loop that measures between two steps calls brov_solve. */
+int brov_solve_ticks(brov_solver* s, void* stream, int ticks, int row_stride, int32_t* status_log /*DEVICE or NULL*/);
 int brov_synchronize(brov_solver* s, void* stream);
 /* Stream ordering.  One solver, one stream at a time: every call that enqueues work (brov_solve*, brov_plant_step, the *_device
  * setters, the trajectory / candidate window builders, brov_ekf_*_solver) first waits -- on the host -- for the stream the solver

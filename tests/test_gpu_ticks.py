@@ -1,0 +1,117 @@
+"""brov_solve_ticks: `ticks` RTI steps of every instance in one call -- on the fused kernels ONE launch (rti_fused_kernel_ticks) in which an
+instance goes on to its next step as soon as its own is done.  Different scheduling, the same arithmetic: records, iterates and the status
+of every step must equal, bit for bit, `ticks` x { brov_set_yref_from_traj(line + k * row_stride); brov_solve } -- on a batch whose
+instances run the QP loop for different numbers of Newton systems (the case the call exists for), with a moving and with a standing
+window, per-instance windows, and on the solvers that fall back to a launch per step (windowed horizons, general grids, a window that
+runs off the end of the trajectory table)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import bluerov2_amd
+    return bluerov2_amd
+
+
+def _inputs(B, seed, sat=0.25):
+    from bench import synthetic_inputs, saturate
+    x0, circ = synthetic_inputs(B, seed=seed)
+    if sat:
+        x0 = saturate(x0, sat, seed=seed + 1)
+    return x0, circ
+
+
+def _pair(ba, B, N, Ts, x0, circ, **kw):
+    out = []
+    for _ in range(2):
+        s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, **kw))
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(circ)
+        out.append(s)
+    return out
+
+
+def _same(a, b, what):
+    assert a.results().tobytes() == b.results().tobytes(), what
+    for ia, ib in zip(a.get_iterate(), b.get_iterate()):
+        assert np.array_equal(ia, ib, equal_nan=True), what
+
+
+@pytest.mark.parametrize("N,B,stride,ticks,early", [(20, 1500, 1, 7, 1), (20, 700, 0, 5, 1), (10, 300, 2, 6, 1), (23, 260, 1, 4, 0), (7, 64, 1, 9, 1)])
+def test_one_launch_of_many_steps_equals_the_steps_launched_one_by_one(ba, N, B, stride, ticks, early):
+    import torch
+    Ts = 1.0 / max(N, 20)
+    x0, circ = _inputs(B, seed=100 + N)
+    one, many = _pair(ba, B, N, Ts, x0, circ, qp_early_exit=early)
+    status = []
+    for k in range(ticks):
+        one.set_yref_from_trajectory(3 + k * stride, 16); one.solve()
+        status.append(one.results()["status"].copy())
+    log = torch.full((ticks, B), -7, dtype=torch.int32, device="cuda")
+    many.set_yref_from_trajectory(3, 16)
+    many.solve_ticks(ticks, stride, status_log_ptr=log.data_ptr(), sync=True)
+    assert many.last_kernel_path() == ba.PATH_FUSED
+    _same(one, many, (N, B, stride))
+    assert np.array_equal(log.cpu().numpy(), np.array(status))
+    r = one.results()
+    assert (r["qp_iter"] > 0).sum() > B // 10                      # the batch does run the QP loop, for different numbers of systems
+    assert len(np.unique(r["qp_iter"])) >= (3 if early else 2)
+    # the window in force afterwards is the last step's: one more ordinary step on both
+    one.solve(); many.solve()
+    _same(one, many, "step after")
+    one.close(); many.close()
+
+
+def test_per_instance_windows_stand_still(ba):
+    """row_stride = 0 with per-instance windows (candidate references): several SQP iterations on one problem per instance"""
+    B, N, Ts = 512, 20, 0.05
+    rng = np.random.default_rng(3)
+    amp, frq, ph = rng.uniform(1, 3, B), rng.uniform(0.25, 0.75, B), rng.uniform(0, 2 * np.pi, B)
+    x0 = np.zeros((B, 12)); x0[:, 0] = 2.0; x0[:, 2] = -20.0
+    sols = []
+    for _ in range(2):
+        s = ba.BatchSolver(B, ba.SolverOptions(N, Ts)); s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+        s.set_candidate_params("lemniscate", amp, frq, ph); s.set_yref_candidates_tick(0.0, Ts)
+        sols.append(s)
+    one, many = sols
+    for _ in range(6):
+        one.solve()
+    many.solve_ticks(6, 0, sync=True)
+    _same(one, many, "candidates")
+    one.close(); many.close()
+
+
+@pytest.mark.parametrize("N,B,grid,line,kw", [(40, 96, False, 3, {}), (20, 200, True, 3, {}), (20, 200, False, 4080, {}), (20, 120, False, 3, {"kernel_path": 1})])
+def test_solvers_the_fused_kernel_does_not_serve_take_a_launch_per_step(ba, N, B, grid, line, kw):
+    """windowed horizon / general grid / a window that runs off the end of the 4096-row table (rows repeated: not rows in place) / the
+    streaming pair: the same call, the same result, by `ticks` launches"""
+    Ts = 1.0 / max(N, 20)
+    x0, table = _inputs(B, seed=7)           # (a 4096-row table)
+    one, many = _pair(ba, B, N, Ts, x0, table, **kw)
+    if grid:
+        for s in (one, many):
+            s.set_time_steps(Ts * 1.01 ** np.arange(N))
+    ticks = 5
+    for k in range(ticks):
+        one.set_yref_from_trajectory(line + 2 * k, 16); one.solve()
+    many.set_yref_from_trajectory(line, 16)
+    many.solve_ticks(ticks, 2, sync=True)
+    _same(one, many, (N, grid, line))
+    one.close(); many.close()
+
+
+def test_a_moving_window_needs_a_trajectory_window(ba):
+    s = ba.BatchSolver(8, ba.SolverOptions(20, 0.05)); s.set_params(ba.P_NOMINAL)
+    yref = np.zeros((21, 16)); yref[:, 2] = -20.0
+    s.set_yref(yref)
+    with pytest.raises(RuntimeError, match="brov_set_yref_from_traj"):
+        s.solve_ticks(3, 1)
+    s.solve_ticks(3, 0, sync=True)           # a standing window needs none
+    assert np.all(s.results()["status"] == 0)
+    with pytest.raises(RuntimeError):
+        s.solve_ticks(0, 0)
+    s.close()
