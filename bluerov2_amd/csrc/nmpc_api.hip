@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "nmpc_device.hpp"
@@ -109,6 +110,7 @@ struct brov_solver {
     bool pit_ran = false;            // the last solve launched rti_pit_kernel
     int32_t* pit_done = nullptr;     // [B]: written by rti_pit_kernel (parallel-in-time step-0 solve), read by the resident kernel launched behind it
     int32_t mail_seq = 0;
+    double tick_us[5] = {0, 0, 0, 0, 0};   // BROV_TICK_BREAKDOWN=1: host time of the last brov_tick_host by part (brov_dev_tick_breakdown)
     DevKnobs k;                      // development knobs (BROV_* environment), read once in brov_create: no getenv on the path of a solve
 };
 
@@ -134,6 +136,7 @@ static DevKnobs read_knobs() {
     k.force_windowed = env_int("BROV_DEV_FORCE_WINDOWED", 0) != 0;
     k.fused_waves = env_int("BROV_DEV_FUSED_WAVES", 0);           // 1 / 2: force a variant of the fused kernel (default by LDS size)
     k.lds_pad = env_int("BROV_DEV_LDS_PAD", 0);
+    k.tick_breakdown = env_int("BROV_TICK_BREAKDOWN", 0) != 0;
     return k;
 }
 extern "C" int brov_dev_reload_knobs(brov_solver* s) {
@@ -1078,6 +1081,10 @@ extern "C" int brov_tick_buffers(brov_solver* s, double** x0, double** yref_shar
 extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yref_shared, const double* par_stage, int rti_phase,
                               brov_result* res) {
     if (!s || rti_phase < 0 || rti_phase > 2) return BROV_ERR_ARG;
+    using clk = std::chrono::steady_clock;
+    const bool brk = s->k.tick_breakdown != 0;
+    clk::time_point tb0, tb1, tb2, tb3, tb4;
+    if (brk) tb0 = clk::now();
     HIPCHK(hipSetDevice(s->device));
     const size_t B = s->B, N1 = s->N + 1;
     const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8;
@@ -1154,7 +1161,9 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     const int passed = (x0 ? 1 : 0) | (yref_shared ? 2 : 0) | (par_stage ? 4 : 0);
     const bool behind_copies = s->copies_pending && (s->copy_mask & ~passed) != 0;
     s->in_tick = zerocopy && !behind_copies;
+    if (brk) tb1 = clk::now();
     const int rc = brov_solve_phase(s, st, rti_phase);
+    if (brk) tb2 = clk::now();
     s->in_tick = false;
     const int32_t seq = s->mail_seq;
     s->mail = nullptr; s->mail_flag = nullptr;
@@ -1171,6 +1180,7 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         s->copy_mask = (s->copies_pending && !behind_copies) ? (s->copy_mask | passed) : passed;   // (arrays written by copies no kernel on st is ordered behind yet)
         s->copies_pending = true;
     }
+    if (brk) tb3 = clk::now();
     if (mailbox) {
         size_t done = 0;
         for (unsigned long spin = 1; done < B; spin++) {
@@ -1194,6 +1204,11 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         if (!bulk) HIPCHK(hipMemcpyAsync(pr, s->res, B * sizeof(brov_result), hipMemcpyDeviceToHost, st));
         if (zerocopy) HIPCHK(hipEventSynchronize(s->ev_tick));
         else HIPCHK(hipStreamSynchronize(st));
+    }
+    if (brk) {
+        tb4 = clk::now();
+        auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        s->tick_us[0] = us(tb0, tb1); s->tick_us[1] = us(tb1, tb2); s->tick_us[2] = us(tb2, tb3); s->tick_us[3] = us(tb3, tb4); s->tick_us[4] = us(tb0, tb4);
     }
     if (res && res != (brov_result*)pr) std::memcpy(res, pr, B * sizeof(brov_result));
     // a caller that builds its inputs IN the staging buffers (brov_tick_buffers) is free to write the next tick's as soon as this call is back:
@@ -1233,6 +1248,14 @@ extern "C" int brov_last_kernel_path(const brov_solver* s) {
 }
 // which instances of the LAST solve were completed by the parallel-in-time kernel (rti_pit_kernel, batches the resident windowed mode
 // serves): done[b] = 1, else 0 -- all zero when that kernel did not run.  Test / bench instrumentation.
+// development (BROV_TICK_BREAKDOWN=1 at create): host time of the last brov_tick_host in microseconds -- [0] entry to launch (device selection,
+// staging: copies into the pinned buffer, waits for earlier refresh copies), [1] brov_solve_phase (parameter block, kernel launch(es)), [2] what is
+// enqueued behind the launch (events, refresh copies), [3] the wait for the records (mailbox poll / event / stream), [4] the whole call
+extern "C" int brov_dev_tick_breakdown(brov_solver* s, double us[5]) {
+    if (!s || !us) return BROV_ERR_ARG;
+    for (int k = 0; k < 5; k++) us[k] = s->tick_us[k];
+    return BROV_OK;
+}
 extern "C" int brov_pit_last(brov_solver* s, int32_t* done) {
     if (!s || !done) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));

@@ -90,11 +90,11 @@ __device__ __forceinline__ d4 sweep12(d4 S, int rg, int cl, bool& ok) {
 // repetitions on one box, scripts/gpu_r4_ao.sh): the register allocation of its tail shifts.  Keep the two in step by hand.)
 // the result record of an early exit (what qp_body's emit_record writes): device copy, thrust allocation epilogue
 // (bluerov2_dob.cpp:390-395), and -- brov_tick_host -- the host mailbox
-__device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int lane, double cost_lane, double u0_lane, double kkt, int qp_iter) {
+__device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int lane, double cost_lane, double u0_lane, double kkt, int qp_iter, int status = BROV_STATUS_SUCCESS) {
     const double cs = wave_sum(cost_lane);
     if (lane == 0) {
         brov_result* r = P.res + b;
-        r->cost = cs; r->kkt = kkt; r->status = BROV_STATUS_SUCCESS; r->qp_iter = qp_iter;
+        r->cost = cs; r->kkt = kkt; r->status = status; r->qp_iter = qp_iter;
     }
     const double a0 = readlane_f64(u0_lane, 0), a1 = readlane_f64(u0_lane, 1), a2 = readlane_f64(u0_lane, 2), a3 = readlane_f64(u0_lane, 3);
     const double s0 = (lane == 0 || lane == 1) ? -a0 : a0;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void pit_emit_record(const DevParams& P, int b, int l
         brov_result* m = P.mail + b;
         if (lane < 4) m->u0[lane] = u0_lane;
         if (lane < 6) m->thrust[lane] = th;
-        if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = BROV_STATUS_SUCCESS; m->qp_iter = qp_iter; }
+        if (lane == 0) { m->cost = cs; m->kkt = kkt; m->status = status; m->qp_iter = qp_iter; }
         if (P.mail_flag) {
             __threadfence_system();
             if (lane == 0) __hip_atomic_store(P.mail_flag + b, P.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -130,7 +130,9 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     if (b >= P.B) return;
     {   // worth trying?  The previous step of this instance was an early exit (its record says so; a fresh solver: zeros = yes)
         const brov_result* prev = P.res + b;
-        const bool try_it = P.pit == 2 || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter <= (P.pit_try ? PIT_TRIES : 0));
+        // (round 5: the kernel runs the whole QP loop -- tries and interior-point iterations -- so every instance is offered; BROV_PIT_TRY=0, the
+        // development knob that keeps the loop out of it, leaves it the instances whose previous step was an early exit, as in round 3)
+        const bool try_it = P.pit == 2 || P.pit_try || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter == 0);
         if (!try_it) { if (threadIdx.x == 0) P.pit_done[b] = 0; return; }
     }
     double* ba_s = smem;
@@ -521,100 +523,267 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
         wave_fence();
     };
     const bool early = all_feas && P.early_exit;
-    double gel[2] = {0.0, 0.0};        // the accepted try's input gradient of this lane's elements (bound multipliers)
-    int tries = 0;                     // Newton systems of the QP loop this kernel has solved for the answer it commits
+    double gel[2] = {0.0, 0.0};        // the committed point's input gradient of this lane's elements (bound multipliers)
+    int tries = 0;                     // Newton systems of the QP loop (tries + interior-point iterations) behind the answer this kernel commits
+    int status = BROV_STATUS_SUCCESS;
     if (!early) {
-        // ---- 5. ONE active-set try (qp_body's first try, element for element): the inputs of the Newton point that violate their bounds are
-        // pinned there (Gamma = POL_BIG and the right-hand side that lands them on the bound), the system is solved by a second pass, pinned
-        // inputs are snapped onto their bounds, and the point is THE minimiser if no free input leaves the box and no pinned input's multiplier
-        // has the wrong sign.  Then it is committed with one Newton system in its record; if not (15 % of the QPs that run the loop on the
-        // mixed batch), nothing has been touched and the resident kernel behind this one does the step.
-        if (!P.pit_try || P.qp_iter_max < 1) {   // (no try of its own / no Newton system allowed: the resident kernel's)
+        // ---- 5. qp_body's QP loop, parallel in time (round 5: all of it; round 4: its first three tries).  Every Newton system of the loop --
+        // an active-set try with the guessed inputs pinned, the predictor and the corrector of an interior-point iteration -- is ONE more
+        // solve_pass over the four segments with its own Gamma and right-hand side; the element loops run on the two elements a lane holds
+        // of its segment, their reductions meet in LDS.  The schedule is qp_body's (the oracle's "ACTIVE-SET POLISH"), state for state:
+        //   TRY    inputs of the guess pinned (Gamma = POL_BIG, right-hand side landing them on their bounds), solve, snap, adjoint sweep of the
+        //          segment (entering with the relay's costate), repairs counted: none -> THE minimiser, committed
+        //   START  interior start: the last point clamped 5 % into the box; its state steps and input gradient come from a pass with EVERY
+        //          input pinned at that point (zero gains: the closed-loop machinery run open loop) -- where qp_body runs a roll-out and an
+        //          adjoint sweep, which have no parallel form; mu0, multipliers, residual
+        //   PRED   Gamma = ll / tl + lu / tu, right-hand side of the affine step, solve; step length, centring, corrector right-hand side
+        //   CORR   the same Gamma, the corrector's right-hand side: a second factor pass (qp_body runs a solve-only sweep here: 55 k cycles
+        //          on one wave; the factor pass of four waves is 48 k + relay), solve; step, update, classification, termination test
+        //   FINAL  an answer that is not an accepted try (the converged interior-point iterate, or the last point at the iteration limit):
+        //          one pass with every input pinned at it gives the state steps and multipliers the full step commits
+        // Anything that goes wrong -- a pivot block not positive definite or ill-conditioned, a NaN, a relay check that fails -- leaves the
+        // iterate untouched for the resident kernel behind this one, as before.
+        if (!P.pit_try || P.qp_iter_max < 1) {   // (no loop of its own / no Newton system allowed: the resident kernel's)
             if (threadIdx.x == 0) P.pit_done[bq] = 0;
             return;
         }
+        int slot = 0;                  // reductions over the block rotate through five groups of four LDS words: a group is rewritten five barriers later
+        auto meet = [&](double v) __attribute__((always_inline)) -> lds_f64* {
+            lds_f64* g = flag_s + 4 + 4 * slot;
+            slot = slot == 4 ? 0 : slot + 1;
+            if (lane == 0) g[wv] = v;
+            __syncthreads();
+            return g;
+        };
+        auto block_sum = [&](double v) __attribute__((always_inline)) -> double { lds_f64* g = meet(wave_sum(v)); return (g[0] + g[1]) + (g[2] + g[3]); };
+        auto block_max = [&](double v) __attribute__((always_inline)) -> double { lds_f64* g = meet(wave_max(v)); return fmax(fmax(g[0], g[1]), fmax(g[2], g[3])); };
+        auto block_min = [&](double v) __attribute__((always_inline)) -> double { lds_f64* g = meet(wave_min(v)); return fmin(fmin(g[0], g[1]), fmin(g[2], g[3])); };
+        auto block_any = [&](bool f) __attribute__((always_inline)) -> bool { lds_f64* g = meet(__ballot(f) != 0ull ? 1.0 : 0.0); return (g[0] + g[1]) + (g[2] + g[3]) != 0.0; };
+        __syncthreads();               // (the verdict flags above have been read by every wave)
         // first guess: the inputs of the Newton point that violate their bounds
-        double act[2];
+        double act[2], V[2] = {0.0, 0.0}, TL[2] = {1.0, 1.0}, TU[2] = {1.0, 1.0}, LL[2] = {0.0, 0.0}, LU[2] = {0.0, 0.0}, DVA[2] = {0.0, 0.0}, GM[2] = {0.0, 0.0},
+               RTC[2] = {0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int j = lane + 64 * t;
             const double vj = vh[j < nu ? j : 0];
             act[t] = vj < lbI - uo[t] ? -1.0 : (vj > ubI - uo[t] ? 1.0 : 0.0);
         }
-        // ... and up to kPitTries - 1 repairs of it, qp_body's first ROUND of tries (POL_FIRST of them; three until round 5) -- as far as it goes without an interior-point iteration: a
-        // try that asks for more than POL_NCHG repairs ends the round there too
-        constexpr int kPitTries = PIT_TRIES;
-        bool accepted = false;
+        enum { M_TRY = 0, M_START, M_PRED, M_CORR, M_FINAL };
+        const int nvt = 4 * N;
+        const double inv2nv = 1.0 / (2.0 * nvt);
+        int mode = M_TRY, iters = 0, round_k = 0, round_cap = POL_FIRST, nchg_prev = nvt + 1;
+        double mu = 0.0, rho = 0.0, smu = 0.0, mu_gate = 1e300;
+        bool ipm_on = false, converged = false, polished = false, give_up = false;
+        status = BROV_STATUS_MAXITER;
 #pragma clang loop unroll(disable)
-        for (int tk = 0; tk < kPitTries; tk++) {
-            if (tk + 1 > P.qp_iter_max) break;
-            {
+        for (;;) {
+            if (mode != M_CORR && mode != M_FINAL) {   // which Newton system is next (qp_body's loop head)
+                if (iters >= P.qp_iter_max) mode = M_FINAL;
+                else mode = round_k < round_cap ? M_TRY : (ipm_on ? M_PRED : M_START);
+            }
+            if (mode == M_FINAL && polished) break;
+            {   // Gamma and right-hand side of this system, into the interior-point arrays the factor stage reads
                 double* GAM = I.ipm + (size_t)IPM_GAM * I.nv + (size_t)s0 * 4;
                 double* RT = I.ipm + (size_t)IPM_RT * I.nv + (size_t)s0 * 4;
+                double ssum = 0.0;
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     const int j = lane + 64 * t;
-                    const double uj = uo[t], ac = act[t];
-                    const double gm = ac != 0.0 ? POL_BIG : 0.0;
+                    const bool in = j < nu;
+                    const double uj = uo[t], lb = lbI - uj, ub = ubI - uj;
                     const double rr = rd[t] * (uj - ur[t]);
-                    if (j < nu) { GAM[j] = gm; RT[j] = rr - gm * ((ac < 0.0 ? lbI : ubI) - uj); }
+                    double gm, rt;
+                    if (mode == M_TRY) {
+                        const double ac = act[t];
+                        gm = ac != 0.0 ? POL_BIG : 0.0;
+                        rt = rr - gm * (ac < 0.0 ? lb : ub);
+                    } else if (mode == M_START) {
+                        const double wdt = ub - lb;
+                        double vj = vh[in ? j : 0];
+                        const double lo = lb + IPM_TAU0 * wdt, hi = ub - IPM_TAU0 * wdt;
+                        vj = (vj < lo) ? lo : vj;
+                        vj = (vj > hi) ? hi : vj;
+                        V[t] = vj; TL[t] = vj - lb; TU[t] = ub - vj;
+                        gm = POL_BIG; rt = rr - POL_BIG * vj;
+                    } else if (mode == M_PRED) {
+                        if (in) ssum += LL[t] * TL[t] + LU[t] * TU[t];
+                        gm = LL[t] / TL[t] + LU[t] / TU[t];
+                        GM[t] = gm;
+                        rt = rr - gm * V[t];
+                    } else if (mode == M_CORR) {
+                        gm = GM[t]; rt = RTC[t];
+                    } else {   // M_FINAL: every input pinned at the answer
+                        double vj = ipm_on ? V[t] : fmin(fmax((double)vh[in ? j : 0], lb), ub);
+                        V[t] = vj;
+                        gm = POL_BIG; rt = rr - POL_BIG * vj;
+                    }
+                    if (in) { GAM[j] = gm; RT[j] = rt; }
                 }
+                if (mode == M_TRY) { iters++; round_k++; }
+                if (mode == M_PRED) { iters++; mu = block_sum(ssum) * inv2nv; }
             }
-            __syncthreads();   // (every wave is done with the hand-over buffers and flags of the pass before)
+            __syncthreads();   // (every wave is done with the hand-over buffers of the pass before)
             solve_pass(false);
+            const bool pinned_all = mode == M_START || mode == M_FINAL;
             bool bad = false;
+            if (mode == M_TRY || pinned_all) {
 #pragma unroll
-            for (int t = 0; t < 2; t++) {   // pinned inputs exactly onto their bounds; free inputs that leave the box are marked (+-2: to be pinned)
-                const int j = lane + 64 * t;
-                const double uj = uo[t], lb = lbI - uj, ub = ubI - uj;
-                double vj = vh[j < nu ? j : 0];
-                bad = bad | ((j < nu) & !(vj == vj));
-                if (act[t] != 0.0) vj = act[t] < 0.0 ? lb : ub;
-                else act[t] = vj < lb ? -2.0 : (vj > ub ? 2.0 : 0.0);
-                lds_f64* o = j < nu ? vh + j : tr_w + 16;
-                *o = vj;
+                for (int t = 0; t < 2; t++) {   // pinned inputs exactly onto their points; (tries) free inputs that leave the box are marked (+-2: to be pinned)
+                    const int j = lane + 64 * t;
+                    const double uj = uo[t], lb = lbI - uj, ub = ubI - uj;
+                    double vj = vh[j < nu ? j : 0];
+                    bad = bad | ((j < nu) & !(vj == vj));
+                    if (pinned_all) vj = V[t];
+                    else if (act[t] != 0.0) vj = act[t] < 0.0 ? lb : ub;
+                    else act[t] = vj < lb ? -2.0 : (vj > ub ? 2.0 : 0.0);
+                    lds_f64* o = j < nu ? vh + j : tr_w + 16;
+                    *o = vj;
+                }
+                const bool seg_bad = __ballot(bad) != 0ull || seg_nan() || !good;
+                seg_adjoint();   // multipliers of this point: its state steps are the forward sweep's (the snap of a pinned input is a rounding error)
+                double gmx = 0.0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int j = lane + 64 * t;
+                    gel[t] = I.lds_kff[j < nu ? j : 0];
+                    if (j < nu) gmx = fmax(gmx, fabs(gel[t]));
+                }
+                gmx = block_max(gmx);
+                if (block_any(seg_bad)) { give_up = true; break; }
+                if (mode == M_FINAL) break;
+                if (mode == M_START) {
+                    const double mu0 = fmax(IPM_MU0F * gmx, 1e-4);
+                    double r0 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        LL[t] = mu0 / TL[t]; LU[t] = mu0 / TU[t];
+                        if (lane + 64 * t < nu) r0 = fmax(r0, fabs(gel[t] - LL[t] + LU[t]));
+                    }
+                    rho = block_max(r0);
+                    ipm_on = true;
+                    continue;
+                }
+                double cnt = 0.0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int j = lane + 64 * t;
+                    if (j < nu) {
+                        const double g = gel[t];
+                        double ac = act[t];
+                        const double tolg = POL_TOL_G * rd[t] + POL_TOL_GREL * gmx;
+                        if (ac == 2.0 || ac == -2.0) { ac *= 0.5; cnt += 1.0; }                                          // newly pinned
+                        else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) { ac = 0.0; cnt += 1.0; }          // released
+                        act[t] = ac;
+                    }
+                }
+                const int nchg = (int)block_sum(cnt);
+                if (nchg == 0) { polished = true; status = BROV_STATUS_SUCCESS; break; }
+                if (nchg > POL_NCHG || (nchg > nchg_prev && ipm_on)) round_cap = 0;
+                nchg_prev = nchg;
+                if (round_k >= round_cap) {   // failed round: the next one waits until the interior-point loop has halved mu
+                    if (ipm_on) mu_gate = mu;
+                    if (converged) { mode = M_FINAL; }
+                }
+                continue;
             }
-            const bool seg_bad = __ballot(bad) != 0ull || seg_nan() || !good;
-            seg_adjoint();
-            double gmx = 0.0;
+            if (block_any(!good || seg_nan())) { give_up = true; break; }
+            if (mode == M_PRED) {   // group B: predictor step length, centring, corrector right-hand side
+                double aaff = 1.0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int j = lane + 64 * t;
+                    const double ll = LL[t], lu = LU[t], tl = TL[t], tu = TU[t];
+                    const double dv = (double)vh[j < nu ? j : 0] - V[t];
+                    DVA[t] = dv;
+                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                    if (j < nu) {
+                        if (dv < 0) aaff = fmin(aaff, -tl / dv);
+                        if (dv > 0) aaff = fmin(aaff, tu / dv);
+                        if (dll < 0) aaff = fmin(aaff, -ll / dll);
+                        if (dlu < 0) aaff = fmin(aaff, -lu / dlu);
+                    }
+                }
+                aaff = block_min(aaff);
+                double sa = 0.0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const double ll = LL[t], lu = LU[t], tl = TL[t], tu = TU[t], dv = DVA[t];
+                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                    if (lane + 64 * t < nu) sa += (ll + aaff * dll) * (tl + aaff * dv) + (lu + aaff * dlu) * (tu - aaff * dv);
+                }
+                const double muaff = block_sum(sa) * inv2nv;
+                double sigma = muaff / mu;
+                sigma = sigma * sigma * sigma;
+                smu = sigma * mu;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const double ll = LL[t], lu = LU[t], tl = TL[t], tu = TU[t], dv = DVA[t];
+                    const double dll = -ll - ll / tl * dv, dlu = -lu + lu / tu * dv;
+                    const double cl_ = dll * dv, cu_ = -dlu * dv;
+                    RTC[t] = rd[t] * (uo[t] - ur[t]) - GM[t] * V[t] - (smu - cl_) / tl + (smu - cu_) / tu;
+                }
+                mode = M_CORR;
+                continue;
+            }
+            // M_CORR, group C: step length of the combined direction, update, classification of the bounds
+            double amax = 1e300, dllv[2], dluv[2];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 const int j = lane + 64 * t;
-                gel[t] = I.lds_kff[j < nu ? j : 0];
-                if (j < nu) gmx = fmax(gmx, fabs(gel[t]));
-            }
-            gmx = wave_max(gmx);
-            if (lane == 0) { flag_s[12 + wv] = seg_bad ? __builtin_nan("") : gmx; }
-            __syncthreads();
-            bool any_bad = false;
-            gmx = 0.0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) { const double v = flag_s[12 + w]; any_bad = any_bad | !(v == v); gmx = fmax(gmx, v); }
-            double cnt = 0.0;
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int j = lane + 64 * t;
+                const double ll = LL[t], lu = LU[t], tl = TL[t], tu = TU[t], dva = DVA[t];
+                const double dlla = -ll - ll / tl * dva, dlua = -lu + lu / tu * dva;
+                const double cl_ = dlla * dva, cu_ = -dlua * dva;
+                const double dv = (double)vh[j < nu ? j : 0] - V[t];
+                const double dll = (smu - cl_) / tl - ll - ll / tl * dv;
+                const double dlu = (smu - cu_) / tu - lu + lu / tu * dv;
                 if (j < nu) {
-                    const double g = gel[t];
-                    double ac = act[t];
-                    const double tolg = POL_TOL_G * rd[t] + POL_TOL_GREL * gmx;
-                    if (ac == 2.0 || ac == -2.0) { ac *= 0.5; cnt += 1.0; }                                          // newly pinned
-                    else if ((ac < 0.0 && g < -tolg) || (ac > 0.0 && g > tolg)) { ac = 0.0; cnt += 1.0; }          // released
-                    act[t] = ac;
+                    if (dv < 0) amax = fmin(amax, -tl / dv);
+                    if (dv > 0) amax = fmin(amax, tu / dv);
+                    if (dll < 0) amax = fmin(amax, -ll / dll);
+                    if (dlu < 0) amax = fmin(amax, -lu / dlu);
+                }
+                dllv[t] = dll; dluv[t] = dlu;
+            }
+            amax = block_min(amax);
+            double alpha;
+            {
+                const double a = amax < 1.0 ? amax : 1.0;
+                alpha = (IPM_FTB * amax >= 1.0) ? 1.0 : a * ((1.0 - a) * IPM_FTBLO + a * IPM_FTB);
+            }
+            double s2 = 0.0, unres = 0.0;
+            bool nanv = false;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int j = lane + 64 * t;
+                const double dv = (double)vh[j < nu ? j : 0] - V[t];
+                const double vj = V[t] + alpha * dv;
+                const double tl = TL[t] + alpha * dv, tu = TU[t] - alpha * dv;
+                const double ll = LL[t] + alpha * dllv[t], lu = LU[t] + alpha * dluv[t];
+                V[t] = vj; TL[t] = tl; TU[t] = tu; LL[t] = ll; LU[t] = lu;
+                if (j < nu) {
+                    nanv = nanv | !(vj == vj);
+                    s2 += ll * tl + lu * tu;
+                    const double al = ll / rd[t], au = lu / rd[t];
+                    unres = fmax(unres, fmax(fmin(tl, al), fmin(tu, au)));
+                    act[t] = al > tl ? -1.0 : (au > tu ? 1.0 : 0.0);
                 }
             }
-            cnt = wave_sum(cnt);
-            if (lane == 0) flag_s[16 + wv] = cnt;
-            __syncthreads();
-            const double nchg = (flag_s[16] + flag_s[17]) + (flag_s[18] + flag_s[19]);
-            if (any_bad) break;
-            if (nchg == 0.0) { accepted = true; tries = tk + 1; break; }
-            if (nchg > (double)POL_NCHG) break;   // (the round ends: an interior-point iteration is next -- the resident kernel's)
+            if (block_any(nanv)) { give_up = true; break; }
+            rho *= (1.0 - alpha);
+            mu = block_sum(s2) * inv2nv;
+            unres = block_max(unres);
+            if (unres <= P.tol_mu && rho <= P.tol_stat) converged = true;
+            if (converged || (mu <= POL_MU_GATE * mu_gate && alpha >= POL_ALPHA_GATE)) { round_k = 0; round_cap = POL_LOOP; nchg_prev = nvt + 1; }
+            mode = M_PRED;   // (the loop head decides: a round of tries, or the next iteration)
         }
-        if (!accepted) {
+        __syncthreads();   // (the last reduction's words have been read: the objective's shares go into one of those groups below)
+        if (give_up) {
             if (threadIdx.x == 0) P.pit_done[bq] = 0;
             return;
         }
+        if (converged && status == BROV_STATUS_MAXITER) status = BROV_STATUS_SUCCESS;
+        tries = iters;
     }
     PIT_STAMP(4);
     // full step of the segment and its share of the objective at the new iterate
@@ -652,7 +821,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     __syncthreads();
     if (wv == 0) {   // the record: as soon as the four shares of the objective are in
         const double ctot = ((flag_s[20] + flag_s[21]) + (flag_s[22] + flag_s[23]));
-        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt, early ? 0 : tries);
+        pit_emit_record(P, bq, lane, lane == 0 ? ctot : 0.0, u0v, kkt, early ? 0 : tries, status);
         PIT_STAMP(5);
     }
     if (early) seg_adjoint();   // (an accepted try has run it already: its multipliers are the ones to keep)

@@ -96,7 +96,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             if (P.pit_left_host) {
                 int done = 0;
                 for (int j = lane0; j < P.B; j += 64)
-                    done += P.pit_done ? P.pit_done[j] != 0 : (P.res[j].status == BROV_STATUS_SUCCESS && P.res[j].qp_iter <= (P.pit_try ? PIT_TRIES : 0));
+                    done += P.pit_done ? P.pit_done[j] != 0 : (P.pit_try || (P.res[j].status == BROV_STATUS_SUCCESS && P.res[j].qp_iter == 0));
                 done = (int)wave_sum((double)done);
                 if (lane0 == 0) __hip_atomic_store(P.pit_left_host, ((unsigned long long)(unsigned)P.pit_seq << 32) | (unsigned)(P.B - done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }

@@ -101,7 +101,7 @@ def _load():
         "brov_debug_dump_linearisation": [vp, C.c_int], "brov_get_yref_host": [vp, dp], "brov_get_params_host": [vp, dp],
         "brov_tick_host": [vp, dp, dp, dp, C.c_int, vp],
         "brov_tick_buffers": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
-        "brov_pit_last": [vp, C.POINTER(C.c_int32)], "brov_dev_reload_knobs": [vp], "brov_solve_ticks": [vp, vp, C.c_int, C.c_int, vp],
+        "brov_pit_last": [vp, C.POINTER(C.c_int32)], "brov_dev_reload_knobs": [vp], "brov_dev_tick_breakdown": [vp, dp], "brov_solve_ticks": [vp, vp, C.c_int, C.c_int, vp],
         "brov_set_time_steps": [vp, dp], "brov_set_stage0_weight": [vp, dp], "brov_general_grid": [vp],
         "brov_enable_dist6": [vp, C.c_int], "brov_dist6_enabled": [vp], "brov_set_rp_disturbance_host": [vp, dp, C.c_int],
         "brov_set_params18_host": [vp, dp, C.c_int], "brov_plant_set_rp_disturbance_host": [vp, dp], "brov_get_rp_disturbance_host": [vp, dp],
@@ -285,6 +285,12 @@ class BatchSolver:
         self._chk(self._L.brov_solve_ticks(self._h, C.c_void_p(stream or 0), int(ticks), int(row_stride), C.c_void_p(status_log_ptr or 0)), "solve_ticks")
         if sync:
             self._chk(self._L.brov_synchronize(self._h, C.c_void_p(stream or 0)), "synchronize")
+
+    def tick_breakdown(self):
+        """development (BROV_TICK_BREAKDOWN=1 at create): host microseconds of the last tick -- staging, launch, post-launch, wait, total"""
+        us = np.zeros(5)
+        self._chk(self._L.brov_dev_tick_breakdown(self._h, _dp(us)), "tick_breakdown")
+        return us
 
     def reload_knobs(self):
         """development: the solver reads its BROV_* environment knobs once, at create; a test that flips one between two solves of the

@@ -229,6 +229,8 @@ int brov_tick_buffers(brov_solver* s, double** x0 /*[B][12]*/, double** yref_sha
  * BROV_PARTIAL_REFACTOR, ...: DESIGN.md section 4.6 lists them); a solver reads them ONCE, in brov_create -- no call on the path of a
  * solve touches the environment.  brov_dev_reload_knobs reads them again (tests that flip a switch between two solves of one solver). */
 int brov_dev_reload_knobs(brov_solver* s);
+/* BROV_TICK_BREAKDOWN=1: host microseconds of the last brov_tick_host -- staging, launch, post-launch enqueues, wait for the records, total */
+int brov_dev_tick_breakdown(brov_solver* s, double us[5]);
 /* replace weights / bounds / Ts / QP options of an existing solver (N must not change) */
 int brov_set_opts(brov_solver* s, const brov_opts* opts);
 int brov_get_opts(const brov_solver* s, brov_opts* opts);

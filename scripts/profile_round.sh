@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun): bench lines of every config, rocprofv3 kernel-trace stats of the default bench command,
 # counter passes (HBM traffic, SQ, LDS) of the headline and of the long-horizon kernels, FETCH_SIZE/WRITE_SIZE calibration.
 # Outputs land in gpurun_out/prof_$1/ ; scripts/collect_profiles.py turns them into the committed summaries under profiles/.
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

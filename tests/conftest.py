@@ -93,18 +93,27 @@ def scenario_ticks(g, name):
     return k
 
 
-def status_agreement(r_status, o_status, o_kkt, max_ambiguous=4):
+def status_agreement(r_status, o_status, o_kkt, max_ambiguous=3):
     """Status parity rule shared by the batch tests.  Wherever the step is numerically meaningful (entering KKT <= 1e6) the GPU
     and the oracle must report the same status -- no exceptions.  Once an iterate has diverged (KKT > 1e6: QP data of size
     1e6..1e17; full-step SQP has no globalisation, as in the reference) the Riccati recursion works on numbers whose rounding
     errors exceed the input weights, and whether / where the step is declared failed -- a pivot block that stops being positive
     definite (4), the iteration limit (2), a NaN (1), or not at all -- depends on the summation order (MFMA tiles vs scalar
     loops).  At most `max_ambiguous` such instances may disagree, and their meaningless iterates are not compared on that tick.
+    Round 5: the disagreements have ONE direction and one cause, and the rule holds them to it.  The kernels take the Cholesky pivot
+    form (which the oracle always uses) only while the entering KKT is <= 1e6; above it they keep the explicit 2 x 2-block inverse,
+    which loses positive definiteness earlier -- so the GPU reports QP failure (4) on steps the oracle still factorises (0, rarely 2).
+    Measured (profiles/r5_status_direction.txt): with the limit lifted (BROV_ROBUST_PIVOT=3) 20 of the suite's 24 disagreements vanish,
+    and the mixed batch / the config-4 shard lose 29 % / 23 % to diverged instances grinding through the iteration limit.  The
+    allowance is what the suite shows (3 per call), not a round number.
     Returns the mask of instances whose values are to be compared (all but the ambiguous ones)."""
     r_status, o_status, o_kkt = np.asarray(r_status), np.asarray(o_status), np.asarray(o_kkt)
     mism = r_status != o_status
     assert np.all((o_kkt[mism] > 1e6) | ~np.isfinite(o_kkt[mism])), (np.nonzero(mism)[0], r_status[mism], o_status[mism], o_kkt[mism])
     assert mism.sum() <= max_ambiguous, (np.nonzero(mism)[0], r_status[mism], o_status[mism])
+    if os.environ.get("BROV_ROBUST_PIVOT", "1") == "1" and "BROV_ROBUST_KKT_MAX" not in os.environ:   # (the product's setting)
+        assert np.all(r_status[mism] == 4) and np.all((o_status[mism] == 0) | (o_status[mism] == 2)), (
+            "a status disagreement in the other direction", np.nonzero(mism)[0], r_status[mism], o_status[mism], o_kkt[mism])
     if mism.sum():
         print(f"[status_agreement] {int(mism.sum())} status-ambiguous instance(s) (entering KKT > 1e6): gpu {r_status[mism]} oracle {o_status[mism]}")
     _parity_note("status", "status", len(mism), mism.sum(), kkt=o_kkt[mism], gpu=r_status[mism], oracle=o_status[mism])

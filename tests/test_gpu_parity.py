@@ -530,4 +530,7 @@ def test_nominal_model_fuzz_at_the_headline_step(ba, oracle, golden_traj):
                  smallest_cond_left_out=float(lo[:, 5].min()) if len(lo) else None)
     assert not bad, bad[:8]
     assert checked_headline > 1000 and headline_left_out <= 4 and n_ipm_draws > 350
-    assert len(lo) < 0.05 * checked
+    # pinned to what is measured (round-4 advisor: an allowance of 5 % -- 2457 -- would not notice a regression that costs a digit): 980 .. 986
+    # instance-ticks left out over the runs of round 5, the best-conditioned of them at cond 1.6e11 -- sixteen times the limit
+    assert len(lo) <= 1040, len(lo)
+    assert lo[:, 5].min() >= 1e11, lo[:, 5].min()

@@ -103,8 +103,6 @@ def test_parallel_in_time_step_matches_the_oracle(ba, oracle, golden_traj, N, B,
         _compare(r, it, ro, x, u, pi, lam, (N, B, far, mode, k))
         early = (ro["status"] == 0) & (ro["qp_iter"] == 0)
         one = (ro["status"] == 0) & (ro["qp_iter"] <= 1)          # no active bound, or a first active-set guess that is right
-        few = (ro["status"] == 0) & (ro["qp_iter"] <= PIT_TRIES)  # ... or one that up to four repairs make right (the kernel's round of tries = qp_body's first)
-        assert not np.any(done.astype(bool) & ~few), "more than PIT_TRIES Newton systems: the resident kernel's"
         assert np.array_equal(r["qp_iter"][done.astype(bool)], ro["qp_iter"][done.astype(bool)])   # the same number of systems as the oracle's schedule
         if mode == "2":
             assert np.all(done.astype(bool)[early]), (k, done, early)                 # every early exit is found
@@ -149,8 +147,7 @@ def test_between_one_and_two_instances_per_cu_the_kernel_runs_one_block_per_inst
         if mode == "0":
             assert not done.any()
         else:
-            was_early = np.ones(B, dtype=bool) if prev is None else (prev["status"] == 0) & (prev["qp_iter"] <= PIT_TRIES)
-            tried = was_early if mode == "1" else np.ones(B, dtype=bool)
+            tried = np.ones(B, dtype=bool)                 # (round 5: the kernel runs the whole QP loop and is offered every instance)
             assert np.all(done[early & tried]) and not np.any(done & ~tried)
             assert np.array_equal(r["qp_iter"][done], ro["qp_iter"][done])
         prev = ro
@@ -226,9 +223,42 @@ def test_forced_loop_option_goes_through_the_parallel_try(ba, oracle, golden_tra
         prev = ro
         _compare(r, it, ro, x, u, pi, lam, ("forced", k))
         assert np.all(ro["qp_iter"][ro["status"] == 0] >= 1)
-        assert not np.any(done.astype(bool) & (ro["qp_iter"] > PIT_TRIES))
         n_done += int(done.sum())
     assert n_done >= 3 * B
+    s.close()
+
+
+@pytest.mark.parametrize("N,B,box,seed", [(40, 10, 8.0, 5), (80, 6, 10.0, 6), (60, 8, 5.0, 7), (24, 8, 8.0, 8), (80, 1, 6.0, 9)])
+def test_the_whole_qp_loop_parallel_in_time(ba, oracle, golden_traj, N, B, box, seed):
+    """Round 5: tries AND interior-point iterations run on the block's four waves -- every Newton system of qp_body's schedule is one more pass of
+    the kernel's factor / relay / forward machinery, the interior start and a non-polished answer get their state steps and multipliers from a pass
+    with every input pinned.  Small input boxes with half the instances metres off: 5 .. 15 Newton systems per QP (the oracle's count), every
+    tick against the oracle like every other mode; the kernel completes these instances itself, with the oracle's number of Newton systems."""
+    os.environ["BROV_PIT"] = "1"
+    Ts = 1.0 / N
+    kw = dict(lbu=[-box] * 4, ubu=[box] * 4)
+    x0, circ = _inputs(golden_traj, B, seed=seed, far=0.5 if B > 1 else 1.0)
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, **kw)); s.set_x0(x0); s.set_params(P_NOMINAL)
+    assert s.window_stages() == N
+    op = oracle.opts(N, Ts, **kw)
+    x, u, pi, lam = oracle.init_iterate(op, B)
+    pf = np.ascontiguousarray(np.broadcast_to(P_NOMINAL, (B, N + 1, 16)))
+    prev, n_done, n_ipm_done, n_total, n_count_off = None, 0, 0, 0, 0
+    for k in range(6):
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        s.set_yref(yref); s.solve()
+        r, it, done = s.results(), s.get_iterate(), s.pit_last().astype(bool)
+        _, ro = oracle.rti_step_batch(op, x0, np.ascontiguousarray(np.broadcast_to(yref, (B, N + 1, 16))), pf, x, u, pi, lam, res_prev=prev)
+        prev = ro
+        _compare(r, it, ro, x, u, pi, lam, ("loop", N, B, k))
+        assert np.all(ro["status"] == 0)
+        n_done += int(done.sum()); n_total += B
+        n_ipm_done += int((done & (ro["qp_iter"] > PIT_TRIES)).sum())
+        n_count_off += int((r["qp_iter"][done] != ro["qp_iter"][done]).sum())
+    print(f"[pit loop] N={N} B={B} box +-{box}: {n_done} of {n_total} instance-ticks completed parallel in time, {n_ipm_done} of them with interior-point "
+          f"iterations, {n_count_off} with a Newton-system count other than the oracle's")
+    assert n_done >= 0.9 * n_total and n_ipm_done >= (3 if B > 1 else 1)
+    assert n_count_off <= max(1, n_done // 20)     # (an iteration more or less where a step-length or gate test sits on a rounding error)
     s.close()
 
 
@@ -345,7 +375,6 @@ def test_long_closed_loop_with_reference_jumps_switches_between_the_two_kernels(
         err = np.abs(ra["u0"] - rb["u0"]).max() / max(1.0, np.abs(rb["u0"]).max())
         worst = max(worst, err)
         assert err < 1e-8, (k, err, done)
-        assert bool(done[0]) <= (ra["qp_iter"][0] <= PIT_TRIES)
         n_pit += int(done[0]); n_res += int(not done[0]); n_loop += int(ra["qp_iter"][0] > 0)
         a.plant_step(1.0 / N)
     print(f"[pit soak] {T} ticks: {n_pit} by the parallel-in-time kernel, {n_res} by the resident kernel ({n_loop} with active bounds), worst relative |du0| {worst:.1e}")
