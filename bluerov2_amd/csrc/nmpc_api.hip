@@ -18,7 +18,6 @@
 using namespace brov;
 
 #define kTickMailboxMaxBatch 64          /* brov_tick_host: up to this many instances deliver their records through the host mailbox */
-#define kPitPause 8                        /* solves without the parallel-in-time kernel after it left some (not all) instances of a batch behind */
 #define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N > 81: up to this many instances run on the streaming kernels */
 
 static thread_local std::string g_err;
@@ -76,11 +75,7 @@ struct brov_solver {
     int win_blocks = 0, win_L = 0;
     double* ws_split = nullptr;      // fused-kernel horizons, at most one instance per CU: per-instance workspace of the resident kernel's split launches (rti_phase 1 / 2)
     int alt_blocks = 0, alt_L = 0;   // parallel-in-time rounds (pit_rounds_stages): the resident configuration a solve may use instead
-    unsigned long long* pit_left_host = nullptr;   // pinned word: (sequence number << 32 | instances the parallel-in-time kernel left to the resident kernel) of the last solve it ran in
-    int32_t pit_seq = 0, pit_ignore_upto = 0, pit_probe_seq = 0;   // solves with that kernel issued so far / reports up to here are old news / the probe whose report is awaited
-    bool pit_want_probe = false;
     int prep_path = 0;               // the last rti_phase-1 call: 1 streaming pair (linearisation in HBM), 2 resident split (factorised LDS image parked), 3 the latter, invalidated by a setter
-    int pit_pause = 0;               // ... solves still to run without the parallel-in-time kernel before it is tried again
     bool force_windowed = false;
     unsigned long long* dbg = nullptr;
     // general grid (streaming kernels): per-stage time steps and / or a separate stage-0 weight
@@ -101,7 +96,11 @@ struct brov_solver {
     hipEvent_t ev_up = nullptr;          // a preparation tick (rti_phase 1): its uploads have left the pinned staging buffer
     hipEvent_t ev_tick = nullptr;        // ticks with inputs read in place: the kernel's end (neither the host nor the next tick's kernel waits for the copies behind it)
     hipStream_t copy_stream = nullptr;   // ... those copies (pinned staging buffer -> the device arrays every other entry point works on) run here, behind ev_tick
-    hipEvent_t ev_copy = nullptr;        // ... and end here
+    hipEvent_t ev_copy = nullptr;        // ... and end here (alias of the ev_set[] recorded last)
+    hipEvent_t ev_set[2] = {nullptr, nullptr};   // the refresh copies out of input set 0 / 1 of the pinned staging buffer (see brov_tick_host)
+    bool set_pending[2] = {false, false};
+    int pin_sel = 0;                     // input set the last copying tick used
+    bool buffers_out = false;            // brov_tick_buffers has handed set 0 out
     bool copies_pending = false;         // ev_copy recorded and not yet waited for by the host
     int copy_mask = 0;                   // ... which device arrays those copies write: 1 x0, 2 shared window, 4 stage parameters
     bool in_tick = false;                // brov_tick_host is calling brov_solve_phase (whose kernel reads the pinned inputs: no need to order it behind the copies)
@@ -128,7 +127,6 @@ static DevKnobs read_knobs() {
     k.pit = env_int("BROV_PIT", 1);                               // 0 off, 1 product rule, 2 every instance is tried
     k.split_parallel = env_int("BROV_SPLIT_PARALLEL", 1) != 0;
     k.pit_try = env_int("BROV_PIT_TRY", 1) != 0;
-    k.pit_adapt = env_int("BROV_PIT_ADAPT", 1) != 0;
     k.tick_mailbox = env_int("BROV_TICK_MAILBOX", 1) != 0;
     k.tick_bulk = env_int("BROV_TICK_BULK", 1) != 0;
     k.tick_zerocopy = env_int("BROV_TICK_ZEROCOPY", 1) != 0;
@@ -315,10 +313,6 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
             ws_doubles = alt > ws_doubles ? alt : ws_doubles;
         }
         AL(ws, ws_doubles);
-        if (B > 1 && (s->alt_L || windowed_is_resident(s->win_L))) {   // the parallel-in-time kernel may serve this solver: its report word
-            if (hipHostMalloc((void**)&s->pit_left_host, 64, hipHostMallocDefault) != hipSuccess) { s->pit_left_host = nullptr; rc = BROV_ERR_HIP; }
-            else *s->pit_left_host = 0;
-        }
     }
     // rti_phase 1 / 2 at a horizon the fused kernels serve: the resident kernel's split launches need a workspace per instance
     if (fused_supported(opts->N) && !s->force_windowed && opts->kernel_path != BROV_PATH_STREAMING && split_resident_horizon(opts->N) &&
@@ -366,11 +360,10 @@ extern "C" void brov_destroy(brov_solver* s) {
     if (s->traj) hipFree(s->traj);
     if (s->dbg) hipFree(s->dbg);
     if (s->pin) hipHostFree(s->pin);
-    if (s->pit_left_host) hipHostFree(s->pit_left_host);
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->ev_tick) hipEventDestroy(s->ev_tick);
     if (s->ev_up) hipEventDestroy(s->ev_up);
-    if (s->ev_copy) hipEventDestroy(s->ev_copy);
+    for (int k = 0; k < 2; k++) if (s->ev_set[k]) hipEventDestroy(s->ev_set[k]);
     if (s->tick_stream) hipStreamDestroy(s->tick_stream);
     for (int k = 0; k < 3; k++)
         if (s->ev[k]) hipEventDestroy(s->ev[k]);
@@ -931,44 +924,12 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
                 P.pit_try = s->k.pit_try;
             }
             P.pit_blocks = P.win_blocks;
-            // The parallel kernel runs AHEAD of the resident one: what it leaves (instances that need an interior-point iteration or a fourth
-            // try, and those its hint does not even let it try) STARTS only when it is over.  Alone, such an instance costs nothing extra (its
-            // block of the parallel kernel ends at once); next to instances the parallel kernel does complete it makes the solve LONGER than
-            // without that kernel -- 64 instances at N = 80 with a quarter saturated: the launch waits ~0.06 ms longer for its last three;
-            // 512 instances, two per CU: 0.465 against 0.375 ms on the windowed kernel.  The resident kernel therefore reports how many
-            // instances were left to it into a pinned host word, and when the last report (a solve or two old: nobody waits for it) says
-            // "some, not all" -- such instances stay for many ticks -- the solves go without the parallel kernel: the resident kernel alone
-            // (which keeps reporting: the parallel kernel is back as soon as nothing would be left) or, for batches of two per CU, the
-            // windowed kernel for kPitPause solves, then one probe.  A batch of one never pauses.  BROV_PIT_ADAPT=0: never.
-            bool pit_now = pit_can && (s->alt_L != 0 || pit_supported(s->N, P.win_L));
-            bool probe = false, resident_report = false;
-            if (pit_now && pit != 2 && s->pit_left_host && s->k.pit_adapt) {
-                // (the host may be many solves ahead of the device: reports carry the sequence number of their solve.  A report that
-                // starts a pause makes everything issued up to then old news; after the pause ONE solve probes, and until ITS report is
-                // in the solves go without the parallel kernel)
-                const unsigned long long rep = __atomic_load_n(s->pit_left_host, __ATOMIC_RELAXED);
-                const int32_t rs = (int32_t)(rep >> 32), left = (int32_t)(rep & 0xffffffffu);
-                const bool some = left > 0 && left < (int32_t)s->B;
-                if (!s->alt_L) {
-                    // at most one instance per CU: without the parallel kernel the solve is the resident kernel's as well, which then reports what
-                    // that kernel WOULD leave (its hint, from the records of the solve before) -- no pause to count, no probe: the parallel
-                    // kernel runs whenever the latest report says "none" or "all"
-                    pit_now = !some;
-                    resident_report = true;
-                } else if (s->pit_pause > 0) {
-                    pit_now = false;
-                    if (--s->pit_pause == 0) s->pit_want_probe = true;
-                } else if (s->pit_probe_seq) {
-                    if (rs == s->pit_probe_seq) {
-                        s->pit_probe_seq = 0;
-                        if (some) { s->pit_pause = kPitPause - 1; s->pit_ignore_upto = s->pit_seq; pit_now = false; }
-                    } else pit_now = false;
-                } else if (s->pit_want_probe) {
-                    s->pit_want_probe = false; probe = true;
-                } else if (some && rs > s->pit_ignore_upto) {
-                    s->pit_pause = kPitPause - 1; s->pit_ignore_upto = s->pit_seq; pit_now = false;
-                }
-            }
+            // Round 5: a constant rule.  The parallel kernel runs the whole QP loop itself (qp/pit.hpp), so what it leaves to the resident kernel
+            // behind it are the instances it gives up on -- a NaN, a pivot block that fails or is ill-conditioned: verdicts of its first pass --, and
+            // those cost it next to nothing.  Round 4's kernel left every instance that needed a fourth try or an interior-point iteration, which then
+            // STARTED only when it was over; the host followed a pinned report word, paused the kernel for eight solves and probed (forty lines here).
+            // All of that is gone: the kernel runs whenever it can serve the solve.
+            const bool pit_now = pit_can && (s->alt_L != 0 || pit_supported(s->N, P.win_L));
             if (pit_now && s->alt_L) {   // between one and two instances per CU: the resident configuration, one rti_pit_kernel block per instance
                 P.win_L = s->alt_L; P.win_blocks = s->alt_blocks; P.ws_stride = (int64_t)windowed_ws_doubles(s->N, s->alt_L);
                 P.pit_blocks = (int32_t)s->B;
@@ -976,15 +937,6 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             if (pit_now && pit_supported(s->N, P.win_L)) {
                 P.pit = pit; P.pit_done = s->pit_done;
                 P.pit_try = s->k.pit_try;
-                P.pit_left_host = s->pit_left_host;
-                P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
-                if (s->pit_seq == 1) s->pit_ignore_upto = 0;   // (wrapped)
-                if (probe) s->pit_probe_seq = s->pit_seq;
-            }
-            if (resident_report && !P.pit) {   // (the resident kernel alone: its estimate goes into the same word)
-                P.pit_left_host = s->pit_left_host;
-                P.pit_try = s->k.pit_try;          // (... by the parallel kernel's own rule)
-                P.pit_seq = s->pit_seq = (s->pit_seq == 0x7fffffff ? 1 : s->pit_seq + 1);
             }
             s->pit_ran = P.pit != 0;
             launch_windowed(P, st); s->win_tick++;   // persistent blocks; the two hand-out counters alternate
@@ -1055,11 +1007,14 @@ extern "C" int brov_solve_ticks(brov_solver* s, void* stream, int ticks, int row
 static int tick_pin(brov_solver* s) {
     const size_t B = s->B, N1 = s->N + 1;
     const size_t n_x0 = B * 12, n_y = N1 * 16, n_p = B * N1 * 16, n_r = (B * sizeof(brov_result) + 7) / 8, n_f = (B * sizeof(int32_t) + 7) / 8;
-    if (s->pin_doubles < n_x0 + n_y + n_p + n_r + n_f) {
+    // (x0 | window | parameters) | records | sequence words | a second (x0 | window | parameters): ticks that copy their arguments in alternate
+    // between the two input sets
+    const size_t n_all = 2 * (n_x0 + n_y + n_p) + n_r + n_f;
+    if (s->pin_doubles < n_all) {
         if (s->pin) hipHostFree(s->pin);
         s->pin = nullptr; s->pin_doubles = 0;
-        HIPCHK(hipHostMalloc((void**)&s->pin, (n_x0 + n_y + n_p + n_r + n_f) * sizeof(double), hipHostMallocDefault));
-        s->pin_doubles = n_x0 + n_y + n_p + n_r + n_f;
+        HIPCHK(hipHostMalloc((void**)&s->pin, n_all * sizeof(double), hipHostMallocDefault));
+        s->pin_doubles = n_all;
         std::memset(s->pin, 0, s->pin_doubles * sizeof(double));
     }
     return BROV_OK;
@@ -1071,6 +1026,7 @@ extern "C" int brov_tick_buffers(brov_solver* s, double** x0, double** yref_shar
     HIPCHK(hipSetDevice(s->device));
     if (int rc = tick_pin(s)) return rc;
     const size_t B = s->B, N1 = s->N + 1;
+    s->buffers_out = true;
     if (x0) *x0 = s->pin;
     if (yref_shared) *yref_shared = s->pin + B * 12;
     if (par_stage) *par_stage = s->pin + B * 12 + N1 * 16;
@@ -1092,17 +1048,22 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     if (int rc = tick_pin(s)) return rc;
     hipStream_t st = s->tick_stream;
     if (s->last_stream != st) HIPCHK(sync_last(s));   // an earlier solve on the caller's stream
-    double* px = s->pin; double* py = px + n_x0; double* pp = py + n_y; double* pr = pp + n_p;
+    double* pr = s->pin + n_x0 + n_y + n_p;
     volatile int32_t* pf = (volatile int32_t*)(pr + n_r);
     // The refresh copies a zero-copy tick leaves running behind its kernel (pinned staging buffer -> device arrays, copy_stream) still READ the
-    // staging regions they were enqueued for: before the host rewrites one of those regions the copies must be over (round-4 advisor: a
-    // torn or already-next-tick x0 in the device array).  They are 21 KB behind a kernel that has long ended: the query almost always says so.
-    const int passed_now = (x0 ? 1 : 0) | (yref_shared ? 2 : 0) | (par_stage ? 4 : 0);
-    if (s->copies_pending && (s->copy_mask & passed_now) && hipEventQuery(s->ev_copy) != hipSuccess) {
+    // input set they were enqueued for (round-4 advisor: rewriting it under them leaves a torn or already-next-tick x0 in the device array).
+    // Waiting for them at the top of the next tick costs a back-to-back control loop 30 us (the kernel's tail and the copies behind it; measured,
+    // round 5) -- so the staging buffer holds TWO input sets and ticks that copy their arguments in alternate: a set is rewritten two ticks
+    // after its copies were enqueued, and the check below almost always finds them done.  Set 0 is the one brov_tick_buffers hands out.
+    const bool in_place = (x0 && x0 == s->pin) || (yref_shared && yref_shared == s->pin + n_x0) || (par_stage && par_stage == s->pin + n_x0 + n_y);
+    // (a caller that holds set 0 through brov_tick_buffers keeps it to itself: its copying ticks, if any, all use set 1)
+    const int sel = in_place ? 0 : (s->buffers_out ? 1 : (s->pin_sel ^= 1));
+    double* px = sel ? pr + n_r + (B * sizeof(int32_t) + 7) / 8 : s->pin; double* py = px + n_x0; double* pp = py + n_y;
+    if (s->set_pending[sel] && hipEventQuery(s->ev_set[sel]) != hipSuccess) {
         (void)hipGetLastError();
-        HIPCHK(hipEventSynchronize(s->ev_copy));
+        HIPCHK(hipEventSynchronize(s->ev_set[sel]));
     }
-    const bool in_place = (x0 && x0 == px) || (yref_shared && yref_shared == py) || (par_stage && par_stage == pp);
+    s->set_pending[sel] = false;
     if (x0 && x0 != px) std::memcpy(px, x0, n_x0 * sizeof(double));   // (equal: the caller wrote into the staging buffer, brov_tick_buffers)
     if (yref_shared) {
         if (yref_shared != py) std::memcpy(py, yref_shared, n_y * sizeof(double));
@@ -1142,7 +1103,9 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         if (!s->copy_stream) {
             HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&s->ev_tick, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&s->ev_copy, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_set[0], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_set[1], hipEventDisableTiming));
+            s->ev_copy = s->ev_set[0];
         }
     }
     // Results.  Small batches (the ROS node's batch of one): the kernel writes every record into the pinned buffer itself and then the
@@ -1176,7 +1139,9 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         HIPCHK(hipEventRecord(s->ev_tick, st));
         HIPCHK(hipStreamWaitEvent(s->copy_stream, s->ev_tick, 0));
         if (int rc2 = upload(s->copy_stream)) return rc2;
+        s->ev_copy = s->ev_set[sel];
         HIPCHK(hipEventRecord(s->ev_copy, s->copy_stream));
+        s->set_pending[sel] = true;
         s->copy_mask = (s->copies_pending && !behind_copies) ? (s->copy_mask | passed) : passed;   // (arrays written by copies no kernel on st is ordered behind yet)
         s->copies_pending = true;
     }

@@ -88,19 +88,6 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     if (blockIdx.x == 0) {
         sched_zero_next(P, lane0);
         if (lane0 == 0) *P.counter_next = 0;   // the next launch's hand-out counter (this launch uses the other one)
-        if constexpr (RES) {
-            // batches between one and two instances per CU (pit_rounds_stages): how many instances the parallel-in-time kernel has left to
-            // this one -- into a pinned host word the host reads, a solve or two later, when it chooses the mode of a solve
-            // (without that kernel in front -- the host has paused it --: how many it WOULD leave, by its own hint: the records of the solve
-            // before, read here before any block of this launch can have written one)
-            if (P.pit_left_host) {
-                int done = 0;
-                for (int j = lane0; j < P.B; j += 64)
-                    done += P.pit_done ? P.pit_done[j] != 0 : (P.pit_try || (P.res[j].status == BROV_STATUS_SUCCESS && P.res[j].qp_iter == 0));
-                done = (int)wave_sum((double)done);
-                if (lane0 == 0) __hip_atomic_store(P.pit_left_host, ((unsigned long long)(unsigned)P.pit_seq << 32) | (unsigned)(P.B - done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
     }
     double* ws = P.ws + (size_t)blockIdx.x * P.ws_stride;
     Win W;
