@@ -574,6 +574,24 @@ def configs_block(ba, args, device):
                                        status_nonzero=int((r["status"] != 0).sum()), ekf_status_nonzero=int((st != 0).sum()),
                                        median_abs_yaw_estimate_error=float(np.median(np.abs(mp[:, 3] - d[:, 3]))))
     e.close(); s.close()
+    # ... and without the observer (the controller keeps its nominal parameters, the plant has the true disturbance): brov_closed_loop, which on
+    # the fused kernels is ONE launch for all ticks (round 5: window -> RTI step -> plant step of every tick inside rti_fused_kernel_ticks, every
+    # Monte-Carlo draw running its own loop at its own pace) -- against the same loop as three launches per tick (BROV_CLOSED_LOOP_FUSED=0)
+    cl = {}
+    for name, fused in (("one_launch", "1"), ("three_launches_per_tick", "0")):
+        os.environ["BROV_CLOSED_LOOP_FUSED"] = fused
+        try:
+            s = ba.BatchSolver(B, ba.SolverOptions(N, TS), device=device)
+        finally:
+            os.environ.pop("BROV_CLOSED_LOOP_FUSED", None)
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_plant_params(pt); s.set_trajectory(circ)
+        s.closed_loop(W, line0=0, log=False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        s.closed_loop(K, line0=W, log=False)
+        torch.cuda.synchronize(); dtc = (time.perf_counter() - t0) / K
+        cl[name] = dict(ticks_per_s=B / dtc, ms_per_tick=dtc * 1e3, status_nonzero=int((s.results()["status"] != 0).sum()))
+        s.close()
+    leg["closed_loop_plant_only"] = cl
     out["config3"] = leg
 
     # ---- configs[3], one of its 8 shards: 8192 of the 65 536 lemniscate candidates, windows rebuilt on the device, then the RCCL

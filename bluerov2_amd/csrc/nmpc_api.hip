@@ -134,6 +134,7 @@ static DevKnobs read_knobs() {
     k.force_windowed = env_int("BROV_DEV_FORCE_WINDOWED", 0) != 0;
     k.fused_waves = env_int("BROV_DEV_FUSED_WAVES", 0);           // 1 / 2: force a variant of the fused kernel (default by LDS size)
     k.lds_pad = env_int("BROV_DEV_LDS_PAD", 0);
+    k.closed_loop_fused = env_int("BROV_CLOSED_LOOP_FUSED", 1) != 0;   // 0: brov_closed_loop as three launches per tick (A/B, tests)
     k.tick_breakdown = env_int("BROV_TICK_BREAKDOWN", 0) != 0;
     return k;
 }
@@ -752,6 +753,7 @@ extern "C" int brov_get_x0_host(brov_solver* s, double* x0) {
     HIPCHK(hipMemcpy(x0, s->x0, (size_t)s->B * 12 * sizeof(double), hipMemcpyDeviceToHost));
     return BROV_OK;
 }
+static DevParams make_params(const brov_solver* s);
 extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols, double dt, int substeps, double* u_log, double* x_log,
                                 int32_t* st_log) {
     if (!s || ticks < 1 || !s->traj || (ncols != 12 && ncols != 16) || !(dt > 0.0) || substeps < 1) {
@@ -777,7 +779,27 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
         g_err = "brov_closed_loop: log copy failed";
         rc = BROV_ERR_HIP;
     }
-    for (int k = 0; k < ticks && rc == BROV_OK; k++) {
+    // One launch for the whole loop where the fused kernels serve the solver and every window is rows of the table in place (round 5,
+    // rti_fused_kernel_ticks with the plant update behind every step): every instance runs its own closed loop at its own pace -- no launch
+    // boundaries, three launches per tick saved, and a tick on which one instance grinds through the QP loop holds nobody else.
+    const bool one_launch = rc == BROV_OK && s->k.closed_loop_fused && ncols == 16 && line0 >= 0 && line0 + (ticks - 1) + s->N <= s->traj_rows - 1 &&
+                            fused_supported(s->N) && !s->force_windowed && s->opts.kernel_path != BROV_PATH_STREAMING && !general_grid(s) && !s->dump_lin;
+    if (one_launch) {
+        rc = brov_set_yref_from_traj(s, line0, 16, st);
+        if (rc == BROV_OK) rc = order_behind_last(s, st);
+        if (rc == BROV_OK) {
+            DevParams P = make_params(s);
+            P.sched = nullptr;
+            P.ticks = ticks; P.tick_yref = 16; P.tick_status = dst;
+            P.plant_pp = s->pplant; P.plant_rp = plant_rp(s); P.plant_rp_stride = plant_rp_stride(s); P.plant_substeps = substeps; P.plant_dt = dt;
+            P.x0_rw = s->x0; P.plant_xlog = dx ? dx + B * 12 : nullptr; P.plant_ulog = du;
+            s->pit_ran = false;
+            launch_fused_ticks(P, st, s->k);
+            s->prep_path = 0; s->last_fused = true; s->last_windowed = false; s->last_stream = st;
+            s->traj_line = line0 + ticks - 1; s->yref_view = s->traj + (size_t)s->traj_line * 16;
+        }
+    }
+    for (int k = 0; k < ticks && rc == BROV_OK && !one_launch; k++) {
         s->yref_view = nullptr; s->traj_line = -1;
         launch_window(s->traj, s->traj_rows, nullptr, line0 + k, 1, s->N, ncols, s->yref_sh, st);
         s->yref_shared = true;

@@ -82,6 +82,14 @@ struct DevParams {
     int32_t ticks;
     int64_t tick_yref;
     int32_t* tick_status;    // [ticks][B] or nullptr
+    // ... and, for brov_closed_loop, the plant update behind every step: x0 <- ERK4(x0, u0 of the step, plant parameters) (nullptr: no plant, x0 held)
+    const double* plant_pp;  // [B][16] true plant parameters
+    const double* plant_rp;  // 6-disturbance variant: roll / pitch moments, instance b at plant_rp + b * plant_rp_stride (or nullptr)
+    int32_t plant_rp_stride, plant_substeps;
+    double plant_dt;
+    double* x0_rw;           // = x0, writable
+    double* plant_xlog;      // [ticks][B][12] states after every step, or nullptr
+    double* plant_ulog;      // [ticks][B][4] applied inputs, or nullptr
     unsigned long long* dbg;  // optional per-instance phase timestamps (s_memtime), 8 slots per instance; nullptr = off
 };
 
@@ -89,7 +97,7 @@ struct DevParams {
 struct DevKnobs {
     double robust_kkt_max = 1e6;
     int robust_pivot = 1, partial_refactor = 1, mail_early = 1, split_resident = 1, pit = 1, split_parallel = 1, pit_try = 1;
-    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0, tick_breakdown = 0;
+    int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0, tick_breakdown = 0, closed_loop_fused = 1;
 };
 
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_ACT, IPM_NARR };

@@ -81,6 +81,48 @@ __device__ __forceinline__ bool rti_fused_step(const DevParams& P, int b, int la
     qp_body<W, std::conditional_t<GRID, InstGrid, Inst>, DF>(P, I, b, part, nanp);
     return I.ran_loop;
 }
+// the plant update of brov_closed_loop inside the step loop (traj_kernel.hip, plant_kernel: the same arithmetic, one lane per instance there;
+// here every lane of the instance's wave computes it -- a wave's issue slots cost the same for one lane as for sixty-four -- and lane 0 stores)
+__device__ __forceinline__ void plant_step_wave(const DevParams& P, int b, int lane, int tk) {
+    double x[NX], u[NU], k[NX], xs[NX], acc[NX];
+    double* x0 = P.x0_rw + (size_t)b * NX;
+#pragma unroll
+    for (int j = 0; j < NX; j++) x[j] = x0[j];
+#pragma unroll
+    for (int j = 0; j < NU; j++) u[j] = P.res[b].u0[j];
+    const ModelPar m = make_par(P.plant_pp + (size_t)b * NP);
+    Wrench w = make_wrench(u);
+    if (P.plant_rp) { w.k3 = P.plant_rp[(size_t)b * P.plant_rp_stride]; w.k4 = P.plant_rp[(size_t)b * P.plant_rp_stride + 1]; }
+    const double h = P.plant_dt / P.plant_substeps;
+    StagePoint sp;
+    for (int s = 0; s < P.plant_substeps; s++) {
+        model_f(x, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) { acc[j] = x[j] + (h / 6.0) * k[j]; xs[j] = x[j] + 0.5 * h * k[j]; }
+        model_f(xs, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * k[j]; xs[j] = x[j] + 0.5 * h * k[j]; }
+        model_f(xs, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) { acc[j] += (h / 3.0) * k[j]; xs[j] = x[j] + h * k[j]; }
+        model_f(xs, w, m, k, sp);
+#pragma unroll
+        for (int j = 0; j < NX; j++) x[j] = acc[j] + (h / 6.0) * k[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NX; j++) x0[j] = x[j];
+        if (P.plant_xlog) {
+#pragma unroll
+            for (int j = 0; j < NX; j++) P.plant_xlog[((size_t)tk * P.B + b) * NX + j] = x[j];
+        }
+        if (P.plant_ulog) {
+#pragma unroll
+            for (int j = 0; j < NU; j++) P.plant_ulog[((size_t)tk * P.B + b) * NU + j] = u[j];
+        }
+    }
+}
+
 template <int W, bool GRID = false, bool DF = false, bool MULTI = false>
 __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
     const int b = __builtin_amdgcn_readfirstlane(sched_map(P, blockIdx.x));
@@ -103,6 +145,11 @@ __device__ __forceinline__ void rti_fused_body(const DevParams& P) {
             if (P.tick_status && lq == 0) P.tick_status[(size_t)tk * P.B + bq] = P.res[bq].status;   // (lane 0 wrote the record itself)
             __syncthreads();       // single wave: the step's stores (iterate, record) against the next step's loads
             wave_fence();
+            if (P.plant_pp) {      // brov_closed_loop: the plant moves on with the step's first input; the next step measures the new state
+                plant_step_wave(P, bq, lq, tk);
+                __syncthreads();
+                wave_fence();
+            }
         }
     }
 }

@@ -115,3 +115,39 @@ def test_a_moving_window_needs_a_trajectory_window(ba):
     with pytest.raises(RuntimeError):
         s.solve_ticks(0, 0)
     s.close()
+
+
+@pytest.mark.parametrize("N,B,substeps", [(20, 1200, 1), (10, 300, 2), (23, 130, 1)])
+def test_closed_loop_in_one_launch_equals_three_launches_per_tick(ba, N, B, substeps):
+    """brov_closed_loop on the fused kernels: window -> RTI step -> plant step of every tick inside ONE launch, every instance running its own
+    closed loop at its own pace (rti_fused_kernel_ticks with the plant update behind every step), against the same loop as three launches per
+    tick (BROV_CLOSED_LOOP_FUSED=0): applied inputs, plant states, statuses, the final records and iterates -- with true plant parameters that
+    differ from the controller's (a disturbance per instance) and a quarter of the instances far off, so that the loops differ in length."""
+    import os
+    Ts = 1.0 / max(N, 20)
+    x0, circ = _inputs(B, seed=40 + N)
+    rng = np.random.default_rng(N)
+    pt = np.tile(ba.P_NOMINAL, (B, 1)); pt[:, 0:3] += rng.uniform(-60, 60, (B, 3))
+    out = []
+    for fused in ("1", "0"):
+        os.environ["BROV_CLOSED_LOOP_FUSED"] = fused
+        try:
+            s = ba.BatchSolver(B, ba.SolverOptions(N, Ts))
+        finally:
+            os.environ.pop("BROV_CLOSED_LOOP_FUSED", None)
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_plant_params(pt); s.set_trajectory(circ)
+        ul, xl, sl = s.closed_loop(9, line0=2, ncols=16, dt=0.05, substeps=substeps)
+        out.append((ul, xl, sl, s.results().copy(), s.get_iterate(), s.get_x0()))
+        s.solve()                                   # the window in force afterwards is the last tick's on both
+        out[-1] += (s.results().copy(),)
+        s.close()
+    a, b = out
+    assert np.array_equal(a[2], b[2]) and (a[3]["qp_iter"] > 0).any()
+    for k, (fa, fb) in enumerate(zip(a, b)):
+        if isinstance(fa, tuple):
+            for ia, ib in zip(fa, fb):
+                assert np.array_equal(ia, ib, equal_nan=True), k
+        elif fa.dtype.names:
+            assert fa.tobytes() == fb.tobytes(), k
+        else:
+            assert np.array_equal(fa, fb, equal_nan=True), (k, np.nanmax(np.abs(fa - fb)))
