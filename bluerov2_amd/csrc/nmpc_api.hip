@@ -95,6 +95,7 @@ struct brov_solver {
     const double *tick_x0 = nullptr, *tick_yref = nullptr, *tick_par = nullptr;
     hipEvent_t ev_up = nullptr;          // a preparation tick (rti_phase 1): its uploads have left the pinned staging buffer
     hipEvent_t ev_tick = nullptr;        // ticks with inputs read in place: the kernel's end (neither the host nor the next tick's kernel waits for the copies behind it)
+    hipEvent_t ev_pre = nullptr;         // large batches: recorded AHEAD of the tick's kernel -- its refresh copies run next to the kernel, not behind it
     hipStream_t copy_stream = nullptr;   // ... those copies (pinned staging buffer -> the device arrays every other entry point works on) run here, behind ev_tick
     hipEvent_t ev_copy = nullptr;        // ... and end here (alias of the ev_set[] recorded last)
     hipEvent_t ev_set[2] = {nullptr, nullptr};   // the refresh copies out of input set 0 / 1 of the pinned staging buffer (see brov_tick_host)
@@ -363,6 +364,7 @@ extern "C" void brov_destroy(brov_solver* s) {
     if (s->pin) hipHostFree(s->pin);
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->ev_tick) hipEventDestroy(s->ev_tick);
+    if (s->ev_pre) hipEventDestroy(s->ev_pre);
     if (s->ev_up) hipEventDestroy(s->ev_up);
     for (int k = 0; k < 2; k++) if (s->ev_set[k]) hipEventDestroy(s->ev_set[k]);
     if (s->tick_stream) hipStreamDestroy(s->tick_stream);
@@ -1125,6 +1127,7 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         if (!s->copy_stream) {
             HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&s->ev_tick, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&s->ev_set[0], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&s->ev_set[1], hipEventDisableTiming));
             s->ev_copy = s->ev_set[0];
@@ -1147,6 +1150,13 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
     const bool behind_copies = s->copies_pending && (s->copy_mask & ~passed) != 0;
     s->in_tick = zerocopy && !behind_copies;
     if (brk) tb1 = clk::now();
+    // Large batches (records written by the kernel, the host waits for the launch once): the refresh copies of the tick's inputs run NEXT TO the
+    // kernel -- it reads the pinned copies, they write the device arrays, which nothing of this launch reads -- ordered only behind what was
+    // enqueued ahead of it.  They are over long before the kernel is (0.4 MB against 0.16 ms), so a caller that owns the staging buffers
+    // (brov_tick_buffers) does not pay for them at the end of the call.  Small batches keep them BEHIND the kernel: next to it they would share
+    // the PCIe reads of a 50 us launch whose latency is the point.
+    const bool copies_beside = zerocopy && bulk && !behind_copies;
+    if (copies_beside) HIPCHK(hipEventRecord(s->ev_pre, st));
     const int rc = brov_solve_phase(s, st, rti_phase);
     if (brk) tb2 = clk::now();
     s->in_tick = false;
@@ -1159,7 +1169,7 @@ extern "C" int brov_tick_host(brov_solver* s, const double* x0, const double* yr
         // neither the host (which waits for the kernel's end / the mailbox) nor the next tick's kernel waits for them; whatever else touches
         // those arrays is ordered behind ev_copy (order_behind_last, sync_last)
         HIPCHK(hipEventRecord(s->ev_tick, st));
-        HIPCHK(hipStreamWaitEvent(s->copy_stream, s->ev_tick, 0));
+        HIPCHK(hipStreamWaitEvent(s->copy_stream, copies_beside ? s->ev_pre : s->ev_tick, 0));
         if (int rc2 = upload(s->copy_stream)) return rc2;
         s->ev_copy = s->ev_set[sel];
         HIPCHK(hipEventRecord(s->ev_copy, s->copy_stream));
