@@ -756,6 +756,8 @@ extern "C" int brov_get_x0_host(brov_solver* s, double* x0) {
     return BROV_OK;
 }
 static DevParams make_params(const brov_solver* s);
+static int ticks_kernel(const brov_solver* s);
+static void launch_ticks(brov_solver* s, DevParams& P, hipStream_t st, int which);
 extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols, double dt, int substeps, double* u_log, double* x_log,
                                 int32_t* st_log) {
     if (!s || ticks < 1 || !s->traj || (ncols != 12 && ncols != 16) || !(dt > 0.0) || substeps < 1) {
@@ -784,8 +786,8 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
     // One launch for the whole loop where the fused kernels serve the solver and every window is rows of the table in place (round 5,
     // rti_fused_kernel_ticks with the plant update behind every step): every instance runs its own closed loop at its own pace -- no launch
     // boundaries, three launches per tick saved, and a tick on which one instance grinds through the QP loop holds nobody else.
-    const bool one_launch = rc == BROV_OK && s->k.closed_loop_fused && ncols == 16 && line0 >= 0 && line0 + (ticks - 1) + s->N <= s->traj_rows - 1 &&
-                            fused_supported(s->N) && !s->force_windowed && s->opts.kernel_path != BROV_PATH_STREAMING && !general_grid(s) && !s->dump_lin;
+    const int which = ticks_kernel(s);
+    const bool one_launch = rc == BROV_OK && s->k.closed_loop_fused && ncols == 16 && line0 >= 0 && line0 + (ticks - 1) + s->N <= s->traj_rows - 1 && which != 0;
     if (one_launch) {
         rc = brov_set_yref_from_traj(s, line0, 16, st);
         if (rc == BROV_OK) rc = order_behind_last(s, st);
@@ -795,9 +797,7 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
             P.ticks = ticks; P.tick_yref = 16; P.tick_status = dst;
             P.plant_pp = s->pplant; P.plant_rp = plant_rp(s); P.plant_rp_stride = plant_rp_stride(s); P.plant_substeps = substeps; P.plant_dt = dt;
             P.x0_rw = s->x0; P.plant_xlog = dx ? dx + B * 12 : nullptr; P.plant_ulog = du;
-            s->pit_ran = false;
-            launch_fused_ticks(P, st, s->k);
-            s->prep_path = 0; s->last_fused = true; s->last_windowed = false; s->last_stream = st;
+            launch_ticks(s, P, st, which);
             s->traj_line = line0 + ticks - 1; s->yref_view = s->traj + (size_t)s->traj_line * 16;
         }
     }
@@ -981,6 +981,21 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
 }
 extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phase(s, stream, 0); }
 
+// steps in one launch: 1 = rti_fused_kernel_ticks (N <= 23), 2 = rti_window_kernel_ticks (longer horizons, large batches: the windowed kernel's
+// persistent blocks), 0 = neither (general grid, streaming pair, a dumped linearisation, the resident / parallel-in-time configurations of small
+// batches -- those are latency paths: a launch per step)
+static int ticks_kernel(const brov_solver* s) {
+    if (s->opts.kernel_path == BROV_PATH_STREAMING || general_grid(s) || s->dump_lin) return 0;
+    if (fused_supported(s->N) && !s->force_windowed) return 1;
+    if (s->ws != nullptr && !windowed_is_resident(s->win_L) && s->alt_L == 0) return 2;
+    return 0;
+}
+static void launch_ticks(brov_solver* s, DevParams& P, hipStream_t st, int which) {
+    if (which == 1) { launch_fused_ticks(P, st, s->k); s->last_fused = true; s->last_windowed = false; }
+    else { launch_windowed(P, st); s->win_tick++; s->last_fused = false; s->last_windowed = true; }
+    s->pit_ran = false; s->prep_path = 0; s->last_stream = st;
+}
+
 // `ticks` RTI steps of every instance with ONE launch where the fused kernels serve the solver (N <= 23, uniform grid): rti_fused_kernel_ticks,
 // every instance going on to its next step as soon as its own is done.  Elsewhere (and when the moving window would leave the resident
 // table): the same steps as `ticks` launches.  Either way the result equals `ticks` x { brov_set_yref_from_traj(line + k row_stride); brov_solve }.
@@ -993,8 +1008,8 @@ extern "C" int brov_solve_ticks(brov_solver* s, void* stream, int ticks, int row
     HIPCHK(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     const int line0 = s->traj_line, ncols = s->traj_ncols;
-    const bool one_launch = fused_supported(s->N) && !s->force_windowed && s->opts.kernel_path != BROV_PATH_STREAMING && !general_grid(s) && !s->dump_lin &&
-                            (row_stride == 0 || (s->yref_view != nullptr && line0 + (ticks - 1) * row_stride + s->N <= s->traj_rows - 1));
+    const int which = ticks_kernel(s);
+    const bool one_launch = which != 0 && (row_stride == 0 || (s->yref_view != nullptr && line0 + (ticks - 1) * row_stride + s->N <= s->traj_rows - 1));
     if (!one_launch) {
         for (int k = 0; k < ticks; k++) {
             if (k > 0 && row_stride > 0)
@@ -1009,12 +1024,9 @@ extern "C" int brov_solve_ticks(brov_solver* s, void* stream, int ticks, int row
     DevParams P = make_params(s);
     P.sched = nullptr;                 // a launch of many steps neither reads nor writes the work ordering: every instance follows its own history
     P.ticks = ticks; P.tick_yref = (int64_t)row_stride * 16; P.tick_status = status_log;
-    s->pit_ran = false;
     if (s->timing) { hipEventRecord(s->ev[0], st); hipEventRecord(s->ev[1], st); }
-    launch_fused_ticks(P, st, s->k);
+    launch_ticks(s, P, st, which);
     if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
-    s->prep_path = 0;
-    s->last_fused = true; s->last_windowed = false; s->last_stream = st;
     if (row_stride > 0) {              // the window in force is the last step's
         s->traj_line = line0 + (ticks - 1) * row_stride;
         s->yref_view = s->traj + (size_t)s->traj_line * 16;

@@ -36,9 +36,12 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // PREPARATION launch linearises, factorises and parks the LDS image in the instance's workspace, and the FEEDBACK launch fetches it and runs
 // qp_body from the forward sweep on: what is left between the arrival of a measurement and u0 is the forward sweep, the bound check, the
 // step and the record.  Separate instantiations (rti_window_kernel_res_split, _split_grid).
-template <bool RES, bool GRID = false, bool SPLIT = false>
+// MULTI (rti_window_kernel_ticks; large batches only): P.ticks RTI steps of an instance back to back once a block has taken it from the counter --
+// brov_solve_ticks / brov_closed_loop at the horizons the fused kernels do not serve (see MULTI in qp/fused.hpp)
+template <bool RES, bool GRID = false, bool SPLIT = false, bool MULTI = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
     static_assert(!SPLIT || RES, "the split launches exist for the resident mode");
+    static_assert(!MULTI || (!RES && !SPLIT && !GRID), "steps in one launch: the large-batch kernel on the uniform grid");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane0 = threadIdx.x & 63;       // (RES: four waves per block, see below)
@@ -132,8 +135,17 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             ws_vhat = ws + (size_t)nc * win_img_doubles(Lc); ws_dxb = ws_vhat + (size_t)N * 4; ws_Ks = ws_dxb + (size_t)(N + 1) * NX;
             ws_Mt = ws_Ks + (size_t)N * 64; ws_Pb = ws_Mt + (size_t)N * 64; ws_ipm = ws_Pb + (size_t)N * NX; ws_ck = ws_ipm + (size_t)IPM_NARR * 4 * N;
         }
+        // (steps of a MULTI launch: a backward jump rather than a loop statement around the body -- with a loop, even one of a single trip, the
+        // single-step kernels compile 2 - 3 % slower: measured, scripts/dev/ab_libs.sh, N = 40 / 80)
+        int tk = 0;
+    next_step:
+        const size_t yoff = MULTI ? (size_t)tk * (size_t)P.tick_yref : 0;
+        if constexpr (MULTI) {   // (opaque per step, as in the instance loop: nothing lane- or instance-dependent is hoisted across the steps)
+            asm volatile("v_mov_b32 %0, %0" : "+v"(lane));
+            asm volatile("s_mov_b32 %0, %0" : "+s"(b));
+        }
         auto setup = [&](InstT& I) __attribute__((always_inline)) {
-            setup_inst(P, I, b, lane, &lc);
+            setup_inst(P, I, b, lane, &lc, yoff);
             I.Ks = ws_Ks; I.Mt = ws_Mt; I.Pb = ws_Pb; I.ipm = ws_ipm;
             I.vhat = ws_vhat; I.dxb = ws_dxb; I.kff = nullptr; I.Kt = ws_ck;
             // partial refactorisation of the active-set tries: the checkpoint is the state of the factor sweep as it enters window 0
@@ -179,14 +191,14 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             double xq = 0.0, yq = 0.0, wq = 0.0;
             if (c < nc - 1 && lane < NX) {
                 xq = P.x[((size_t)b * (N + 1) + i0 + n) * NX + lane];
-                yq = P.yref[(size_t)b * P.yref_stride + (size_t)(i0 + n) * NY + lane];
+                yq = P.yref[yoff + (size_t)b * P.yref_stride + (size_t)(i0 + n) * NY + lane];
                 wq = GRID ? P.wst[(size_t)(i0 + n) * 16 + lane] : P.Ts * P.cst[lane];   // scaled state weight of stage i0 + n
             }
             __syncthreads();
             if (RES && trip == 0) {
                 // first instance of the block: this wave takes the first quarter of the horizon, waves 1..3 the others
                 const int lsub = (n + 3) >> 2;
-                lin_phase<true, GRID>(P, b, 0, lsub, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+                lin_phase<true, GRID>(P, b, 0, lsub, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false, yoff);
                 __syncthreads();
                 for (int wv = 1; wv < 4; wv++) {
                     const double v = ((const lds_f64*)kt_s)[(size_t)wv * lsub * kRecInterval + lane];
@@ -194,7 +206,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                     part = fmax(part, v);
                 }
             } else if (!RES || n <= kLinMaxIntervals) {
-                lin_phase<true, GRID>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false);
+                lin_phase<true, GRID>(P, b, i0, n, lane, ba_s, bv_s, kt_s, q_s, r_s, part, nanp, false, yoff);
             } else {
                 // resident mode (one window = the whole horizon in a 160 KB slice, small batches): the wave-wide linearisation takes
                 // at most 23 intervals at a time -- sub-chunks, each into its own part of the slice (row n_j of a sub-chunk's q is
@@ -203,7 +215,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
                 for (int j0 = 0; j0 < n; j0 += lsub) {
                     const int nj = n - j0 < lsub ? n - j0 : lsub;
                     lin_phase<true, GRID>(P, b, i0 + j0, nj, lane, ba_s + (size_t)j0 * kBaStage, bv_s + (size_t)j0 * NX, kt_s, q_s + (size_t)j0 * NX,
-                                          r_s + (size_t)j0 * NU, part, nanp, false);
+                                          r_s + (size_t)j0 * NU, part, nanp, false, yoff);
                     __syncthreads();
                 }
             }
@@ -308,6 +320,16 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         if (P.dbg && lane == 0) { P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 3] = W.t_fetch; P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 4] = W.n_fetch; }
 #endif
         __syncthreads();
+        if constexpr (MULTI) {
+            if (P.tick_status && lane == 0) P.tick_status[(size_t)tk * P.B + b] = P.res[b].status;   // (lane 0 wrote the record itself)
+            wave_fence();
+            if (P.plant_pp) {      // brov_closed_loop: the plant moves on with the step's first input
+                plant_step_wave(P, b, lane, tk);
+                __syncthreads();
+                wave_fence();
+            }
+            if (++tk < P.ticks) goto next_step;
+        }
     }
 }
 

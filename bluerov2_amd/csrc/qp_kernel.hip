@@ -115,6 +115,8 @@ namespace brov {
 __global__ __launch_bounds__(64, 1) void rti_window_kernel(DevParams P) { rti_window_body<false>(P); }
 // the same on a general grid: per-interval time steps, per-stage scaled weights (DevParams::tsv / wst)
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_grid(DevParams P) { rti_window_body<false, true>(P); }
+// brov_solve_ticks / brov_closed_loop at N >= 24, large batches: P.ticks steps per instance in one launch (see MULTI in qp/windowed.hpp)
+__global__ __launch_bounds__(64, 1) void rti_window_kernel_ticks(DevParams P) { rti_window_body<false, false, false, true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res(DevParams P) { rti_window_body<true>(P); }
 __global__ __launch_bounds__(256, 1) void rti_window_kernel_res_grid(DevParams P) { rti_window_body<true, true>(P); }
 // rti_phase 1 / 2 as separate launches in the resident mode (see SPLIT above)
@@ -224,6 +226,15 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
         else if (P.rti_split) hipLaunchKernelGGL(rti_window_kernel_res_split, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_res_grid, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
+    }
+    else if (P.ticks > 0) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
+            (void)hipFuncSetAttribute((const void*)rti_window_kernel_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(rti_window_kernel_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     }
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
