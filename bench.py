@@ -690,6 +690,14 @@ def configs_block(ba, args, device):
                    stage_solves_per_s=leg["solves_per_s"] * N, device_bytes=s.device_bytes)
         if lds["kind"].startswith("fused, two"):
             leg["kernel"] = "rti_fused_kernel_w2"
+        # the same K steps as ONE launch (brov_solve_ticks: rti_fused_kernel_ticks / rti_window_kernel_ticks)
+        s.init_iterate_default()
+        for k in range(W):
+            s.set_yref_from_trajectory(k, 16); s.solve()
+        torch.cuda.synchronize(); t0_ = time.perf_counter()
+        s.set_yref_from_trajectory(W, 16); s.solve_ticks(K, 1)
+        torch.cuda.synchronize()
+        leg["steps_in_one_launch_solves_per_s"] = B * K / (time.perf_counter() - t0_)
         # HBM traffic of the leg's kernel measured in THIS run (round 4 quoted a committed counter file here): two --pmc child runs per horizon
         cal = pmc_calibration()
         profiled = bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")

@@ -190,9 +190,10 @@ int brov_solve_phase(brov_solver* s, void* stream, int rti_phase);
  * resident trajectory table per step (0: the window in force stays -- several SQP iterations on one problem, e.g. candidates iterated to
  * convergence; > 0 needs the window to come from brov_set_yref_from_traj).  Result: exactly that of
  *     for k in 0 .. ticks-1: brov_set_yref_from_traj(s, line + k * row_stride, ncols, stream); brov_solve(s, stream)
- * (records of the last step; status_log, DEVICE [ticks][B] or NULL, keeps every step's status) -- but where the fused kernels serve the
- * solver (N <= 23, uniform grid) it is ONE launch in which every instance goes on to its next step as soon as its own is done
- * (rti_fused_kernel_ticks): a step with a slow instance -- 13 .. 47 Newton systems on a diverging one -- no longer holds the whole batch at a
+ * (records of the last step; status_log, DEVICE [ticks][B] or NULL, keeps every step's status) -- but on the uniform grid it is ONE launch in
+ * which every instance goes on to its next step as soon as its own is done (rti_fused_kernel_ticks for N <= 23, rti_window_kernel_ticks for
+ * longer horizons and batches beyond two instances per CU; smaller batches at long horizons, general grids and the streaming pair take a
+ * launch per step): a step with a slow instance -- 13 .. 47 Newton systems on a diverging one -- no longer holds the whole batch at a
  * launch boundary, and there are no launch gaps.  For workloads whose steps do not depend on each other through the host (parameter sweeps,
  * candidate libraries, Monte-Carlo draws at a fixed measurement); a control loop that measures between two steps calls brov_solve. */
 int brov_solve_ticks(brov_solver* s, void* stream, int ticks, int row_stride, int32_t* status_log /*DEVICE or NULL*/);
