@@ -155,3 +155,57 @@ def test_closed_loop_in_one_launch_equals_three_launches_per_tick(ba, N, B, subs
             assert fa.tobytes() == fb.tobytes(), k
         else:
             assert np.array_equal(fa, fb, equal_nan=True), (k, np.nanmax(np.abs(fa - fb)))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_loops_in_one_launch(ba, seed):
+    """Drawn: horizon (fused and windowed kernels), batch, weights, asymmetric boxes down to +-6, failure policy, early exit, per-stage model
+    parameters, the 6-disturbance variant with a plant disturbance of its own, plant sub-steps, instances metres off, one NaN measurement.
+    brov_closed_loop in one launch against three launches per tick, and brov_solve_ticks against a launch per step: every logged input,
+    state and status, the final records and iterates, bit for bit (NaN == NaN)."""
+    import os
+    rng = np.random.default_rng(7000 + seed)
+    N = int(rng.choice([5, 9, 13, 14, 20, 23, 24, 33, 40, 64, 80]))
+    B = int(rng.integers(40, 400)) if N <= 23 else int(rng.integers(1030, 1400))
+    Ts = float(rng.uniform(0.5, 1.0) / max(N, 20))
+    base = ba.SolverOptions(N)
+    kw = dict(W=list(np.asarray(base.W) * rng.uniform(0.4, 2.5, 16)), We=list(np.asarray(base.We) * rng.uniform(0.4, 2.5, 12)),
+              lbu=list(-rng.uniform(6.0, 60.0, 4)), ubu=list(rng.uniform(6.0, 60.0, 4)), on_failure=int(rng.integers(0, 2)), qp_early_exit=int(rng.integers(0, 2)))
+    x0, circ = _inputs(B, seed=7100 + seed, sat=float(rng.choice([0.0, 0.2, 0.5])))
+    x0[3, 1] = np.nan
+    p = np.tile(ba.P_NOMINAL, (B, N + 1, 1)); p[..., 4:] *= rng.uniform(0.8, 1.2, (B, N + 1, 12)); p[..., :4] = rng.uniform(-100, 100, (B, 1, 4))
+    pt = np.tile(ba.P_NOMINAL, (B, 1)); pt[:, 0:4] += rng.uniform(-80, 80, (B, 4))
+    dist6 = bool(rng.integers(0, 2))
+    substeps, ticks, stride = int(rng.integers(1, 3)), int(rng.integers(3, 8)), int(rng.integers(0, 3))
+    out = []
+    for fused in ("1", "0"):
+        os.environ["BROV_CLOSED_LOOP_FUSED"] = fused
+        try:
+            s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, **kw))
+        finally:
+            os.environ.pop("BROV_CLOSED_LOOP_FUSED", None)
+        s.set_x0(x0); s.set_params(p); s.set_plant_params(pt); s.set_trajectory(circ)
+        if dist6:
+            s.enable_dist6(True); s.set_rp_disturbance(rng.uniform(-0.3, 0.3, (B, 2)) * 0 + np.linspace(-0.3, 0.3, 2 * B).reshape(B, 2))
+            s.set_plant_rp_disturbance(np.linspace(0.2, -0.2, 2 * B).reshape(B, 2))
+        ul, xl, sl = s.closed_loop(ticks, line0=1, ncols=16, dt=Ts, substeps=substeps)
+        rec = [ul, xl, sl, s.results().copy(), s.get_iterate()]
+        # ... and, from where the loop has left the solver, steps with the measurement held
+        if fused == "1":
+            s.set_yref_from_trajectory(1 + ticks, 16); s.solve_ticks(ticks, stride, sync=True)
+        else:
+            for k in range(ticks):
+                s.set_yref_from_trajectory(1 + ticks + k * stride, 16); s.solve()
+        rec += [s.results().copy(), s.get_iterate()]
+        out.append(rec)
+        s.close()
+    a, b = out
+    for k, (fa, fb) in enumerate(zip(a, b)):
+        if isinstance(fa, tuple):
+            for ia, ib in zip(fa, fb):
+                assert np.array_equal(ia, ib, equal_nan=True), (seed, N, B, k)
+        elif fa.dtype.names:
+            assert fa.tobytes() == fb.tobytes(), (seed, N, B, k)
+        else:
+            assert np.array_equal(fa, fb, equal_nan=True), (seed, N, B, k)
+    assert a[3]["status"][3] != 0                                 # the NaN measurement fails its steps, in both forms alike
