@@ -73,6 +73,28 @@ def test_two_ranks_on_one_gpu_over_gloo_select_what_a_single_rank_selects():
     assert (a["index"], a["cost"], a["u0"], a["thrust"]) == (b["index"], b["cost"], b["u0"], b["thrust"])     # bit for bit
 
 
+def test_the_drivers_default_command_with_four_ranks_on_the_visible_gpus_over_gloo():
+    """`python bench.py --gpus 4` exactly as the driver's SCALE run issues it (default config, weak scaling, plus the strong legs of configs 4 / 5 a
+    default multi-rank run appends), with the four ranks sharing whatever GPUs the box has and the collective over gloo: the first SCALE run on an
+    8-GPU node must not be the first execution of this path with more than one rank"""
+    import torch
+    assert torch.cuda.is_available()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BROV_BENCH_BACKEND"] = "gloo"
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert pr.returncode == 0 and len(lines) == 1, (pr.returncode, pr.stdout[-2000:], pr.stderr[-3000:])
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 4 and o["ranks_seen"] == [0, 1, 2, 3] and o["scaling"] == "weak" and o["total_instances"] == 4 * 4096
+    assert o["instances_per_rank"] == [4096] * 4 and len(o["per_rank_ms"]) == 4 and o["value"] > 0 and o["solver_status_nonzero"] == 0
+    c4, c5 = o["config4_strong"], o["config5_strong"]
+    assert c4["total_instances"] == 65536 and c4["instances_per_rank"] == [16384] * 4 and c4["select_best"]["records_gathered"] == 65536
+    assert c4["select_best"]["selected_every_step_on_device"] and c4["select_best"]["index"] == c4["select_best"]["last_step_index_on_device"]
+    assert c5["total_instances"] == 32768 and set(c5["sweep"]) == {"N10", "N20", "N40", "N80"}
+
+
 def test_two_rank_rccl_run():
     """two GPUs visible: the real thing -- two processes, RCCL all-gather over xGMI, global arg-min"""
     import torch
