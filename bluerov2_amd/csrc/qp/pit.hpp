@@ -262,6 +262,12 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     // (Gamma = POL_BIG and a right-hand side that lands them on their bounds: qp_body's first try, same arithmetic).
     bool good = !pre_bad;
     d4 lam = z4;   // the costate at this segment's end boundary (the adjoint sweep of the segment enters with it)
+    // What the last-to-first relay left this wave -- W, c - G pc, the (Pc, pc) it was built with, the exact cost-to-go at the segment's start -- in
+    // the last pass that ran all three hops with no pinned input behind the first segment.  A try whose pins all sit in the first segment (98 % of
+    // them: a far-off instance saturates its first stages) changes nothing behind it: segments 1 .. 3 reproduce their local sweeps bit for bit, so
+    // hops 3 -> 2 and 2 -> 1 would reproduce these values, and only hop 1 -> 0 is run (two of the relay's three serial hops, ~13 k cycles per try).
+    d4 kW = z4, kvv = z4, kpcn = z4, kPcn = z4, kPst = z4, kpst = z4;
+    bool relay_cached = false, only0 = false;   // (block-uniform; only0: this pass pins inputs of the first segment only -- set by the QP loop)
     auto solve_pass = [&](const bool step0) __attribute__((always_inline)) {
         // ---- 1. local factor sweep with the condensing accumulators
         BwdState S;
@@ -327,8 +333,11 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
                 W = Pcn;
                 vv = cbar;
             }
-        } else
-        for (int j = 3; j >= 1; j--) {
+        }
+        const bool short_relay = !parked && !step0 && only0 && relay_cached;
+        if (short_relay && wv >= 1) { W = kW; vv = kvv; pcn = kpcn; Pcn = kPcn; Pst = kPst; pst = kpst; }
+        if (!parked)
+        for (int j = short_relay ? 1 : 3; j >= 1; j--) {
             if (wv == j) publish(Pst, pst);
             __syncthreads();
             if (wv == j - 1) {
@@ -359,6 +368,10 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
                 }
             }
             __syncthreads();
+        }
+        if (!parked && !short_relay) {
+            relay_cached = step0 || only0;
+            if (relay_cached) { kW = W; kvv = vv; kpcn = pcn; kPcn = Pcn; kPst = Pst; kpst = pst; }
         }
         const unsigned long long t_cb = P.dbg ? __builtin_readcyclecounter() : 0;
         // ---- 2b. first boundary to last: boundary states and the costates at the segment ends
@@ -620,7 +633,13 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
                     }
                     if (in) { GAM[j] = gm; RT[j] = rt; }
                 }
-                if (mode == M_TRY) { iters++; round_k++; }
+                if (mode == M_TRY) {
+                    iters++; round_k++;
+                    bool deep = false;   // a pinned input behind the first segment?
+#pragma unroll
+                    for (int t = 0; t < 2; t++) deep = deep | ((lane + 64 * t < nu) & (act[t] != 0.0) & (wv >= 1));
+                    only0 = !block_any(deep);
+                } else only0 = false;
                 if (mode == M_PRED) { iters++; mu = block_sum(ssum) * inv2nv; }
             }
             __syncthreads();   // (every wave is done with the hand-over buffers of the pass before)
