@@ -128,6 +128,7 @@ static DevKnobs read_knobs() {
     k.pit = env_int("BROV_PIT", 1);                               // 0 off, 1 product rule, 2 every instance is tried
     k.split_parallel = env_int("BROV_SPLIT_PARALLEL", 1) != 0;
     k.pit_try = env_int("BROV_PIT_TRY", 1) != 0;
+    k.pit_light = env_int("BROV_PIT_LIGHT", 1) != 0;
     k.tick_mailbox = env_int("BROV_TICK_MAILBOX", 1) != 0;
     k.tick_bulk = env_int("BROV_TICK_BULK", 1) != 0;
     k.tick_zerocopy = env_int("BROV_TICK_ZEROCOPY", 1) != 0;
@@ -945,7 +946,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             // four quarters at once from what the preparation parked; the resident feedback launch behind it for what it leaves
             if (rti_phase == 2 && pit && s->pit_done && pit_supported(s->N, P.win_L) && s->k.split_parallel) {
                 P.pit = pit; P.pit_done = s->pit_done; P.pit_blocks = P.win_blocks;
-                P.pit_try = s->k.pit_try;
+                P.pit_try = s->k.pit_try; P.pit_light = s->k.pit_light;
             }
             P.pit_blocks = P.win_blocks;
             // Round 5: a constant rule.  The parallel kernel runs the whole QP loop itself (qp/pit.hpp), so what it leaves to the resident kernel
@@ -960,7 +961,7 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
             }
             if (pit_now && pit_supported(s->N, P.win_L)) {
                 P.pit = pit; P.pit_done = s->pit_done;
-                P.pit_try = s->k.pit_try;
+                P.pit_try = s->k.pit_try; P.pit_light = s->k.pit_light;
             }
             s->pit_ran = P.pit != 0;
             launch_windowed(P, st); s->win_tick++;   // persistent blocks; the two hand-out counters alternate

@@ -21,6 +21,7 @@ struct DevParams {
     int32_t B, N;
     int32_t qp_iter_max, early_exit;
     int32_t pit;             // parallel-in-time step-0 solve ahead of the resident windowed kernel: 0 off, 1 instances whose previous step was an early exit, 2 every instance (tests)
+    int32_t pit_light;       // ... tries whose pins sit below the first segment's checkpoint reuse the step-0 pass (default 1; BROV_PIT_LIGHT=0: A/B, tests)
     int32_t pit_try;         // ... and, when the step-0 answer leaves the box, ONE active-set try parallel in time as well (default 1; BROV_PIT_TRY=0: A/B)
     int32_t pit_blocks;      // blocks of rti_pit_kernel = tickets it serves (win_blocks; B where every instance has a workspace of its own: pit_rounds_stages)
     int32_t* pit_done;       // [B]: rti_pit_kernel has completed the instance's step (the resident kernel behind it skips it); nullptr when pit = 0
@@ -96,7 +97,7 @@ struct DevParams {
 // development knobs (BROV_* environment variables), read once per solver by the host API (nmpc_api.hip, read_knobs)
 struct DevKnobs {
     double robust_kkt_max = 1e6;
-    int robust_pivot = 1, partial_refactor = 1, mail_early = 1, split_resident = 1, pit = 1, split_parallel = 1, pit_try = 1;
+    int robust_pivot = 1, partial_refactor = 1, mail_early = 1, split_resident = 1, pit = 1, split_parallel = 1, pit_try = 1, pit_light = 1;
     int tick_mailbox = 1, tick_bulk = 1, tick_zerocopy = 1, sched = 1, force_windowed = 0, fused_waves = 0, lds_pad = 0, tick_breakdown = 0, closed_loop_fused = 1;
 };
 

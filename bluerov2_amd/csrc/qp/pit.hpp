@@ -135,6 +135,9 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
         const bool try_it = P.pit == 2 || P.pit_try || (prev->status == BROV_STATUS_SUCCESS && prev->qp_iter == 0);
         if (!try_it) { if (threadIdx.x == 0) P.pit_done[b] = 0; return; }
     }
+    // the step-0 pass keeps what "light" tries reuse (below) only for instances that ran the QP loop in their previous step -- saturated inputs stay
+    // saturated for many ticks --: the split sweep and the stores cost a tracking tick 2 us (measured), which is 3 % of what the node pays every tick
+    const bool keep_step0 = !FB && P.pit_light && P.res[b].qp_iter > 0;
     double* ba_s = smem;
     double* bv_s = smem + win_off_bv(Lc);
     double* q_s = smem + win_off_q(Lc);
@@ -268,6 +271,15 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
     // hops 3 -> 2 and 2 -> 1 would reproduce these values, and only hop 1 -> 0 is run (two of the relay's three serial hops, ~13 k cycles per try).
     d4 kW = z4, kvv = z4, kpcn = z4, kPcn = z4, kPst = z4, kpst = z4;
     bool relay_cached = false, only0 = false;   // (block-uniform; only0: this pass pins inputs of the first segment only -- set by the QP loop)
+    // ... and a try whose pins all sit below the first segment's checkpoint stage (ceil(nseg / 4): the same 98 %) changes nothing ABOVE it either: what
+    // the step-0 pass computed for the stages behind the checkpoint -- and for the whole of segments 1 .. 3 -- is kept and reused ("light" pass):
+    // wave 0 refactorises the stages below its checkpoint from the saved (P, p, Psi, G), waves 1 .. 3 do not sweep at all.  Saved by the step-0 pass in
+    // the block's (otherwise unused) parked-image area: per wave Psi | G | local feed-forward terms | the head of the K^T area (which the segment's
+    // adjoint sweep overwrites with multipliers), and wave 0's checkpoint.  `clean`: every pass since the step-0 pass would have qualified.
+    bool clean = false, light_ok = false;
+    double* const sv = ws + (size_t)wv * 1024;   // this wave's save area: Psi 256 | G 256 | kff <= 128 | K^T head <= 384
+    double* const svck = ws + 4096;              // wave 0: (P, p, Psi, G) entering stage ckst - 1
+    const int ckst = (nseg + 3) >> 2;
     auto solve_pass = [&](const bool step0) __attribute__((always_inline)) {
         // ---- 1. local factor sweep with the condensing accumulators
         BwdState S;
@@ -286,8 +298,44 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
             for (int r = 0; r < 4; r++) acc.Psi[r] = pj[r * 64 + lane];
             acc.G = d4{0.0, 0.0, 0.0, pj[256 + lane]};
             S.P = z4; S.pv = z4; S.ok = true;
-        } else if (step0) bwd_chunk<true, 3, false, true, false, InstT, true>(I, S);
-        else bwd_chunk<true, 3, false, false, false, InstT, true>(I, S);   // (the try: Gamma and its right-hand side from the interior-point arrays)
+        } else if (step0) {
+            // (in two parts with wave 0's checkpoint between them -- out of ONE call site, as in the fused kernels)
+            const bool split = keep_step0 && wv == 0 && nseg > ckst;
+#pragma clang loop unroll(disable)
+            for (int ph = 0; ph < 2; ph++) {
+                if (ph == 1) {
+                    if (!split) break;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { svck[r * 64 + lane] = S.P[r]; svck[256 + r * 64 + lane] = S.pv[r]; svck[512 + r * 64 + lane] = acc.Psi[r]; svck[768 + r * 64 + lane] = acc.G[r]; }
+                }
+                bwd_chunk<true, 3, false, true, false, InstT, true>(I, S, ph == 0 ? nseg : ckst, (ph == 0 && split) ? ckst : 0);
+            }
+        } else {
+            const bool light = !FB && light_ok;   // (uniform over the block)
+            if (light) {
+                // what the segment's adjoint sweep and the feed-forward correction of the pass before have overwritten, from the step-0 pass
+                const int f0 = wv == 0 ? ckst * 4 : 0;
+                for (int j = f0 + lane; j < nseg * 4; j += 64) I.lds_kff[j] = sv[512 + j];
+                if (wv != 0) {
+                    for (int j = lane; j < nseg * NX; j += 64) I.lds_kt[j] = sv[640 + j];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { acc.Psi[r] = sv[r * 64 + lane]; acc.G[r] = sv[256 + r * 64 + lane]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { S.P[r] = svck[r * 64 + lane]; S.pv[r] = svck[256 + r * 64 + lane]; acc.Psi[r] = svck[512 + r * 64 + lane]; acc.G[r] = svck[768 + r * 64 + lane]; }
+                }
+                wave_fence();
+            }
+            // (the try: Gamma and its right-hand side from the interior-point arrays)
+            if (!light || wv == 0) bwd_chunk<true, 3, false, false, false, InstT, true>(I, S, light ? ckst : nseg, 0);
+        }
+        if (step0 && keep_step0) {   // the step-0 pass: what a light pass will need of it -- issued AHEAD of the fence the sweep's own tile stores need anyway
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the sweep's LDS writes, read back by other lanes here)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { sv[r * 64 + lane] = acc.Psi[r]; sv[256 + r * 64 + lane] = acc.G[r]; }
+            for (int j = lane; j < nseg * 4; j += 64) sv[512 + j] = I.lds_kff[j];
+            for (int j = lane; j < nseg * NX; j += 64) sv[640 + j] = I.lds_kt[j];
+        }
         wave_fence();
         good = good && S.ok && !S.illc;
         const unsigned long long t_fac = P.dbg ? __builtin_readcyclecounter() : 0;
@@ -369,6 +417,7 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
             }
             __syncthreads();
         }
+        if (step0) clean = keep_step0;
         if (!parked && !short_relay) {
             relay_cached = step0 || only0;
             if (relay_cached) { kW = W; kvv = vv; kpcn = pcn; kPcn = Pcn; kPst = Pst; kpst = pst; }
@@ -638,8 +687,15 @@ __device__ __forceinline__ void rti_pit_body(const DevParams& P) {
                     bool deep = false;   // a pinned input behind the first segment?
 #pragma unroll
                     for (int t = 0; t < 2; t++) deep = deep | ((lane + 64 * t < nu) & (act[t] != 0.0) & (wv >= 1));
-                    only0 = !block_any(deep);
-                } else only0 = false;
+                    bool high = deep;    // ... or at / behind the first segment's checkpoint stage?
+#pragma unroll
+                    for (int t = 0; t < 2; t++) high = high | ((lane + 64 * t < nu) & (act[t] != 0.0) & (wv == 0) & (lane + 64 * t >= 4 * ckst));
+                    lds_f64* g2 = meet((__ballot(deep) != 0ull ? 1.0 : 0.0) + (__ballot(high) != 0ull ? 16.0 : 0.0));
+                    const double tot = (g2[0] + g2[1]) + (g2[2] + g2[3]);
+                    only0 = ((int)tot & 15) == 0;
+                    clean = clean && tot == 0.0;
+                    light_ok = clean && relay_cached && only0;
+                } else { only0 = false; clean = false; light_ok = false; }
                 if (mode == M_PRED) { iters++; mu = block_sum(ssum) * inv2nv; }
             }
             __syncthreads();   // (every wave is done with the hand-over buffers of the pass before)

@@ -26,7 +26,7 @@ def ba():
 
 @pytest.fixture(autouse=True)
 def _restore_env():
-    old = {k: os.environ.get(k) for k in ("BROV_PIT", "BROV_PIT_TRY")}
+    old = {k: os.environ.get(k) for k in ("BROV_PIT", "BROV_PIT_TRY", "BROV_PIT_LIGHT")}
     yield
     for k, v in old.items():
         if v is None:
@@ -225,6 +225,33 @@ def test_the_whole_qp_loop_parallel_in_time(ba, oracle, golden_traj, N, B, box, 
     assert n_done >= 0.9 * n_total and n_ipm_done >= (3 if B > 1 else 1)
     assert n_count_off <= max(1, n_done // 20)     # (an iteration more or less where a step-length or gate test sits on a rounding error)
     s.close()
+
+
+@pytest.mark.parametrize("N,B,box", [(80, 12, 50.0), (40, 9, 50.0), (60, 7, 12.0), (24, 6, 50.0), (80, 1, 50.0)])
+def test_light_tries_change_nothing_but_the_time(ba, golden_traj, N, B, box):
+    """A try whose pins all sit in the first stages reuses what the step-0 pass computed behind them (two relay hops skipped, segments 1 .. 3 not
+    swept at all, wave 0 refactorising from its stage checkpoint; kept for instances that ran the loop in their previous step).  The reused values are
+    the ones a full pass would recompute: records and iterates bit for bit against BROV_PIT_LIGHT=0, over ticks on which far-off instances stay
+    saturated (steady tries), a box that also pins inputs deep in the horizon (full passes in between), and a measurement that moves."""
+    os.environ["BROV_PIT"] = "1"
+    x0, circ = _inputs(golden_traj, B, seed=300 + N, far=0.5 if B > 1 else 1.0)
+    kw = dict(lbu=[-box] * 4, ubu=[box] * 4)
+    out = []
+    for light in ("1", "0"):
+        os.environ["BROV_PIT_LIGHT"] = light
+        s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, **kw)); s.set_params(P_NOMINAL)
+        rec = []
+        for k in range(8):
+            s.set_x0(x0 + 0.01 * k); s.set_yref(np.ascontiguousarray(circ[k:k + N + 1])); s.solve()
+            rec.append((s.results().copy(), s.get_iterate(), s.pit_last().copy()))
+        out.append(rec); s.close()
+    n_loop = 0
+    for k, ((ra, ia, da), (rb, ib, db)) in enumerate(zip(*out)):
+        assert ra.tobytes() == rb.tobytes() and np.array_equal(da, db), k
+        for a, b_ in zip(ia, ib):
+            assert np.array_equal(a, b_, equal_nan=True), k
+        n_loop += int(((ra["qp_iter"] > 0) & (da != 0)).sum())
+    assert n_loop >= 6          # instances that ran tries inside the kernel, tick after tick
 
 
 def test_off_is_the_resident_kernel_alone_and_on_agrees_with_it(ba, golden_traj):
