@@ -172,6 +172,7 @@ static const char* opts_problem(const brov_opts* o) {
     if (o->N < 1 || o->N > BROV_MAX_N) return "N out of range";
     if (!(o->Ts > 0.0) || !(o->Ts < 1e6)) return "Ts must be positive and finite";
     if (o->kernel_path < 0 || o->kernel_path > 2) return "kernel_path must be BROV_PATH_AUTO / _STREAMING / _FUSED";
+    if (o->N > BROV_MAX_N_LDS && o->kernel_path == BROV_PATH_FUSED) return "BROV_PATH_FUSED serves N <= 128 (beyond: the streaming pair, BROV_PATH_AUTO / _STREAMING)";
     if (o->on_failure < 0 || o->on_failure > 1) return "on_failure must be BROV_ON_FAILURE_KEEP / _RESTART";
     for (int j = 0; j < 16; j++)
         if (!(o->W[j] >= 0.0) || !(o->W[j] < 1e300)) return "stage weights must be finite and >= 0";
@@ -306,7 +307,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     // needs no workspace (profiles/r3_small_batch_latency.txt)
     const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed &&
                      windowed_stage_count(opts->N, B) != opts->N;
-    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few) {
+    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few && opts->N <= BROV_MAX_N_LDS) {
         s->win_L = windowed_stage_count(opts->N, B);
         s->win_blocks = windowed_blocks(opts->N, B, s->win_L);
         size_t ws_doubles = (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L);

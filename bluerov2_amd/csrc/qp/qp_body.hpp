@@ -199,7 +199,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             unsigned long long ipm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipm_last = __builtin_readcyclecounter();
 #endif
             constexpr bool CACHE = (LDS >= 3);   // windowed kernel: register copies per loop group (IpmVec MODE 2)
-            constexpr int kIpmT = EL ? 2 : 8;    // elements per lane; streaming / windowed path: nv <= 512
+            constexpr int kIpmT = EL ? 2 : (LDS == 0 ? 16 : 8);   // elements per lane; windowed kernels: nv <= 512 (register copies per loop group); streaming kernel (vectors in HBM): nv <= 1024
             using Vec = IpmVec<EL ? 1 : (CACHE ? 2 : 0), kIpmT>;
             Vec vV{{}, V}, vTL{{}, TL}, vTU{{}, TU}, vLL{{}, LL}, vLU{{}, LU}, vDVA{{}, DVA},
                 vDLL{{}, GAM}, vDLU{{}, RT},   // dual steps: registers, or (streaming) parked in GAM / RT, both rebuilt every iteration

@@ -17,7 +17,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(HERE, "lib", "libbluerov2_nmpc.so")
 NX, NU, NP, NY = 12, 4, 16, 16
-MAX_N = 128
+MAX_N = 256      # BROV_MAX_N (streaming pair)
+MAX_N_LDS = 128  # BROV_MAX_N_LDS (LDS-resident kernels)
 PATH_AUTO, PATH_STREAMING, PATH_FUSED, PATH_WINDOWED = 0, 1, 2, 3
 
 # nominal hydrodynamic parameters the nodes pass every tick (bluerov2_dob.cpp:340-353); p[0:4] = disturbance

@@ -87,10 +87,13 @@ typedef struct brov_opts {
 
 #define BROV_PATH_WINDOWED 3  /* reported by brov_last_kernel_path only: the windowed flavour of BROV_PATH_FUSED / _AUTO (N >= 24) */
 
-/* Longest horizon.  The reference's create_with_discretization takes any N (acados_solver_bluerov2.c:734-783); here the QP loop keeps the
- * 4 N inputs of an instance as 8 elements per lane of its wavefront (4 N <= 8 * 64), in every kernel family: 128 is structural, not a
- * tuning choice.  (The reference ships N = 80; brov_create refuses N > 128 with BROV_ERR_ARG and the drop-in's create returns non-zero.) */
-#define BROV_MAX_N 128
+/* Longest horizon.  The reference's create_with_discretization takes any N (acados_solver_bluerov2.c:734-783).  Here the QP loop keeps the 4 N
+ * inputs of an instance as elements per lane of its wavefront: 8 per lane in the LDS-resident kernels (register copies: N <= 128 =
+ * BROV_MAX_N_LDS, structural), 16 per lane in the streaming pair, whose vectors live in HBM (N <= 256; round 5).  BROV_PATH_AUTO takes the
+ * streaming pair beyond 128; BROV_PATH_FUSED there and any N > 256 are refused by brov_create with BROV_ERR_ARG (the drop-in's create returns
+ * non-zero).  (The reference ships N = 80.) */
+#define BROV_MAX_N 256
+#define BROV_MAX_N_LDS 128
 
 /* 104-byte per-instance result record; this is also the record all-gathered across GPUs ("optimal
  * thrusts/costs for selection") */

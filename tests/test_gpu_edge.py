@@ -129,6 +129,34 @@ def test_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B, pat
         assert np.abs(gx - it[0]).max() < 1e-7 and np.abs(gu - it[1]).max() < 1e-7
 
 
+@pytest.mark.parametrize("N,B,big,path", [(129, 3, 2.5, 0), (160, 4, 2.5, 0), (200, 2, 0.0, 1), (256, 3, 2.5, 0)])
+def test_horizons_beyond_the_lds_resident_kernels(ba, oracle, golden_traj, N, B, big, path):
+    """128 < N <= 256 (round 5: BROV_MAX_N 128 -> 256; the reference's create_with_discretization takes any N): the streaming pair, whose
+    interior-point vectors live in HBM (sixteen elements per lane), under BROV_PATH_AUTO and on request; three ticks against the oracle, with
+    far-off instances that run the QP loop over up to 1024 inputs"""
+    x0, circ = _inputs(golden_traj, B, seed=N, big=big)
+    Ts = 2.0 / N
+    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, kernel_path=path))
+    s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+    op = oracle.opts(N, Ts)
+    it = oracle.init_iterate(op, B)
+    win = np.concatenate([circ, np.repeat(circ[-1:], 400, axis=0)])[:N + 4]
+    n_loop = 0
+    for k in range(3):
+        s.set_yref(win[k:k + N + 1]); s.solve()
+        assert s.last_kernel_path() == ba.PATH_STREAMING
+        worst, ro = _oracle_step(oracle, op, x0, win[k:k + N + 1], ba.P_NOMINAL, it)
+        r = s.results()
+        assert np.array_equal(r["status"], ro["status"]) and np.all(r["status"] == 0)
+        assert np.abs(r["u0"] - ro["u0"]).max() < 1e-7 * max(1.0, ro["kkt"].max())
+        gx, gu, gpi, glam = s.get_iterate()
+        assert np.abs(gx - it[0]).max() < 1e-7 * max(1.0, ro["kkt"].max()) and np.abs(gu - it[1]).max() < 1e-7 * max(1.0, ro["kkt"].max())
+        n_loop += int((r["qp_iter"] > 0).sum())
+    if big:
+        assert n_loop > 0
+    s.close()
+
+
 @pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("N,on_failure", [(20, 1), (20, 0), (40, 1)])
 def test_nan_input_is_contained(ba, oracle, golden_traj, path, N, on_failure):
@@ -412,7 +440,9 @@ def test_setters_reject_bad_shapes(ba):
     with pytest.raises(ValueError):
         s.set_yref(np.zeros((3, 10, 16)))
     with pytest.raises(RuntimeError):
-        ba.BatchSolver(1, ba.SolverOptions(200))  # N > BROV_MAX_N
+        ba.BatchSolver(1, ba.SolverOptions(300))  # N > BROV_MAX_N
+    with pytest.raises(RuntimeError):
+        ba.BatchSolver(1, ba.SolverOptions(200, kernel_path=ba.PATH_FUSED))  # N > BROV_MAX_N_LDS on the LDS-resident kernels
 
 
 @pytest.mark.parametrize("kw,what", [
