@@ -251,11 +251,12 @@ def test_runtime_option_change_and_reset(ba, oracle, golden_traj):
     assert np.all(s.get_iterate()[0][:, :, 2] == -20.0)
 
 
-def test_rti_phase_split_equals_full_step(ba, golden_traj):
-    N, B = 20, 7
+@pytest.mark.parametrize("N,B", [(20, 7), (160, 3)])   # (N = 160: beyond the LDS-resident kernels, where the streaming pair is what BROV_PATH_AUTO runs)
+def test_rti_phase_split_equals_full_step(ba, golden_traj, N, B):
     x0, circ = _inputs(golden_traj, B, seed=6)
-    full = ba.BatchSolver(B, ba.SolverOptions(N, kernel_path=1))
-    split = ba.BatchSolver(B, ba.SolverOptions(N, kernel_path=1))
+    circ = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])
+    full = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, kernel_path=1))
+    split = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, kernel_path=1))
     for s in (full, split):
         s.set_params(ba.P_NOMINAL); s.set_yref(circ[:N + 1])
     full.set_x0(x0); full.solve()
@@ -266,7 +267,7 @@ def test_rti_phase_split_equals_full_step(ba, golden_traj):
     assert split._L.brov_solve_phase(split._h, C.c_void_p(0), 2) == 0
     assert np.array_equal(full.results()["u0"], split.results()["u0"])
     # the same split through the tick call (the drop-in's rti_phase option): phase 1 delivers no record, phase 2 the step's
-    tk = ba.BatchSolver(B, ba.SolverOptions(N, kernel_path=1))
+    tk = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N, kernel_path=1 if N <= 128 else 0))
     tk.set_params(ba.P_NOMINAL); tk.set_yref(circ[:N + 1])
     tk.tick(rti_phase=1)
     r = tk.tick(x0=x0, rti_phase=2)

@@ -38,12 +38,14 @@ def _inputs(golden_traj, B, seed):
 # BROV_PATH_STREAMING keeps the streaming pair
 GRID_CASES = [(20, 1.08, True, 48, 0, 2), (7, 1.3, True, 48, 0, 2), (13, 1.1, False, 300, 2, 2), (23, 1.05, True, 64, 0, 2),
               (40, 1.04, False, 320, 0, 3), (80, 1.01, True, 320, 2, 3), (57, 1.02, True, 300, 0, 3),
-              (40, 1.04, False, 48, 0, 3), (80, 1.01, True, 48, 0, 3), (80, 1.01, True, 3, 2, 3), (40, 1.04, False, 48, 1, 1), (20, 1.08, True, 48, 1, 1)]
+              (40, 1.04, False, 48, 0, 3), (80, 1.01, True, 48, 0, 3), (80, 1.01, True, 3, 2, 3), (40, 1.04, False, 48, 1, 1), (20, 1.08, True, 48, 1, 1),
+              (160, 1.005, True, 6, 0, 1), (256, 1.002, False, 3, 0, 1)]   # (beyond BROV_MAX_N_LDS: the streaming pair under BROV_PATH_AUTO)
 
 
 @pytest.mark.parametrize("N,grow,with_w0,B,path,ran", GRID_CASES)
 def test_geometric_grid_and_stage0_weight_against_the_oracle(ba, oracle, golden_traj, N, grow, with_w0, B, path, ran):
     x0, circ = _inputs(golden_traj, B, seed=N)
+    circ = np.concatenate([circ, np.repeat(circ[-1:], max(0, N + 4 - len(circ)), axis=0)])
     ts = (0.5 / N) * grow ** np.arange(N)
     rng = np.random.default_rng(N + 1)
     W0 = np.array(ba.SolverOptions(N).W) * rng.uniform(0.5, 2.0, 16) if with_w0 else None

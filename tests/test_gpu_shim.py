@@ -127,3 +127,54 @@ def test_reference_generated_example_runs_on_the_shim(golden_rti):
     assert np.abs(xv - golden_rti["main_harness_N80/x0"]).max() < 1e-4
     m = re.search(r"KKT ([-+0-9.e]+)", r.stdout)
     assert m and float(m.group(1)) >= 0.0
+
+
+def test_create_with_discretization_beyond_the_generated_horizon(golden_traj, oracle):
+    """bluerov2_acados_create_with_discretization(capsule, N, new_time_steps) with N = 200 > BLUEROV2_N (acados_solver_bluerov2.c:734-783 takes
+    any N with a time-step vector; round 5: the drop-in does up to BROV_MAX_N = 256, beyond 128 on the streaming pair), through the reference's
+    own setters and getters from ctypes: three ticks against the oracle at that horizon"""
+    import ctypes as C
+    import torch
+    assert torch.cuda.is_available()   # (torch's HIP runtime first, as in every other in-process test: a process must not end up with two of them)
+    import bluerov2_amd as ba
+    L = C.CDLL(os.path.join(LIBDIR, "libacados_ocp_solver_bluerov2.so"))
+    vp, dp = C.c_void_p, C.POINTER(C.c_double)
+    L.bluerov2_acados_create_capsule.restype = vp
+    for f in ("nlp_config", "nlp_dims", "nlp_in", "nlp_out"):
+        getattr(L, "bluerov2_acados_get_" + f).restype = vp
+        getattr(L, "bluerov2_acados_get_" + f).argtypes = [vp]
+    L.bluerov2_acados_create_with_discretization.argtypes = [vp, C.c_int, dp]
+    L.ocp_nlp_constraints_model_set.argtypes = [vp, vp, vp, C.c_int, C.c_char_p, vp]
+    L.ocp_nlp_cost_model_set.argtypes = [vp, vp, vp, C.c_int, C.c_char_p, vp]
+    L.ocp_nlp_out_get.argtypes = [vp, vp, vp, C.c_int, C.c_char_p, vp]
+    L.bluerov2_acados_update_params.argtypes = [vp, C.c_int, dp, C.c_int]
+    for f in ("bluerov2_acados_solve", "bluerov2_acados_free", "bluerov2_acados_free_capsule"):
+        getattr(L, f).argtypes = [vp]
+    N, Ts = 200, 0.01
+    cap = L.bluerov2_acados_create_capsule()
+    assert L.bluerov2_acados_create_with_discretization(cap, 300, (C.c_double * 300)(*([Ts] * 300))) != 0      # beyond BROV_MAX_N: refused
+    ts = (C.c_double * N)(*([Ts] * N))
+    assert L.bluerov2_acados_create_with_discretization(cap, N, ts) == 0
+    cfg, dims, nin, nout = (getattr(L, "bluerov2_acados_get_" + f)(cap) for f in ("nlp_config", "nlp_dims", "nlp_in", "nlp_out"))
+    circ = golden_traj["circle"]
+    circ = np.concatenate([circ, np.repeat(circ[-1:], 300, axis=0)])
+    x0 = np.zeros(12); x0[:6] = circ[0, :6]; x0[0] += 0.4; x0[1] -= 0.3
+    p = np.ascontiguousarray(ba.P_NOMINAL, dtype=np.float64)
+    op = oracle.opts(N, Ts)
+    x, u, pi, lam = oracle.init_iterate(op)
+    for k in range(3):
+        yref = np.ascontiguousarray(circ[k:k + N + 1])
+        L.ocp_nlp_constraints_model_set(cfg, dims, nin, 0, b"lbx", x0.ctypes.data)
+        L.ocp_nlp_constraints_model_set(cfg, dims, nin, 0, b"ubx", x0.ctypes.data)
+        for i in range(N + 1):
+            L.bluerov2_acados_update_params(cap, i, p.ctypes.data_as(dp), 16)
+            L.ocp_nlp_cost_model_set(cfg, dims, nin, i, b"yref", yref[i].ctypes.data)
+        assert L.bluerov2_acados_solve(cap) == 0
+        u0, x1 = np.zeros(4), np.zeros(12)
+        L.ocp_nlp_out_get(cfg, dims, nout, 0, b"u", u0.ctypes.data)
+        L.ocp_nlp_out_get(cfg, dims, nout, 1, b"x", x1.ctypes.data)
+        ro = oracle.rti_step(op, x0, yref, np.broadcast_to(p, (N + 1, 16)).copy(), x, u, pi, lam)
+        assert ro["status"] == 0
+        assert np.abs(u0 - u[0]).max() < 1e-7 and np.abs(x1 - x[1]).max() < 1e-7
+    assert L.bluerov2_acados_free(cap) == 0
+    L.bluerov2_acados_free_capsule(cap)

@@ -89,7 +89,8 @@ def test_per_instance_windows_stand_still(ba):
     one.close(); many.close()
 
 
-@pytest.mark.parametrize("N,B,grid,line,kw", [(40, 96, False, 3, {}), (20, 200, True, 3, {}), (20, 200, False, 4080, {}), (20, 120, False, 3, {"kernel_path": 1})])
+@pytest.mark.parametrize("N,B,grid,line,kw", [(40, 96, False, 3, {}), (20, 200, True, 3, {}), (20, 200, False, 4080, {}), (20, 120, False, 3, {"kernel_path": 1}),
+                                              (160, 12, False, 3, {}), (200, 5, True, 3, {})])   # (N > 128: the streaming pair)
 def test_solvers_the_fused_kernel_does_not_serve_take_a_launch_per_step(ba, N, B, grid, line, kw):
     """a small batch at a windowed horizon (resident configuration) / general grid / a window that runs off the end of the 4096-row table (rows repeated: not rows in place) / the
     streaming pair: the same call, the same result, by `ticks` launches"""
