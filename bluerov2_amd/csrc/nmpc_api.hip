@@ -172,7 +172,6 @@ static const char* opts_problem(const brov_opts* o) {
     if (o->N < 1 || o->N > BROV_MAX_N) return "N out of range";
     if (!(o->Ts > 0.0) || !(o->Ts < 1e6)) return "Ts must be positive and finite";
     if (o->kernel_path < 0 || o->kernel_path > 2) return "kernel_path must be BROV_PATH_AUTO / _STREAMING / _FUSED";
-    if (o->N > BROV_MAX_N_LDS && o->kernel_path == BROV_PATH_FUSED) return "BROV_PATH_FUSED serves N <= 128 (beyond: the streaming pair, BROV_PATH_AUTO / _STREAMING)";
     if (o->on_failure < 0 || o->on_failure > 1) return "on_failure must be BROV_ON_FAILURE_KEEP / _RESTART";
     for (int j = 0; j < 16; j++)
         if (!(o->W[j] >= 0.0) || !(o->W[j] < 1e300)) return "stage weights must be finite and >= 0";
@@ -307,7 +306,7 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     // needs no workspace (profiles/r3_small_batch_latency.txt)
     const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed &&
                      windowed_stage_count(opts->N, B) != opts->N;
-    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few && opts->N <= BROV_MAX_N_LDS) {
+    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few) {
         s->win_L = windowed_stage_count(opts->N, B);
         s->win_blocks = windowed_blocks(opts->N, B, s->win_L);
         size_t ws_doubles = (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L);
@@ -926,7 +925,8 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
         return BROV_ERR_ARG;
     }
     if (rti_phase == 1) s->prep_path = split_res ? 2 : 1;
-    const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING;
+    // (128 < N <= 256: rti_window_kernel_long, the large-batch kernel on the uniform grid -- a general grid at such a horizon runs on the streaming pair)
+    const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING && !(s->N > BROV_MAX_N_LDS && general_grid(s));
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed && !(split_res && split_fused_h);
     const bool windowed = lds_path && !fused && (s->ws != nullptr || (split_res && split_fused_h));
     if (split_res && split_fused_h) {   // the resident configuration of a fused-kernel horizon: one window = the horizon, one block per instance
@@ -987,7 +987,7 @@ extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phas
 // persistent blocks), 0 = neither (general grid, streaming pair, a dumped linearisation, the resident / parallel-in-time configurations of small
 // batches -- those are latency paths: a launch per step)
 static int ticks_kernel(const brov_solver* s) {
-    if (s->opts.kernel_path == BROV_PATH_STREAMING || general_grid(s) || s->dump_lin) return 0;
+    if (s->opts.kernel_path == BROV_PATH_STREAMING || general_grid(s) || s->dump_lin || s->N > BROV_MAX_N_LDS) return 0;
     if (fused_supported(s->N) && !s->force_windowed) return 1;
     if (s->ws != nullptr && !windowed_is_resident(s->win_L) && s->alt_L == 0) return 2;
     return 0;

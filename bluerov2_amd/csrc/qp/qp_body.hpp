@@ -37,7 +37,10 @@ namespace brov {
 // step-0 factorisation has already run, fused with the linearisation: pre_ok)
 // DF (fused kernel of the mailbox ticks, rti_fused_kernel_mail): an early exit sends its record BEFORE the adjoint sweep, as the resident windowed
 // kernel does -- nothing in the record depends on the multipliers that sweep computes for the iterate
-template <int LDS, class IT = Inst, bool DF = false>
+// LONGV (rti_window_kernel_long, 128 < N <= 256): the interior-point vectors of the windowed kernel without their per-group register copies --
+// 16 elements a lane, element by element out of HBM as in the streaming kernel (the copies of 8 a lane are what limits the other LDS-resident
+// kernels to nv <= 512)
+template <int LDS, class IT = Inst, bool DF = false, bool LONGV = false>
 __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double lin_part, bool lin_nan, Win* W = nullptr,
                                         bool pre_ok = true, bool pre_illc = false) {
     constexpr bool EL = (LDS == 1 || LDS == 2);
@@ -198,8 +201,8 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
 #ifdef BROV_DBG_IPM
             unsigned long long ipm_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ipm_last = __builtin_readcyclecounter();
 #endif
-            constexpr bool CACHE = (LDS >= 3);   // windowed kernel: register copies per loop group (IpmVec MODE 2)
-            constexpr int kIpmT = EL ? 2 : (LDS == 0 ? 16 : 8);   // elements per lane; windowed kernels: nv <= 512 (register copies per loop group); streaming kernel (vectors in HBM): nv <= 1024
+            constexpr bool CACHE = (LDS >= 3) && !LONGV;   // windowed kernel: register copies per loop group (IpmVec MODE 2)
+            constexpr int kIpmT = EL ? 2 : ((LDS == 0 || LONGV) ? 16 : 8);   // elements per lane; windowed kernels: nv <= 512 (register copies per loop group); streaming kernel (vectors in HBM): nv <= 1024
             using Vec = IpmVec<EL ? 1 : (CACHE ? 2 : 0), kIpmT>;
             Vec vV{{}, V}, vTL{{}, TL}, vTU{{}, TU}, vLL{{}, LL}, vLU{{}, LU}, vDVA{{}, DVA},
                 vDLL{{}, GAM}, vDLU{{}, RT},   // dual steps: registers, or (streaming) parked in GAM / RT, both rebuilt every iteration

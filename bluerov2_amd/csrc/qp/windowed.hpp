@@ -38,8 +38,10 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // step and the record.  Separate instantiations (rti_window_kernel_res_split, _split_grid).
 // MULTI (rti_window_kernel_ticks; large batches only): P.ticks RTI steps of an instance back to back once a block has taken it from the counter --
 // brov_solve_ticks / brov_closed_loop at the horizons the fused kernels do not serve (see MULTI in qp/fused.hpp)
-template <bool RES, bool GRID = false, bool SPLIT = false, bool MULTI = false>
+// LONG (rti_window_kernel_long): horizons beyond BROV_MAX_N_LDS = 128 on the large-batch kernel (see qp_body's LONGV)
+template <bool RES, bool GRID = false, bool SPLIT = false, bool MULTI = false, bool LONG = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
+    static_assert(!LONG || (!RES && !SPLIT && !GRID && !MULTI), "long horizons: the large-batch kernel on the uniform grid, a launch per step");
     static_assert(!SPLIT || RES, "the split launches exist for the resident mode");
     static_assert(!MULTI || (!RES && !SPLIT && !GRID), "steps in one launch: the large-batch kernel on the uniform grid");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;
@@ -314,7 +316,7 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
         W.t_fetch = 0; W.n_fetch = 0;
 #endif
 #if !defined(BROV_WIN_EXP) || BROV_WIN_EXP != 1
-        qp_body<(RES ? 4 : 3)>(P, I, b, part, nanp, &W, S.ok, S.illc);
+        qp_body<(RES ? 4 : 3), InstT, false, LONG>(P, I, b, part, nanp, &W, S.ok, S.illc);
 #endif
 #ifdef BROV_DBG_WIN
         if (P.dbg && lane == 0) { P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 3] = W.t_fetch; P.dbg[(size_t)P.B * 8 + (size_t)b * 8 + 4] = W.n_fetch; }

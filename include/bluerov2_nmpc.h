@@ -88,10 +88,12 @@ typedef struct brov_opts {
 #define BROV_PATH_WINDOWED 3  /* reported by brov_last_kernel_path only: the windowed flavour of BROV_PATH_FUSED / _AUTO (N >= 24) */
 
 /* Longest horizon.  The reference's create_with_discretization takes any N (acados_solver_bluerov2.c:734-783).  Here the QP loop keeps the 4 N
- * inputs of an instance as elements per lane of its wavefront: 8 per lane in the LDS-resident kernels (register copies: N <= 128 =
- * BROV_MAX_N_LDS, structural), 16 per lane in the streaming pair, whose vectors live in HBM (N <= 256; round 5).  BROV_PATH_AUTO takes the
- * streaming pair beyond 128; BROV_PATH_FUSED there and any N > 256 are refused by brov_create with BROV_ERR_ARG (the drop-in's create returns
- * non-zero).  (The reference ships N = 80.) */
+ * inputs of an instance as elements per lane of its wavefront: 8 per lane as register copies in the LDS-resident kernels (N <= 128 =
+ * BROV_MAX_N_LDS: fused, windowed, its resident mode, the parallel-in-time kernel, steps in one launch, general grids), 16 per lane read from HBM
+ * element by element beyond (N <= 256; round 5): the streaming pair and the large-batch windowed kernel's long-horizon instantiation
+ * (rti_window_kernel_long, uniform grid).  128 < N <= 256 under BROV_PATH_AUTO: the streaming pair for a handful of instances, the windowed
+ * kernel for more; a general grid there runs on the streaming pair.  N > 256 is refused by brov_create with BROV_ERR_ARG (the drop-in's create
+ * returns non-zero).  (The reference ships N = 80.) */
 #define BROV_MAX_N 256
 #define BROV_MAX_N_LDS 128
 

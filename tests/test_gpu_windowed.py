@@ -115,7 +115,7 @@ def test_ragged_last_round(ba, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("N,B,blocks", [(24, 64, 24), (57, 96, 32), (80, 64, 21), (128, 48, 16)])
+@pytest.mark.parametrize("N,B,blocks", [(24, 64, 24), (57, 96, 32), (80, 64, 21), (128, 48, 16), (160, 96, 32), (256, 40, 16)])   # (N > 128: rti_window_kernel_long)
 def test_several_instances_per_block_at_small_batches(ba, oracle, N, B, blocks):
     s, *_ = _run_against_oracle(ba, oracle, N, B, ticks=2, blocks=blocks, resident=False)
     s.close()
