@@ -18,7 +18,6 @@
 using namespace brov;
 
 #define kTickMailboxMaxBatch 64          /* brov_tick_host: up to this many instances deliver their records through the host mailbox */
-#define BROV_AUTO_WINDOWED_MIN_BATCH 8   /* BROV_PATH_AUTO, N > 81: up to this many instances run on the streaming kernels */
 
 static thread_local std::string g_err;
 extern "C" const char* brov_last_error(void) { return g_err.c_str(); }
@@ -300,13 +299,12 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
     // development knob: BROV_DEV_FORCE_WINDOWED=1 runs the windowed kernel for every horizon (one window when N <= 20)
     s->k = read_knobs();
     s->force_windowed = s->k.force_windowed != 0;
-    // BROV_PATH_AUTO at long horizons and a handful of instances (the ROS node's batch of one): when the whole horizon fits one
-    // window (N <= 81: resident mode, no parking and no window fetches) the windowed kernel has the shorter latency (N = 80, B = 1:
-    // 128 vs 172 us); beyond that the streaming pair, which spreads the linearisation over several wavefronts, is as fast and
-    // needs no workspace (profiles/r3_small_batch_latency.txt)
-    const bool few = B <= BROV_AUTO_WINDOWED_MIN_BATCH && opts->kernel_path == BROV_PATH_AUTO && !s->force_windowed &&
-                     windowed_stage_count(opts->N, B) != opts->N;
-    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING && !few) {
+    // BROV_PATH_AUTO beyond the horizons the fused kernels serve: the windowed kernel at every batch size -- its resident mode where the whole horizon
+    // fits one window (N <= 81, at most one instance per CU), windows of <= 20 stages otherwise.  (Rounds 3-4 sent up to eight instances at N > 81 to
+    // the streaming pair, then as fast; since round 5 the windowed kernel is ahead there too -- one instance at N = 82 / 128 / 160 / 256: 0.196 / 0.278 /
+    // 0.342 / 0.535 ms per step against 0.207 / 0.301 / 0.366 / 0.558, eight instances 0.198 / 0.281 / 0.344 / 0.539 against 0.241 / 0.343 / 0.421 /
+    // 0.686: scripts/dev/long_horizon_small_batches.py.)
+    if ((!fused_supported(opts->N) || s->force_windowed) && opts->kernel_path != BROV_PATH_STREAMING) {
         s->win_L = windowed_stage_count(opts->N, B);
         s->win_blocks = windowed_blocks(opts->N, B, s->win_L);
         size_t ws_doubles = (size_t)s->win_blocks * windowed_ws_doubles(opts->N, s->win_L);

@@ -24,19 +24,20 @@ def circle(rows, dt):
     return tr
 
 
-B = 4096
-for N, path in ((80, 0), (80, 1), (128, 0), (128, 1), (160, 0), (200, 0), (256, 0)):
-    Ts = 1.0 / N
-    x0, _ = bench.synthetic_inputs(B, seed=4)
-    tr = circle(N + 64, Ts)
-    s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, kernel_path=path)); s.set_x0(x0); s.set_params(ba.P_NOMINAL)
-    for k in range(5):
-        s.set_yref(tr[k:k + N + 1]); s.solve()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for k in range(5, 25):
-        s.set_yref(tr[k:k + N + 1]); s.solve()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-    r = s.results()
-    print(f"N={N} path asked {path} ran {s.last_kernel_path()}: {B / dt / 1e6:.3f} M solves/s ({dt * 1e3:.3f} ms per step), status {np.bincount(r['status'], minlength=5).tolist()}, "
-          f"instances in the QP loop {int((r['qp_iter'] > 0).sum())}, kkt max {float(r['kkt'].max()):.2e}")
-    s.close()
+if __name__ == "__main__":
+  B = 4096
+  for N, path in ((80, 0), (80, 1), (128, 0), (128, 1), (160, 0), (200, 0), (256, 0)):
+      Ts = 1.0 / N
+      x0, _ = bench.synthetic_inputs(B, seed=4)
+      tr = circle(N + 64, Ts)
+      s = ba.BatchSolver(B, ba.SolverOptions(N, Ts, kernel_path=path)); s.set_x0(x0); s.set_params(ba.P_NOMINAL)
+      for k in range(5):
+          s.set_yref(tr[k:k + N + 1]); s.solve()
+      torch.cuda.synchronize(); t0 = time.perf_counter()
+      for k in range(5, 25):
+          s.set_yref(tr[k:k + N + 1]); s.solve()
+      torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+      r = s.results()
+      print(f"N={N} path asked {path} ran {s.last_kernel_path()}: {B / dt / 1e6:.3f} M solves/s ({dt * 1e3:.3f} ms per step), status {np.bincount(r['status'], minlength=5).tolist()}, "
+            f"instances in the QP loop {int((r['qp_iter'] > 0).sum())}, kkt max {float(r['kkt'].max()):.2e}")
+      s.close()

@@ -78,9 +78,9 @@ def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
 
 def test_auto_path_selection(ba, golden_traj):
     """BROV_PATH_AUTO: fused for N <= 23; at longer horizons the windowed kernel (for small batches with the whole horizon in one
-    window, N <= 81), except for a handful of instances (<= 8) at N > 81, where the streaming pair is as fast and needs no workspace"""
+    window, N <= 81) -- at every batch size since round 5 (rounds 3-4: the streaming pair for up to eight instances at N > 81)"""
     for N, B, want in ((20, 1, ba.PATH_FUSED), (23, 300, ba.PATH_FUSED), (24, 8, ba.PATH_WINDOWED), (80, 1, ba.PATH_WINDOWED),
-                       (82, 8, ba.PATH_STREAMING), (128, 1, ba.PATH_STREAMING), (82, 9, ba.PATH_WINDOWED), (80, 64, ba.PATH_WINDOWED)):
+                       (82, 8, ba.PATH_WINDOWED), (128, 1, ba.PATH_WINDOWED), (82, 9, ba.PATH_WINDOWED), (80, 64, ba.PATH_WINDOWED), (200, 1, ba.PATH_WINDOWED)):
         x0, circ = _inputs(golden_traj, B, seed=N)
         s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
         win = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])[:N + 1]   # the golden head is short: pad like the reference
@@ -130,11 +130,11 @@ def test_chunk_boundaries_and_maximum_horizon(ba, oracle, golden_traj, N, B, pat
 
 
 @pytest.mark.parametrize("N,B,big,path", [(129, 3, 2.5, 0), (160, 4, 2.5, 0), (200, 2, 0.0, 1), (256, 3, 2.5, 0),
-                                          (129, 40, 2.5, 0), (160, 24, 2.5, 0), (200, 3, 2.5, 2), (256, 20, 2.5, 0), (256, 12, 0.0, 2)])
+                                          (129, 40, 2.5, 0), (160, 24, 2.5, 1), (200, 3, 2.5, 2), (256, 20, 2.5, 0), (256, 12, 0.0, 1)])
 def test_horizons_beyond_the_lds_resident_kernels(ba, oracle, golden_traj, N, B, big, path):
     """128 < N <= 256 (round 5: BROV_MAX_N 128 -> 256; the reference's create_with_discretization takes any N): interior-point vectors of sixteen
-    elements per lane, read from HBM element by element -- the streaming pair (a handful of instances under BROV_PATH_AUTO, or on request) and the
-    large-batch windowed kernel's long-horizon instantiation (rti_window_kernel_long: larger batches, or BROV_PATH_FUSED); three ticks against the
+    elements per lane, read from HBM element by element -- the windowed kernel's long-horizon instantiation (rti_window_kernel_long: BROV_PATH_AUTO /
+    _FUSED) and the streaming pair (on request); three ticks against the
     oracle, with far-off instances that run the QP loop over up to 1024 inputs"""
     x0, circ = _inputs(golden_traj, B, seed=N, big=big)
     Ts = 2.0 / N
@@ -146,7 +146,7 @@ def test_horizons_beyond_the_lds_resident_kernels(ba, oracle, golden_traj, N, B,
     n_loop = 0
     for k in range(3):
         s.set_yref(win[k:k + N + 1]); s.solve()
-        assert s.last_kernel_path() == (ba.PATH_STREAMING if (path == 1 or (path == 0 and B <= 8)) else ba.PATH_WINDOWED)
+        assert s.last_kernel_path() == (ba.PATH_STREAMING if path == 1 else ba.PATH_WINDOWED)
         worst, ro = _oracle_step(oracle, op, x0, win[k:k + N + 1], ba.P_NOMINAL, it)
         r = s.results()
         assert np.array_equal(r["status"], ro["status"]) and np.all(r["status"] == 0)
