@@ -923,8 +923,8 @@ extern "C" int brov_solve_phase(brov_solver* s, void* stream, int rti_phase) {
         return BROV_ERR_ARG;
     }
     if (rti_phase == 1) s->prep_path = split_res ? 2 : 1;
-    // (128 < N <= 256: rti_window_kernel_long, the large-batch kernel on the uniform grid -- a general grid at such a horizon runs on the streaming pair)
-    const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING && !(s->N > BROV_MAX_N_LDS && general_grid(s));
+    // (128 < N <= 256: rti_window_kernel_long / _long_grid)
+    const bool lds_path = (rti_phase == 0 || split_res) && path != BROV_PATH_STREAMING;
     const bool fused = lds_path && fused_supported(s->N) && !s->force_windowed && !(split_res && split_fused_h);
     const bool windowed = lds_path && !fused && (s->ws != nullptr || (split_res && split_fused_h));
     if (split_res && split_fused_h) {   // the resident configuration of a fused-kernel horizon: one window = the horizon, one block per instance

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel_grid(DevParams P) { rti
 // 128 < N <= 256 (round 5): the large-batch windowed kernel with its interior-point vectors element by element out of HBM (qp_body's LONGV);
 // defined behind the other kernels, whose device code stays byte for byte what it was
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_long(DevParams P) { rti_window_body<false, false, false, false, true>(P); }
+__global__ __launch_bounds__(64, 1) void rti_window_kernel_long_grid(DevParams P) { rti_window_body<false, true, false, false, true>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
@@ -176,6 +177,7 @@ int windowed_blocks(int N, int B, int L) {
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_long, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rti_window_kernel_long_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -240,6 +242,7 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
         }
         hipLaunchKernelGGL(rti_window_kernel_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     }
+    else if (P.tsv && P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else if (P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);

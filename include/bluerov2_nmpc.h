@@ -65,8 +65,7 @@ typedef struct brov_opts {
                              * the bound's multiplier divided by the input's weight is below it */
     double  qp_tol_stat;    /* interior point, stationarity target (1e-9, tracked residual, absolute) */
     int32_t qp_early_exit;  /* 1: accept the equality-constrained minimiser when it satisfies the bounds (exact) */
-    int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above; a general grid at N > 128
-                             * runs on the streaming pair), _STREAMING, _FUSED */
+    int32_t kernel_path;    /* BROV_PATH_AUTO (LDS-resident kernels: whole horizon for N <= 23, windowed above), _STREAMING, _FUSED */
     int32_t on_failure;     /* what happens to an instance whose step fails (status NAN / MINSTEP / QP_FAILURE):
                              *   BROV_ON_FAILURE_KEEP    iterate left untouched -- what acados' SQP_RTI does (it returns before
                              *                           update_variables); a diverged iterate then fails again every tick
@@ -89,10 +88,9 @@ typedef struct brov_opts {
 
 /* Longest horizon.  The reference's create_with_discretization takes any N (acados_solver_bluerov2.c:734-783).  Here the QP loop keeps the 4 N
  * inputs of an instance as elements per lane of its wavefront: 8 per lane as register copies in the LDS-resident kernels (N <= 128 =
- * BROV_MAX_N_LDS: fused, windowed, its resident mode, the parallel-in-time kernel, steps in one launch, general grids), 16 per lane read from HBM
- * element by element beyond (N <= 256; round 5): the streaming pair and the large-batch windowed kernel's long-horizon instantiation
- * (rti_window_kernel_long, uniform grid).  128 < N <= 256 under BROV_PATH_AUTO: that windowed kernel; a general grid there runs on the
- * streaming pair.  N > 256 is refused by brov_create with BROV_ERR_ARG (the drop-in's create
+ * BROV_MAX_N_LDS: fused, windowed, its resident mode, the parallel-in-time kernel, steps in one launch), 16 per lane read from HBM
+ * element by element beyond (N <= 256; round 5): the streaming pair and the large-batch windowed kernel's long-horizon instantiations
+ * (rti_window_kernel_long, _long_grid), which BROV_PATH_AUTO runs there.  N > 256 is refused by brov_create with BROV_ERR_ARG (the drop-in's create
  * returns non-zero).  (The reference ships N = 80.) */
 #define BROV_MAX_N 256
 #define BROV_MAX_N_LDS 128

@@ -39,7 +39,7 @@ def _inputs(golden_traj, B, seed):
 GRID_CASES = [(20, 1.08, True, 48, 0, 2), (7, 1.3, True, 48, 0, 2), (13, 1.1, False, 300, 2, 2), (23, 1.05, True, 64, 0, 2),
               (40, 1.04, False, 320, 0, 3), (80, 1.01, True, 320, 2, 3), (57, 1.02, True, 300, 0, 3),
               (40, 1.04, False, 48, 0, 3), (80, 1.01, True, 48, 0, 3), (80, 1.01, True, 3, 2, 3), (40, 1.04, False, 48, 1, 1), (20, 1.08, True, 48, 1, 1),
-              (160, 1.005, True, 6, 0, 1), (256, 1.002, False, 3, 0, 1)]   # (beyond BROV_MAX_N_LDS: the streaming pair under BROV_PATH_AUTO)
+              (160, 1.005, True, 6, 0, 3), (256, 1.002, False, 3, 0, 3), (200, 1.003, True, 40, 0, 3), (160, 1.005, True, 6, 1, 1)]   # (beyond BROV_MAX_N_LDS: rti_window_kernel_long_grid)
 
 
 @pytest.mark.parametrize("N,grow,with_w0,B,path,ran", GRID_CASES)
