@@ -985,7 +985,7 @@ extern "C" int brov_solve(brov_solver* s, void* stream) { return brov_solve_phas
 // persistent blocks), 0 = neither (general grid, streaming pair, a dumped linearisation, the resident / parallel-in-time configurations of small
 // batches -- those are latency paths: a launch per step)
 static int ticks_kernel(const brov_solver* s) {
-    if (s->opts.kernel_path == BROV_PATH_STREAMING || general_grid(s) || s->dump_lin || s->N > BROV_MAX_N_LDS) return 0;
+    if (s->opts.kernel_path == BROV_PATH_STREAMING || general_grid(s) || s->dump_lin) return 0;
     if (fused_supported(s->N) && !s->force_windowed) return 1;
     if (s->ws != nullptr && !windowed_is_resident(s->win_L) && s->alt_L == 0) return 2;
     return 0;

@@ -41,7 +41,7 @@ __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
 // LONG (rti_window_kernel_long): horizons beyond BROV_MAX_N_LDS = 128 on the large-batch kernel (see qp_body's LONGV)
 template <bool RES, bool GRID = false, bool SPLIT = false, bool MULTI = false, bool LONG = false>
 __device__ __forceinline__ void rti_window_body(const DevParams& P) {
-    static_assert(!LONG || (!RES && !SPLIT && !MULTI), "long horizons: the large-batch kernel, a launch per step");
+    static_assert(!LONG || (!RES && !SPLIT), "long horizons: the large-batch kernel");
     static_assert(!SPLIT || RES, "the split launches exist for the resident mode");
     static_assert(!MULTI || (!RES && !SPLIT && !GRID), "steps in one launch: the large-batch kernel on the uniform grid");
     using InstT = std::conditional_t<GRID, InstGrid, Inst>;

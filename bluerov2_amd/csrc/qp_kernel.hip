@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, 1) void rti_pit_kernel_grid(DevParams P) { rti
 // defined behind the other kernels, whose device code stays byte for byte what it was
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_long(DevParams P) { rti_window_body<false, false, false, false, true>(P); }
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_long_grid(DevParams P) { rti_window_body<false, true, false, false, true>(P); }
+__global__ __launch_bounds__(64, 1) void rti_window_kernel_long_ticks(DevParams P) { rti_window_body<false, false, false, true, true>(P); }
 
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
@@ -238,9 +239,11 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
             (void)hipFuncSetAttribute((const void*)rti_window_kernel_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)rti_window_kernel_long_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done[dev] = true;
         }
-        hipLaunchKernelGGL(rti_window_kernel_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+        if (P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+        else hipLaunchKernelGGL(rti_window_kernel_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     }
     else if (P.tsv && P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);

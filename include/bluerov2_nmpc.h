@@ -88,9 +88,8 @@ typedef struct brov_opts {
 
 /* Longest horizon.  The reference's create_with_discretization takes any N (acados_solver_bluerov2.c:734-783).  Here the QP loop keeps the 4 N
  * inputs of an instance as elements per lane of its wavefront: 8 per lane as register copies in the LDS-resident kernels (N <= 128 =
- * BROV_MAX_N_LDS: fused, windowed, its resident mode, the parallel-in-time kernel, steps in one launch), 16 per lane read from HBM
- * element by element beyond (N <= 256; round 5): the streaming pair and the large-batch windowed kernel's long-horizon instantiations
- * (rti_window_kernel_long, _long_grid), which BROV_PATH_AUTO runs there.  N > 256 is refused by brov_create with BROV_ERR_ARG (the drop-in's create
+ * BROV_MAX_N_LDS), 16 per lane read from HBM element by element beyond (N <= 256; round 5): the streaming pair and the large-batch windowed
+ * kernel's long-horizon instantiations (rti_window_kernel_long, _long_grid, _long_ticks), which BROV_PATH_AUTO runs there.  N > 256 is refused by brov_create with BROV_ERR_ARG (the drop-in's create
  * returns non-zero).  (The reference ships N = 80.) */
 #define BROV_MAX_N 256
 #define BROV_MAX_N_LDS 128

@@ -43,7 +43,8 @@ def _same(a, b, what):
 
 
 @pytest.mark.parametrize("N,B,stride,ticks,early", [(20, 1500, 1, 7, 1), (20, 700, 0, 5, 1), (10, 300, 2, 6, 1), (23, 260, 1, 4, 0), (7, 64, 1, 9, 1),
-                                                    (40, 1300, 1, 4, 1), (80, 1100, 2, 3, 1), (57, 1040, 0, 3, 0)])   # (N >= 24, large batches: rti_window_kernel_ticks)
+                                                    (40, 1300, 1, 4, 1), (80, 1100, 2, 3, 1), (57, 1040, 0, 3, 0),   # (N >= 24, large batches: rti_window_kernel_ticks)
+                                                    (160, 1060, 1, 3, 1), (256, 1030, 0, 2, 0)])                    # (N > 128: rti_window_kernel_long_ticks)
 def test_one_launch_of_many_steps_equals_the_steps_launched_one_by_one(ba, N, B, stride, ticks, early):
     import torch
     Ts = 1.0 / max(N, 20)
