@@ -123,7 +123,7 @@ def test_a_moving_window_needs_a_trajectory_window(ba):
     s.close()
 
 
-@pytest.mark.parametrize("N,B,substeps", [(20, 1200, 1), (10, 300, 2), (23, 130, 1), (40, 1100, 1), (80, 1030, 2)])
+@pytest.mark.parametrize("N,B,substeps", [(20, 1200, 1), (10, 300, 2), (23, 130, 1), (40, 1100, 1), (80, 1030, 2), (160, 1030, 1)])
 def test_closed_loop_in_one_launch_equals_three_launches_per_tick(ba, N, B, substeps):
     """brov_closed_loop on the fused kernels: window -> RTI step -> plant step of every tick inside ONE launch, every instance running its own
     closed loop at its own pace (rti_fused_kernel_ticks with the plant update behind every step), against the same loop as three launches per
