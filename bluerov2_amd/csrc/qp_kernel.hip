@@ -214,6 +214,9 @@ bool pit_supported(int N, int win_L) {
     return windowed_resident(win_L) && win_L == N && N >= 24 && N <= 80 && windowed_lds_bytes(win_L) + kPitExtraDoubles * sizeof(double) <= 160 * 1024;
 }
 void launch_windowed(const DevParams& P, hipStream_t st) {
+    // development knob, read once per process: the long-horizon instantiations (interior-point vectors without register copies) at every horizon (A/B)
+    static const bool force_long = getenv("BROV_DEV_WIN_LONG") && atoi(getenv("BROV_DEV_WIN_LONG")) != 0;
+    const bool long_h = P.N > BROV_MAX_N_LDS || force_long;
     if (windowed_resident(P.win_L) || P.rti_split) {   // (the split launches are the resident mode's at every horizon)
         if (P.pit && P.pit_done && first_launch_on_device(3)) {
             (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -242,12 +245,12 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
             (void)hipFuncSetAttribute((const void*)rti_window_kernel_long_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done[dev] = true;
         }
-        if (P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+        if (long_h) hipLaunchKernelGGL(rti_window_kernel_long_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     }
-    else if (P.tsv && P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+    else if (P.tsv && long_h) hipLaunchKernelGGL(rti_window_kernel_long_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else if (P.tsv) hipLaunchKernelGGL(rti_window_kernel_grid, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
-    else if (P.N > BROV_MAX_N_LDS) hipLaunchKernelGGL(rti_window_kernel_long, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
+    else if (long_h) hipLaunchKernelGGL(rti_window_kernel_long, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     else hipLaunchKernelGGL(rti_window_kernel, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
 }
 bool windowed_is_resident(int win_L) { return windowed_resident(win_L); }
