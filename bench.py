@@ -734,6 +734,27 @@ def configs_block(ba, args, device):
                                kernel_kind=s.lds_kernel_info()["kind"])
             s.close()
         out[key] = dict(workload=what, **small)
+
+    # ---- horizons beyond the register copies of the interior-point vectors (128 < N <= 256, round 5: rti_window_kernel_long), 4096 instances.  The
+    # circle is sampled at the solver's own Ts = 1/N here: the sweep's window above advances one 0.05 s table row per node whatever Ts is, which at
+    # N >= 160 is a reference 8 to 13 times faster than the vehicle (the full-step SQP then diverges, in the oracle as on the GPU).
+    longh = {}
+    for N in (160, 256):
+        B, Ts = BATCH_PER_GPU, 1.0 / N
+        x0, _ = synthetic_inputs(B, seed=4)
+        t = np.arange(N + 1 + args.steps + args.warmup + 8) * Ts
+        tr = circle_trajectory(len(t))
+        tr[:, 0] = -2.0 * np.cos(t * 0.75); tr[:, 1] = -2.0 * np.sin(t * 0.75); tr[:, 5] = t * 0.75 - 0.5 * np.pi
+        s = ba.BatchSolver(B, ba.SolverOptions(N, Ts), device=device)
+        s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_trajectory(tr)
+        s.init_iterate_default()
+        dt = timed(lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()))
+        r = s.results()
+        longh[f"N{N}"] = dict(solves_per_s=B / dt, ms_per_step=dt * 1e3, status_nonzero=int((r["status"] != 0).sum()),
+                              ipm_instance_fraction=float((r["qp_iter"] > 0).mean()), kernel_path=int(s.last_kernel_path()))
+        s.close()
+    out["long_horizons"] = dict(workload="4096 instances, x0 as config 2 (seed 4), shared circle window sampled at Ts = 1/N; BROV_PATH_AUTO "
+                                         "(kernel_path 3 = windowed: its long-horizon instantiation)", **longh)
     return out
 
 
