@@ -585,7 +585,8 @@ def configs_block(ba, args, device):
         finally:
             os.environ.pop("BROV_CLOSED_LOOP_FUSED", None)
         s.set_x0(x0); s.set_params(ba.P_NOMINAL); s.set_plant_params(pt); s.set_trajectory(circ)
-        s.closed_loop(W, line0=0, log=False)
+        if W > 0:   # (--warmup 0 is a legal command line)
+            s.closed_loop(W, line0=0, log=False)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         s.closed_loop(K, line0=W, log=False)
         torch.cuda.synchronize(); dtc = (time.perf_counter() - t0) / K
