@@ -1125,6 +1125,9 @@ def main(argv=None):
         legs, out = [], None
         for (N, Ts) in wl["horizons"]:
             s, tick, shared = wl["make"](N, Ts, early)
+            if W == 0:   # --warmup 0: the one-off cost of the process's first launch (code object load, kernel attributes) is not a step of the workload
+                s0 = ba.BatchSolver(1, ba.SolverOptions(N, Ts), device=local_rank)
+                s0.set_params(ba.P_NOMINAL); s0.solve(sync=True); s0.close()
             # pass 1: the timed region that defines `value` (no per-kernel events inside)
             dt, _, (_, _, info) = run(s, tick, K, W, False, select)
             n_bad = int((s.results()["status"] != 0).sum())
