@@ -781,6 +781,15 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def carrier_order():
+    """the carriers of the per-step record all-gather, in the order they are probed (bluerov2_amd.distributed.choose_collective).
+    BROV_BENCH_COLLECTIVES="rccl,copy,gloo" is the default; BROV_BENCH_BACKEND=gloo (rounds 4-5: the development route that lets ranks
+    share a GPU) still means "gloo only"."""
+    if os.environ.get("BROV_BENCH_BACKEND", "nccl") != "nccl":
+        return [os.environ["BROV_BENCH_BACKEND"]]
+    return [c.strip() for c in os.environ.get("BROV_BENCH_COLLECTIVES", "rccl,copy,gloo").split(",") if c.strip()]
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -936,8 +945,27 @@ def dry_run(args, rank, world):
     lo, hi, total = shard_of(args, rank, world, 64)
     counts = [shard_of(args, r, world, 64)[1] - shard_of(args, r, world, 64)[0] for r in range(world)]
     B, Bmax = hi - lo, max(counts)
+    coll, trail = None, []
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # the same start-up as the real run: control plane with a bounded rendezvous, then the carriers probed in order under the watchdog
+        # (no GPU here: "rccl" and "copy" fail their probes on every rank and the selection lands on "gloo"; BROV_BENCH_FAULT injects hangs)
+        timeout_s = float(os.environ.get("BROV_BENCH_COLLECTIVE_TIMEOUT_S", "120"))
+        try:
+            D.init_control_plane(rank, world, timeout_s)
+        except D.RendezvousError as e:
+            if rank == 0:
+                sys.stdout.write(json.dumps({"metric": "NMPC RTI solves/s", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+                                             "warmup": args.warmup, "dry_run": True, "collective": "failed: " + str(e)}) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+        coll, trail = D.choose_collective(carrier_order(), rank, world, "cpu", timeout_s)
+        if coll is None:
+            if rank == 0:
+                sys.stdout.write(json.dumps({"metric": "NMPC RTI solves/s", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+                                             "warmup": args.warmup, "dry_run": True, "collective": "failed: " + D.describe_trail(trail),
+                                             "collective_trail": trail}) + "\n")
+                sys.stdout.flush()
+            os._exit(0)    # (a probe thread may be left hanging: no interpreter shutdown, no destructor of a half-built group)
     rec = np.zeros(B, dtype=RESULT_DTYPE)
     g = np.arange(lo, hi)
     rec["cost"] = 100.0 + ((g * 7919 + 266) % 1013) + g * 1e-9   # global minimum at a known, unique index
@@ -947,7 +975,11 @@ def dry_run(args, rank, world):
     local[: B * D.RECORD_BYTES] = torch.from_numpy(np.frombuffer(rec.tobytes(), dtype=np.uint8).copy())
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
-        allb = D.gather_records(local)
+        if coll is None:
+            allb = local.clone()
+        else:
+            allb = torch.empty(world * local.numel(), dtype=torch.uint8)
+            coll.all_gather_into(allb, local)
     dt = time.perf_counter() - t0
     ranks = torch.tensor([rank], dtype=torch.int64)
     seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
@@ -966,6 +998,7 @@ def dry_run(args, rank, world):
            "config": {"workload": "launcher / collective plumbing only", "config": args.config, "total_instances": total,
                       "instances_per_rank": counts},
            "ranks_seen": sorted(int(t.item()) for t in seen),
+           "collective": coll.name if coll else "none (one rank)", "collective_trail": trail,
            "select_best": {"index": gidx, "expected_index": int(np.argmin(cost)), "cost": float(best["cost"]),
                            "records_gathered": valid, "record_slots_gathered": int(allb.numel() // D.RECORD_BYTES)}}
     if world > 1:
@@ -998,30 +1031,34 @@ def main(argv=None):
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
-    # BROV_BENCH_BACKEND=gloo: development route -- the ranks share the visible GPUs round-robin (two ranks on the ONE GPU of a test
-    # box: real solvers, real records, real device-side selection, the collective through the host), since RCCL refuses two ranks on a GPU
+    # Ranks share the visible GPUs round-robin when asked to (BROV_BENCH_SHARE_GPUS=1, or the rounds-4/5 spelling BROV_BENCH_BACKEND=gloo):
+    # several ranks on the ONE GPU of a test box -- real solvers, real records, real device-side selection; RCCL refuses that placement,
+    # so the carrier selection below falls through to the peer-copy or the gloo carrier, which is exactly what the tests want to see.
     backend = os.environ.get("BROV_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
+    if backend != "nccl" or os.environ.get("BROV_BENCH_SHARE_GPUS") == "1":
         local_rank = local_rank % torch.cuda.device_count()
         os.environ["LOCAL_RANK"] = str(local_rank)   # workload() places its solver by it
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     gather0 = world > 1 or args.force_gather
-    if world > 1 or args.force_gather:
-        # RCCL writes its debug/warn lines to stdout; keep them away from the one JSON line this script must print
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
     import bluerov2_amd as ba
     from bluerov2_amd import distributed as D
-    def measure(args, extras_ok=True):
-        """one workload (args.config / args.scaling / ...) on this rank's GPU, all ranks together: (rank 0: the result line as a dict, else None)"""
+    # mrank / mworld: what measure() shards by (a rank that lost its peers at the rendezvous measures on its own: 0 / 1)
+    mrank, mworld = rank, world
+    coll, trail = None, []
+    timeout_s = float(os.environ.get("BROV_BENCH_COLLECTIVE_TIMEOUT_S", "120"))
+
+    def emit(line):
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+
+    def measure(args, extras_ok=True, solve_only=False):
+        """one workload (args.config / args.scaling / ...) on this rank's GPU, all ranks together: (rank 0: the result line as a dict, else None).
+        solve_only: no record all-gather in the steps (the pre-measurement a multi-rank run takes before it touches any data-plane collective)"""
+        rank, world = mrank, mworld
         wl = workload(args, rank, world)
-        gather = gather0 or (wl.get("always_gather", False) and dist.is_initialized())
+        gather = (gather0 or (wl.get("always_gather", False) and dist.is_initialized())) and not solve_only and coll is not None
         B, K, W = wl["B"], args.steps, args.warmup
         total = wl["total"]
         counts = [shard_of(args, r, world, B)[1] - shard_of(args, r, world, B)[0] for r in range(world)] if args.scaling == "strong" else [B] * world
@@ -1041,7 +1078,7 @@ def main(argv=None):
             gev = []   # (before gather, after gather, after select) events, one triple per timed step of the pass that times kernels
             if gather:   # communicator set-up and the first use of the buffers stay out of the timed region even with --warmup 0
                 with torch.cuda.stream(side):
-                    D.all_gather_into(gathered[0], stage[0])
+                    coll.all_gather_into(gathered[0], stage[0])
                 torch.cuda.synchronize()
             s.init_iterate_default()
             s.enable_timing(False)
@@ -1070,7 +1107,7 @@ def main(argv=None):
                         if not direct:
                             stage[j][: B * D.RECORD_BYTES].copy_(res_view, non_blocking=True)
                         if te: te[0].record(main)
-                        D.all_gather_into(gathered[j], res_view if direct else stage[j])
+                        coll.all_gather_into(gathered[j], res_view if direct else stage[j])
                         if te: te[1].record(main)
                         if select:
                             best = D.select_best_device(gathered[j])   # stays on the device; read after the timed region
@@ -1083,7 +1120,7 @@ def main(argv=None):
                     side.wait_event(ready[j])
                     with torch.cuda.stream(side):
                         if te: te[0].record(side)
-                        D.all_gather_into(gathered[j], stage[j])
+                        coll.all_gather_into(gathered[j], stage[j])
                         if te: te[1].record(side)
                         if select:
                             best = D.select_best_device(gathered[j])
@@ -1096,7 +1133,7 @@ def main(argv=None):
             ksec = np.zeros(2)
             torch.cuda.synchronize()
             if world > 1:
-                dist.barrier()
+                (coll.barrier() if gather else dist.barrier())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(warmup, warmup + steps):
@@ -1106,17 +1143,16 @@ def main(argv=None):
                     ksec += k2
             torch.cuda.synchronize()
             if world > 1:
-                dist.barrier()
+                (coll.barrier() if gather else dist.barrier())
             dt = time.perf_counter() - t0
             info = dict(per_rank_ms=[dt / max(steps, 1) * 1e3])
             if gev:   # side-stream event pairs: the collective itself and the device-side arg-min, per step
                 info["gather_ms"] = float(np.mean([a.elapsed_time(b) for a, b, _ in gev]))
                 info["select_ms"] = float(np.mean([b.elapsed_time(c) for _, b, c in gev])) if select else None
-            if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                every = torch.empty(world, dtype=torch.float64, device="cuda")
-                D.all_gather_into(every, tt)
-                info["per_rank_ms"] = [float(v) / max(steps, 1) * 1e3 for v in every.cpu()]
+            if world > 1:   # (control plane: host tensors over gloo)
+                every = torch.empty(world, dtype=torch.float64)
+                dist.all_gather_into_tensor(every, torch.tensor([dt], dtype=torch.float64))
+                info["per_rank_ms"] = [float(v) / max(steps, 1) * 1e3 for v in every]
                 dt = float(every.max().item())
             return dt, ksec / max(steps, 1), (gathered[(warmup + steps - 1) & 1] if gather else None, best, info)
 
@@ -1145,11 +1181,10 @@ def main(argv=None):
         value = total * K * len(legs) / total_dt
 
         ranks_seen = [0]
-        if dist.is_initialized():
-            rk = torch.tensor([rank], dtype=torch.int64, device=dev)
-            allr = torch.empty(world, dtype=torch.int64, device=dev)
-            D.all_gather_into(allr, rk)
-            ranks_seen = sorted(int(v) for v in allr.cpu())
+        if dist.is_initialized() and world > 1:
+            allr = torch.empty(world, dtype=torch.int64)
+            dist.all_gather_into_tensor(allr, torch.tensor([rank], dtype=torch.int64))
+            ranks_seen = sorted(int(v) for v in allr)
 
         if rank == 0:
             lg = legs[-1] if len(legs) == 1 else max(legs, key=lambda l: l["dt"])   # roofline: the (slowest) leg's dominant kernel
@@ -1207,8 +1242,10 @@ def main(argv=None):
                            "parallelism": (f"instances sharded over {world} GPU(s), one process per GPU, one all-gather of 104 B result "
                                            "records per step, enqueued behind the solve on its stream") if world > 1 else "single GPU"},
                 "ranks_seen": ranks_seen,
-                **({} if backend == "nccl" or not dist.is_initialized() else
-                   {"collective_backend": backend + " (development route: ranks share GPUs, collective through the host -- NOT a scaling measurement)"}),
+                "collective": (coll.name if gather else ("none: solve-only pre-measurement" if solve_only and world > 1 else "none (one rank, no gather)")),
+                **({"collective_trail": trail} if trail else {}),
+                **({"ranks_share_gpus": "ranks placed round-robin on the visible GPUs -- NOT a scaling measurement"}
+                   if world > torch.cuda.device_count() else {}),
                 "solver_status_nonzero": lg["n_bad"], "status_histogram": lg["status_hist"],
                 "mean_qp_iter": float(lg["qp_iter"].mean()), "ipm_instance_fraction": float((lg["qp_iter"] > 0).mean()),
                 "kernel_ms": kernel_ms, "device_bytes": lg["device_bytes"],
@@ -1237,7 +1274,9 @@ def main(argv=None):
         if gather:
             fin = torch.full((Bmax * D.RECORD_BYTES,), 0xFF, dtype=torch.uint8, device=dev)
             fin[: B * D.RECORD_BYTES].copy_(D.records_tensor_from_solver(s))
-            allrec = D.gather_records(fin)  # every rank takes part in the collective
+            allrec = torch.empty(world * fin.numel(), dtype=torch.uint8, device=dev)
+            coll.all_gather_into(allrec, fin)  # every rank takes part in the collective
+            torch.cuda.synchronize()
             if rank == 0:
                 idx, brec = D.select_best(allrec)
                 idx = D.padded_to_global(idx, counts)
@@ -1335,7 +1374,47 @@ def main(argv=None):
             out["host_boundary"] = host_boundary(ba, B)
         return out if rank == 0 else None
 
+    if gather0:
+        # ---- multi-rank start-up (round 6): nothing here may hang into the driver's timeout ----------------------------------------------
+        # (1) control plane, rendezvous bounded by BROV_BENCH_COLLECTIVE_TIMEOUT_S (default 120 s).  A rank whose peers never arrive
+        #     measures on its own; rank 0 still prints a line: "collective": "failed: rendezvous ...", value = what IT solved.
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")   # RCCL's warn lines stay away from the one JSON line on stdout
+        try:
+            D.init_control_plane(rank, world, timeout_s)
+        except D.RendezvousError as e:
+            if rank == 0:
+                mrank, mworld = 0, 1
+                pre_args = argparse.Namespace(**vars(args)); pre_args.no_traffic = pre_args.no_extra = True
+                pre = measure(pre_args, extras_ok=False, solve_only=True)
+                pre.update(n_gpus=world, collective="failed: " + str(e), note_collective="rank 0 alone: its own solve-only rate; no other rank was reached")
+                emit(pre)
+            os._exit(0)
+        # (2) every rank's solve-only rate, synchronised through the control plane only: known BEFORE any data-plane collective is touched
+        pre_args = argparse.Namespace(**vars(args)); pre_args.no_traffic = pre_args.no_extra = True
+        pre = measure(pre_args, extras_ok=False, solve_only=True)
+        cancel_guard = None
+        if rank == 0:
+            pre["note_collective"] = ("value = whole-job solves/s WITHOUT the per-step all-gather of result records (max over ranks, barrier through "
+                                      "the gloo control plane): the data-plane collective did not come up")
+            pre["per_rank_solve_only_solves_per_s"] = [pre["config"]["batch_per_gpu"] / (ms * 1e-3) for ms in pre["per_rank_ms"]]
+            import tempfile
+            fd, guard_path = tempfile.mkstemp(prefix="brov_bench_line_", suffix=".json")
+            with os.fdopen(fd, "w") as f:
+                f.write(json.dumps(dict(pre, collective="failed: deadline -- the run did not finish (BROV_BENCH_DEADLINE_S)")))
+            cancel_guard = D.start_deadline_guard(guard_path, float(os.environ.get("BROV_BENCH_DEADLINE_S", "1500")))
+        # (3) the carrier of the record all-gather: rccl -> copy -> gloo, each probed under a watchdog, all ranks deciding alike
+        coll, trail = D.choose_collective(carrier_order(), rank, world, f"cuda:{local_rank}", timeout_s)
+        if coll is None:
+            if rank == 0:
+                pre.update(collective="failed: " + D.describe_trail(trail), collective_trail=trail)
+                if cancel_guard:
+                    cancel_guard()
+                emit(pre)
+            os._exit(0)   # (a probe may be left hanging on its thread, and a collective kernel on the device: no interpreter shutdown)
     out = measure(args)
+    if gather0 and rank == 0:
+        out["solve_only"] = {"value": pre["value"], "unit": "solves/s", "ms_per_step": pre["ms_per_step"], "per_rank_ms": pre["per_rank_ms"],
+                             "note": "the same steps without the per-step all-gather (measured first, control-plane barrier only)"}
     default_run = args.config == 2 and args.scaling == "weak" and not args.force_ipm and not args.no_extra and not args.batch and not args.horizon
     if default_run and world == 1 and rank == 0 and os.environ.get("BROV_BENCH_STRONG_LEGS") != "1":
         # BASELINE.json configs[2..4] in the SAME line the driver records (round 3 had them in builder-run side files only)
@@ -1358,12 +1437,19 @@ def main(argv=None):
         out["cpu_baseline"] = cpu_baseline(BATCH_PER_GPU)
         if extra:
             out["cpu_baseline_single_thread"] = cpu_single_thread()
+    if coll is not None:
+        coll.close()
     if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.write(json.dumps(out) + "\n")
-        sys.stdout.flush()
+        if gather0 and cancel_guard:
+            cancel_guard()
+        emit(out)
+    if dist.is_initialized():
+        dist.barrier()
+        if trail and trail[0]["outcome"] != "ok":
+            os._exit(0)   # a carrier failed its probe on the way: its half-built group is not worth a destructor that may wait for peers
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -25,10 +25,14 @@ struct brov_shim_state {
     bool dirty_x0 = true, dirty_yref = true, dirty_par = true, dirty_iter = false, dirty_opts = false;
     bool iter_host_valid = true;  // host mirror of the iterate is current
     int rti_phase = 0;
+    int last_phase = 0;       // the phase the last call actually ran (a feedback call without a preparation runs phase 0)
+    bool prepared = false;    // a preparation (rti_phase 1) of the current iterate, under the current options, is parked in the solver
     double time_tot = 0.0, time_lin = 0.0, time_qp = 0.0;
     bool times_valid = false, timing_on = false;
     brov_result last{};
-    int last_status = 0;
+    int last_status = 0;      // NLP status of the last call as acados reports it (ocp_nlp_get "status")
+    int last_qp_status = 0;   // the QP's own verdict (ocp_nlp_get "qp_status", the qp_stat column of "statistics")
+    bool strict_maxiter = false;   // BROV_SHIM_MAXITER_STATUS=2: hand the batched API's status 2 through instead of acados' 0
 };
 
 static brov_shim_state* st_of(bluerov2_solver_capsule* c) { return c ? c->shim : nullptr; }
@@ -80,6 +84,14 @@ int bluerov2_acados_create_with_discretization(bluerov2_solver_capsule* c, int N
         const char* of = std::getenv("BROV_ON_FAILURE");
         s->opts.on_failure = (of && (!std::strcmp(of, "restart") || !std::strcmp(of, "RESTART") || !std::strcmp(of, "1")))
                                  ? BROV_ON_FAILURE_RESTART : BROV_ON_FAILURE_KEEP;
+    }
+    // SQP_RTI's return code when the QP stopped at its iteration limit (qp_iter_max, :668): upstream takes the step and returns
+    // ACADOS_SUCCESS -- the node's `if (acados_status != 0) return;` (mpc.cpp:63-68) therefore publishes
+    // on such a tick -- and so does the drop-in; the QP's own status 2 stays visible through "qp_status" / "statistics" /
+    // print_stats.  BROV_SHIM_MAXITER_STATUS=2 hands the batched API's 2 through instead (a stricter caller's choice).
+    {
+        const char* ms = std::getenv("BROV_SHIM_MAXITER_STATUS");
+        s->strict_maxiter = ms && std::atoi(ms) == ACADOS_MAXITER;
     }
     // which GPU: the reference has no such notion; BROV_DEVICE selects one on a multi-GPU host (default 0)
     const char* dev_env = std::getenv("BROV_DEVICE");
@@ -164,6 +176,8 @@ int bluerov2_acados_reset(bluerov2_solver_capsule* c, int) {  // :797-830: itera
     if (brov_reset(s->solver) != BROV_OK) return 1;
     s->last = brov_result{};
     s->last_status = 0;
+    s->last_qp_status = 0;
+    s->prepared = false;
     s->iter_host_valid = true;
     s->dirty_iter = false;   // brov_reset has zeroed the device iterate too
     return 0;
@@ -224,25 +238,36 @@ int ocp_nlp_solve(ocp_nlp_solver* solver, ocp_nlp_in*, ocp_nlp_out* out) {  // w
     brov_shim_state* s = solver ? solver->shim : nullptr;
     if (!s) return ACADOS_QP_FAILURE;
     const auto t0 = std::chrono::steady_clock::now();
+    // A FEEDBACK call (rti_phase 2) without a preparation of the current iterate -- none yet, a second feedback on one preparation, or
+    // options / grid / iterate rewritten in between: acados would solve the QP left in its memory, i.e. step on a linearisation of an
+    // iterate that is gone.  The batched API refuses that (BROV_ERR_ARG); the drop-in takes the whole step (preparation + feedback in
+    // one launch) on the CURRENT iterate instead -- the call does not fail and the step is never staler than acados' would be.
+    // (Documented in INTEGRATION.md section 1; the reference's callers only use phase 0.)
+    int phase = s->rti_phase;
+    if (phase == 2 && (!s->prepared || s->dirty_opts || s->dirty_grid || s->dirty_iter)) phase = 0;
     int rc = push_rare_inputs(s);
     brov_result r{};
     if (rc == BROV_OK) {
         rc = brov_tick_host(s->solver, s->dirty_x0 ? s->x0.data() : nullptr, s->dirty_yref ? s->yref.data() : nullptr,
-                            s->dirty_par ? s->par.data() : nullptr, s->rti_phase, &r);
+                            s->dirty_par ? s->par.data() : nullptr, phase, &r);
         if (rc == BROV_OK) s->dirty_x0 = s->dirty_yref = s->dirty_par = false;
     }
+    s->prepared = rc == BROV_OK && phase == 1;
     if (rc != BROV_OK) {
         std::fprintf(stderr, "bluerov2_acados_solve: MI355X solver error %d: %s\n", rc, brov_last_error());
         return ACADOS_QP_FAILURE;
     }
     s->iter_host_valid = false;
-    s->last = r;
+    s->last_phase = phase;
+    if (phase != 1) s->last = r;   // (a preparation moves nothing: the record of the last step stays what the getters answer from)
     s->times_valid = false;   // kernel times are read from the events when (if) the caller asks for them: not a wait of every tick
     s->time_tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (s->rti_phase == 1) return ACADOS_SUCCESS;  // preparation only: nothing to report
+    if (phase == 1) return ACADOS_SUCCESS;  // preparation only: nothing to report
     if (out) out->inf_norm_res = r.kkt;
-    s->last_status = r.status;
-    return r.status;
+    // status mapping (see create): QP at its iteration limit, step taken -> ACADOS_SUCCESS as upstream SQP_RTI; 1 / 3 / 4 as they are
+    s->last_qp_status = r.status;
+    s->last_status = (r.status == ACADOS_MAXITER && !s->strict_maxiter) ? ACADOS_SUCCESS : r.status;
+    return s->last_status;
 }
 
 int ocp_nlp_precompute(ocp_nlp_solver*, ocp_nlp_in*, ocp_nlp_out*) { return ACADOS_SUCCESS; }
@@ -268,7 +293,7 @@ void bluerov2_acados_print_stats(bluerov2_solver_capsule* c) {  // :1001-1028 (R
     brov_shim_state* s = st_of(c);
     if (!s) return;
     std::printf("iter\tqp_stat\tqp_iter\n");
-    std::printf("%d\t%d\t%d\n", 1, s->last.status == 0 ? 0 : s->last.status, s->last.qp_iter);
+    std::printf("%d\t%d\t%d\n", 1, s->last_qp_status, s->last.qp_iter);
 }
 
 int bluerov2_acados_custom_update(bluerov2_solver_capsule*, double*, int) {  // :1030-1036
@@ -395,7 +420,7 @@ void ocp_nlp_out_get(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_out* out, int stage
     if (stage < 0 || stage > s->N) return;
     // the node's per-tick read (bluerov2_dob.cpp:388: "u" of stage 0) is answered from the result record of the last solve: after a
     // successful step its u0 IS the new first input, after a failed one the held input (below) -- no copy of the iterate off the device
-    if (stage == 0 && !std::strcmp(field, "u") && !s->iter_host_valid && s->rti_phase != 1) { std::memcpy(v, s->last.u0, 4 * sizeof(double)); return; }
+    if (stage == 0 && !std::strcmp(field, "u") && !s->iter_host_valid && s->last_phase != 1) { std::memcpy(v, s->last.u0, 4 * sizeof(double)); return; }
     pull_iterate(s);
     if (!std::strcmp(field, "x")) std::memcpy(v, &s->x[(size_t)stage * 12], 12 * sizeof(double));
     else if (!std::strcmp(field, "u")) {
@@ -428,11 +453,12 @@ void ocp_nlp_get(ocp_nlp_config*, ocp_nlp_solver* solver, const char* field, voi
     else if (!std::strcmp(field, "sqp_iter")) *(int*)value = 1;                   // RTI: one iteration per call
     else if (!std::strcmp(field, "qp_iter")) *(int*)value = s->last.qp_iter;
     else if (!std::strcmp(field, "status")) *(int*)value = s->last_status;
+    else if (!std::strcmp(field, "qp_status") || !std::strcmp(field, "qp_stat")) *(int*)value = s->last_qp_status;
     else if (!std::strcmp(field, "stat_n")) *(int*)value = 2;
     else if (!std::strcmp(field, "stat_m")) *(int*)value = 2;
     else if (!std::strcmp(field, "statistics")) {  // (stat_n+1) x nrow, column-major: [iter, qp_stat, qp_iter]
         double* st = (double*)value;
-        st[0] = 0; st[1] = 1; st[2] = 0; st[3] = s->last.status; st[4] = 0; st[5] = s->last.qp_iter;
+        st[0] = 0; st[1] = 1; st[2] = 0; st[3] = s->last_qp_status; st[4] = 0; st[5] = s->last.qp_iter;
     } else if (!std::strcmp(field, "cost_value")) *(double*)value = s->last.cost;
 }
 

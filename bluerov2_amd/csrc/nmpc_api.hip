@@ -259,6 +259,10 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
         return BROV_ERR_NO_DEVICE;
     }
     HIPCHK(hipSetDevice(device));
+    {   // the kernels' dynamic-LDS limits on this device (once per device, checked): a refusal fails the create, not the first launch
+        std::string why;
+        if (int prc = prepare_kernels_on_device(&why)) { g_err = "brov_create: " + why; return prc; }
+    }
     brov_solver* s = new brov_solver();
     s->device = device;
     s->B = B;
@@ -322,7 +326,6 @@ extern "C" int brov_create(brov_solver** out, int device, int B, const brov_opts
         (void)hipGetDevice(&dev_);
         (void)hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_);
         if (B <= cus_) {
-            (void)windowed_blocks(opts->N, B, opts->N);   // (sets the kernels' LDS attribute on first use)
             AL(ws_split, (size_t)B * windowed_ws_doubles(opts->N, opts->N));
         }
     }
@@ -624,10 +627,11 @@ extern "C" int brov_traj_set_host(brov_solver* s, const double* traj, int rows) 
     if (!s || !traj || rows < 1) return BROV_ERR_ARG;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(sync_last(s));
-    if (s->yref_view) {   // the window in force is a view into the table that is about to go: keep a copy
+    if (s->yref_view)     // the window in force is a view into the table that is about to go: keep a copy
         HIPCHK(hipMemcpy(s->yref_sh, s->yref_view, (size_t)(s->N + 1) * 16 * sizeof(double), hipMemcpyDeviceToDevice));
-        s->yref_view = nullptr; s->traj_line = -1;
-    }
+    // whatever window is in force -- a view, or one launch_window built from the OLD table (12 columns, end padding) -- no longer names a
+    // line of the table that is coming: brov_solve_ticks(row_stride > 0) must not walk the new table from the old one's line
+    s->yref_view = nullptr; s->traj_line = -1;
     if (s->traj) { hipFree(s->traj); s->traj = nullptr; }
     HIPCHK(hipMalloc((void**)&s->traj, (size_t)rows * 16 * sizeof(double)));
     HIPCHK(hipMemcpy(s->traj, traj, (size_t)rows * 16 * sizeof(double), hipMemcpyHostToDevice));
@@ -643,7 +647,7 @@ extern "C" int brov_set_yref_from_traj(brov_solver* s, int line, int ncols, void
         // the window is N+1 consecutive whole rows of the resident table: use them where they lie (no kernel, no copy)
         s->yref_view = s->traj + (size_t)line * 16;
     } else {
-        s->yref_view = nullptr; s->traj_line = -1;
+        s->yref_view = nullptr;
         launch_window(s->traj, s->traj_rows, nullptr, line, 1, s->N, ncols, s->yref_sh, (hipStream_t)stream);
     }
     s->traj_line = line; s->traj_ncols = ncols;
@@ -796,7 +800,9 @@ extern "C" int brov_closed_loop(brov_solver* s, int ticks, int line0, int ncols,
             P.ticks = ticks; P.tick_yref = 16; P.tick_status = dst;
             P.plant_pp = s->pplant; P.plant_rp = plant_rp(s); P.plant_rp_stride = plant_rp_stride(s); P.plant_substeps = substeps; P.plant_dt = dt;
             P.x0_rw = s->x0; P.plant_xlog = dx ? dx + B * 12 : nullptr; P.plant_ulog = du;
+            if (s->timing) { hipEventRecord(s->ev[0], st); hipEventRecord(s->ev[1], st); }   // (as brov_solve_ticks: brov_last_solve_seconds then reports THIS launch)
             launch_ticks(s, P, st, which);
+            if (s->timing) { hipEventRecord(s->ev[2], st); s->ev_valid = true; }
             s->traj_line = line0 + ticks - 1; s->yref_view = s->traj + (size_t)s->traj_line * 16;
         }
     }
@@ -1062,6 +1068,10 @@ extern "C" int brov_tick_buffers(brov_solver* s, double** x0, double** yref_shar
     HIPCHK(hipSetDevice(s->device));
     if (int rc = tick_pin(s)) return rc;
     const size_t B = s->B, N1 = s->N + 1;
+    // input set 0 is the caller's from here on and "may be rewritten freely" (header): refresh copies an EARLIER copying tick left running out
+    // of set 0 (copy_stream; they read it) must be over before the pointers go out -- the wait at the top of the next brov_tick_host comes
+    // after the caller's writes (round-5 advisor)
+    if (s->set_pending[0]) { HIPCHK(hipEventSynchronize(s->ev_set[0])); s->set_pending[0] = false; }
     s->buffers_out = true;
     if (x0) *x0 = s->pin;
     if (yref_shared) *yref_shared = s->pin + B * 12;
@@ -1233,7 +1243,7 @@ extern "C" int brov_set_opts(brov_solver* s, const brov_opts* o) {
     if (o->kernel_path == BROV_PATH_FUSED && !fused_supported(o->N) && !s->ws) {
         // the windowed kernel's workspace is allocated at create, from the path and batch asked for then
         g_err = "brov_set_opts: BROV_PATH_FUSED at this horizon needs the windowed kernel's workspace, which this solver was created without "
-                "(created with BROV_PATH_STREAMING, or BROV_PATH_AUTO at a batch of <= 8): create it with BROV_PATH_FUSED";
+                "(created with BROV_PATH_STREAMING): create it with BROV_PATH_AUTO or BROV_PATH_FUSED";
         return BROV_ERR_ARG;
     }
     HIPCHK(hipSetDevice(s->device));

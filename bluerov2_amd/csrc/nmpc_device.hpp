@@ -1,5 +1,6 @@
 // nmpc_device.hpp -- device-side parameter block and HBM layout shared by the kernels and the host API.
 #pragma once
+#include <string>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -104,6 +105,7 @@ struct DevKnobs {
 enum { IPM_V = 0, IPM_TL, IPM_TU, IPM_LL, IPM_LU, IPM_GAM, IPM_RT, IPM_DVA, IPM_ACT, IPM_NARR };
 
 int sched_buffer_ints_host(int B);   // int32 per work-ordering buffer (three of them)
+int prepare_kernels_on_device(std::string* why);   // dynamic-LDS limits of every solver kernel on the CURRENT device, once per device, checked (brov_create)
 void launch_linearise(const DevParams& P, hipStream_t st);
 void launch_qp(const DevParams& P, hipStream_t st);
 void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k);

@@ -34,6 +34,8 @@
 // and this file: the __global__ instantiations between the layers they need (qp_kernel + lin_wave_kernel[_grid] streaming pair,
 // rti_fused_kernel / _w2 / _grid / _mail, rti_window_kernel[_grid], its resident mode rti_window_kernel_res[_grid][_split], rti_pit_kernel[_fb][_grid]),
 // their launchers and two test hooks.
+#include <mutex>
+#include <string>
 #include <type_traits>
 
 #include "lin_device.hpp"
@@ -98,15 +100,6 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel_ticks(DevParams P) { r
 // SIMD, because the step loop's few live values no longer fit the 256 registers of the two-wave form without scratch)
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_ticks_w2(DevParams P) { rti_fused_body<2, false, false, true>(P); }
 
-// function attributes are per device (a process may hold solvers on several GPUs): one flag per (launcher, device)
-static bool first_launch_on_device(int which) {
-    static bool done[4][64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    const bool first = !done[which][dev];
-    done[which][dev] = true;
-    return first;
-}
 }  // namespace brov
 
 #include "qp/windowed.hpp"
@@ -138,13 +131,56 @@ __global__ __launch_bounds__(64, 1) void rti_window_kernel_long(DevParams P) { r
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_long_grid(DevParams P) { rti_window_body<false, true, false, false, true>(P); }
 __global__ __launch_bounds__(64, 1) void rti_window_kernel_long_ticks(DevParams P) { rti_window_body<false, false, false, true, true>(P); }
 
+// The dynamic-LDS limit of every solver kernel (anything above 64 KB has to be asked for, per function and PER DEVICE), set ONCE per device and
+// CHECKED: brov_create calls this with its device current, so a runtime that refuses a limit fails the create with its reason instead of the
+// first launch with "invalid argument" -- and no launcher carries a lazy "first launch" flag any more.  Round 5's flags were plain statics,
+// flipped BEFORE the attribute calls ran: a second host thread making its first launch on the same device (one rank object per thread,
+// tests/test_gpu_group_loopback.py) could launch with > 64 KB ahead of the attribute.  std::call_once blocks that thread until the calls are over.
+int prepare_kernels_on_device(std::string* why) {
+    struct KernelLimit { const void* fn; int bytes; const char* name; };
+#define BROV_KL(k, kb) {(const void*)k, kb * 1024, #k}
+    static const KernelLimit limits[] = {
+        BROV_KL(lin_wave_kernel, 64), BROV_KL(lin_wave_kernel_grid, 64),
+        BROV_KL(rti_fused_kernel, 160), BROV_KL(rti_fused_kernel_w2, 160), BROV_KL(rti_fused_kernel_grid, 160), BROV_KL(rti_fused_kernel_mail, 160),
+        BROV_KL(rti_fused_kernel_ticks, 160), BROV_KL(rti_fused_kernel_ticks_w2, 160),
+        BROV_KL(rti_window_kernel, 160), BROV_KL(rti_window_kernel_grid, 160), BROV_KL(rti_window_kernel_ticks, 160),
+        BROV_KL(rti_window_kernel_res, 160), BROV_KL(rti_window_kernel_res_grid, 160), BROV_KL(rti_window_kernel_res_split, 160),
+        BROV_KL(rti_window_kernel_res_split_grid, 160),
+        BROV_KL(rti_window_kernel_long, 160), BROV_KL(rti_window_kernel_long_grid, 160), BROV_KL(rti_window_kernel_long_ticks, 160),
+        BROV_KL(rti_pit_kernel, 160), BROV_KL(rti_pit_kernel_grid, 160), BROV_KL(rti_pit_kernel_fb, 160), BROV_KL(rti_pit_kernel_fb_grid, 160),
+    };
+#undef BROV_KL
+    constexpr int kMaxDev = 64;
+    static std::once_flag once[kMaxDev];
+    static std::string failure[kMaxDev];   // written inside call_once, read after it: ordered by call_once itself
+    auto set_all = [](std::string& err) {
+        for (const KernelLimit& k : limits) {
+            const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                err = std::string("hipFuncSetAttribute(") + k.name + ", MaxDynamicSharedMemorySize, " + std::to_string(k.bytes) + "): " + hipGetErrorString(e);
+                return;
+            }
+        }
+    };
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { if (why) *why = "hipGetDevice failed"; return BROV_ERR_HIP; }
+    std::string local;
+    if (dev >= 0 && dev < kMaxDev) {
+        std::call_once(once[dev], [&] { set_all(failure[dev]); });
+        local = failure[dev];
+    } else {
+        static std::mutex mu;   // (a device index beyond the table: no cache, one thread at a time)
+        std::lock_guard<std::mutex> g(mu);
+        set_all(local);
+    }
+    if (!local.empty()) { if (why) *why = local; return BROV_ERR_HIP; }
+    return BROV_OK;
+}
+
 void launch_linearise(const DevParams& P, hipStream_t st) {
     const int C = lin_chunk_len(P.N);
     const size_t lds = ((size_t)C * (kBaStage + NX + kRecInterval + NU) + (size_t)(C + 1) * NX + 64) * sizeof(double);
-    if (first_launch_on_device(0)) {
-        (void)hipFuncSetAttribute((const void*)lin_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)lin_wave_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    }
     if (P.tsv) hipLaunchKernelGGL(lin_wave_kernel_grid, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
     else hipLaunchKernelGGL(lin_wave_kernel, dim3(P.B * lin_chunks(P.N)), dim3(64), lds, st, P);
 }
@@ -173,16 +209,6 @@ int windowed_stage_count(int N, int B) {
 size_t windowed_ws_doubles(int N, int L) { return win_ws_doubles(N, L); }
 static bool windowed_resident(int L) { return L > kWinMaxStages; }
 int windowed_blocks(int N, int B, int L) {
-    if (first_launch_on_device(2)) {
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_long, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_long_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_window_kernel_res_split_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     int dev = 0, cus = 256, per_cu = 4;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -200,7 +226,8 @@ int windowed_blocks(int N, int B, int L) {
 // it leaves, instead of the windowed kernel: 512 instances at N = 80 take 0.154 ms against 0.192 ms (N = 60: 0.135 / ~0.153; N = 40:
 // 0.120 / 0.114 -- hence the lower limit; scripts/dev/mid_batch_rate.py).  What the parallel kernel leaves (instances with many active
 // bounds) starts only then, on one wave: a batch with a quarter of its instances saturated would lose 20 % against the windowed kernel --
-// the host follows the number of instances left (nmpc_api.hip, kPitPause; BROV_PIT_ROUNDS=0 keeps the windowed kernel altogether).  Decided per solve: the solver is created for the windowed kernel and with a
+// since round 5 the parallel kernel runs the whole QP loop itself (qp/pit.hpp), so what it leaves are only the instances it gives up on
+// (BROV_PIT_ROUNDS=0 keeps the windowed kernel altogether).  Decided per solve: the solver is created for the windowed kernel and with a
 // workspace that serves either.  Returns the resident stage count (= N) or 0.
 constexpr int kPitRounds = 2, kPitRoundsMinN = 48;
 int pit_rounds_stages(int N, int B) {
@@ -218,12 +245,6 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
     static const bool force_long = getenv("BROV_DEV_WIN_LONG") && atoi(getenv("BROV_DEV_WIN_LONG")) != 0;
     const bool long_h = P.N > BROV_MAX_N_LDS || force_long;
     if (windowed_resident(P.win_L) || P.rti_split) {   // (the split launches are the resident mode's at every horizon)
-        if (P.pit && P.pit_done && first_launch_on_device(3)) {
-            (void)hipFuncSetAttribute((const void*)rti_pit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)rti_pit_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)rti_pit_kernel_fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)rti_pit_kernel_fb_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
         if (P.pit && P.pit_done && P.rti_split == 2) {   // feedback of a split tick: the quarters rolled out at once from what the preparation parked
             if (P.tsv) hipLaunchKernelGGL(rti_pit_kernel_fb_grid, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
             else hipLaunchKernelGGL(rti_pit_kernel_fb, dim3(P.pit_blocks), dim3(256), windowed_lds_bytes(P.win_L) + kPitExtraDoubles * sizeof(double), st, P);
@@ -238,13 +259,6 @@ void launch_windowed(const DevParams& P, hipStream_t st) {
         else hipLaunchKernelGGL(rti_window_kernel_res, dim3(P.win_blocks), dim3(256), windowed_lds_bytes(P.win_L), st, P);
     }
     else if (P.ticks > 0) {
-        static bool attr_done[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
-            (void)hipFuncSetAttribute((const void*)rti_window_kernel_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)rti_window_kernel_long_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done[dev] = true;
-        }
         if (long_h) hipLaunchKernelGGL(rti_window_kernel_long_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
         else hipLaunchKernelGGL(rti_window_kernel_ticks, dim3(P.win_blocks), dim3(64), windowed_lds_bytes(P.win_L), st, P);
     }
@@ -276,13 +290,11 @@ void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4], const Dev
         fn = res ? (const void*)rti_window_kernel_res : (const void*)rti_window_kernel;
         threads = res ? 256 : 64;
         kind = res ? 4 : 3;
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     } else {
         lds = fused_lds_bytes(N);
         const bool w2 = fused_two_wave(lds, k.fused_waves);
         fn = w2 ? (const void*)rti_fused_kernel_w2 : (const void*)rti_fused_kernel;
         kind = w2 ? 2 : 1;
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = -1;
@@ -290,25 +302,12 @@ void lds_kernel_info(int N, int win_L, bool windowed, int32_t info[4], const Dev
 }
 void launch_fused_ticks(const DevParams& P, hipStream_t st, const DevKnobs& k) {
     const size_t lds = fused_lds_bytes(P.N);
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_ticks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_ticks_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done[dev] = true;
-    }
     // the variant a single step of this solver runs (two waves per SIMD for short horizons): the steps are then the same code on the same data
     if (fused_two_wave(lds, k.fused_waves)) hipLaunchKernelGGL(rti_fused_kernel_ticks_w2, dim3(P.B), dim3(64), lds + (size_t)k.lds_pad, st, P);
     else hipLaunchKernelGGL(rti_fused_kernel_ticks, dim3(P.B), dim3(64), lds + (size_t)k.lds_pad, st, P);
 }
 void launch_fused(const DevParams& P, hipStream_t st, const DevKnobs& k) {
     const size_t lds = fused_lds_bytes(P.N);
-    if (first_launch_on_device(1)) {
-        (void)hipFuncSetAttribute((const void*)rti_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_grid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rti_fused_kernel_mail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     // development knobs (scripts/dev/occupancy_probe.py): pad the LDS request / force a variant (1, 2; default by LDS size)
     const size_t pad = (size_t)k.lds_pad;
     const bool w2 = fused_two_wave(lds, k.fused_waves);

@@ -1,7 +1,20 @@
 /* acados_shim/acados_solver_bluerov2.h -- drop-in for the reference's generated solver header
  * (/root/reference/bluerov2_dobmpc/scripts/c_generated_code/acados_solver_bluerov2.h:42-167): same macros, same capsule
  * member names, same entry points; implemented by libacados_ocp_solver_bluerov2.so of THIS repository on top of the
- * MI355X batched solver (include/bluerov2_nmpc.h) with batch = 1.  See INTEGRATION.md. */
+ * MI355X batched solver (include/bluerov2_nmpc.h) with batch = 1.  See INTEGRATION.md.
+ *
+ * Where the drop-in has a choice the generated code does not state, it follows upstream acados, and each
+ * choice has an opt-out in the environment, read once at bluerov2_acados_create:
+ *   return code    0 = step taken (also when the QP stopped at qp_iter_max: SQP_RTI returns ACADOS_SUCCESS there; "qp_status" /
+ *                  "statistics" / print_stats keep the QP's 2), 1 = NaN, 3 / 4 = step not taken.  BROV_SHIM_MAXITER_STATUS=2
+ *                  returns the 2 instead.
+ *   failed step    the iterate stays as it was (acados returns before update_variables) and ocp_nlp_out_get(.., 0, "u") holds the
+ *                  last successfully computed input, clamped into the box.  BROV_ON_FAILURE=restart cold-starts the iterate at
+ *                  the measured state instead.
+ *   rti_phase 2    without a preparation of the current iterate: preparation + feedback in one call (acados would reuse the QP in
+ *                  its memory; the batched brov_solve_phase refuses).
+ *   BROV_DEVICE=<i> selects the GPU (default 0); BROV_SHIM_TIMING=1 records kernel times ("time_lin" / "time_qp_sol") from the
+ *                  first tick on (default: from the first request on; "time_tot" is always the host wall time of the call). */
 #ifndef ACADOS_SOLVER_bluerov2_H_
 #define ACADOS_SOLVER_bluerov2_H_
 

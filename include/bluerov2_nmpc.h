@@ -186,7 +186,10 @@ int brov_solve(brov_solver* s, void* stream);
  * instance per CU at N <= 81: the preparation also runs the step-0 factor sweep -- it does not depend on x0 -- and
  * parks the factorised LDS image; the feedback is forward sweep + bound check + step + record (a batch of one at N = 80 through
  * brov_tick_host: 33 us from the measurement to u0, against 71 us for rti_phase 0); a call that changes the iterate, the grid or the options
- * between the two makes the feedback fail (BROV_ERR_ARG: repeat the preparation).  Elsewhere: linearisation / QP on the streaming pair. */
+ * between the two makes the feedback fail (BROV_ERR_ARG: repeat the preparation) -- and so does a feedback call with no fresh preparation
+ * at all (none since the last step, e.g. a second rti_phase 2 on one preparation): the iterate that was linearised is gone.  acados itself
+ * would re-solve the QP in its memory; the acados-shaped drop-in turns such a call into a whole step (rti_phase 0) instead of failing.
+ * Elsewhere: linearisation / QP on the streaming pair. */
 int brov_solve_phase(brov_solver* s, void* stream, int rti_phase);
 /* `ticks` consecutive RTI steps of every instance, the measured state held, the shared reference window moving on `row_stride` rows of the
  * resident trajectory table per step (0: the window in force stays -- several SQP iterations on one problem, e.g. candidates iterated to

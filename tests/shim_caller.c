@@ -2,7 +2,8 @@
  * same sequence of calls as the reference's control tick (BLUEROV2_DOB::solve, bluerov2_dobmpc/src/bluerov2_dob.cpp:306-388):
  * lbx/ubx <- x0, update_params for stages 0..N, yref for stages 0..N, solve, status / inf_norm_res / time_tot / u0.
  * Inputs come from a binary file written by the test (x0[12], p[16], nticks, yref[nticks][N+1][16]); results go to stdout.
- * A second argument "F" appends a failed step (NaN measurement) and a recovery tick; "G" creates the solver on a non-uniform grid. */
+ * A second argument "F" appends a failed step (NaN measurement) and a recovery tick; "G" creates the solver on a non-uniform grid;
+ * "M" appends a tick whose QP stops at its iteration limit (qp_iter_max = 1, inputs limited to +-8, the vehicle metres off). */
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -89,6 +90,28 @@ int main(int argc, char** argv) {
         st = bluerov2_acados_solve(mpc_capsule);
         ocp_nlp_out_get(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_out, 0, "u", (void*)u0);
         printf("RECOVERED status %d u0 %.17g %.17g %.17g %.17g\n", st, u0[0], u0[1], u0[2], u0[3]);
+    }
+    if (argc >= 3 && argv[2][0] == 'M') {
+        /* the QP at its iteration limit: acados' SQP_RTI takes the step and returns ACADOS_SUCCESS, so the
+         * node's `if (acados_status != 0) return;` (mpc.cpp:63-68) publishes the new input; the QP's own status stays readable */
+        double lb[BLUEROV2_NU] = {-8, -8, -8, -8}, ub[BLUEROV2_NU] = {8, 8, 8, 8}, far[BLUEROV2_NX], u0[BLUEROV2_NU];
+        int one = 1, nlp_status = -1, qp_status = -1, qp_iter = -1;
+        for (int j = 0; j < BLUEROV2_NX; j++) far[j] = x0[j];
+        far[0] += 6.0; far[1] -= 6.0; far[2] += 4.0;
+        for (int i = 0; i < BLUEROV2_N; i++) {   /* acados_solver_bluerov2.c:559-573: the same box on every stage */
+            ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, i, "lbu", lb);
+            ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, i, "ubu", ub);
+        }
+        ocp_nlp_solver_opts_set(mpc_capsule->nlp_config, mpc_capsule->nlp_opts, "qp_iter_max", &one);
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "lbx", far);
+        ocp_nlp_constraints_model_set(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_in, 0, "ubx", far);
+        int st = bluerov2_acados_solve(mpc_capsule);
+        ocp_nlp_get(mpc_capsule->nlp_config, mpc_capsule->nlp_solver, "status", &nlp_status);
+        ocp_nlp_get(mpc_capsule->nlp_config, mpc_capsule->nlp_solver, "qp_status", &qp_status);
+        ocp_nlp_get(mpc_capsule->nlp_config, mpc_capsule->nlp_solver, "qp_iter", &qp_iter);
+        ocp_nlp_out_get(mpc_capsule->nlp_config, mpc_capsule->nlp_dims, mpc_capsule->nlp_out, 0, "u", (void*)u0);
+        printf("MAXITER returned %d status %d qp_status %d qp_iter %d u0 %.17g %.17g %.17g %.17g\n", st, nlp_status, qp_status, qp_iter,
+               u0[0], u0[1], u0[2], u0[3]);
     }
     bluerov2_acados_print_stats(mpc_capsule);
     /* misuse that must not kill the process */

@@ -253,7 +253,7 @@ def test_runtime_option_change_and_reset(ba, oracle, golden_traj):
     assert np.all(s.get_iterate()[0][:, :, 2] == -20.0)
 
 
-@pytest.mark.parametrize("N,B", [(20, 7), (160, 3)])   # (N = 160: beyond the LDS-resident kernels, where the streaming pair is what BROV_PATH_AUTO runs)
+@pytest.mark.parametrize("N,B", [(20, 7), (160, 3)])   # (N = 160: the windowed kernel's long-horizon instantiation under BROV_PATH_AUTO; its rti_phase 1 / 2 run on the streaming pair)
 def test_rti_phase_split_equals_full_step(ba, golden_traj, N, B):
     x0, circ = _inputs(golden_traj, B, seed=6)
     circ = np.concatenate([circ, np.repeat(circ[-1:], 200, axis=0)])

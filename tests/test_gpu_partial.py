@@ -1,7 +1,7 @@
 """Partial refactorisation of the active-set tries (round 4, fused kernels: riccati_backward_partial in qp_kernel.hip): a try whose
 pinned inputs all sit in the first ceil(N / 4) stages restarts its factor sweep from the checkpoint the step-0 sweep left behind.
 What it computes for the skipped stages is what a full sweep would compute again, so the results must be BIT-IDENTICAL with the
-feature switched off (BROV_PARTIAL_REFACTOR=0, read at every solve) -- iterate, multipliers, records, Newton-system counts -- on
+feature switched off (BROV_PARTIAL_REFACTOR=0, read when the solver is created) -- iterate, multipliers, records, Newton-system counts -- on
 workloads that take the partial path (far-off instances under the shipped box: pins in the first stages), that fall back to full
 sweeps (tight boxes: pins deep into the horizon; interior-point iterations) and that mix both within one QP."""
 import os
