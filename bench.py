@@ -225,6 +225,26 @@ def algorithmic_bytes(N, shared_yref):
     return 8 * (12 + yref + 16 * (N + 1) + 2 * (12 * (N + 1) + 4 * N)) + 104
 
 
+def survey_bytes(N):
+    """SURVEY.md 8(d)'s two per-solve figures, as the survey states them (56-byte output record): `general` -- per-stage reference and
+    per-stage parameters as the callers pass them (N = 20: 10 840 B) -- and `shared_constant` -- one reference window for the batch,
+    constant parameters (5 592 B).  algorithmic_bytes() above is this build's figure for what the kernels are actually handed (shared
+    window, per-stage parameters, the 104-byte record: 8 200 B).  Every traffic ratio of the line is quoted on `general`, so that rounds
+    stay comparable; the other two ratios ride along."""
+    it = 2 * (12 * (N + 1) + 4 * N)
+    return dict(general=8 * (12 + 16 * (N + 1) + 16 * (N + 1) + it) + 56, shared_constant=8 * (12 + 16 + it) + 56)
+
+
+def traffic_ratios(traffic, B, N):
+    """measured HBM bytes per launch over the three algorithmic figures (see survey_bytes)"""
+    sb = survey_bytes(N)
+    return dict(traffic_over_algorithmic=traffic / (B * sb["general"]),
+                traffic_over_algorithmic_shared_window=traffic / (B * algorithmic_bytes(N, True)),
+                traffic_over_algorithmic_shared_constant=traffic / (B * sb["shared_constant"]),
+                traffic_over_algorithmic_convention="SURVEY.md 8(d) general figure (per-stage reference and parameters, 56-B record); rounds 1-5 "
+                                                    "quoted the shared-window figure, which rides along as traffic_over_algorithmic_shared_window")
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -706,7 +726,7 @@ def configs_block(ba, args, device):
             counts, why = live_pmc(["--config", "5", "--horizon", str(N), "--batch", str(B)], leg["kernel"], (("FETCH_SIZE",), ("WRITE_SIZE",)))
             if counts is not None:
                 leg["traffic"], leg["traffic_source"] = traffic_from_counts(counts, cal)
-                leg["traffic_over_algorithmic"] = leg["traffic"] / (B * algorithmic_bytes(N, True))
+                leg.update(traffic_ratios(leg["traffic"], B, N))
             else:
                 leg["traffic"], leg["traffic_source"] = None, f"not measured in this run ({why})"
         sweep[f"N{N}"] = leg
@@ -894,7 +914,9 @@ def workload(args, rank, world):
                 "window advancing one row per step, per-instance x0 noise (seed 1), nominal parameters" % (B, N, Ts)) if cfg == 2 else (
                 "BASELINE.json configs[2]: batch=%d DOB-MPC Monte-Carlo current-disturbance draws per GPU (p[0..3] per instance, "
                 "seed 2), N=%d, Ts=%g s, shared circle window" % (B, N, Ts))
-        return dict(name=name, B=B, lo=lo, total=total, horizons=[(N, Ts)], make=make)
+        # inputs(): this rank's x0 without a solver (tests: rank 0 of any weak-scaling world solves what the single-GPU run solves)
+        return dict(name=name, B=B, lo=lo, total=total, horizons=[(N, Ts)], make=make,
+                    inputs=lambda: global_x0(1 if cfg == 2 else 2, total, lo, hi, noise=(cfg == 2))[0])
     if cfg == 4:
         amp, frq, ph = candidate_params()
         lo, hi, total = shard_of(args, rank, world, CAND_TOTAL // CAND_SHARDS)
@@ -1258,6 +1280,9 @@ def main(argv=None):
                 "roofline_hbm": {"bound": "hbm", "achieved": per_gpu_rate * alg_bytes / 1e9, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": per_gpu_rate * alg_bytes / 1e9 / PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_solve": alg_bytes,
+                                 "algorithmic_bytes_survey_general": survey_bytes(N)["general"],
+                                 "algorithmic_bytes_survey_shared_constant": survey_bytes(N)["shared_constant"],
+                                 **(traffic_ratios(traffic, B, N) if traffic else {}),
                                  "formula": "8*[12 + (0 if one window is shared by the batch else 16(N+1)) + 16(N+1) + 2*(12(N+1)+4N)] + 104"},
             }
             if len(legs) > 1:

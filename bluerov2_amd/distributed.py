@@ -148,8 +148,10 @@ def init_control_plane(rank, world, timeout_s):
     box = {}
 
     def go():
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_dt.timedelta(seconds=max(float(timeout_s), 1.0)))
-    outcome, detail = run_with_watchdog(go, timeout_s + 5.0, box)
+        # the group's OWN timeout bounds every later control-plane operation, and a rank may legitimately wait there for a peer that is sitting
+        # out a probe's timeout: well above timeout_s.  The rendezvous itself is bounded by the watchdog around this call.
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_dt.timedelta(seconds=3.0 * float(timeout_s) + 60.0))
+    outcome, detail = run_with_watchdog(go, float(timeout_s), box)
     if outcome != "ok":
         raise RendezvousError(f"gloo rendezvous of {world} ranks at {_os.environ.get('MASTER_ADDR')}:{_os.environ.get('MASTER_PORT')} "
                               f"{'timed out' if outcome == 'timeout' else 'failed'} after {timeout_s:g} s: {detail}")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev: A/B of two builds of libbluerov2_nmpc.so on ONE box, alternating: bluerov2_amd/lib/libbluerov2_nmpc.so (new) against
-# bluerov2_amd/lib/libbluerov2_nmpc_head.so (the library of the last commit, built by hand into the ignored lib/ directory).
+# bluerov2_amd/lib/libbluerov2_nmpc_head.so (the library of a commit, built ON DEMAND by scripts/dev/build_head_lib.sh into the ignored lib/ directory; remove it afterwards).
 # usage (through gpurun): bash scripts/dev/ab_libs.sh <bench args...>
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; L=bluerov2_amd/lib
 cp $L/libbluerov2_nmpc.so /tmp/new.so; cp $L/libbluerov2_nmpc_head.so /tmp/head.so

@@ -19,6 +19,9 @@ def pytest_configure(config):
 # session writes the lot to gpurun_out/parity_excused.json (scripts/collect_profiles.py copies its summary into profiles/): a
 # count creeping from 0 to the allowance shows in a committed file, not only in a log nobody reads.
 _PARITY_LOG = []
+SUITE_MAX_STATUS_AMBIGUOUS = 30     # measured 23 (rounds 5 and 6)
+SUITE_MAX_VALUES_DIVERGED = 4       # measured 0
+SUITE_MAX_U0_EXCUSED = 2            # measured 0
 
 
 def _parity_note(rule, what, n_checked, n_excused, **detail):
@@ -45,8 +48,18 @@ def pytest_sessionfinish(session, exitstatus):
                    bvls_abs=[dict(what=e["what"], instances_x_ticks=e["checked"], kkt_hist=e["kkt_hist"], worst_u=e["worst_u"],
                                   worst_u0=e["worst_u0"], active_bounds=e["active_bounds"]) for e in _PARITY_LOG if e["rule"] == "bvls_abs_1e-8"],
                    entries_with_excused=[e for e in _PARITY_LOG if e["excused"] > 0][:200])
+    # Suite-wide ceilings (round 6): the per-call allowances above are what ONE comparison may excuse, these are what
+    # the WHOLE session may -- pinned to what the suite shows, so that a regression of one digit turns the run red although every single
+    # call stays inside its allowance.  Measured over the sessions of rounds 5-6: 23 status-ambiguous instance-ticks of 497 k (all GPU = 4
+    # against oracle = 0 / 2 at entering KKT > 1e6), 0 values outside the scaled tolerance, 0 excused u0.
+    ceilings = {"status": SUITE_MAX_STATUS_AMBIGUOUS, "values_scaled": SUITE_MAX_VALUES_DIVERGED, "u0_abs": SUITE_MAX_U0_EXCUSED}
+    over = {r: (by_rule[r]["excused"], c) for r, c in ceilings.items() if r in by_rule and by_rule[r]["excused"] > c}
+    summary["suite_ceilings"] = dict(ceilings=ceilings, exceeded=over)
     with open(os.path.join(out, "parity_excused.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    if over:
+        sys.stderr.write(f"\nPARITY ALLOWANCES EXCEEDED SUITE-WIDE (excused, ceiling): {over} -- see gpurun_out/parity_excused.json\n")
+        session.exitstatus = pytest.ExitCode.TESTS_FAILED
 
 
 @pytest.fixture(scope="session")

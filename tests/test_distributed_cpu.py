@@ -162,3 +162,85 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert pr.returncode != 0 and not out and "no CPU fallback" in pr.stderr
     pr, out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert pr.returncode != 0 and not out
+
+
+# ---- round 6: the first multi-GPU run must produce a line whatever the fabric does -------------------------------
+
+def test_carrier_selection_probes_rccl_then_copy_then_gloo():
+    """bench.py --gpus 2 brings up a gloo control plane, then probes the carriers of the record all-gather in order under a watchdog
+    (bluerov2_amd.distributed.choose_collective).  No GPU here: "rccl" and "copy" fail their probes on both ranks, the selection lands
+    on "gloo", the line names it and carries the trail -- the same code that falls back on a GPU box whose RCCL does not come up."""
+    pr, out = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert pr.returncode == 0 and len(out) == 1, pr.stderr[-2000:]
+    o = out[0]
+    assert o["collective"] == "gloo" and [t["carrier"] for t in o["collective_trail"]] == ["rccl", "copy", "gloo"]
+    assert [t["outcome"] for t in o["collective_trail"]] == ["error", "error", "ok"]
+    assert set(o["collective_trail"][0]["ranks"]) == {"0", "1"}            # every rank reported why
+    sb = o["select_best"]
+    assert sb["index"] == sb["expected_index"] and sb["records_gathered"] == 128
+    # an explicit order is honoured
+    pr, out = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"], env_extra={"BROV_BENCH_COLLECTIVES": "gloo"})
+    assert pr.returncode == 0 and out[0]["collective"] == "gloo" and len(out[0]["collective_trail"]) == 1
+
+
+@pytest.mark.parametrize("fault", ["hang:rccl:1", "hang:gloo:0", "error:gloo:1"])
+def test_a_probe_that_hangs_or_fails_on_one_rank_still_yields_one_line(fault):
+    """a collective that never completes on ONE rank (BROV_BENCH_FAULT injects it into the probe): the watchdog expires after
+    BROV_BENCH_COLLECTIVE_TIMEOUT_S, the ranks agree over the control plane, rank 0 prints ONE line with "collective": "failed: ..." and
+    exit code 0 -- instead of hanging into the driver's timeout.  (error:gloo:1 -- the LAST carrier raising on one rank -- leaves the
+    other rank waiting inside that carrier's group creation: same verdict.)"""
+    import time
+    t0 = time.time()
+    pr, out = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                         env_extra={"BROV_BENCH_FAULT": fault, "BROV_BENCH_COLLECTIVE_TIMEOUT_S": "3"})
+    assert pr.returncode == 0 and len(out) == 1, (pr.returncode, pr.stdout[-500:], pr.stderr[-2000:])
+    assert time.time() - t0 < 60
+    o = out[0]
+    assert o["n_gpus"] == 2 and o["collective"].startswith("failed: ") and fault.split(":")[1] in o["collective"]
+    assert o["collective_trail"][-1]["outcome"] == "timeout"
+
+
+def test_a_rendezvous_that_never_completes_still_yields_a_line():
+    """rank 0 of a two-rank job whose second rank never starts: the gloo rendezvous is bounded, rank 0 reports the failure in its line"""
+    import json
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               BROV_BENCH_COLLECTIVE_TIMEOUT_S="3")
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    lines = [json.loads(ln) for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert pr.returncode == 0 and len(lines) == 1, pr.stderr[-2000:]
+    assert lines[0]["collective"].startswith("failed: gloo rendezvous of 2 ranks") and lines[0]["n_gpus"] == 2
+
+
+def test_deadline_guard_prints_the_waiting_line_and_ends_a_wedged_process(tmp_path):
+    """the last resort for a hang that holds the interpreter itself: a child process prints the line rank 0 left waiting and ends rank 0
+    (bluerov2_amd.distributed.start_deadline_guard); a cancelled guard prints nothing"""
+    import subprocess
+    prog = ("import sys, time, json\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "from bluerov2_amd.distributed import start_deadline_guard\n"
+            "path = sys.argv[1]\n"
+            "open(path, 'w').write(json.dumps({'value': 1.5, 'collective': 'failed: deadline'}))\n"
+            "cancel = start_deadline_guard(path, 2.0)\n"
+            "if sys.argv[2] == 'cancel':\n"
+            "    cancel(); print(json.dumps({'value': 2.5})); sys.exit(0)\n"
+            "time.sleep(600)\n")
+    pr = subprocess.run([sys.executable, "-c", prog, str(tmp_path / "line.json"), "wedge"], stdout=subprocess.PIPE, text=True, timeout=60)
+    assert pr.returncode == -9 and pr.stdout.strip() == '{"value": 1.5, "collective": "failed: deadline"}'
+    pr = subprocess.run([sys.executable, "-c", prog, str(tmp_path / "line2.json"), "cancel"], stdout=subprocess.PIPE, text=True, timeout=60)
+    assert pr.returncode == 0 and pr.stdout.strip() == '{"value": 2.5}'
+
+
+def test_rank0_of_a_weak_scaling_sweep_solves_the_single_gpu_workload():
+    """SCALE's N = 1 point and the N = 8 point's rank 0 must be the same workload: same config.workload string, same seeded x0 (weak
+    scaling: rank r draws seed + 1000 r); the other ranks draw their own"""
+    import bench
+    one = bench.workload(bench.parse_args(["--gpus", "1"]), 0, 1)
+    for world in (2, 4, 8):
+        a = bench.parse_args(["--gpus", str(world)])
+        w0 = bench.workload(a, 0, world)
+        assert w0["name"] == one["name"] and w0["B"] == one["B"] == 4096 and w0["total"] == world * 4096
+        assert np.array_equal(w0["inputs"](), one["inputs"]())
+        w3 = bench.workload(a, world - 1, world)
+        assert w3["name"] == one["name"] and not np.array_equal(w3["inputs"](), one["inputs"]())

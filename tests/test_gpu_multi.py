@@ -64,7 +64,8 @@ def test_two_ranks_on_one_gpu_over_gloo_select_what_a_single_rank_selects():
         return json.loads(lines[0])
     two = run(2, [])
     assert two["n_gpus"] == 2 and two["ranks_seen"] == [0, 1] and two["instances_per_rank"] == [1025, 1024] and two["total_instances"] == 2049
-    assert "gloo" in two["collective_backend"] and two["value"] > 0
+    assert two["collective"] == "gloo" and "ranks_share_gpus" in two and two["value"] > 0
+    assert two["solve_only"]["value"] > 0          # the pre-measurement a multi-rank run takes before it touches a data-plane collective
     one = run(1, ["--force-gather"])
     assert one["instances_per_rank"] == [2049]
     a, b = two["select_best"], one["select_best"]
@@ -93,6 +94,62 @@ def test_the_drivers_default_command_with_four_ranks_on_the_visible_gpus_over_gl
     assert c4["total_instances"] == 65536 and c4["instances_per_rank"] == [16384] * 4 and c4["select_best"]["records_gathered"] == 65536
     assert c4["select_best"]["selected_every_step_on_device"] and c4["select_best"]["index"] == c4["select_best"]["last_step_index_on_device"]
     assert c5["total_instances"] == 32768 and set(c5["sweep"]) == {"N10", "N20", "N40", "N80"}
+
+
+def test_default_carrier_order_with_two_ranks_on_one_gpu_falls_back_and_selects_the_same_candidate():
+    """The DEFAULT start-up of a multi-rank run (gloo control plane, then rccl -> copy -> gloo probed under the watchdog) with both ranks on
+    the box's one GPU (BROV_BENCH_SHARE_GPUS=1): RCCL refuses two ranks on a GPU, so its probe fails on both ranks and the run goes on
+    over the peer-copy carrier (IPC-exported staging buffers, device-to-device pulls) -- or over gloo where IPC is not available -- and
+    says which in the line.  Whatever carried the records, the selection is the single-rank run's, bit for bit."""
+    import torch
+    assert torch.cuda.is_available()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("BROV_BENCH_BACKEND", None)
+    env["BROV_BENCH_SHARE_GPUS"] = "1"
+    env["BROV_BENCH_COLLECTIVE_TIMEOUT_S"] = "60"
+    common = ["--config", "4", "--scaling", "strong", "--batch", "2049", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+
+    def run(gpus, extra):
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), *common, *extra], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+        lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+        assert pr.returncode == 0 and len(lines) == 1, (pr.returncode, pr.stdout[-2000:], pr.stderr[-3000:])
+        return json.loads(lines[0])
+    two = run(2, [])
+    trail = two["collective_trail"]
+    if torch.cuda.device_count() == 1:
+        assert trail[0]["carrier"] == "rccl" and trail[0]["outcome"] == "error" and two["collective"] in ("copy", "gloo")
+    assert trail[-1]["outcome"] == "ok" and trail[-1]["carrier"] == two["collective"]
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == [0, 1] and two["instances_per_rank"] == [1025, 1024]
+    one = run(1, ["--force-gather"])
+    assert one["collective"] == "rccl"             # one rank: RCCL itself
+    a, b = two["select_best"], one["select_best"]
+    assert a["records_gathered"] == 2049 and a["index"] == a["last_step_index_on_device"]
+    assert (a["index"], a["cost"], a["u0"], a["thrust"]) == (b["index"], b["cost"], b["u0"], b["thrust"])     # bit for bit
+
+
+def test_a_collective_that_never_completes_yields_the_solve_only_line():
+    """rank 1's probe of the first carrier hangs (BROV_BENCH_FAULT): after BROV_BENCH_COLLECTIVE_TIMEOUT_S the ranks agree to stop, and rank 0
+    prints the line it prepared BEFORE touching any data-plane collective: "collective": "failed: ...", value = the whole job's solves/s
+    without the per-step gather, every rank's own rate -- exit code 0, well inside the driver's patience"""
+    import time
+    import torch
+    assert torch.cuda.is_available()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("BROV_BENCH_BACKEND", None)
+    env.update(BROV_BENCH_SHARE_GPUS="1", BROV_BENCH_COLLECTIVE_TIMEOUT_S="8", BROV_BENCH_FAULT="hang:rccl:1")
+    t0 = time.time()
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert pr.returncode == 0 and len(lines) == 1, (pr.returncode, pr.stdout[-2000:], pr.stderr[-3000:])
+    assert time.time() - t0 < 240
+    o = json.loads(lines[0])
+    assert o["collective"].startswith("failed: rccl: timeout") and o["n_gpus"] == 2 and o["value"] > 0
+    assert len(o["per_rank_solve_only_solves_per_s"]) == 2 and min(o["per_rank_solve_only_solves_per_s"]) > 0
+    assert o["total_instances"] == 2 * 4096 and o["config"]["workload"].startswith("BASELINE.json configs[1]")
 
 
 def test_two_rank_rccl_run():
