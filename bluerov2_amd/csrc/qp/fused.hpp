@@ -43,7 +43,11 @@ __device__ __forceinline__ bool rti_fused_step(const DevParams& P, int b, int la
     // partial refactorisation of the active-set tries (riccati_backward_tries): checkpoint stage = ceil(N / 4); off for horizons too
     // short to gain from it and for instances the previous solve did not list as expensive
 #ifndef BROV_EXP_NO_SPLIT
-    I.ckpt = (N >= 8 && P.partial_refactor && listed) ? (N + 3) >> 2 : 0;
+    // (`listed` arrives in a vector register -- a plain load, requested ahead of the linearisation.  It is the same in every lane, and saying so
+    // here keeps the checkpoint, hence the bounds of the factor sweep's stage loop, in scalar registers: with a vector bound the compiler
+    // drives that loop, and every guard inside it, through exec masks)
+    const bool listed_u = __builtin_amdgcn_readfirstlane((int)listed) != 0;
+    I.ckpt = (N >= 8 && P.partial_refactor && listed_u) ? (N + 3) >> 2 : 0;
 #else
     I.ckpt = 0; (void)listed;
 #endif

