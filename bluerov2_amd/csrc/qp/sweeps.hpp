@@ -27,7 +27,7 @@ __device__ __forceinline__ BwdIn load_bwd(const IT& I, int i, const double* gam,
     const int ig = I.i0 + i;   // HBM-resident operands are indexed by the global stage
     if constexpr (FACTOR && LDS != 0) {
         if (b1) {
-            const lds_f64* t = I.lds_ba + i * b1->str;
+            const lds_f64* t = I.lds_ba + lmul(i, b1->str);
             s.bv = d4{t[b1->off[0]], t[b1->off[1]], t[b1->off[2]], 0.0};
         } else {
             s.bv = get_bv<LDS>(I, i);
@@ -197,7 +197,13 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
     // and row R / row C of Z and the entry of E^-1 are sums of the wave-uniform X, E^-1 entries against per-lane 0 / +-1 indicators
     // (loop invariant): 17 multiply-adds per lane, no select, and the part that does not involve M22 runs under the second
     // reciprocal's latency chain.  The negative sign makes T = -M Hu the gain operand itself and M gu the feed-forward term.
+    // Only the one-wave fused kernels (LDS = 1) have the registers for it.  Measured in the ISA of round 6: the two-wave kernel (LDS = 2) and the
+    // accumulating sweeps of the parallel-in-time kernel go into scratch with it (36 .. 164 bytes per lane), and in the large-batch windowed kernel
+    // the loop-invariant operands -- or P and p themselves -- end up in accumulation registers and are moved in every stage (38 .. 71 moves per
+    // stage against the 30 instructions saved).  The windowed family also needs its factor sweeps with and without the condensing accumulators
+    // to agree bit for bit (the split launches, tests/test_gpu_edge.py), so it stays on one form as a whole.
     constexpr bool kR6 = LDS == 1 && !ROBUST;
+    constexpr bool kR6Z = kR6;
     const int pR = rg, pC = cl & 3;
     const double sR0 = pR == 0 ? 1.0 : 0.0, sR1 = pR == 1 ? 1.0 : 0.0, nR2 = pR == 2 ? -1.0 : 0.0, nR3 = pR == 3 ? -1.0 : 0.0;
     const double nC0 = pC == 0 ? -1.0 : 0.0, nC1 = pC == 1 ? -1.0 : 0.0, cC2 = pC == 2 ? 1.0 : 0.0, cC3 = pC == 3 ? 1.0 : 0.0;
@@ -209,6 +215,8 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
     const int kt_ststr = (cl < NX) ? kKtStage : 0;
     lds_f64* const kf_st0 = (LDS != 0 && cl == 0) ? I.lds_kff + rg : I.lds_tr + 16;
     const int kf_ststr = (cl == 0) ? 4 : 0;
+    lds_f64* ktp = kt_st0 + lmul(N - 1, kt_ststr);   // kR6: running store addresses (the stages are visited in order N-1 .. lo)
+    lds_f64* kfp = kf_st0 + lmul(N - 1, kf_ststr);
     unsigned long long illm = 0;   // kR6: the watch accumulates in a lane mask (scalar registers)
     Ba1Off b1o;
     if constexpr (LDS != 0) {
@@ -349,7 +357,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 const double detS = fma(-s01, s01, ss), iS = fast_rcp(detS);
                 m22 = s11 * iS; m32 = -s01 * iS; m33 = s00 * iS;            // M22 = Sc^-1
                 if (!(a00 > 0.0 && detE > 0.0 && s00 > 0.0 && detS > 0.0)) ok = false;
-                if constexpr (kR6) {
+                if constexpr (kR6Z) {
                     // rows R and C of Z = [-X; I] and the entry of E^-1, per lane (independent of the second reciprocal)
                     const double nzr0 = fma(sR0, x00, fma(sR1, x10, nR2)), nzr1 = fma(sR0, x01, fma(sR1, x11, nR3));   // -Z[R][:]
                     const double zc0 = fma(nC0, x00, fma(nC1, x10, cC2)), zc1 = fma(nC0, x01, fma(nC1, x11, cC3));     //  Z[C][:]
@@ -357,21 +365,19 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                     const double w0 = fma(m22, zc0, m32 * zc1), w1 = fma(m32, zc0, m33 * zc1);                         // M22 Z[C][:]'
                     msel = fma(nzr0, w0, fma(nzr1, w1, nE));                                                           // -M[R][C]
                     mt = msel;   // columns >= 4 of the operand only reach rows >= 4 of the products, which nobody reads
-#ifndef BROV_EXP_NO_WATCH
-                    illm |= __ballot(detE < kPivotRho * aa) | __ballot(s00 < kPivotRho * a22) | __ballot(s11 < kPivotRho * a33) | __ballot(detS < kPivotRho * ss);
-#endif
                 } else {
                     m20 = -(x00 * m22 + x01 * m32); m30 = -(x00 * m32 + x01 * m33);  // M12' (rows 2,3 x cols 0,1)
                     m21 = -(x10 * m22 + x11 * m32); m31 = -(x10 * m32 + x11 * m33);
                     m00 = e00 - (m20 * x00 + m30 * x01); m10 = e01 - (m20 * x10 + m30 * x11);
                     m11 = e11 - (m21 * x10 + m31 * x11);                          // M11 = E^-1 - M12 X'
-                    // the relative pivots of the elimination (kPivotRho): four compares, off the chain
-#ifndef BROV_EXP_NO_WATCH
-                    illc = illc | (detE < kPivotRho * aa) | (s00 < kPivotRho * a22) | (s11 < kPivotRho * a33) | (detS < kPivotRho * ss);
-#endif
                 }
+                // the relative pivots of the elimination (kPivotRho): four compares, off the chain
+#ifndef BROV_EXP_NO_WATCH
+                if constexpr (kR6) illm |= __ballot(detE < kPivotRho * aa) | __ballot(s00 < kPivotRho * a22) | __ballot(s11 < kPivotRho * a33) | __ballot(detS < kPivotRho * ss);
+                else illc = illc | (detE < kPivotRho * aa) | (s00 < kPivotRho * a22) | (s11 < kPivotRho * a33) | (detS < kPivotRho * ss);
+#endif
             }
-            if constexpr (!kR6) {
+            if constexpr (!kR6Z) {
                 // Mtile: lane (rg = m, cl = n < 4) = M[m][n]; msel: the same element for every column n = cl & 3
                 const int cq = cl & 3;
                 const int a = rg > cq ? rg : cq, c = rg > cq ? cq : rg;  // (max, min)
@@ -380,7 +386,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 const double r2 = (c == 0) ? m20 : ((c == 1) ? m21 : m22);
                 const double r3 = (c == 0) ? m30 : ((c == 1) ? m31 : ((c == 2) ? m32 : m33));
                 msel = (a == 0) ? r0 : ((a == 1) ? r1 : ((a == 2) ? r2 : r3));
-                mt = (cl < 4) ? msel : 0.0;
+                mt = (kR6 || cl < 4) ? msel : 0.0;   // (kR6: see the Z form)
             }
             H[0] = blend(mk_col0, lane == 0 ? P[0] + dg[0] : t0, H[0]);   // H[0][0] = (P e_0)[0] + Ts W_0
             H[1] = blend(mk_col0, t1, H[1]);
@@ -406,7 +412,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 ks = -T[0];
             } else {
                 T = tn1(mt, H[3], z4);
-                ks = kR6 ? T[0] : -T[0];
+                ks = kR6Z ? T[0] : -T[0];
                 S = tn1(H[3], ks, H);
             }
             // kff = -M gu and p = gx + K^T gu in ONE product: the operand carries the gain in columns 0..11 and M in columns
@@ -430,14 +436,14 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             }
             // store factors
             if (STORE_IPM) {  // only the corrector solve of an IPM iteration re-reads this: gain | M as one operand tile
-                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = kR6 ? ((cl < NX) ? ks : -msel) : xt2;
+                I.Ks[(size_t)(I.i0 + i) * 64 + lane] = kR6Z ? ((cl < NX) ? ks : -msel) : xt2;
             }
             if constexpr (LDS) {
                 // K^T[k][m] = -T[m][k] is ks at lane (rg = m, cl = k): the compact LDS image [12][4] is written straight from
                 // that register (no transposing MFMA); lanes cl >= 12 are parked on the constant-zero slot
                 // ... as the gain itself, row-major [4][12] (what the VALU forward sweep reads: row m contiguous)
                 if constexpr (kR6) {
-                    kt_st0[i * kt_ststr] = ks;
+                    *ktp = ks; ktp -= kt_ststr;
                 } else {
                     lds_f64* t = (cl < NX) ? I.lds_kt + i * kKtStage + rg * NX + cl : I.lds_zero;
                     *t = (cl < NX) ? ks : 0.0;
@@ -449,7 +455,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             }
             if constexpr (LDS) {  // only column 0 of rows 12..15 is M gu: the other lanes are parked on the constant-zero slot
                 if constexpr (kR6) {
-                    kf_st0[i * kf_ststr] = pn[3];   // -M gu: the operand tile carries -M
+                    *kfp = kR6Z ? pn[3] : -pn[3]; kfp -= kf_ststr;   // (kR6Z: the operand tile carries -M)
                 } else {
                     lds_f64* kp = (cl == 0) ? I.lds_kff + i * 4 + rg : I.lds_zero;
                     *kp = (cl == 0) ? -pn[3] : 0.0;
@@ -463,9 +469,9 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 const double bPsi = R[0];
                 R[0] = (rg == 0) ? acc->Psi[0] : R[0];         // the true row 0 of A'Psi is row 0 of Psi (column 0 of A is e_0)
                 const d4 MZt = tn1(mt, R[3], z4);              // rows 0..3: M Z' -- what a costate at the segment end adds to this stage's feed-forward term
-                const double MZ0 = kR6 ? -MZt[0] : MZt[0];     // (kR6: the operand tile carries -M)
+                const double MZ0 = kR6Z ? -MZt[0] : MZt[0];    // (kR6Z: the operand tile carries -M)
                 I.Ks[(size_t)(I.i0 + i) * 64 + lane] = MZ0;    // (the gain | M tile of the in-loop sweeps lives there otherwise: no loop in this kernel)
-                const double kffb = dpp_f64<0x150>(kR6 ? pn[3] : -pn[3]);    // row_newbcast:0 -- kff_m in every lane of row m
+                const double kffb = dpp_f64<0x150>(kR6Z ? pn[3] : -pn[3]);    // row_newbcast:0 -- kff_m in every lane of row m
                 const double Xg = (cl < NX) ? MZ0 : ((cl == NX) ? kffb : 0.0);
                 d4 Gn = tn1(Xg, R[3], acc->G);                 // rows 0..11 += Z M Z', row 12 += kff' Z'
                 Gn[3] += (rg == 0) ? bPsi : 0.0;               // row 12 += b'Psi
@@ -561,7 +567,7 @@ template <int LDS>
 __device__ __forceinline__ FwdIn load_fwd(const Inst& I, int i) {
     FwdIn s;
     if constexpr (LDS) {
-        const lds_f64* t = I.lds_ba + i * I.kt_str;  // offsets are relative to the start of the LDS slice
+        const lds_f64* t = I.lds_ba + lmul(i, I.kt_str);  // offsets are relative to the start of the LDS slice
         s.kt = d4{t[I.kt_off[0]], t[I.kt_off[1]], t[I.kt_off[2]], 0.0};
     } else {
         s.kt = load_tile3(I.Kt + (size_t)i * 192, I.lane);
@@ -618,6 +624,9 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx, lds_f64* first 
         const int mstr = rowx ? kBaStage : kKtStage;
         const lds_f64* klo0 = I.lds_kt + km * NX;                              // always a valid address (A rows: value unused)
         const lds_f64* brow0 = I.lds_ba + ka * kBaStride + 9;                  // B row k (rows 12..15: unused)
+        // (round 6, measured and not kept: reading the structural entries -- columns 0..2 of the A rows, a zero B row for the gain rows -- out of a
+        // 4 x 4 table in LDS with stride 0 instead of selecting them removes 8 v_cndmask per stage and makes the sweep 21 cycles per stage SLOWER:
+        // profiles/r6_fused_experiments.txt)
         const lds_f64* cvec0 = rowx ? I.lds_bv + k : I.lds_kff + km;          // b_k / kff_m
         const int cstr = rowx ? NX : 4;
         lds_f64* out0 = rowx ? I.lds_dxb + NX + k : I.lds_vhat + km;          // x+_k -> state-step row i+1, v_m -> inputs of stage i
@@ -630,8 +639,9 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx, lds_f64* first 
         // 64-lane ds_read_b64 occupies the CU's LDS (shared by the four resident waves, all of them in the same phase) for 4
         // clocks, a 16-lane one for 1 -- with 17 reads per stage that is the difference between 9.2 k and 7.7 k cycles per sweep.
         double xcur = x_in[rowx ? k : 0];
+        lds_f64* outp = out0;   // running store address (stages in order 0 .. N-1)
         if (I.lane < 16)
-        pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(mrow0 + kk * mstr, klo0 + kk * kKtStage, brow0 + kk * kBaStage, cvec0 + kk * cstr); },
+        pipelined<kLdsDist<LDS>, FwdV>(N, [&](int kk) { return load_fwd_v(mrow0 + lmul(kk, mstr), klo0 + kk * kKtStage, brow0 + kk * kBaStage, cvec0 + lmul(kk, cstr)); },
                                        [&](int i, const FwdV& in) {
             const double m0 = rowx ? e0 : in.m[0], m1 = rowx ? e1 : in.m[1], m2 = rowx ? e2 : in.m[2];
             // The sweep is a recurrence on one wave: a dependent FP64 DPP operation issues ~13 cycles behind its producer
@@ -643,7 +653,7 @@ __device__ __forceinline__ void fwd_chunk(const Inst& I, d4& xx, lds_f64* first 
             double xa = dot, xb = 0.0;                  // + B v, the inputs v_m out of lanes 12..15 of the same register
             fmac_bc4(xa, xb, dot, in.b4[0], in.b4[1], in.b4[2], in.b4[3]);
             const double xn = xa + xb;
-            out0[i * ostr] = rowx ? xn : dot;
+            *outp = rowx ? xn : dot; outp += ostr;
             xcur = xn;
         });
         // the last state step back into the row-replicated form the callers carry between windows
@@ -712,8 +722,8 @@ __device__ __forceinline__ void roll_chunk(const Inst& I, d4& xx, const double* 
             double pa = a0 * z0;
             pa = fma(a1, z1, pa); pa = fma(a2, z2, pa); pa = fma(in.a[3], z3, pa);
             const double xn = quad_sum(pa) + in.bk;
-            xpark[i * xstr] = rowx ? xn : 0.0;
-            const lds_f64* zr = zr0 + (i + 1 < N ? i + 1 : i) * zstr;
+            xpark[lmul(i, xstr)] = rowx ? xn : 0.0;
+            const lds_f64* zr = zr0 + lmul(i + 1 < N ? i + 1 : i, zstr);
             z0 = zr[0]; z1 = zr[1]; z2 = zr[2]; z3 = zr[3];
         });
         const lds_f64* xl = I.lds_dxb + N * NX + rg;
@@ -805,11 +815,13 @@ __device__ __forceinline__ void adj_chunk(const IT& I, d4& atpi, const double* v
         lds_f64* gpark = rowx ? I.lds_tr + (I.lane & 15) : I.lds_kff + (c - NX);
         const int gstr = rowx ? 0 : 4;
         const double rd = I.Ts * I.Wuq;
+        lds_f64* pp = ppark + lmul(N - 1, pstr);   // running store addresses (stages in order N-1 .. 0)
+        lds_f64* gp = gpark + lmul(N - 1, gstr);
         pipelined<kLdsDist<LDS>, AdjV>(N, [&](int kk) { return load_adj_v(I, om, ox, ou, N - 1 - kk); }, [&](int kk, const AdjV& in) {
             const int i = N - 1 - kk;
             const double qd = IT::kGrid ? in.wq : ((I.i0 + i + 1 == I.NT) ? I.Weq : I.Ts * I.Wq);
             const double pic = fma(qd, in.dxc, in.qc + gq);
-            ppark[i * pstr] = rowx ? pic : 0.0;
+            *pp = pic; pp -= pstr;   // (parked lanes store what they have: their slots are never read)
             const lds_f64* pr = I.lds_kt + i * NX + 4 * q3;
             const double p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
             __builtin_amdgcn_sched_barrier(0);
@@ -818,7 +830,7 @@ __device__ __forceinline__ void adj_chunk(const IT& I, d4& atpi, const double* v
             acc = fma(m1, p1, acc); acc = fma(m2, p2, acc); acc = fma(m3, p3, acc);
             acc = colx ? acc : 0.0;
             const double G = quad_sum(acc);
-            gpark[i * gstr] = rowx ? 0.0 : fma(IT::kGrid ? in.wr : rd, in.vm, in.rm + G);
+            *gp = fma(IT::kGrid ? in.wr : rd, in.vm, in.rm + G); gp -= gstr;   // (parked lanes: see above)
             gq = G;
         });
         // hand A'pi of this window's first stage on, row-replicated

@@ -16,6 +16,9 @@ typedef __attribute__((address_space(1))) const void glb_cvoid;
 __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// stage index x per-lane element stride (both far below 2^23): the 24-bit multiply issues at full rate, v_mul_lo_u32 -- what `i * stride` compiles
+// to when the stride lives in a vector register -- at a quarter of it (16 cycles; round 6: two to four of them per stage of every sweep)
+__device__ __forceinline__ int lmul(int i, int stride) { return __mul24(i, stride); }
 // C + Xt^T Y over K4*4 rows
 template <int K4>
 __device__ __forceinline__ d4 tn(const d4& xt, const d4& y, d4 c) {
@@ -160,7 +163,7 @@ constexpr int kKtStage = NX * 4;          // K^T compact [12][4] per stage
 template <int LDS>
 __device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: rows k = rg+4r (0..11), cols c = cl
     if constexpr (LDS) {
-        const lds_f64* t = I.lds_ba + i * I.ba_str;
+        const lds_f64* t = I.lds_ba + lmul(i, I.ba_str);
         return d4{t[I.ba_off[0]], t[I.ba_off[1]], t[I.ba_off[2]], 0.0};
     } else {
         return load_tile3(I.BA + (size_t)i * 192, I.lane);
@@ -169,8 +172,8 @@ __device__ __forceinline__ d4 get_ba(const Inst& I, int i) {  // [A B] image: ro
 template <int LDS>
 __device__ __forceinline__ d4 get_bat(const Inst& I, int i) {  // [A B]^T image: rows c = rg+4r (0..15), cols k = cl (< 12)
     if constexpr (LDS) {
-        const lds_f64* t = I.lds_ba + i * I.bat_str;
-        return d4{I.lds_ba[i * I.bat_str0 + I.bat_off[0]], t[I.bat_off[1]], t[I.bat_off[2]], t[I.bat_off[3]]};
+        const lds_f64* t = I.lds_ba + lmul(i, I.bat_str);
+        return d4{I.lds_ba[lmul(i, I.bat_str0) + I.bat_off[0]], t[I.bat_off[1]], t[I.bat_off[2]], t[I.bat_off[3]]};
     } else {
         // transposed view of the row-major [A B] tile: element (c = rg + 4r, k = cl) = [A B](k, c); lanes cl >= 12 are padding.
         // Four 8-byte gathers that touch the tile's 12 cache lines -- cheaper than writing and re-reading a second, transposed
@@ -235,7 +238,7 @@ __device__ __forceinline__ void fmac_bc12(double& d0, double& d1, double& d2, do
         "v_fmac_f64_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf"
-        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "+&v"(d0), "+&v"(d1), "+&v"(d2), "+&v"(d3)   // (early clobber: an input with the same value -- the broadcast source -- must not share a register)
         : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7), "v"(m8), "v"(m9), "v"(m10), "v"(m11));
 }
 __device__ __forceinline__ void fmac_bc4(double& da, double& db, double src, double k0, double k1, double k2, double k3) {
@@ -245,7 +248,7 @@ __device__ __forceinline__ void fmac_bc4(double& da, double& db, double src, dou
         "v_fmac_f64_dpp %1, %2, %5 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %0, %2, %4 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %1, %2, %6 row_newbcast:15 row_mask:0xf bank_mask:0xf"
-        : "+v"(da), "+v"(db)
+        : "+&v"(da), "+&v"(db)
         : "v"(src), "v"(k0), "v"(k1), "v"(k2), "v"(k3));
 }
 
