@@ -668,7 +668,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             for (int t = 0; t < UX; t++) {
                 const int j = lane + 64 * t;
                 const int jj = j < nxe ? j : 0;
-                const int i = jj / 12, c = jj - i * 12;
+                const int i = div12(jj), c = jj - i * 12;
                 xpre[t] = x_it[jj];
                 ypre[t] = I.yref[(size_t)i * 16 + c];
                 if constexpr (LDS == 1) wxpre[t] = cst[(i == N) ? 16 + c : c];
@@ -762,7 +762,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
                 for (int t = 0; t < UX; t++) {
                     const int j = j0 + 64 * t;
                     const int jj = j < nxe ? j : 0;
-                    const int i = jj / 12, c = jj - i * 12;
+                    const int i = div12(jj), c = jj - i * 12;
                     xo[t] = (EL && j0 == lane) ? xpre[t] : x_it[jj];
                     dj[t] = (EL && j0 == lane) ? djp[EL ? t : 0] : rd_dxb(jj);
                     yr[t] = (EL && j0 == lane) ? ypre[t] : I.yref[(size_t)i * 16 + c];
@@ -771,7 +771,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
                 for (int t = 0; t < UX; t++) {
                     const int j = j0 + 64 * t;
                     if (j < nxe) {
-                        const int i = j / 12, c = j - i * 12;
+                        const int i = div12(j), c = j - i * 12;
                         const double xn = xo[t] + dj[t];
                         x_it[j] = xn;
                         const double e = xn - yr[t];

@@ -197,13 +197,13 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
     // and row R / row C of Z and the entry of E^-1 are sums of the wave-uniform X, E^-1 entries against per-lane 0 / +-1 indicators
     // (loop invariant): 17 multiply-adds per lane, no select, and the part that does not involve M22 runs under the second
     // reciprocal's latency chain.  The negative sign makes T = -M Hu the gain operand itself and M gu the feed-forward term.
-    // Only the one-wave fused kernels (LDS = 1) have the registers for it.  Measured in the ISA of round 6: the two-wave kernel (LDS = 2) and the
+    // Only the one-wave fused kernels (LDS = 1) have the registers for all of it.  Measured in the ISA of round 6: with (b) the two-wave kernel (LDS = 2) and the
     // accumulating sweeps of the parallel-in-time kernel go into scratch with it (36 .. 164 bytes per lane), and in the large-batch windowed kernel
     // the loop-invariant operands -- or P and p themselves -- end up in accumulation registers and are moved in every stage (38 .. 71 moves per
     // stage against the 30 instructions saved).  The windowed family also needs its factor sweeps with and without the condensing accumulators
     // to agree bit for bit (the split launches, tests/test_gpu_edge.py), so it stays on one form as a whole.
-    constexpr bool kR6 = LDS == 1 && !ROBUST;
-    constexpr bool kR6Z = kR6;
+    constexpr bool kR6 = (LDS == 1 || LDS == 2) && !ROBUST;
+    constexpr bool kR6Z = kR6 && LDS == 1;   // (the two-wave kernel, 256 registers: everything but the per-lane constants of (b) -- it keeps the select tree)
     const int pR = rg, pC = cl & 3;
     const double sR0 = pR == 0 ? 1.0 : 0.0, sR1 = pR == 1 ? 1.0 : 0.0, nR2 = pR == 2 ? -1.0 : 0.0, nR3 = pR == 3 ? -1.0 : 0.0;
     const double nC0 = pC == 0 ? -1.0 : 0.0, nC1 = pC == 1 ? -1.0 : 0.0, cC2 = pC == 2 ? 1.0 : 0.0, cC3 = pC == 3 ? 1.0 : 0.0;

@@ -19,6 +19,9 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
 // stage index x per-lane element stride (both far below 2^23): the 24-bit multiply issues at full rate, v_mul_lo_u32 -- what `i * stride` compiles
 // to when the stride lives in a vector register -- at a quarter of it (16 cycles; round 6: two to four of them per stage of every sweep)
 __device__ __forceinline__ int lmul(int i, int stride) { return __mul24(i, stride); }
+// j / 12 for 0 <= j < 2^16 (element index -> stage): one full-rate 24-bit multiply and a shift; the compiler's division by a constant is a
+// v_mul_hi_u32 (quarter rate).  43691 = ceil(2^19 / 12); exact while j * (43691 * 12 - 2^19) < 2^19, i.e. j < 131072.
+__device__ __forceinline__ int div12(int j) { return (int)(__umul24((unsigned)j, 43691u) >> 19); }
 // C + Xt^T Y over K4*4 rows
 template <int K4>
 __device__ __forceinline__ d4 tn(const d4& xt, const d4& y, d4 c) {
