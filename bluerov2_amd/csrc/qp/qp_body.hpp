@@ -88,6 +88,9 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
             if (lane + 64 * t < nv) ureg[t] = I.u[lane + 64 * t];
     }
     int status = 0, iters = 0;
+#if BROV_EXP_WIN_FUSE
+    WinFast wfast;   // (large-batch windowed kernel: see win_forward_fast)
+#endif
     double mu = 0.0, rho = 0.0;
     bool early = false, polished = false, use_vhat = false;
     int sched_p = -1;   // this instance's place in the next solve's list of expensive instances (work ordering; wave-uniform)
@@ -164,7 +167,14 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
     if (__ballot(!ok) != 0ull) {
         status = BROV_STATUS_QP_FAILURE;
     } else {
-        sw_forward<LDS>(I, W, d0, cst);
+        // (large-batch windowed kernel, development build -DBROV_EXP_WIN_FUSE=1: forward sweep, check, adjoint sweep and full step in ONE pass over
+        // the windows when the answer stays inside the box -- win_forward_fast in qp/window.hpp, measured and not shipped)
+        bool fast_pass = false;
+#if BROV_EXP_WIN_FUSE
+        if constexpr (LDS == 3) fast_pass = P.early_exit != 0 && !robust;
+        if constexpr (LDS == 3) { if (fast_pass) wfast = win_forward_fast(P, I, *W, b, d0); }
+#endif
+        if (!fast_pass) sw_forward<LDS>(I, W, d0, cst);
         DBG_STAMP(3);
         bool feas = true;
         if constexpr (LDS >= 3) {
@@ -653,6 +663,11 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
         if constexpr (LDS >= 3) {
             if (W->nan) {
                 status = BROV_STATUS_NAN;
+#if BROV_EXP_WIN_FUSE
+            } else if (LDS == 3 && wfast.committed) {   // win_forward_fast has taken the step window by window
+                cost = wfast.cost_lane; u0v = wfast.u0_lane;
+                wrote_u0 = true;
+#endif
             } else {
                 win_adjoint_commit<LDS == 4>(P, I, *W, b, vfin, early, cost, u0v, P.mail != nullptr && P.mail_early != 0,
                                              [&](double cost_lane, double u0_lane) __attribute__((always_inline)) { emit_record(cost_lane, u0_lane, true); });

@@ -34,6 +34,16 @@ struct Win {
     bool nan, feas;     // set by the forward / roll-out wrappers: a NaN among the inputs / state steps they produced; all inputs of
                         // the last forward sweep inside their bounds (wave-uniform)
 };
+// what win_forward_fast hands back to qp_body (by value: as fields of Win -- which lives across the kernel's instance loop -- they would be live
+// across every phase of every instance): the step-0 answer was accepted AND the full step taken window by window; this lane's share of the
+// objective at the new iterate; lanes 0..3: its first input
+struct WinFast { bool committed = false; double cost_lane = 0.0, u0_lane = 0.0; };
+// per-block scratch behind the windows' images (I.Kt points at it in the windowed kernels): [0, 384) (P, p) entering window 0 / the checkpoint stage,
+// [384, 896) resident mode: step-0 feed-forward terms + split header, then 4 x kSegPark of the split launches' quarters (kWinCk in all); round 6:
+// (P, p) at every inner window boundary (384 each: as they enter window c - 1, c = 1 .. nc - 1) and the staged rows of win_forward_fast
+constexpr int kSegPark = 704;
+constexpr int kWinCk = 384 + 512 + 4 * kSegPark;
+__host__ __device__ constexpr int win_stage_doubles(int N) { return (N + 1) * 12 + N * 4 + N * 12 + N * 8; }
 __host__ __device__ constexpr int win_lin_doubles(int L) { return 184 * L + 12; }
 __host__ __device__ constexpr int win_img_doubles(int L) { return 236 * L + 12; }
 __host__ __device__ constexpr int win_off_bv(int L) { return 156 * L; }
@@ -214,6 +224,173 @@ __device__ __forceinline__ void sw_forward(Inst& I, Win* W, const d4& d0, const 
         wave_fence();
     }
 }
+#ifndef BROV_EXP_WIN_FUSE
+#define BROV_EXP_WIN_FUSE 0
+#endif
+#if BROV_EXP_WIN_FUSE
+// Round 6 (large-batch windowed kernel, verdict item 2) -- MEASURED AND NOT SHIPPED, kept as a development build (make EXTRA=-DBROV_EXP_WIN_FUSE=1;
+// profiles/r6_window_traffic.txt has the numbers): forward sweep, bound check, ADJOINT SWEEP AND FULL STEP of a window while it is resident.
+// The regular schedule walks the windows 0 .. nc-1 forward (fetching [A B] | b | K' | kff of all but the first), learns that the step-0 answer is
+// inside the box, and walks back nc-1 .. 0 for the multipliers and the step -- fetching [A B] | q | r of all but the last AGAIN, with the state steps
+// and inputs going through HBM in between.  Here the adjoint sweep of window c runs right behind its forward sweep: it does not need its neighbour,
+// because the costate at the window's last node IS the gradient of the cost-to-go there, lambda = P x + p with the (P, p) the factor sweep carried
+// across that boundary in pass 1 (parked per boundary, 3 KB) -- the algebra the parallel-in-time kernel uses between its segments:
+//     A' pi entering the window's sweep  :=  (P dx_e + p) - (Q dx_e + q_e).
+// The step of a window cannot be taken before the LAST window has passed the bound check, so the new rows of x, u, pi, lambda of the windows before
+// it are STAGED in the block's scratch and copied into the iterate when it has (the last window commits directly); an answer that leaves the box in
+// window c simply stops the extra work -- windows c .. nc-1 get the plain forward sweep, the iterate was never touched, qp_body goes on as before.
+// What it saves per early-exit solve at nc = 4: three prefix fetches (172 L doubles each) and their waits, against 36 doubles per stage staged and
+// copied.  The multipliers differ from the plain recursion's by rounding (the boundary relation is exact in exact arithmetic).
+template <class IT>
+__device__ __forceinline__ WinFast win_forward_fast(const DevParams& P, IT& I, Win& W, int b, const d4& d0) {
+    WinFast out;
+    const double* __restrict__ cst = P.cst;
+    opaque_lane(I);
+    wave_fence();
+    const int lane = I.lane, NT = I.NT, L = W.Lc, nc = W.nc, rg = I.rg;
+    double* x_it = P.x + (size_t)b * (NT + 1) * 12;
+    double* u_it = P.u + (size_t)b * NT * 4;
+    double* pi_it = P.pi + (size_t)b * NT * 12;
+    double* lam_it = P.lam + (size_t)b * NT * 8;
+    const double* bnd = I.Kt + kWinCk;
+    double* sx = I.Kt + kWinCk + (size_t)(nc - 1) * 384;
+    double* su = sx + (size_t)(NT + 1) * 12;
+    double* spi = su + (size_t)NT * 4;
+    double* slam = spi + (size_t)NT * 12;
+    const lds_f64* vh = (const lds_f64*)(W.lds + win_off_vh(L));
+    const lds_f64* dx = (const lds_f64*)(W.lds + win_off_dx(L));
+    const lds_f64* ql = (const lds_f64*)(W.lds + win_off_q(L));
+    d4 xx = d0;
+    bool bad = false, infeas = false;
+    bool fast = true;   // wave-uniform: every window so far inside the box, nothing NaN
+    double cost = 0.0, u0v = 0.0;
+    const double lbm = cst[32 + (lane & 3)], ubm = cst[36 + (lane & 3)];
+    for (int c = 0; c < nc; c++) {
+        const bool last = c == nc - 1;
+        const int i0 = c * L, n = (NT - i0 < L) ? NT - i0 : L;
+        const int nu = n * 4, nxr = (last ? n + 1 : n) * NX;
+        // the window's rows of the iterate and of the reference: requested before the window is fetched and swept
+        double uo[2], ur[2], wu[2], xo[4], yr[4], wx[4];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t, jj = j < nu ? j : 0;
+            uo[t] = u_it[i0 * 4 + jj];
+            ur[t] = I.yref[(size_t)(i0 + (jj >> 2)) * 16 + 12 + (jj & 3)];
+            wu[t] = IT::kGrid ? I.wst[(size_t)(i0 + (jj >> 2)) * 16 + 12 + (jj & 3)] : P.Ts * cst[12 + (jj & 3)];
+        }
+        if (fast) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = lane + 64 * t, jj = j < nxr ? j : 0;
+                const int i = div12(jj), cc = jj - i * 12;
+                xo[t] = x_it[i0 * 12 + jj];
+                yr[t] = I.yref[(size_t)(i0 + i) * 16 + cc];
+                wx[t] = IT::kGrid ? I.wst[(size_t)(i0 + i) * 16 + cc] : ((i0 + i == NT) ? cst[16 + cc] : P.Ts * cst[cc]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) { xo[t] = 0.0; yr[t] = 0.0; wx[t] = 0.0; }
+        }
+        win_need(I, W, c, (fast || last) ? (WM_LIN | WM_GAIN) : (WM_AB | WM_BV | WM_GAIN), nullptr);
+        fwd_chunk<3>(I, xx);
+        __syncthreads();
+        win_flush_small(I.vhat + I.i0 * 4, W.lds + win_off_vh(L), I.N * 4, lane);
+        win_flush_small(I.dxb + I.i0 * NX, W.lds + win_off_dx(L), (I.N + 1) * NX, lane);
+        W.valid |= WM_DX;
+        bad = bad | win_nan_check<false>(I, W, c == 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = lane + 64 * t;
+            const double vj = vh[j < nu ? j : 0], lb = lbm - uo[t], ub = ubm - uo[t];
+            infeas = infeas | ((j < nu) & !(vj >= lb && vj <= ub));
+        }
+        if (fast) fast = __ballot(bad | infeas) == 0ull;
+        if (fast) {
+            // costate at the window's last node -> A' pi entering the sweep (row-replicated); zero behind the terminal node
+            d4 atpi = {0, 0, 0, 0};
+            if (!last) {
+                const double* ck = bnd + (size_t)c * 384;
+                d4 Pc, pr;
+#pragma unroll
+                for (int r = 0; r < 3; r++) { Pc[r] = ck[r * 64 + lane]; pr[r] = dpp_f64<0x150>(ck[192 + r * 64 + lane]); }   // (p sits in column 0: row_newbcast:0)
+                Pc[3] = 0.0; pr[3] = 0.0;
+                const d4 lam = tn<3>(Pc, xx, pr);
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const int row = rg + 4 * r;
+                    const double qd = IT::kGrid ? I.wst[(size_t)(i0 + n) * 16 + row] : I.Ts * I.Wr[r];
+                    atpi[r] = lam[r] - fma(qd, xx[r], (double)ql[n * NX + row]);
+                }
+            }
+            adj_chunk<true, 3>(I, atpi, nullptr, nullptr, nullptr);
+            W.valid &= ~WM_GAIN;   // multipliers / input gradient are staged in the K^T / feed-forward areas
+            __syncthreads();
+            win_flush_small((last ? pi_it : spi) + (size_t)i0 * NX, W.lds + win_off_kt(L), n * NX, lane);
+            double* xd = last ? x_it : sx;
+            double* ud = last ? u_it : su;
+            double* ld = last ? lam_it : slam;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int j = lane + 64 * t;
+                if (j < nu) {
+                    const int i = j >> 2, m = j & 3;
+                    ld[(size_t)(i0 + i) * 8 + m] = 0.0;        // (an answer inside the box: no bound multipliers)
+                    ld[(size_t)(i0 + i) * 8 + 4 + m] = 0.0;
+                    const double un = uo[t] + vh[j];
+                    ud[i0 * 4 + j] = un;
+                    if (i0 == 0 && j < 4) u0v = un;
+                    const double e = un - ur[t];
+                    cost += 0.5 * wu[t] * e * e;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = lane + 64 * t;
+                if (j < nxr) {
+                    const double xn = xo[t] + dx[j];
+                    xd[i0 * 12 + j] = xn;
+                    const double e = xn - yr[t];
+                    cost += 0.5 * wx[t] * e * e;
+                }
+            }
+        }
+    }
+    W.nan = __ballot(bad) != 0ull;
+    W.feas = __ballot(infeas) == 0ull;
+    if (fast) {
+        // every window passed: the staged rows of the windows 0 .. nc-2 into the iterate (all loads requested before the first store)
+        wave_fence();
+        const int ns = (nc - 1) * L;   // staged stages
+        auto copy_rows = [&](double* dst, const double* src, int nd) __attribute__((always_inline)) {
+            for (int o0 = 0; o0 < nd; o0 += 1024) {
+                dbl2 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int o = o0 + (k * 64 + lane) * 2;
+                    v[k] = *(const dbl2*)(src + (o < nd ? o : 0));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int o = o0 + (k * 64 + lane) * 2;
+                    if (o < nd) *(dbl2*)(dst + o) = v[k];
+                }
+            }
+        };
+        copy_rows(x_it, sx, ns * 12);
+        copy_rows(u_it, su, ns * 4);
+        copy_rows(pi_it, spi, ns * 12);
+        copy_rows(lam_it, slam, ns * 8);
+        if (lane < 4) P.res[b].u0[lane] = u0v;
+        out.committed = true;
+        out.cost_lane = cost;
+        out.u0_lane = u0v;
+    }
+    wave_fence();
+    return out;
+}
+#endif   // BROV_EXP_WIN_FUSE
 template <int LDS>
 __device__ __forceinline__ void sw_rollout(Inst& I, Win* W, const d4& d0, const double* varr) {
     if constexpr (LDS < 3) {

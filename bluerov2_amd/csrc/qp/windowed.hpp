@@ -20,13 +20,13 @@ __host__ __device__ inline int win_len(int N) { const int nc = win_chunks(N); re
 // resident split launches: what the preparation parks per quarter of the horizon for a feedback that rolls out the four quarters at once --
 // the quarter's closed-loop transition (Psi = Phi', 256), its affine term (row 12 of G as the lanes hold it, 64), and the cost-to-go (P, p) at
 // the quarter's END (192 + 192)
-constexpr int kSegPark = 704;
 __host__ __device__ inline size_t win_ws_doubles(int N, int L) {
     return (size_t)((N + L - 1) / L) * win_img_doubles(L)                  // parked window images
            + (size_t)N * 4 + (size_t)(N + 1) * NX                          // vhat, dx (flat over the horizon)
            + (size_t)N * (64 + 64 + NX) + (size_t)IPM_NARR * 4 * N         // Ks Mt Pb | interior-point vectors
-           + 384 + 512 + 4 * kSegPark;                                     // (P, p) entering window 0 (resident mode: stage ckpt): checkpoint of the partial
+           + kWinCk                                                        // (P, p) entering window 0 (resident mode: stage ckpt): checkpoint of the partial
                                                                            // refactorisation; resident mode: + the step-0 feed-forward terms (4 N <= 512)
+           + (size_t)((N + L - 1) / L) * 384 + win_stage_doubles(N);       // development build BROV_EXP_WIN_FUSE: (P, p) at the inner window boundaries, staged rows (win_forward_fast)
 }
 // RES: resident mode -- one window = the whole horizon (N <= 81) in a slice of up to 160 KB, one block per CU; for batches of at most
 // one instance per CU.  Nothing is parked and no window is fetched.  A separate instantiation (rti_window_kernel_res), so that the
@@ -271,6 +271,13 @@ __device__ __forceinline__ void rti_window_body(const DevParams& P) {
             } else {
                 bwd_chunk<true, 3, false, true>(I, S);
             }
+#if BROV_EXP_WIN_FUSE
+            if (!RES && c >= 1) {   // round 6: (P, p) as they cross the boundary into window c - 1 (win_forward_fast: the costate there)
+                double* bd = ws_ck + kWinCk + (size_t)(c - 1) * 384;
+#pragma unroll
+                for (int r = 0; r < 3; r++) { bd[r * 64 + lane] = S.P[r]; bd[192 + r * 64 + lane] = S.pv[r]; }
+            }
+#endif
             if (!RES && c == 1 && I.ckpt > 0) {   // (P, p) as they enter window 0: six coalesced 512-byte stores, never waited for
 #pragma unroll
                 for (int r = 0; r < 3; r++) { ws_ck[r * 64 + lane] = S.P[r]; ws_ck[192 + r * 64 + lane] = S.pv[r]; }
