@@ -13,7 +13,7 @@ first, last = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, last):
     try:
-        T.test_randomised_options_against_oracle(ba, orc, traj, seed)
+        T.test_randomised_options_against_oracle(ba, orc, traj, seed % 12, rng_seed=seed)   # (the suite's seed picks the horizon class: 0..8 LDS-resident, 9..11 streaming)
     except AssertionError as e:
         bad += 1
         print(f"seed {seed}: FAILED: {str(e)[:300]}")
