@@ -6,6 +6,7 @@ fails on the CPU, before any GPU test runs."""
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -164,3 +165,23 @@ def test_build_gate_catches_the_defect_in_real_compiler_output(tmp_path):
         out[name] = chk.scan(open(asm).read().split("\n"))
     assert out["product"] == []
     print(f"canary order (-DBROV_SCHED_TICKET_LATE) compiled now: {len(out['late'])} join block(s) with the defect", [h[0] for h in out["late"]])
+
+
+def test_device_integer_helpers_and_the_slow_multiplies_they_replace():
+    """Round 6.  (1) qp/tiles.hpp div12(): j / 12 as (j * 43691) >> 19 -- one full-rate 24-bit multiply -- must be exact over the element
+    indices the kernels form (up to 257 x 12 at N = 256) and its operands must fit 24 bits.  (2) v_mul_lo_u32 is a quarter-rate instruction on
+    gfx950 (16 cycles); `stage index x per-lane stride` compiled to it two to four times per stage of every sweep until lmul() (v_mul_i32_i24)
+    took over: the fused kernel's hot loops -- factor stage, forward, adjoint -- must stay free of the 32-bit multiplies."""
+    import numpy as np
+    j = np.arange(0, 131072, dtype=np.int64)
+    assert np.array_equal((j * 43691) >> 19, j // 12) and 43691 < 2 ** 24 and j.max() < 2 ** 24
+    assert ((np.int64(131075) * 43691) >> 19) != 131075 // 12   # (the bound in the comment is the real one)
+    obj = os.path.join(ROOT, "bluerov2_amd", "lib", "obj", "qp_kernel.o")
+    if not os.path.exists(obj):
+        pytest.skip("no object file (library not built here)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dev", "isa_loops.py"), obj, "16rti_fused_kernelENS", "100"],
+                         capture_output=True, text=True, check=True).stdout
+    # three stages of a factor sweep / of a DPP sweep per trip (the stage loops themselves: under 800 instructions, not the QP loop around them)
+    hot = [ln for ln in out.splitlines() if (" 30 MFMA" in ln or "f64 dpp=48" in ln) and int(re.search(r"(\d+) instr", ln).group(1)) < 800]
+    assert len(hot) >= 3, out[:400]
+    assert not any("mul32=" in ln for ln in hot), [ln for ln in hot if "mul32=" in ln]
