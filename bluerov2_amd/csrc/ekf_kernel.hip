@@ -414,6 +414,7 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDppFilters = 4;
 constexpr int kDppLds = 3 * kMat + 4 * EN;       // doubles per filter: buffers A, B, C + x_new, x_pred, innovation, measurement
+constexpr int kSpLds = 2 * kMat + 4 * EN;        // ekf_update_kernel_sp: two buffers (left operands that are a lane's own rows come out of registers)
 
 struct Rows { double p[EN], s[EN]; };   // row layout: p = row l of the matrix, s = row 16 + l (lanes 0, 1), else 0
 
@@ -774,6 +775,441 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Structured variant of the DPP kernel (default since round 6; ekf_update_kernel_dpp stays behind BROV_EKF_VARIANT=1).
+// Same mapping (one filter per 16-lane DPP row, rows of the right operand broadcast out of registers), same arithmetic in
+// the same order -- what it leaves out are operations whose operand is an EXACT zero of a finite-difference Jacobian, and
+// function evaluations whose result is known without them:
+//   * a component of the RK4 map / of h that does not depend on the perturbed state comes out bit-identical in the perturbed
+//     and the unperturbed evaluation (same instruction stream, same inputs), so its forward difference is exactly 0.
+//     F = d(RK4)/dx: nothing depends on the position (bluerov2_dob.cpp:637-702 read x(3..17) only), so columns 0..2 are
+//     e_r ((x_r + d) + inc_r - (x_r + inc_r)) / d with the increment of the UNPERTURBED evaluation; rows 12..17 (disturbances: no
+//     dynamics) are e_r ((x_r + d) - x_r) / d.  H = dh/dx (:705-727): rows 0..11 are the states themselves, rows 12..17 depend on
+//     phi, theta, the six velocities and their own disturbance.
+//   * so the 19 evaluations of the RK4 map are 16: lane 0 evaluates the unperturbed map, lanes 1 / 2 the ones perturbed in
+//     states 16 / 17, lanes 3..15 their own state, and columns 0..2 follow from lane 0's increment -- ONE pass of ekf_rk4 per
+//     wave instead of two (the second one ran for three useful lanes of sixteen).  The same for h (one pass instead of three).
+//   * the products that have F, H or their transposes as an operand issue only the multiply-adds of the non-zero pattern:
+//     G = P F' 378 (648), P_pred = F G 292 (360), W = H P_pred 234 (468), S = W H' 84 (360), J = I - Kal H 132 (648) DPP
+//     multiply-adds per wave; Gauss-Jordan, V = J P_pred and the Joseph form are dense and unchanged.
+//   * left operands that are a lane's own rows (W in S = W H', V in P_new = V J') come out of the lane's registers, W is eliminated in
+//     place, P and P_pred share a buffer and so do F', H' and K': TWO 18 x 18 LDS buffers per filter instead of three -- 22.5 KB per
+//     wave, seven waves per CU -- and the leaner products need 224 registers: two waves per SIMD (the dense kernel: 264, one).
+// Skipping a multiply-add whose product is an exact zero leaves the accumulator as it is (up to the sign of a zero); what is NOT
+// bit-identical to the dense kernel is the code the compiler makes of the RK4 map here (one evaluation + the position increments
+// instead of two evaluations), and a last-bit difference there is a 1e-10 relative difference in F.  The two kernels agree like any
+// two FP64 evaluations of the filter do (tests/test_gpu_ekf.py: 1e-6 after a tick, against each other and against the oracle).
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr bool ekf_h21col(int k) { return k == 3 || k == 4 || (k >= 6 && k < 12); }   // columns of H's rows 12..17 (besides their own)
+__host__ __device__ constexpr int ekf_h21idx(int k) { return k < 5 ? k - 3 : k - 4; }                           // 3, 4, 6..11 -> 0..7
+struct NzFt { static constexpr bool at(int k, int j) { return k < 3 ? j == k : (j < 12 || j == k); } };      // F'[k][j] = F[j][k]
+struct NzHt { static constexpr bool at(int k, int j) { return j == k || (j >= 12 && ekf_h21col(k)); } };     // H'[k][j] = H[j][k]
+
+// both halves of a double through 32-bit DPP moves (the 64-bit DPP move knows row_newbcast only); lanes whose source is outside
+// the 16-lane row receive 0
+template <int CTRL>
+__device__ __forceinline__ double dpp32_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// ekf_rk4 and, for the position components, the result the same evaluation would have with x_i + d in place of x_i (the
+// stages do not read the position): the forward difference of columns 0..2 without evaluating them
+__device__ __forceinline__ void ekf_rk4_fd(const EkfConst& c, const double (&x)[EN], const double (&tau)[6], double (&xn)[EN],
+                                           double (&xnp)[3]) {
+    double k1[12], k2[12], k3[12], k4[12], xs[EN];
+#pragma unroll
+    for (int i = 12; i < EN; i++) { xs[i] = x[i]; xn[i] = x[i]; }
+    ekf_f12(c, x, tau, k1);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k1[i] *= c.dt; xs[i] = x[i] + k1[i] * 0.5; }
+    ekf_f12(c, xs, tau, k2);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k2[i] *= c.dt; xs[i] = x[i] + k2[i] * (1.0 / 3.0); }
+    ekf_f12(c, xs, tau, k3);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k3[i] *= c.dt; xs[i] = x[i] + k3[i]; }
+    ekf_f12(c, xs, tau, k4);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        k4[i] *= c.dt;
+        xn[i] = x[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (1.0 / 6.0);
+        if (i < 3) xnp[i] = (x[i] + c.d) + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) * (1.0 / 6.0);
+    }
+}
+
+// C += A B over the non-zero pattern NZ of B (NZ::at(row of B, column)); otherwise gemm_block / gemm_dpp
+template <class NZ, int K0, int NK, bool SECB, bool CORNER>
+__device__ __forceinline__ void gemm_block_sp(Rows& C, const Rows& B, const double (&a0)[NK], const double (&a1)[NK]) {
+    for_k(std::make_integer_sequence<int, NK>{}, [&](auto kc) {
+        constexpr int KK = decltype(kc)::value;
+        constexpr int K = K0 + KK;                 // lane that owns the B row
+        constexpr int ROW = SECB ? 16 + K : K;     // the row's index in B
+        for_k(std::make_integer_sequence<int, EN>{}, [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (NZ::at(ROW, J)) {
+                fmac_bc<K>(C.p[J], SECB ? B.s[J] : B.p[J], a0[KK]);
+                if constexpr (!CORNER || J >= 16) fmac_bc<K>(C.s[J], SECB ? B.s[J] : B.p[J], a1[KK]);
+            }
+        });
+    });
+}
+template <class NZ, bool CORNER = false, class AP, class AS>
+__device__ __forceinline__ void gemm_dpp_sp(Rows& C, const Rows& B, AP ap, AS as) {
+    double p0[6], s0[6], p1[6], s1[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { p0[k] = ap(k); s0[k] = as(k); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { p1[k] = ap(6 + k); s1[k] = as(6 + k); }
+    asm volatile("s_nop 1");
+    gemm_block_sp<NZ, 0, 6, false, CORNER>(C, B, p0, s0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p0[k] = ap(12 + k); s0[k] = as(12 + k); }
+    p0[4] = ap(16); s0[4] = as(16); p0[5] = ap(17); s0[5] = as(17);
+    gemm_block_sp<NZ, 6, 6, false, CORNER>(C, B, p1, s1);
+    {
+        const double q0[4] = {p0[0], p0[1], p0[2], p0[3]}, q1[4] = {s0[0], s0[1], s0[2], s0[3]};
+        gemm_block_sp<NZ, 12, 4, false, CORNER>(C, B, q0, q1);
+        const double r0[2] = {p0[4], p0[5]}, r1[2] = {s0[4], s0[5]};
+        gemm_block_sp<NZ, 0, 2, true, CORNER>(C, B, r0, r1);
+    }
+}
+
+__global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double esm[];
+    const EkfConst& c = A.c;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, l = lane & 15;
+    const int inst0 = blockIdx.x * kDppFilters + g;
+    const bool live = inst0 < A.B;
+    const int inst = live ? inst0 : A.B - 1;
+    const bool sec = l < 2;              // owns a secondary row
+    const int ls = sec ? l : 0;
+    // finite-difference roles: lane 0 evaluates the unperturbed map, lanes 1 / 2 perturb states 16 / 17, lanes 3..15 their own state
+    const int pert = l >= 3 ? l : (l == 0 ? -1 : 15 + l);
+    const double idp = l >= 3 ? c.inv_d : 0.0;   // 1 / d where this lane's evaluation is a column of its primary row set
+    const double ids = sec ? c.inv_d : 0.0;      // ... where the evaluation of lane l + 1 is this lane's secondary row
+
+    elds* sm = (elds*)esm + g * kSpLds;
+    elds* bufX = sm;                     // P -> P_pred -> J
+    elds* bufY = bufX + kMat;            // F^T -> H^T -> K^T
+    elds* v_xn = bufY + kMat;            // [18] corrected state (gathered for the output lane)
+    elds* v_xp = v_xn + EN;              // [18] predicted state
+    elds* v_ye = v_xp + EN;              // [18] innovation
+    elds* v_ym = v_ye + EN;              // [18] measurement
+
+    // ---- inputs: every lane keeps x, tau, acc of its filter
+    double x[EN], tau[6], ac[6];
+    {
+        const double* xg = A.x + (size_t)inst * EN;
+        const double* tg = A.thrust + (size_t)inst * 6;
+        const double* ag = A.acc + (size_t)inst * 6;
+        const double* yg = A.y12 + (size_t)inst * 12;
+#pragma unroll
+        for (int j = 0; j < EN; j++) x[j] = xg[j];
+        double th[6], ym[EN];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { th[j] = tg[j]; ac[j] = ag[j]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {   // tau = K * meas_u (bluerov2_dob.cpp:499-500)
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += c.K[i * 6 + j] * th[j];
+            tau[i] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < 12; j++) ym[j] = yg[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) ym[12 + j] = tau[j];
+        store_row(v_ym, ym);   // identical values from the 16 lanes of the filter
+        // P -> bufX (left operand of the first product): the filter's 2592 contiguous bytes in 16-byte pieces, 16 lanes wide
+        const ed2* pg = (const ed2*)(A.P + (size_t)inst * kMat);
+        ed2 pv[11];
+#pragma unroll
+        for (int m = 0; m < 11; m++) { const int q = m * 16 + l; pv[m] = pg[q < kMat / 2 ? q : 0]; }
+#pragma unroll
+        for (int m = 0; m < 11; m++) { const int q = m * 16 + l; if (q < kMat / 2) ((elds2*)bufX)[q] = pv[m]; }
+    }
+
+    // ---- F^T by forward differences of the RK4 map, one evaluation per lane
+    Rows Ft;
+    {
+        double xl[EN], xb[EN], xnp[3];
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((j == pert) ? c.d : 0.0);
+        ekf_rk4_fd(c, xl, tau, xb, xnp);
+        double f0[EN];
+#pragma unroll
+        for (int j = 0; j < EN; j++) f0[j] = bcast<0>(xb[j]);
+        const double q0 = bcast<0>(xnp[0]), q1 = bcast<0>(xnp[1]), q2 = bcast<0>(xnp[2]);
+        const double fd[3] = {(q0 - f0[0]) * c.inv_d, (q1 - f0[1]) * c.inv_d, (q2 - f0[2]) * c.inv_d};
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            const double v = (xb[j] - f0[j]) * idp;
+            Ft.p[j] = (j < 3 && l == j) ? fd[j < 3 ? j : 0] : v;
+            Ft.s[j] = (dpp32_f64<0x101>(xb[j]) - f0[j]) * ids;   // row_shl:1 -- lane 0 <- lane 1 (state 16), lane 1 <- lane 2 (state 17)
+            x[j] = f0[j];                   // from here on x = x_pred
+        }
+        store_row(v_xp, f0);
+    }
+    __syncthreads();
+    // G = P F^T
+    Rows G;
+    zero_rows(G);
+    gemm_dpp_sp<NzFt>(G, Ft, [&](int k) { return bufX[l * EN + k]; }, [&](int k) { const double t = bufX[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    store_rows(bufY, Ft, l);                // F^T row-major: F[l][k] = bufY[k][l]
+    __syncthreads();                        // (also: the reads of P are done, bufX is free)
+    // P_pred = F G + Q.  F[l][k] is zero for k < 3 except on the diagonal (own-lane multiply-add), rows 16 / 17 of F are e_16 / e_17
+    Rows Pq;
+#pragma unroll
+    for (int j = 0; j < EN; j++) { Pq.p[j] = (j == l) ? c.Q[j] : 0.0; Pq.s[j] = (sec && j == 16 + l) ? c.Q[j] : 0.0; }
+    {
+        double a[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) a[k] = bufY[(3 + k) * EN + l];
+        const double fdl = bufY[l * EN + l], a16 = bufY[16 * EN + 16 + ls], a17 = bufY[17 * EN + 16 + ls];
+        const double fd3 = (l < 3) ? fdl : 0.0, s16 = sec ? a16 : 0.0, s17 = sec ? a17 : 0.0;
+#pragma unroll
+        for (int j = 0; j < EN; j++) Pq.p[j] = fma(fd3, G.p[j], Pq.p[j]);
+        asm volatile("s_nop 1");
+        for_k(std::make_integer_sequence<int, 13>{}, [&](auto kc) {
+            constexpr int K = 3 + decltype(kc)::value;
+#pragma unroll
+            for (int j = 0; j < EN; j++) fmac_bc<K>(Pq.p[j], G.p[j], a[K - 3]);
+        });
+#pragma unroll
+        for (int j = 0; j < EN; j++) fmac_bc<0>(Pq.p[j], G.s[j], a[13]);
+        fmac_bc<0>(Pq.s[16], G.s[16], s16); fmac_bc<0>(Pq.s[17], G.s[17], s16);
+#pragma unroll
+        for (int j = 0; j < EN; j++) fmac_bc<1>(Pq.p[j], G.s[j], a[14]);
+        fmac_bc<1>(Pq.s[16], G.s[16], s17); fmac_bc<1>(Pq.s[17], G.s[17], s17);
+    }
+    fill_secondary_from_symmetry(Pq, l);    // P_pred is symmetric: only the 2x2 corner of rows 16, 17 was accumulated
+    store_rows(bufX, Pq, l);                // P_pred stays in bufX (right operand of V = J P_pred)
+    // ---- H^T by forward differences of h at x_pred (one evaluation per lane), innovation
+    Rows Ht;
+    {
+        double xl[EN], yb[EN], ye[EN], ym2[EN];
+        load_row(v_ym, ym2);
+#pragma unroll
+        for (int j = 0; j < EN; j++) xl[j] = x[j] + ((j == pert) ? c.d : 0.0);
+        ekf_h(c, xl, ac, yb);
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            const double y0 = bcast<0>(yb[j]);
+            const double v = (yb[j] - y0) * idp;
+            // columns 0..2: h passes the position through, (x_j + d) - x_j
+            Ht.p[j] = (j < 3 && l == j) ? ((x[j] + c.d) - y0) * c.inv_d : v;
+            Ht.s[j] = (dpp32_f64<0x101>(yb[j]) - y0) * ids;
+            ye[j] = ym2[j] - y0;
+        }
+        store_row(v_ye, ye);
+    }
+    __syncthreads();                        // reads of bufY (F^T) are done
+    store_rows(bufY, Ht, l);                // H^T row-major: H[l][k] = bufY[k][l]
+    __syncthreads();
+    // W = H P_pred.  Rows 0..11 of H are diagonal; rows 12..17 have the eight columns of ekf_h21col and their own
+    Rows W;
+    zero_rows(W);
+    {
+        const bool hi = l >= 12;
+        double a[8], h16[8], h17[8];
+        for_k(std::make_integer_sequence<int, 12>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (ekf_h21col(K)) {
+                constexpr int Q = ekf_h21idx(K);
+                const double t = bufY[K * EN + l];
+                a[Q] = hi ? t : 0.0; h16[Q] = bufY[K * EN + 16]; h17[Q] = bufY[K * EN + 17];
+            }
+        });
+        const double hd = bufY[l * EN + l], hd16 = bufY[16 * EN + 16], hd17 = bufY[17 * EN + 17];
+        asm volatile("s_nop 1");
+        for_k(std::make_integer_sequence<int, 12>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (ekf_h21col(K)) {
+#pragma unroll
+                for (int j = 0; j < EN; j++) fmac_bc<K>(W.p[j], Pq.p[j], a[ekf_h21idx(K)]);
+            }
+        });
+#pragma unroll
+        for (int j = 0; j < EN; j++) W.p[j] = fma(hd, Pq.p[j], W.p[j]);
+        // rows 16, 17 through the symmetry of P_pred, as gemm_dpp_symB does it: lane j computes W[16][j], W[17][j] from its own row
+        double c16 = 0.0, c17 = 0.0, d16 = 0.0, d17 = 0.0;
+        for_k(std::make_integer_sequence<int, 12>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (ekf_h21col(K)) {
+                constexpr int Q = ekf_h21idx(K);
+                c16 = fma(h16[Q], Pq.p[K], c16); c17 = fma(h17[Q], Pq.p[K], c17);
+                d16 = fma(h16[Q], Pq.s[K], d16); d17 = fma(h17[Q], Pq.s[K], d17);
+            }
+        });
+        c16 = fma(hd16, Pq.p[16], c16); d16 = fma(hd16, Pq.s[16], d16);
+        c17 = fma(hd17, Pq.p[17], c17); d17 = fma(hd17, Pq.s[17], d17);
+        for_k(std::make_integer_sequence<int, 16>{}, [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const double t16 = bcast<J>(c16), t17 = bcast<J>(c17);
+            W.s[J] = (l == 0) ? t16 : ((l == 1) ? t17 : 0.0);
+        });
+        const double e16_0 = bcast<0>(d16), e16_1 = bcast<1>(d16), e17_0 = bcast<0>(d17), e17_1 = bcast<1>(d17);
+        W.s[16] = (l == 0) ? e16_0 : ((l == 1) ? e17_0 : 0.0);
+        W.s[17] = (l == 0) ? e16_1 : ((l == 1) ? e17_1 : 0.0);
+    }
+    // S = W H^T + R.  The left operand's elements W[l][k], W[16 + l][k] are this lane's own rows: W never goes through LDS
+    Rows S;
+#pragma unroll
+    for (int j = 0; j < EN; j++) { S.p[j] = (j == l) ? c.R : 0.0; S.s[j] = (sec && j == 16 + l) ? c.R : 0.0; }
+    gemm_dpp_sp<NzHt, true>(S, Ht, [&](int k) { return W.p[k]; }, [&](int k) { return W.s[k]; });
+    fill_secondary_from_symmetry(S, l);     // S is symmetric
+    // ---- K^T = S^-1 W by Gauss-Jordan on [S | W] without pivoting (S is SPD); the pivot row is broadcast with DPP.
+    // Secondary rows of lanes >= 2 are zero and stay zero (their factor is 0).
+    Rows& T = W;                            // Gauss-Jordan on [S | W] in place
+    bool ok = true;
+    for_k(std::make_integer_sequence<int, EN>{}, [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        constexpr bool PS = K >= 16;          // pivot row in the secondary set (lanes 0, 1)
+        constexpr int KL = PS ? K - 16 : K;   // lane that owns the pivot row
+        const double pk = PS ? bcast<KL>(S.s[K]) : bcast<KL>(S.p[K]);
+        ok = ok && (pk > 0.0) && (pk < 1e300);
+        double ip = __builtin_amdgcn_rcp(pk);
+        double e1 = fma(-pk, ip, 1.0);
+        ip = fma(ip, e1, ip);
+        e1 = fma(-pk, ip, 1.0);
+        ip = fma(ip, e1, ip);
+        const double nfp = (!PS && l == KL) ? ip - 1.0 : -(S.p[K] * ip);
+        const double nfs = (PS && l == KL) ? ip - 1.0 : -(S.s[K] * ip);
+#pragma unroll
+        for (int j = K + 1; j < EN; j++) {
+            if (PS) { fmac_bc<KL>(S.p[j], S.s[j], nfp); fmac_bc<KL>(S.s[j], S.s[j], nfs); }
+            else { fmac_bc<KL>(S.s[j], S.p[j], nfs); fmac_bc<KL>(S.p[j], S.p[j], nfp); }
+        }
+#pragma unroll
+        for (int j = 0; j < EN; j++) {
+            if (PS) { fmac_bc<KL>(T.p[j], T.s[j], nfp); fmac_bc<KL>(T.s[j], T.s[j], nfs); }
+            else { fmac_bc<KL>(T.s[j], T.p[j], nfs); fmac_bc<KL>(T.p[j], T.p[j], nfp); }
+        }
+    });
+    if (!ok) zero_rows(T);                  // innovation covariance not positive definite / NaN: keep the prediction
+    // the entries of H that J = I - Kal H needs (right operand in row layout: lane k owns row k -- its diagonal entry and, for rows
+    // 12..17, the eight entries of ekf_h21col), out of bufY before K^T takes its place
+    double hp[8], hs[8];
+    for_k(std::make_integer_sequence<int, 12>{}, [&](auto jc) {
+        constexpr int JJ = decltype(jc)::value;
+        if constexpr (ekf_h21col(JJ)) { hp[ekf_h21idx(JJ)] = bufY[JJ * EN + l]; hs[ekf_h21idx(JJ)] = bufY[JJ * EN + 16 + ls]; }
+    });
+    const double hdJ = bufY[l * EN + l], hsdJ = bufY[(16 + ls) * EN + 16 + ls];
+    __syncthreads();                        // reads of bufY (H^T) are done
+    store_rows(bufY, T, l);                 // K^T row-major: Kal[l][k] = bufY[k][l]
+    __syncthreads();
+    // x_new = x_pred + Kal (y - y_pred)
+    {
+        double dp = 0.0, ds = 0.0, ye[EN];
+        load_row(v_ye, ye);
+#pragma unroll
+        for (int k = 0; k < EN; k++) { dp = fma(bufY[k * EN + l], ye[k], dp); ds = fma(bufY[k * EN + 16 + ls], ye[k], ds); }
+        const double xp_ = v_xp[l] + dp, xs_ = v_xp[16 + ls] + ds;
+        v_xn[l] = xp_;
+        if (sec) v_xn[16 + l] = xs_;
+        if (live) {
+            A.x[(size_t)inst * EN + l] = xp_;
+            if (sec) A.x[(size_t)inst * EN + 16 + l] = xs_;
+        }
+    }
+    // J = I - Kal H
+    Rows J;
+    zero_rows(J);
+    {
+        const double hd = hdJ, hsd = hsdJ;
+        double a0[EN], a1[EN];
+#pragma unroll
+        for (int k = 0; k < EN; k++) { a0[k] = -bufY[k * EN + l]; const double t = -bufY[k * EN + 16 + ls]; a1[k] = sec ? t : 0.0; }
+        asm volatile("s_nop 1");
+        for_k(std::make_integer_sequence<int, 12>{}, [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            fmac_bc<K>(J.p[K], hd, a0[K]); fmac_bc<K>(J.s[K], hd, a1[K]);
+        });
+        for_k(std::make_integer_sequence<int, 4>{}, [&](auto kc) {
+            constexpr int K = 12 + decltype(kc)::value;
+            for_k(std::make_integer_sequence<int, 12>{}, [&](auto jc) {
+                constexpr int JJ = decltype(jc)::value;
+                if constexpr (ekf_h21col(JJ)) { fmac_bc<K>(J.p[JJ], hp[ekf_h21idx(JJ)], a0[K]); fmac_bc<K>(J.s[JJ], hp[ekf_h21idx(JJ)], a1[K]); }
+            });
+            fmac_bc<K>(J.p[K], hd, a0[K]); fmac_bc<K>(J.s[K], hd, a1[K]);
+        });
+        for_k(std::make_integer_sequence<int, 2>{}, [&](auto kc) {
+            constexpr int KL = decltype(kc)::value;
+            constexpr int K = 16 + KL;
+            for_k(std::make_integer_sequence<int, 12>{}, [&](auto jc) {
+                constexpr int JJ = decltype(jc)::value;
+                if constexpr (ekf_h21col(JJ)) { fmac_bc<KL>(J.p[JJ], hs[ekf_h21idx(JJ)], a0[K]); fmac_bc<KL>(J.s[JJ], hs[ekf_h21idx(JJ)], a1[K]); }
+            });
+            fmac_bc<KL>(J.p[K], hsd, a0[K]); fmac_bc<KL>(J.s[K], hsd, a1[K]);
+        });
+    }
+#pragma unroll
+    for (int j = 0; j < EN; j++) {
+        if (!ok) { J.p[j] = 0.0; J.s[j] = 0.0; }   // H may hold NaN: J = I exactly
+        J.p[j] += (j == l) ? 1.0 : 0.0;
+        J.s[j] += (sec && j == 16 + l) ? 1.0 : 0.0;
+    }
+    // V = J P_pred: P_pred out of bufX into registers (right operand), J takes its place (left operand, and J^T below)
+    Rows V;
+    {
+        Rows Pr;
+        load_rows(bufX, Pr, l);
+        __syncthreads();                    // reads of bufX (P_pred) are done
+        store_rows(bufX, J, l);             // J row-major
+        __syncthreads();
+        zero_rows(V);
+        gemm_dpp_symB(V, Pr, [&](int k) { return bufX[l * EN + k]; }, [&](int k) { return bufX[16 * EN + k]; }, [&](int k) { return bufX[17 * EN + k]; }, l);
+    }
+    // P_new = V J^T + R Kal Kal^T   (Joseph form, bluerov2_dob.cpp:537).  Left operand of the first product: V's own rows (registers)
+    Rows Pn;
+    zero_rows(Pn);
+    {
+        Rows Jt;
+        load_rows_t(bufX, Jt, l);
+        gemm_dpp<true>(Pn, Jt, [&](int k) { return V.p[k]; }, [&](int k) { return V.s[k]; });
+        Rows Kt;
+        load_rows(bufY, Kt, l);
+        gemm_dpp<true>(Pn, Kt, [&](int k) { return c.R * bufY[k * EN + l]; }, [&](int k) { const double t = c.R * bufY[k * EN + 16 + ls]; return sec ? t : 0.0; });
+    }
+    if (live) {   // P_new is symmetric: rows 16, 17 are columns 16, 17 of the primary rows (+ the 2x2 corner from lanes 0, 1)
+        double* pg = A.P + (size_t)inst * kMat;
+#pragma unroll
+        for (int j = 0; j < EN; j++) pg[l * EN + j] = Pn.p[j];
+        pg[16 * EN + l] = Pn.p[16];
+        pg[17 * EN + l] = Pn.p[17];
+        if (sec) { pg[(16 + l) * EN + 16] = Pn.s[16]; pg[(16 + l) * EN + 17] = Pn.s[17]; }
+    }
+    // ---- outputs: world-frame disturbance with the MEASURED attitude (:540-545), NMPC parameters (:334-337)
+    __syncthreads();
+    if (l == 0 && live) {
+        double xn[EN];
+        load_row(v_xn, xn);
+        double sph, cph, sth, cth, sps, cps;
+        sincos_pio2(v_ym[3], &sph, &cph);
+        sincos_pio2(v_ym[4], &sth, &cth);
+        sincos_pio2(v_ym[5], &sps, &cps);
+        double* w = A.wf + (size_t)inst * 6;
+        w[0] = (cps * cth) * xn[12] + (-sps * cph + cps * sth * sph) * xn[13] + (sps * sph + cps * cph * sth) * xn[14];
+        w[1] = (sps * cth) * xn[12] + (cps * cph + sph * sth * sps) * xn[13] + (-cps * sph + sth * sps * cph) * xn[14];
+        w[2] = (-sth) * xn[12] + (cth * sph) * xn[13] + (cth * cph) * xn[14];
+        w[3] = xn[15] + (sps * sth / cth) * xn[16] + cph * sth / cth * xn[17];
+        w[4] = cph * xn[16] + sph * xn[17];
+        w[5] = (sph / cth) * xn[16] + (cph / cth) * xn[17];
+        double* mp = A.mp + (size_t)inst * 4;
+        mp[0] = xn[12] * c.inv_cc;
+        mp[1] = xn[13] * c.inv_cc;
+        mp[2] = xn[14] * c.inv_rc;
+        mp[3] = xn[17] * c.inv_rc;
+        bool fin = true;
+#pragma unroll
+        for (int j = 0; j < EN; j++) fin = fin && (fabs(xn[j]) < 1e300);
+        A.status[inst] = !ok ? 1 : (fin ? 0 : 2);
+    }
+}
+
 // measurement assembly for the on-device DOB-MPC loop: y12 = plant state, thrust = allocation of u0 (bluerov2_dob.cpp:390-395)
 // with the OCP model's rotor constant, i.e. exactly the thruster vector brov_plant_step applies; acc = (v - v_prev) / dt
 // (:148-153); one lane per filter
@@ -844,7 +1280,7 @@ struct brov_ekf {
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool ev_valid = false;
-    int variant = 1;   // 1: DPP row-broadcast kernel (default), 0: LDS-broadcast kernel (BROV_EKF_VARIANT=0, kept for A/B runs)
+    int variant = 2;   // 2: structured DPP kernel (default), 1: dense DPP row-broadcast kernel, 0: LDS-broadcast kernel (BROV_EKF_VARIANT, kept for A/B runs)
     std::vector<void*> allocs;
 };
 
@@ -957,7 +1393,7 @@ extern "C" int brov_ekf_create(brov_ekf** out, int device, int B, const brov_ekf
     EKFCHK(hipSetDevice(device));
     brov_ekf* e = new brov_ekf();
     e->device = device; e->B = B;
-    if (const char* v = std::getenv("BROV_EKF_VARIANT")) e->variant = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("BROV_EKF_VARIANT")) { const int k = std::atoi(v); e->variant = (k >= 0 && k <= 2) ? k : 2; }
     if (p) e->par = *p; else brov_ekf_default_params(&e->par);
     make_const(e->par, e->c);
     int rc = BROV_OK;
@@ -1017,7 +1453,8 @@ static int launch_update(brov_ekf* e, const double* thrust, const double* y12, c
         hipLaunchKernelGGL(ekf_update_kernel, dim3(blocks), dim3(64), kPerWave * kLdsPerFilter * sizeof(double), st, a);
     } else {
         const int blocks = (e->B + kDppFilters - 1) / kDppFilters;
-        hipLaunchKernelGGL(ekf_update_kernel_dpp, dim3(blocks), dim3(64), kDppFilters * kDppLds * sizeof(double), st, a);
+        if (e->variant == 1) hipLaunchKernelGGL(ekf_update_kernel_dpp, dim3(blocks), dim3(64), kDppFilters * kDppLds * sizeof(double), st, a);
+        else hipLaunchKernelGGL(ekf_update_kernel_sp, dim3(blocks), dim3(64), kDppFilters * kSpLds * sizeof(double), st, a);
     }
     EKFCHK(hipGetLastError());
     EKFCHK(hipEventRecord(e->ev[1], st));

@@ -187,7 +187,10 @@ def test_batch_mismatch_is_rejected(ba):
 
 
 def test_dpp_and_lds_broadcast_kernels_agree(ba, orc, monkeypatch):
-    """the default DPP row-broadcast kernel against the first (LDS-broadcast) kernel, kept behind BROV_EKF_VARIANT=0"""
+    """the default (structured DPP) kernel against the dense DPP row-broadcast kernel (BROV_EKF_VARIANT=1) and the first, LDS-broadcast
+    kernel (BROV_EKF_VARIANT=0): one tick from the same state.  (Over several ticks of a repeated measurement any two FP64 evaluations
+    drift apart -- the finite-difference Jacobians amplify last-bit differences of the RK4 map by ~1e10; scripts/dev/ekf_variant_diff.py
+    prints that drift for the three kernels and the oracle.)"""
     c = T.np_consts(orc.par)
     rng = np.random.default_rng(31)
     B = 37
@@ -195,12 +198,13 @@ def test_dpp_and_lds_broadcast_kernels_agree(ba, orc, monkeypatch):
     A = rng.normal(size=(B, 18, 18)) * 0.2
     P = np.einsum("bij,bkj->bik", A, A) + np.eye(18) * 0.3
     thrust, y12, acc = consistent_inputs(c, rng, x)
-    out = []
-    for variant in ("1", "0"):
+    out = {}
+    for variant in ("2", "1", "0"):
         monkeypatch.setenv("BROV_EKF_VARIANT", variant)
         e = ba.BatchEkf(B)
         e.set_state(x, P); e.update(thrust, y12, acc)
-        out.append(e.state() + e.outputs())
+        out[variant] = e.state() + e.outputs()
         e.close()
-    for a, b in zip(out[0], out[1]):
-        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+    for other in ("1", "0"):
+        for a, b in zip(out["2"], out[other]):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
