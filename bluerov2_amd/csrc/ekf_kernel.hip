@@ -5,10 +5,12 @@
 // through the explicit inverse of the innovation covariance, Joseph-form covariance update, world-frame disturbance, and the
 // hand-over to the NMPC parameters p[0..3] (:334-337).
 //
-// Two kernels.  ekf_update_kernel_dpp (default): one filter per 16-lane DPP row, right-hand rows of the products broadcast
-// out of registers with v_fmac_f64_dpp row_newbcast -- see the comment in front of it.  ekf_update_kernel (first version,
-// BROV_EKF_VARIANT=0): 19 lanes per filter, right-hand rows broadcast through LDS; kept for A/B measurements.
-// Common to both: 18 does not fit the 16-wide FP64 MFMA tile (a 32x32 padding would waste 3/4 of the issue slots, and FP64
+// Three kernels.  ekf_update_kernel_sp (default since round 6): one filter per 16-lane DPP row, right-hand rows of the products
+// broadcast out of registers with v_fmac_f64_dpp row_newbcast, only the non-zero pattern of the finite-difference Jacobians
+// multiplied, 16 evaluations of the RK4 map in one pass, two LDS buffers, two waves per SIMD -- see the comment in front of it.
+// ekf_update_kernel_dpp (rounds 2-5, BROV_EKF_VARIANT=1): the same mapping, dense.  ekf_update_kernel (first version,
+// BROV_EKF_VARIANT=0): 19 lanes per filter, right-hand rows broadcast through LDS.  The older two are kept for A/B measurements.
+// Common to all: 18 does not fit the 16-wide FP64 MFMA tile (a 32x32 padding would waste 3/4 of the issue slots, and FP64
 // MFMA has the same flop rate as FP64 VALU on this part), so the filter runs on the VALU with one lane per matrix row; the
 // lane that perturbs state r in the finite differences ends up holding column r of the Jacobian, i.e. row r of its
 // transpose, and the products are arranged so that this is the form they need.
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(64) void ekf_update_kernel(EkfArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// DPP variant (default).  The LDS-broadcast kernel above is bound by LDS bandwidth: every lane streams the whole right-hand
+// DPP variant (dense; default until round 5, BROV_EKF_VARIANT=1 since).  The LDS-broadcast kernel above is bound by LDS bandwidth: every lane streams the whole right-hand
 // matrix of every product out of LDS (0.5 MB per update against 128 B/clk per CU).  Here a filter lives in ONE 16-lane DPP
 // row (4 filters per wave) and the right-hand rows are broadcast straight out of the registers of the lane that owns them:
 //     v_fmac_f64_dpp acc, B_row_reg, a   row_newbcast:k      (acc += a * (B_row_reg of lane k of my 16-lane row))

@@ -15,7 +15,7 @@ import os
 import sys
 
 KEEP = ("lin_wave_kernel", "qp_kernel", "rti_fused_kernel", "rti_fused_kernel_w2", "rti_fused_kernel_grid", "rti_window_kernel", "rti_window_kernel_grid", "rti_window_kernel_res", "plant_kernel", "candidates_kernel",
-        "window_kernel", "ekf_update_kernel_dpp")
+        "window_kernel", "ekf_update_kernel_dpp", "ekf_update_kernel_sp")
 
 
 def kname(s):
