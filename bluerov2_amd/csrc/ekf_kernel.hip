@@ -435,6 +435,20 @@ __device__ __forceinline__ double bcast(double src) {
 template <int... Ks, class F>
 __device__ __forceinline__ void for_k(std::integer_sequence<int, Ks...>, F f) { (f(std::integral_constant<int, Ks>{}), ...); }
 
+// A register that a DPP instruction reads must have been written at least two wait states earlier (the hardware does not interlock
+// that case), and the compiler does not see through inline assembly: it is free to sink the instruction that PRODUCES a row element
+// (a select, the last multiply of a finite difference) down to just in front of the asm statement that reads it through DPP -- met in
+// round 6, where a changed operand form moved the finite-difference arithmetic of F^T into the first product and the product read
+// stale registers.  pin_rows() is an empty volatile asm with every element as an in-out operand: volatile asm statements keep their
+// order, so everything that produces the rows is issued before it and the `s_nop 1` behind it; the opaque result cannot be
+// rematerialised later either.  No instruction is emitted for it.
+__device__ __forceinline__ void pin_rows(const Rows& Rc) {
+    Rows& R = const_cast<Rows&>(Rc);
+#pragma unroll
+    for (int j = 0; j < EN; j++) asm volatile("" : "+v"(R.p[j]), "+v"(R.s[j]));
+    asm volatile("s_nop 1");
+}
+
 // C += A B.  B in row layout (registers); ap(k) / as(k) deliver A[l][k] and A[16+l][k] of this lane (as(k) = 0 for l >= 2).
 // The A elements of a block of k's are requested (LDS) before the fmacs of the previous block are issued.
 // CORNER: only columns 16, 17 of the secondary rows are accumulated -- for a symmetric result the rest of rows 16, 17 is
@@ -458,7 +472,7 @@ __device__ __forceinline__ void gemm_dpp(Rows& C, const Rows& B, AP ap, AS as) {
     for (int k = 0; k < 6; k++) { p0[k] = ap(k); s0[k] = as(k); }
 #pragma unroll
     for (int k = 0; k < 6; k++) { p1[k] = ap(6 + k); s1[k] = as(6 + k); }
-    asm volatile("s_nop 1");
+    pin_rows(B);
     gemm_block<0, 6, false, CORNER>(C, B, p0, s0);
 #pragma unroll
     for (int k = 0; k < 4; k++) { p0[k] = ap(12 + k); s0[k] = as(12 + k); }
@@ -473,18 +487,21 @@ __device__ __forceinline__ void gemm_dpp(Rows& C, const Rows& B, AP ap, AS as) {
 }
 // Symmetric result computed with CORNER = true: rows 16, 17 (secondary set of lanes 0, 1), columns 0..15, are columns 16, 17 of
 // the primary rows -- lane 0 / 1 gathers them with 2 x 16 row broadcasts instead of 2 x 16 x 18 fmacs issued for two lanes.
+// ZS = false: lanes >= 2 receive lane 1's values instead of zeros (their secondary set is never read: every DPP read of a secondary row
+// names lane 0 or 1, and only lanes 0, 1 store theirs) -- one select per element instead of two
+template <bool ZS = true>
 __device__ __forceinline__ void fill_secondary_from_symmetry(Rows& C, int l) {
     for_k(std::make_integer_sequence<int, 16>{}, [&](auto jc) {
         constexpr int J = decltype(jc)::value;
         const double t16 = bcast<J>(C.p[16]), t17 = bcast<J>(C.p[17]);
-        C.s[J] = (l == 0) ? t16 : ((l == 1) ? t17 : 0.0);
+        C.s[J] = (l == 0) ? t16 : ((ZS && l != 1) ? 0.0 : t17);
     });
 }
 // C += A B for a SYMMETRIC right operand B, secondary rows of C done the cheap way: C[16+r][j] = sum_k A[16+r][k] B[k][j] and
 // B[k][j] = B[j][k] is element k of the row lane j owns, so lane j computes C[16][j] and C[17][j] with 2 x 18 fmacs on its own
 // registers (a16(k), a17(k): rows 16, 17 of A, identical for the 16 lanes of a filter), then lanes 0 / 1 gather their rows with
 // row broadcasts.  Columns 16, 17 of those rows use B's secondary rows (lanes 0, 1).  init16 / init17: C[16][j], C[17][j] to add to.
-template <class AP, class A16, class A17>
+template <bool ZS = true, class AP, class A16, class A17>
 __device__ __forceinline__ void gemm_dpp_symB(Rows& C, const Rows& B, AP ap, A16 a16, A17 a17, int l) {
     gemm_dpp<true>(C, B, ap, [&](int) { return 0.0; });     // primary rows; the secondary set is rebuilt below
     double c16 = 0.0, c17 = 0.0, d16[2] = {0.0, 0.0}, d17[2] = {0.0, 0.0};
@@ -500,12 +517,12 @@ __device__ __forceinline__ void gemm_dpp_symB(Rows& C, const Rows& B, AP ap, A16
     for_k(std::make_integer_sequence<int, 16>{}, [&](auto jc) {
         constexpr int J = decltype(jc)::value;
         const double t16 = bcast<J>(c16), t17 = bcast<J>(c17);
-        C.s[J] = (l == 0) ? t16 : ((l == 1) ? t17 : 0.0);
+        C.s[J] = (l == 0) ? t16 : ((ZS && l != 1) ? 0.0 : t17);
     });
     {   // corner: lane 0 needs C[16][16] (its own d16), C[16][17] (lane 1's d16); lane 1 needs C[17][16] (lane 0's d17), C[17][17]
         const double e16_0 = bcast<0>(d16[0]), e16_1 = bcast<1>(d16[0]), e17_0 = bcast<0>(d17[0]), e17_1 = bcast<1>(d17[0]);
-        C.s[16] = (l == 0) ? e16_0 : ((l == 1) ? e17_0 : 0.0);
-        C.s[17] = (l == 0) ? e16_1 : ((l == 1) ? e17_1 : 0.0);
+        C.s[16] = (l == 0) ? e16_0 : ((ZS && l != 1) ? 0.0 : e17_0);
+        C.s[17] = (l == 0) ? e16_1 : ((ZS && l != 1) ? 0.0 : e17_1);
     }
     (void)d16[1]; (void)d17[1];
 }
@@ -518,17 +535,19 @@ __device__ __forceinline__ void store_rows(elds* m, const Rows& R, int l) {
     store_row(m + l * EN, R.p);
     if (l < 2) store_row(m + (16 + l) * EN, R.s);
 }
+template <bool ZS = true>
 __device__ __forceinline__ void load_rows(const elds* m, Rows& R, int l) {
     load_row(m + l * EN, R.p);
     double t[EN];
     load_row(m + (16 + (l < 2 ? l : 0)) * EN, t);
 #pragma unroll
-    for (int j = 0; j < EN; j++) R.s[j] = (l < 2) ? t[j] : 0.0;
+    for (int j = 0; j < EN; j++) R.s[j] = (!ZS || l < 2) ? t[j] : 0.0;
 }
 // rows of the TRANSPOSE of the matrix stored row-major at m (strided reads)
+template <bool ZS = true>
 __device__ __forceinline__ void load_rows_t(const elds* m, Rows& R, int l) {
 #pragma unroll
-    for (int j = 0; j < EN; j++) { R.p[j] = m[j * EN + l]; const double t = m[j * EN + 16 + (l < 2 ? l : 0)]; R.s[j] = (l < 2) ? t : 0.0; }
+    for (int j = 0; j < EN; j++) { R.p[j] = m[j * EN + l]; const double t = m[j * EN + 16 + (l < 2 ? l : 0)]; R.s[j] = (!ZS || l < 2) ? t : 0.0; }
 }
 
 __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
@@ -660,6 +679,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
     Rows T;
     load_rows(bufA, T, l);
     bool ok = true;
+    pin_rows(S); pin_rows(T);                 // (fill_secondary_from_symmetry / load_rows end in plain selects)
     for_k(std::make_integer_sequence<int, EN>{}, [&](auto kc) {
         constexpr int K = decltype(kc)::value;
         constexpr bool PS = K >= 16;          // pivot row in the secondary set (lanes 0, 1)
@@ -797,6 +817,9 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_dpp(EkfArgs A) {
 //   * left operands that are a lane's own rows (W in S = W H', V in P_new = V J') come out of the lane's registers, W is eliminated in
 //     place, P and P_pred share a buffer and so do F', H' and K': TWO 18 x 18 LDS buffers per filter instead of three -- 22.5 KB per
 //     wave, seven waves per CU -- and the leaner products need 224 registers: two waves per SIMD (the dense kernel: 264, one).
+//   * the secondary register set (rows 16, 17) of lanes 2..15 holds don't-care values here (the dense kernel keeps it zero with two
+//     selects per element): every DPP read of a secondary row names lane 0 or 1, and only those lanes store theirs.
+//   * every product pins its broadcast rows first (pin_rows): see the hazard note there and scripts/check_dpp_hazard.py.
 // Skipping a multiply-add whose product is an exact zero leaves the accumulator as it is (up to the sign of a zero); what is NOT
 // bit-identical to the dense kernel is the code the compiler makes of the RK4 map here (one evaluation + the position increments
 // instead of two evaluations), and a last-bit difference there is a 1e-10 relative difference in F.  The two kernels agree like any
@@ -864,7 +887,7 @@ __device__ __forceinline__ void gemm_dpp_sp(Rows& C, const Rows& B, AP ap, AS as
     for (int k = 0; k < 6; k++) { p0[k] = ap(k); s0[k] = as(k); }
 #pragma unroll
     for (int k = 0; k < 6; k++) { p1[k] = ap(6 + k); s1[k] = as(6 + k); }
-    asm volatile("s_nop 1");
+    pin_rows(B);
     gemm_block_sp<NZ, 0, 6, false, CORNER>(C, B, p0, s0);
 #pragma unroll
     for (int k = 0; k < 4; k++) { p0[k] = ap(12 + k); s0[k] = as(12 + k); }
@@ -878,7 +901,7 @@ __device__ __forceinline__ void gemm_dpp_sp(Rows& C, const Rows& B, AP ap, AS as
     }
 }
 
-__global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
+__global__ __launch_bounds__(64, 2) void ekf_update_kernel_sp(EkfArgs A) {
     extern __shared__ __attribute__((aligned(16))) double esm[];
     const EkfConst& c = A.c;
     const int lane = threadIdx.x;
@@ -886,8 +909,8 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
     const int inst0 = blockIdx.x * kDppFilters + g;
     const bool live = inst0 < A.B;
     const int inst = live ? inst0 : A.B - 1;
-    const bool sec = l < 2;              // owns a secondary row
-    const int ls = sec ? l : 0;
+    const bool sec = l < 2;              // owns a secondary row.  The secondary register set of the other lanes holds don't-care values in this
+    const int ls = sec ? l : 0;          // kernel (a copy of row 16's arithmetic): nothing reads it, and zeroing it costs two selects per element
     // finite-difference roles: lane 0 evaluates the unperturbed map, lanes 1 / 2 perturb states 16 / 17, lanes 3..15 their own state
     const int pert = l >= 3 ? l : (l == 0 ? -1 : 15 + l);
     const double idp = l >= 3 ? c.inv_d : 0.0;   // 1 / d where this lane's evaluation is a column of its primary row set
@@ -959,7 +982,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
     // G = P F^T
     Rows G;
     zero_rows(G);
-    gemm_dpp_sp<NzFt>(G, Ft, [&](int k) { return bufX[l * EN + k]; }, [&](int k) { const double t = bufX[(16 + ls) * EN + k]; return sec ? t : 0.0; });
+    gemm_dpp_sp<NzFt>(G, Ft, [&](int k) { return bufX[l * EN + k]; }, [&](int k) { return bufX[(16 + ls) * EN + k]; });
     store_rows(bufY, Ft, l);                // F^T row-major: F[l][k] = bufY[k][l]
     __syncthreads();                        // (also: the reads of P are done, bufX is free)
     // P_pred = F G + Q.  F[l][k] is zero for k < 3 except on the diagonal (own-lane multiply-add), rows 16 / 17 of F are e_16 / e_17
@@ -971,10 +994,10 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
 #pragma unroll
         for (int k = 0; k < 15; k++) a[k] = bufY[(3 + k) * EN + l];
         const double fdl = bufY[l * EN + l], a16 = bufY[16 * EN + 16 + ls], a17 = bufY[17 * EN + 16 + ls];
-        const double fd3 = (l < 3) ? fdl : 0.0, s16 = sec ? a16 : 0.0, s17 = sec ? a17 : 0.0;
+        const double fd3 = (l < 3) ? fdl : 0.0, s16 = a16, s17 = a17;
 #pragma unroll
         for (int j = 0; j < EN; j++) Pq.p[j] = fma(fd3, G.p[j], Pq.p[j]);
-        asm volatile("s_nop 1");
+        pin_rows(G);
         for_k(std::make_integer_sequence<int, 13>{}, [&](auto kc) {
             constexpr int K = 3 + decltype(kc)::value;
 #pragma unroll
@@ -987,7 +1010,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
         for (int j = 0; j < EN; j++) fmac_bc<1>(Pq.p[j], G.s[j], a[14]);
         fmac_bc<1>(Pq.s[16], G.s[16], s17); fmac_bc<1>(Pq.s[17], G.s[17], s17);
     }
-    fill_secondary_from_symmetry(Pq, l);    // P_pred is symmetric: only the 2x2 corner of rows 16, 17 was accumulated
+    fill_secondary_from_symmetry<false>(Pq, l);    // P_pred is symmetric: only the 2x2 corner of rows 16, 17 was accumulated
     store_rows(bufX, Pq, l);                // P_pred stays in bufX (right operand of V = J P_pred)
     // ---- H^T by forward differences of h at x_pred (one evaluation per lane), innovation
     Rows Ht;
@@ -1026,7 +1049,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
             }
         });
         const double hd = bufY[l * EN + l], hd16 = bufY[16 * EN + 16], hd17 = bufY[17 * EN + 17];
-        asm volatile("s_nop 1");
+        pin_rows(Pq);
         for_k(std::make_integer_sequence<int, 12>{}, [&](auto kc) {
             constexpr int K = decltype(kc)::value;
             if constexpr (ekf_h21col(K)) {
@@ -1051,22 +1074,22 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
         for_k(std::make_integer_sequence<int, 16>{}, [&](auto jc) {
             constexpr int J = decltype(jc)::value;
             const double t16 = bcast<J>(c16), t17 = bcast<J>(c17);
-            W.s[J] = (l == 0) ? t16 : ((l == 1) ? t17 : 0.0);
+            W.s[J] = (l == 0) ? t16 : t17;
         });
         const double e16_0 = bcast<0>(d16), e16_1 = bcast<1>(d16), e17_0 = bcast<0>(d17), e17_1 = bcast<1>(d17);
-        W.s[16] = (l == 0) ? e16_0 : ((l == 1) ? e17_0 : 0.0);
-        W.s[17] = (l == 0) ? e16_1 : ((l == 1) ? e17_1 : 0.0);
+        W.s[16] = (l == 0) ? e16_0 : e17_0;
+        W.s[17] = (l == 0) ? e16_1 : e17_1;
     }
     // S = W H^T + R.  The left operand's elements W[l][k], W[16 + l][k] are this lane's own rows: W never goes through LDS
     Rows S;
 #pragma unroll
     for (int j = 0; j < EN; j++) { S.p[j] = (j == l) ? c.R : 0.0; S.s[j] = (sec && j == 16 + l) ? c.R : 0.0; }
     gemm_dpp_sp<NzHt, true>(S, Ht, [&](int k) { return W.p[k]; }, [&](int k) { return W.s[k]; });
-    fill_secondary_from_symmetry(S, l);     // S is symmetric
+    fill_secondary_from_symmetry<false>(S, l);     // S is symmetric
     // ---- K^T = S^-1 W by Gauss-Jordan on [S | W] without pivoting (S is SPD); the pivot row is broadcast with DPP.
-    // Secondary rows of lanes >= 2 are zero and stay zero (their factor is 0).
     Rows& T = W;                            // Gauss-Jordan on [S | W] in place
     bool ok = true;
+    pin_rows(S); pin_rows(T);                 // (fill_secondary_from_symmetry / load_rows end in plain selects)
     for_k(std::make_integer_sequence<int, EN>{}, [&](auto kc) {
         constexpr int K = decltype(kc)::value;
         constexpr bool PS = K >= 16;          // pivot row in the secondary set (lanes 0, 1)
@@ -1124,7 +1147,7 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
         const double hd = hdJ, hsd = hsdJ;
         double a0[EN], a1[EN];
 #pragma unroll
-        for (int k = 0; k < EN; k++) { a0[k] = -bufY[k * EN + l]; const double t = -bufY[k * EN + 16 + ls]; a1[k] = sec ? t : 0.0; }
+        for (int k = 0; k < EN; k++) { a0[k] = -bufY[k * EN + l]; a1[k] = -bufY[k * EN + 16 + ls]; }
         asm volatile("s_nop 1");
         for_k(std::make_integer_sequence<int, 12>{}, [&](auto kc) {
             constexpr int K = decltype(kc)::value;
@@ -1158,23 +1181,23 @@ __global__ __launch_bounds__(64, 1) void ekf_update_kernel_sp(EkfArgs A) {
     Rows V;
     {
         Rows Pr;
-        load_rows(bufX, Pr, l);
+        load_rows<false>(bufX, Pr, l);
         __syncthreads();                    // reads of bufX (P_pred) are done
         store_rows(bufX, J, l);             // J row-major
         __syncthreads();
         zero_rows(V);
-        gemm_dpp_symB(V, Pr, [&](int k) { return bufX[l * EN + k]; }, [&](int k) { return bufX[16 * EN + k]; }, [&](int k) { return bufX[17 * EN + k]; }, l);
+        gemm_dpp_symB<false>(V, Pr, [&](int k) { return bufX[l * EN + k]; }, [&](int k) { return bufX[16 * EN + k]; }, [&](int k) { return bufX[17 * EN + k]; }, l);
     }
     // P_new = V J^T + R Kal Kal^T   (Joseph form, bluerov2_dob.cpp:537).  Left operand of the first product: V's own rows (registers)
     Rows Pn;
     zero_rows(Pn);
     {
         Rows Jt;
-        load_rows_t(bufX, Jt, l);
+        load_rows_t<false>(bufX, Jt, l);
         gemm_dpp<true>(Pn, Jt, [&](int k) { return V.p[k]; }, [&](int k) { return V.s[k]; });
         Rows Kt;
-        load_rows(bufY, Kt, l);
-        gemm_dpp<true>(Pn, Kt, [&](int k) { return c.R * bufY[k * EN + l]; }, [&](int k) { const double t = c.R * bufY[k * EN + 16 + ls]; return sec ? t : 0.0; });
+        load_rows<false>(bufY, Kt, l);
+        gemm_dpp<true>(Pn, Kt, [&](int k) { return c.R * bufY[k * EN + l]; }, [&](int k) { return c.R * bufY[k * EN + 16 + ls]; });
     }
     if (live) {   // P_new is symmetric: rows 16, 17 are columns 16, 17 of the primary rows (+ the 2x2 corner from lanes 0, 1)
         double* pg = A.P + (size_t)inst * kMat;

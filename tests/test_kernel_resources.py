@@ -199,3 +199,44 @@ def test_device_integer_helpers_and_the_slow_multiplies_they_replace():
     hot = [ln for ln in out.splitlines() if (" 30 MFMA" in ln or "f64 dpp=48" in ln) and int(re.search(r"(\d+) instr", ln).group(1)) < 800]
     assert len(hot) >= 3, out[:400]
     assert not any("mul32=" in ln for ln in hot), [ln for ln in hot if "mul32=" in ln]
+
+
+# ---- data hazard found in round 6 (scripts/check_dpp_hazard.py): a DPP read of a VGPR less than two wait states behind the VALU write of it.
+_HAZ = """
+0000000000001000 <_ZN4brov6kernelE>:
+	v_mul_f64 v[90:91], v[148:149], v[90:91]
+	v_fmac_f64_dpp v[218:219], v[90:91], v[102:103] row_newbcast:13 row_mask:0xf bank_mask:0xf
+	s_endpgm
+"""
+_HAZ1 = _HAZ.replace("\tv_fmac_f64_dpp", "\tv_add_f64 v[2:3], v[4:5], v[6:7]\n\tv_fmac_f64_dpp")
+_OK_NOP = _HAZ.replace("\tv_fmac_f64_dpp", "\ts_nop 1\n\tv_fmac_f64_dpp")
+_OK_TWO = _HAZ1.replace("\tv_fmac_f64_dpp", "\tds_read_b64 v[8:9], v10\n\tv_fmac_f64_dpp")
+_OK_ACC = _HAZ.replace("v_mul_f64 v[90:91], v[148:149], v[90:91]", "v_mul_f64 v[218:219], v[148:149], v[90:91]")   # the accumulator is not the DPP operand
+
+
+def _hazard_checker():
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "scripts", "check_dpp_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_dpp_hazard_checker_recognises_the_hazard():
+    chk = _hazard_checker()
+    h = chk.scan(_HAZ.split("\n"))
+    assert len(h) == 1 and h[0][0] == "_ZN4brov6kernelE" and h[0][3] == 0, h
+    h = chk.scan(_HAZ1.split("\n"))
+    assert len(h) == 1 and h[0][3] == 1, h
+    for ok in (_OK_NOP, _OK_TWO, _OK_ACC):
+        assert chk.scan(ok.split("\n")) == [], ok
+
+
+def test_library_in_tree_has_no_dpp_hazard():
+    lib = os.path.join(ROOT, "bluerov2_amd", "lib", "libbluerov2_nmpc.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    chk = _hazard_checker()
+    chk.C.OBJDUMP = chk.C.find_objdump()
+    assert chk.scan(chk.C.listing(lib)) == []
