@@ -69,6 +69,49 @@ def test_single_tick_vs_oracle(ba, orc, B):
     e.close()
 
 
+def test_structured_kernel_corner_states_and_other_constants(ba, orc):
+    """the structured kernel (exact zeros of the finite-difference Jacobians skipped, position columns of F from the unperturbed
+    evaluation) at the states where a wrong zero pattern or a wrong closed form would show: velocities, rates and angles exactly 0
+    (|v| v and the trigonometry at their kinks), disturbances 0, yaw of several hundred rad with steep roll / pitch, covariances
+    from 1e-6 to 10 -- and with the model constants varied (the pattern is the model's, not the numbers').  Tail block: B = 4 k + 1."""
+    rng = np.random.default_rng(2024)
+    B = 4 * 64 + 1
+    keep = {f: getattr(orc.par, f) for f in ("dt", "mass", "fd_step")}
+    try:
+        for rep in range(4):
+            par = ba.EkfParams.default()
+            if rep >= 2:
+                par.dt = keep["dt"] * (0.5 if rep == 2 else 1.2); par.mass = keep["mass"] * (1.4 if rep == 2 else 0.8)
+                orc.par.dt, orc.par.mass = par.dt, par.mass
+                orc.lib.orc_ekf_derive(orc.par)
+            c = T.np_consts(orc.par)
+            x = np.stack([T.rand_state(rng) for _ in range(B)]); x[:, 15:17] *= 0.05
+            k = np.arange(B) % 6
+            x[k == 1, 3:12] = 0.0
+            x[k == 2, 12:18] = 0.0
+            x[k == 3, 5] = rng.uniform(-300, 300, (k == 3).sum()); x[k == 3, 3:5] = rng.uniform(-1.0, 1.0, ((k == 3).sum(), 2))
+            x[k == 4, 6:12] = 0.0
+            A = rng.normal(size=(B, 18, 18)) * 0.3
+            P = np.einsum("bij,bkj->bik", A, A) + np.eye(18) * 0.5
+            P *= (10.0 ** rng.integers(-6, 2, B))[:, None, None]
+            thrust, y12, acc = consistent_inputs(c, rng, x)
+            e = ba.BatchEkf(B, par)
+            e.set_state(x, P); e.update(thrust, y12, acc)
+            xg, Pg = e.state(); wfg, mpg, stg = e.outputs(); e.close()
+            xo, Po = x.copy(), P.copy()
+            wfo, mpo, rc = orc.update(xo, Po, thrust, y12, acc)
+            assert rc == 0 and not stg.any(), (rc, np.nonzero(stg))
+            sx = 1.0 + np.abs(xo).max(axis=1, keepdims=True)
+            assert (np.abs(xg - xo) / sx).max() < 2e-6, (rep, (np.abs(xg - xo) / sx).max())
+            sP = np.abs(Po).max(axis=(1, 2), keepdims=True)
+            assert (np.abs(Pg - Po) / sP).max() < 1e-5, (rep, (np.abs(Pg - Po) / sP).max())
+            assert (np.abs(wfg - wfo) / sx).max() < 2e-6, (rep, (np.abs(wfg - wfo) / sx).max())
+    finally:
+        for f, v in keep.items():
+            setattr(orc.par, f, v)
+        orc.lib.orc_ekf_derive(orc.par)
+
+
 def test_closed_loop_estimates_disturbance_like_oracle(ba, orc):
     """the CPU test's simulated loop (plant = the EKF's own model + constant body-frame disturbance), 120 ticks, 4 filters
     with different disturbances: GPU and oracle track each other and both recover the disturbance"""
