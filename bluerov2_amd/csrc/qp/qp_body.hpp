@@ -144,7 +144,7 @@ __device__ __forceinline__ void qp_body(const DevParams& P, IT& I, int b, double
         if (__ballot(nanp) != 0ull) kkt = __builtin_nan("");
     }
     // an ill-conditioned pivot block (kPivotRho): this instance repeats the sweep, and runs every later one, in the Cholesky form
-    // (not in the two-waves-per-SIMD kernel of the short horizons, N <= 13: its 256 registers do not hold the second pivot form
+    // (not in the two-waves-per-SIMD kernel of the short horizons, N <= 11: its 256 registers do not hold the second pivot form
     // without scratch, which the build forbids in a solver kernel)
     constexpr bool ROB = LDS != 2;
     bool robust = false, robust_ok = false;

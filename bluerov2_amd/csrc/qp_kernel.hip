@@ -87,8 +87,10 @@ __global__ __launch_bounds__(64, 1) void lin_wave_kernel_grid(DevParams P) { lin
 namespace brov {
 // One wave per SIMD (up to 512 VGPRs): the variant for horizons whose LDS slice admits only four blocks per CU anyway.
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel(DevParams P) { rti_fused_body<1>(P); }
-// Two waves per SIMD (256 VGPRs, some spilled): short horizons (N <= 13, at least six blocks per CU by LDS), where the
-// second wave fills the first one's MFMA / LDS / dependent-issue waits.
+// Two waves per SIMD (256 VGPRs): short horizons (N <= 11, seven blocks per CU by LDS), where the second wave fills the first one's
+// MFMA / LDS / dependent-issue waits.  (Until round 6: N <= 13, six blocks.  With the round-6 factor stage -- which the 256-register
+// form only takes in part, qp/sweeps.hpp kR6Z -- the one-wave kernel is ahead from N = 12: scripts/dev/w2_crossover.sh, N = 10 / 11 / 12
+// / 13 / 14: 43.4 / 38.9 / 34.9 / 32.8 / 29.3 M solves/s on two waves against 38.6 / 37.6 / 36.3 / 34.1 / 33.3 M on one.)
 __global__ __launch_bounds__(64, 2) void rti_fused_kernel_w2(DevParams P) { rti_fused_body<2>(P); }
 // General grid (per-stage time steps / a separate stage-0 weight), every N <= 23: one wave per SIMD
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_grid(DevParams P) { rti_fused_body<1, true>(P); }
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(64, 1) void rti_fused_kernel_grid(DevParams P) { rt
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_mail(DevParams P) { rti_fused_body<1, false, true>(P); }
 // brov_solve_ticks: P.ticks steps per instance in one launch (see MULTI in qp/fused.hpp)
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_ticks(DevParams P) { rti_fused_body<1, false, false, true>(P); }
-// (N <= 13: the code of rti_fused_kernel_w2 -- qp_body<2> -- so that the steps are bit-identical to single launches; compiled for one wave per
+// (N <= 11: the code of rti_fused_kernel_w2 -- qp_body<2> -- so that the steps are bit-identical to single launches; compiled for one wave per
 // SIMD, because the step loop's few live values no longer fit the 256 registers of the two-wave form without scratch)
 __global__ __launch_bounds__(64, 1) void rti_fused_kernel_ticks_w2(DevParams P) { rti_fused_body<2, false, false, true>(P); }
 
@@ -275,7 +277,7 @@ bool split_resident_horizon(int N) { return N >= 4 && 3 * ((N + 3) >> 2) < N && 
 
 static size_t fused_lds_bytes(int N) { return ((size_t)N * (kBaStage + NX + kKtStage + 4 + 4 + 4) + 2 * (size_t)(N + 1) * NX + 2 + 17) * sizeof(double); }
 static bool fused_two_wave(size_t lds, int force) {   // force: DevKnobs::fused_waves (development knob)
-    return force ? force == 2 : 6 * lds <= 160 * 1024;   // N <= 13
+    return force ? force == 2 : 7 * lds <= 160 * 1024;   // N <= 11 (seven slices per CU)
 }
 // what the LDS-resident kernel of this horizon asks of a CU: info = {dynamic LDS bytes per block, blocks the occupancy query grants
 // per CU, threads per block, 1 fused / 2 fused two-wave / 3 windowed / 4 windowed resident}.  For bench.py's horizon sweep (the

@@ -48,7 +48,7 @@ def test_small_and_ragged_shapes(ba, oracle, golden_traj, N, B, path):
 
 @pytest.mark.parametrize("N", [8, 13])
 def test_fused_one_and_two_wave_variants_agree(ba, golden_traj, monkeypatch, N):
-    """rti_fused_kernel (one wave per SIMD) and rti_fused_kernel_w2 (two, the default for N <= 13) differ only in how the
+    """rti_fused_kernel (one wave per SIMD) and rti_fused_kernel_w2 (two, the default for N <= 11) differ only in how the
     linearisation groups sensitivity columns and in the prefetch distance of the sweeps: same statuses, same early-exit
     decisions, iteration counts equal for > 95 % of the instances (the step-length rule with fraction-to-boundary 0.9999 turns
     last-bit differences into one to three iterations more or less on a few far-off instances); iterates equal to what the
@@ -91,8 +91,8 @@ def test_auto_path_selection(ba, golden_traj):
         assert (info["kind"] == "streaming") == (want == ba.PATH_STREAMING)
         s.close()
     # the LDS-occupancy crossover the horizon sweep reports: four instances in flight per CU up to N = 20, three from N = 21,
-    # two waves per SIMD up to N = 13, one resident window for small batches at long horizons
-    for N, B, kind, per_cu in ((10, 64, "fused, two waves per SIMD", 7), (13, 64, "fused, two waves per SIMD", 6), (14, 64, "fused", 4), (20, 64, "fused", 4),
+    # two waves per SIMD up to N = 11 (seven slices per CU; round 6: the one-wave kernel is ahead from N = 12), one resident window for small batches at long horizons
+    for N, B, kind, per_cu in ((10, 64, "fused, two waves per SIMD", 7), (11, 64, "fused, two waves per SIMD", 7), (12, 64, "fused", 4), (13, 64, "fused", 4), (14, 64, "fused", 4), (20, 64, "fused", 4),
                                (21, 64, "fused", 3), (23, 64, "fused", 3), (40, 4096, "windowed", 4), (80, 4096, "windowed", 4),
                                (80, 64, "windowed, resident", 1)):
         s = ba.BatchSolver(B, ba.SolverOptions(N, 1.0 / N))
