@@ -50,8 +50,17 @@ def main():
     f_read = per_kernel(os.path.join(cal, "cal_fetch"), "FETCH_SIZE").get("calib_read8", [0])[-1]
     w_write = per_kernel(os.path.join(cal, "cal_write"), "WRITE_SIZE").get("calib_write8", [0])[-1]
     fu, wu = (cal_bytes / f_read if f_read else None), (cal_bytes / w_write if w_write else None)
+    cal_src = "this session (scripts/dev/pmc_calib.hip)"
+    if not (fu and wu):
+        # no calibration pass in this session (the calibration binary is built on the GPU box by scripts/profile_round.sh; a session that
+        # could not build it leaves none): the units of the last session that had one -- what bench.py's in-run traffic uses as well
+        prev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r5_pmc_summary.json")
+        if os.path.exists(prev):
+            c = json.load(open(prev))["calibration"]
+            fu, wu = c["bytes_per_FETCH_SIZE_count"], c["bytes_per_WRITE_SIZE_count"]
+            cal_src = "profiles/r5_pmc_summary.json (no calibration pass in this session)"
     out = {"calibration": {"bytes_streamed": cal_bytes, "FETCH_SIZE_reading_1GiB": f_read, "WRITE_SIZE_writing_1GiB": w_write,
-                           "bytes_per_FETCH_SIZE_count": fu, "bytes_per_WRITE_SIZE_count": wu,
+                           "bytes_per_FETCH_SIZE_count": fu, "bytes_per_WRITE_SIZE_count": wu, "units_from": cal_src,
                            "note": "nominal unit is 1024 B; the ratio to it is the gfx950 correction for this access pattern"},
            "runs": {}}
     for spec in sys.argv[2:]:

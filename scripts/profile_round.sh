@@ -33,6 +33,7 @@ $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_forced_ipm --config 5 --horizon 80 --fo
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg4_N20 --config 4
 $R/scripts/pmc_pass.sh $OUT/pmc_cfg5_N80_B64_resident --config 5 --horizon 80 --batch 64
 cd /tmp
+[ -x $R/scripts/dev/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $R/scripts/dev/pmc_calib $R/scripts/dev/pmc_calib.hip > $OUT/pmc_calib_build.log 2>&1   # (git-ignored binary: built where it runs)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch -o f -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o w -- $R/scripts/dev/pmc_calib > /dev/null 2>&1
 python $R/scripts/dev/phase_stamps.py 4096 20 1 0 > $OUT/phase_stamps_N20.txt 2>/dev/null
