@@ -1439,12 +1439,8 @@ extern "C" int brov_ekf_create(brov_ekf** out, int device, int B, const brov_ekf
     }
     rc = brov_ekf_reset(e, nullptr, nullptr);
     if (rc) { brov_ekf_destroy(e); return rc; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ekf_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kPerWave * kLdsPerFilter * (int)sizeof(double));
-        attr_set = true;
-    }
+    // (no hipFuncSetAttribute: the three kernels ask for 35 / 33 / 23 KB of dynamic LDS per block, below the 64 KB a launch may have without it)
+    static_assert(kPerWave * kLdsPerFilter * sizeof(double) <= 64 * 1024 && kDppFilters * kDppLds * sizeof(double) <= 64 * 1024, "dynamic LDS");
     *out = e;
     return BROV_OK;
 }
