@@ -213,8 +213,15 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
     // parked lanes of the per-stage LDS stores write their value to a slot nobody reads (lds_tr[16]) with stride 0
     lds_f64* const kt_st0 = (LDS != 0 && cl < NX) ? I.lds_kt + rg * NX + cl : I.lds_tr + 16;
     const int kt_ststr = (cl < NX) ? kKtStage : 0;
-    lds_f64* const kf_st0 = (LDS != 0 && cl == 0) ? I.lds_kff + rg : I.lds_tr + 16;
-    const int kf_ststr = (cl == 0) ? 4 : 0;
+    // (kKffT, below: the feed-forward term comes out of column 12 of the gain product)
+#ifndef BROV_EXP_NO_KFF_IN_T
+    constexpr bool kKffT = kR6Z;
+#else
+    constexpr bool kKffT = false;
+#endif
+    constexpr int kKffCol = kKffT ? 12 : 0;
+    lds_f64* const kf_st0 = (LDS != 0 && cl == kKffCol) ? I.lds_kff + rg : I.lds_tr + 16;
+    const int kf_ststr = (cl == kKffCol) ? 4 : 0;
     lds_f64* ktp = kt_st0 + lmul(N - 1, kt_ststr);   // kR6: running store addresses (the stages are visited in order N-1 .. lo)
     lds_f64* kfp = kf_st0 + lmul(N - 1, kf_ststr);
     unsigned long long illm = 0;   // kR6: the watch accumulates in a lane mask (scalar registers)
@@ -411,7 +418,19 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
                 T = tn1(li, Y[0], z4);               // L^-T Y = M Hu through the factor, not through the explicit inverse
                 ks = -T[0];
             } else {
-                T = tn1(mt, H[3], z4);
+                if constexpr (kKffT) {
+                    // Round 6.  kff = -M g_u rides in the gain product: columns 12..15 of T = -M Hu are -M Huu = -I, known without
+                    // computing them, and nothing reads them (S and p use rows / columns 0..11 of what they feed) -- so column 12 of
+                    // the right operand carries g_u instead of Huu(:, 0) (one row broadcast of column 0 of g, one select), and the
+                    // separate product M g_u -- a whole 64-cycle MFMA for 16 multiply-adds -- is gone: 9 MFMAs per stage instead of 10.
+                    // (p = g_x + Hu' kff out of column 12 of the Schur product in the same way -- 8 MFMAs -- was built too: the stage gets
+                    // SLOWER, 30.2 -> 33.3 k cycles per sweep, because p then arrives WITH S and has to come back through the vector
+                    // unit, where today its own product runs beside the next stage's P [A B]; profiles/r6_fused_experiments.txt.)
+                    const double gub = dpp_f64<0x150>(g[3]);   // row_newbcast:0 -- g_u[rg] in every lane of row rg
+                    T = tn1(mt, cl == 12 ? gub : H[3], z4);
+                } else {
+                    T = tn1(mt, H[3], z4);
+                }
                 ks = kR6Z ? T[0] : -T[0];
                 S = tn1(H[3], ks, H);
             }
@@ -429,6 +448,9 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             } else if constexpr (LDS == 3) {
                 const d4 gC = {g[0], g[1], g[2], 0.0};
                 pn = tn1(xt2, g[3], gC);
+            } else if constexpr (kKffT) {
+                pn = tn1(ks, g[3], g);
+                pn[3] = ks;   // lanes of column 12: kff (stored from there)
             } else {
                 const d4 kf = tn1(mt, g[3], z4);
                 pn = tn1(ks, g[3], g);

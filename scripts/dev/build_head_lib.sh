@@ -4,7 +4,7 @@
 # (`rm bluerov2_amd/lib/libbluerov2_nmpc_head.so`; the round-5 judge found a stale one shipping).
 set -e
 R=$(cd "$(dirname "$0")/../.." && pwd); REV=${1:-HEAD}; T=$(mktemp -d /tmp/brov_head_XXXX)
-git -C "$R" archive "$REV" bluerov2_amd/csrc include scripts/check_exec_restore.py | tar -x -C "$T"
+git -C "$R" archive "$REV" bluerov2_amd/csrc include scripts/check_exec_restore.py scripts/check_dpp_hazard.py | tar -x -C "$T"
 make -s -j4 -C "$T/bluerov2_amd/csrc" 2>&1 | grep -v "^ \|remark" | tail -3
 cp "$T/bluerov2_amd/lib/libbluerov2_nmpc.so" "$R/bluerov2_amd/lib/libbluerov2_nmpc_head.so"
 rm -rf "$T"; echo "built bluerov2_amd/lib/libbluerov2_nmpc_head.so from $REV"
