@@ -215,7 +215,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
     const int kt_ststr = (cl < NX) ? kKtStage : 0;
     // (kKffT, below: the feed-forward term comes out of column 12 of the gain product)
 #ifndef BROV_EXP_NO_KFF_IN_T
-    constexpr bool kKffT = kR6Z;
+    constexpr bool kKffT = kR6;   // (both fused families: ks carries kff in column 12 with the right sign in either)
 #else
     constexpr bool kKffT = false;
 #endif
@@ -477,7 +477,7 @@ __device__ __forceinline__ void bwd_chunk(const IT& I, BwdState& S, int hi = -1,
             }
             if constexpr (LDS) {  // only column 0 of rows 12..15 is M gu: the other lanes are parked on the constant-zero slot
                 if constexpr (kR6) {
-                    *kfp = kR6Z ? pn[3] : -pn[3]; kfp -= kf_ststr;   // (kR6Z: the operand tile carries -M)
+                    *kfp = (kR6Z || kKffT) ? pn[3] : -pn[3]; kfp -= kf_ststr;   // (kR6Z: the operand tile carries -M; kKffT: pn[3] is ks, the gain operand itself)
                 } else {
                     lds_f64* kp = (cl == 0) ? I.lds_kff + i * 4 + rg : I.lds_zero;
                     *kp = (cl == 0) ? -pn[3] : 0.0;
