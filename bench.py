@@ -613,6 +613,19 @@ def configs_block(ba, args, device):
         cl[name] = dict(ticks_per_s=B / dtc, ms_per_tick=dtc * 1e3, status_nonzero=int((s.results()["status"] != 0).sum()))
         s.close()
     leg["closed_loop_plant_only"] = cl
+    # ... and with the 6-disturbance model variant (BASELINE configs[2] "6 disturbance states"): roll / pitch disturbance moments
+    # per instance next to p[0..3] in the OCP model (brov_enable_dist6) -- the same draws, one launch per step.  (No closed loop on this variant
+    # here: at Ts = 0.05 one RK4 step of the undamped roll / pitch restoring moment is beyond the integrator's stability limit, |lambda| dt = 4.2 --
+    # include/bluerov2_nmpc.h -- and a plant that is PUSHED in roll diverges with it; the reference runs the variant at Ts = 0.0125.)
+    drp = rng.uniform(-0.5, 0.5, (B, 2))
+    s = ba.BatchSolver(B, ba.SolverOptions(N, TS), device=device)
+    s.enable_dist6()
+    s.set_x0(x0); s.set_params(p); s.set_rp_disturbance(drp); s.set_trajectory(circ)
+    l6 = solver_leg(s, lambda k: (s.set_yref_from_trajectory(k, 16), s.solve()), N, True)
+    s.close()
+    leg["dist6"] = dict(solves_per_s=l6["solves_per_s"], ms_per_step=l6["ms_per_step"], kernel_ms=l6["kernel_ms"], kernel=l6["kernel"],
+                        status_nonzero=l6["status_nonzero"], roofline_frac=l6["roofline_frac"],
+                        note="six disturbances in the OCP model: p[0..3] and the roll / pitch moments of brov_enable_dist6, drawn per instance")
     out["config3"] = leg
 
     # ---- configs[3], one of its 8 shards: 8192 of the 65 536 lemniscate candidates, windows rebuilt on the device, then the RCCL
