@@ -628,6 +628,21 @@ def configs_block(ba, args, device):
                         note="six disturbances in the OCP model: p[0..3] and the roll / pitch moments of brov_enable_dist6, drawn per instance")
     out["config3"] = leg
 
+    # ---- the observer of that loop alone: 16 384 EKF updates per launch on resident data, as scripts/bench_ekf.py times it
+    # (0.13 MFLOP and 5.7 KB of HBM per update by SURVEY's dense count -- the structured kernel skips the exact zeros of the finite-difference Jacobians)
+    e = ba.BatchEkf(B)
+    th = rng.uniform(-2, 2, (B, 6)); y12 = np.zeros((B, 12)); y12[:, 2] = -20.0; y12[:, :2] = rng.uniform(-1, 1, (B, 2)); ac = rng.uniform(-0.1, 0.1, (B, 6))
+    e.update(th, y12, ac)
+    t_th, t_y, t_a = (torch.tensor(a, device=f"cuda:{device}") for a in (th, y12, ac))
+    dte = timed(lambda k: e.update_device(t_th.data_ptr(), t_y.data_ptr(), t_a.data_ptr()))
+    kte = e.last_update_seconds()
+    _, _, ste = e.outputs()
+    ekf_flops = 19 * 4 * 150 + 19 * 60 + 9 * 2 * 18 ** 3 + 2 * 18 ** 3 + 2 * 18 * 18
+    out["ekf_observer"] = dict(updates_per_s=B / dte, ms_per_step=dte * 1e3, kernel_ms=kte * 1e3, kernel="ekf_update_kernel_sp", batch=B,
+                               status_nonzero=int((ste != 0).sum()), roofline_frac=ekf_flops * B / kte / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                               note="FP64 vector peak = FP64 matrix peak on this part; flops by SURVEY's dense count (129 828 per update)")
+    e.close()
+
     # ---- configs[3], one of its 8 shards: 8192 of the 65 536 lemniscate candidates, windows rebuilt on the device, then the RCCL
     # all-gather + global arg-min THROUGH THE C ABI's group entry points (brov_group_*: one process, here one device)
     B = CAND_TOTAL // CAND_SHARDS
