@@ -112,6 +112,37 @@ def test_structured_kernel_corner_states_and_other_constants(ba, orc):
         orc.lib.orc_ekf_derive(orc.par)
 
 
+def test_full_size_batch_is_a_permutation_of_independent_filters(ba, orc):
+    """BASELINE config 3's batch (16 384 filters): a filter's update depends on its own data only -- the batch is 2 048 distinct filters, each
+    present eight times at shuffled positions (different waves, different 16-lane rows, different places in the launch's rounds): the eight
+    copies come out BIT-identical, and a 256-filter sample agrees with the oracle to the single-tick tolerances."""
+    c = T.np_consts(orc.par)
+    rng = np.random.default_rng(16384)
+    D, B = 2048, 16384
+    xd = np.stack([T.rand_state(rng) for _ in range(D)]); xd[:, 15:17] *= 0.05
+    A = rng.normal(size=(D, 18, 18)) * 0.3
+    Pd = np.einsum("bij,bkj->bik", A, A) + np.eye(18) * 0.5
+    thd, yd, ad = consistent_inputs(c, rng, xd)
+    perm = rng.permutation(B)
+    src = perm % D                      # position i of the batch holds distinct filter src[i]
+    e = ba.BatchEkf(B)
+    e.set_state(xd[src], Pd[src]); e.update(thd[src], yd[src], ad[src])
+    xg, Pg = e.state(); wfg, mpg, stg = e.outputs(); e.close()
+    assert not stg.any()
+    order = np.argsort(src, kind="stable").reshape(D, B // D)     # the eight positions of every distinct filter
+    for arr in (xg, Pg, wfg, mpg):
+        ref = arr[order[:, 0]]
+        for k in range(1, B // D):
+            assert np.array_equal(arr[order[:, k]], ref)
+    pick = order[:256, 0]
+    xo, Po = xd[:256].copy(), Pd[:256].copy()
+    wfo, mpo, rc = orc.update(xo, Po, thd[:256], yd[:256], ad[:256])
+    assert rc == 0
+    np.testing.assert_allclose(xg[pick], xo, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(Pg[pick], Po, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(wfg[pick], wfo, rtol=1e-6, atol=1e-6)
+
+
 def test_closed_loop_estimates_disturbance_like_oracle(ba, orc):
     """the CPU test's simulated loop (plant = the EKF's own model + constant body-frame disturbance), 120 ticks, 4 filters
     with different disturbances: GPU and oracle track each other and both recover the disturbance"""
